@@ -1,0 +1,87 @@
+"""ctypes binding of libpafc_hip.so -- the only way product code reaches a kernel.
+
+There is no CPU fallback anywhere in this package: if the library is missing or
+a tensor is not on the GPU the call raises.  (The CPU restatement lives under
+oracle/ and is test infrastructure; nothing here imports it.)
+"""
+import ctypes
+import os
+from ctypes import c_int, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libpafc_hip.so")
+
+PAFC_F32, PAFC_BF16 = 0, 1
+_ERRORS = {
+    -1: "null pointer", -2: "bad dims (B, T, C, H must be positive and C == H * 64)", -3: "head size must be 64",
+    -4: "workspace too small", -5: "kernel launch failed", -6: "unsupported dtype", -7: "unsupported",
+}
+
+
+class PafcError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def _sig(fn, restype, *argtypes):
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raise loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise PafcError(
+            f"{SO_PATH} is missing: the HIP extension has not been built "
+            "(python -m paper_accurate_fast_cheap_amd.csrc.build). There is no CPU fallback.")
+    L = ctypes.CDLL(SO_PATH)
+    P, I, Z = c_void_p, c_int, c_size_t
+    _sig(L.pafc_abi_version, I)
+    _sig(L.pafc_wkv6_pick_chunk_len, I, I, I, I, I, I)
+    _sig(L.pafc_wkv6_fwd_workspace_bytes, Z, I, I, I, I, I, I)
+    _sig(L.pafc_wkv6_forward_bf16, I, I, I, I, I, P, P, P, P, P, P, I, P, Z, P)
+    _sig(L.pafc_wkv6_forward_f32, I, I, I, I, I, P, P, P, P, P, P, I, P, Z, P)
+    _sig(L.pafc_wkv6_forward_state, I, I, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, Z, P)
+    _sig(L.pafc_wkv6_forward_bidir, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, I, P, Z, P)
+    _sig(L.pafc_wkv6_bwd_workspace_bytes, Z, I, I, I, I, I)
+    _sig(L.pafc_wkv6_backward, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, I, I, P, Z, P)
+    _lib = L
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise PafcError(f"{what}: {_ERRORS.get(code, code)}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return PAFC_F32
+    if dt == torch.bfloat16:
+        return PAFC_BF16
+    raise PafcError(f"kernels take float32 or bfloat16, got {dt}")
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def stream_of(t: torch.Tensor) -> c_void_p:
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise PafcError("this op runs on the MI355X only (tensor is on %s); there is no CPU fallback" % t.device)
+        if not t.is_contiguous():
+            raise PafcError("kernel operands must be contiguous")

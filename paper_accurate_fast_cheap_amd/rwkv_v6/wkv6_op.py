@@ -1,0 +1,83 @@
+"""WKV-6 op: torch tensors -> C ABI (include/pafc_wkv6.h) -> gfx950 kernels.
+
+Host-side counterpart of the reference's WKV_6 / WKV_6_FP32 autograd Functions
+(wenet/rwkv_v6/src/model.py:108-214) and of its `torch.ops.wkv6.*` bindings
+(cuda/wkv6_op.cpp:34-41): same argument meaning (r, k, v, w: (B, T, C)
+contiguous; u: (H, N); y allocated here), same dtype rules (all operands one
+dtype, bfloat16 or float32), errors raised instead of asserted.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from .. import _lib
+
+HEAD_SIZE = 64
+
+
+def _shape(r, u):
+    B, T, C = r.shape
+    H = u.shape[0]
+    if u.shape != (H, C // H) or C % H:
+        raise _lib.PafcError(f"u must be (H, C // H); got {tuple(u.shape)} for C={C}")
+    return B, T, C, H
+
+
+def _same(*ts):
+    dt = ts[0].dtype
+    for t in ts:
+        if t.dtype != dt:
+            raise _lib.PafcError("r, k, v, w, u must share one dtype (model.py:116-120)")
+    return _lib.dtype_code(dt)
+
+
+def _workspace(B, T, C, H, ndir, chunk_len, device):
+    L = _lib.lib()
+    nbytes = L.pafc_wkv6_fwd_workspace_bytes(B, T, C, H, ndir, chunk_len)
+    if nbytes == 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
+def wkv6_forward(r, k, v, w, u, *, reverse: bool = False, s_in: Optional[torch.Tensor] = None,
+                 want_state: bool = False, chunk_len: int = 0):
+    """y = WKV6(r, k, v, w, u); optionally from an initial state and returning the final one.
+
+    chunk_len: 0 = library heuristic, T (or more) = serial schedule, else steps per chunk.
+    """
+    _lib.require_gpu(r, k, v, w, u, s_in)
+    B, T, C, H = _shape(r, u)
+    code = _same(r, k, v, w, u)
+    y = torch.empty_like(r)
+    s_out = torch.empty(B, H, HEAD_SIZE, HEAD_SIZE, dtype=torch.float32, device=r.device) if want_state else None
+    if s_in is not None and (s_in.dtype != torch.float32 or s_in.shape != (B, H, HEAD_SIZE, HEAD_SIZE)):
+        raise _lib.PafcError("s_in must be float32 (B, H, 64, 64)")
+    ws, nbytes = _workspace(B, T, C, H, 1, chunk_len, r.device)
+    rc = _lib.lib().pafc_wkv6_forward_state(code, B, T, C, H, _lib.ptr(r), _lib.ptr(k), _lib.ptr(v), _lib.ptr(w),
+                                            _lib.ptr(u), _lib.ptr(y), _lib.ptr(s_in), _lib.ptr(s_out), int(reverse),
+                                            chunk_len, _lib.ptr(ws), nbytes, _lib.stream_of(r))
+    _lib.check(rc, "pafc_wkv6_forward_state")
+    return (y, s_out) if want_state else y
+
+
+def wkv6_forward_bidir(fwd: Tuple[torch.Tensor, ...], bwd: Tuple[torch.Tensor, ...], *, chunk_len: int = 0):
+    """Both directions of the bidirectional wrapper in one launch.
+
+    fwd / bwd = (r, k, v, w, u) produced by the left-to-right / right-to-left parameter sets on the SAME,
+    un-flipped time axis; returns (y_fwd, y_bwd), also un-flipped.
+    """
+    rf, kf, vf, wf, uf = fwd
+    rb, kb, vb, wb, ub = bwd
+    _lib.require_gpu(*fwd, *bwd)
+    B, T, C, H = _shape(rf, uf)
+    code = _same(*fwd, *bwd)
+    if rb.shape != rf.shape:
+        raise _lib.PafcError("both directions must have the same (B, T, C)")
+    yf, yb = torch.empty_like(rf), torch.empty_like(rb)
+    ws, nbytes = _workspace(B, T, C, H, 2, chunk_len, rf.device)
+    P = _lib.ptr
+    rc = _lib.lib().pafc_wkv6_forward_bidir(code, B, T, C, H, P(rf), P(kf), P(vf), P(wf), P(uf), P(yf),
+                                            P(rb), P(kb), P(vb), P(wb), P(ub), P(yb),
+                                            chunk_len, P(ws), nbytes, _lib.stream_of(rf))
+    _lib.check(rc, "pafc_wkv6_forward_bidir")
+    return yf, yb

@@ -1,0 +1,28 @@
+"""CTC head (reference: wenet/transformer/ctc.py:20-124): Linear C -> V, log-softmax; CTC loss for training."""
+from typing import Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+class CTC(torch.nn.Module):
+    def __init__(self, odim: int, encoder_output_size: int, dropout_rate: float = 0.0, reduce: bool = True,
+                 blank_id: int = 0):
+        super().__init__()
+        self.dropout_rate = dropout_rate
+        self.ctc_lo = torch.nn.Linear(encoder_output_size, odim)
+        self.ctc_loss = torch.nn.CTCLoss(blank=blank_id, reduction="sum" if reduce else "none", zero_infinity=True)
+
+    def forward(self, hs_pad: torch.Tensor, hlens: torch.Tensor, ys_pad: torch.Tensor, ys_lens: torch.Tensor
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """ctc.py:61-104 (non-focal branch): loss summed over the batch then divided by B; also returns log-probs."""
+        ys_hat = self.ctc_lo(F.dropout(hs_pad, p=self.dropout_rate))
+        ys_hat = ys_hat.transpose(0, 1).log_softmax(2)
+        loss = self.ctc_loss(ys_hat, ys_pad, hlens, ys_lens) / ys_hat.size(1)
+        return loss, ys_hat.transpose(0, 1)
+
+    def log_softmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
+        return F.log_softmax(self.ctc_lo(hs_pad), dim=2)
+
+    def argmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
+        return torch.argmax(self.ctc_lo(hs_pad), dim=2)

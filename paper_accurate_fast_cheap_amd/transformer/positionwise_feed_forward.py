@@ -1,0 +1,16 @@
+"""PositionwiseFeedForward (reference: wenet/transformer/positionwise_feed_forward.py:20-55):
+w_2(dropout(act(w_1 x))), 512 -> 2048 -> 512, activation SiLU in the paper's configs."""
+import torch
+
+
+class PositionwiseFeedForward(torch.nn.Module):
+    def __init__(self, idim: int, hidden_units: int, dropout_rate: float,
+                 activation: torch.nn.Module = torch.nn.ReLU(), bias: bool = True):
+        super().__init__()
+        self.w_1 = torch.nn.Linear(idim, hidden_units, bias=bias)
+        self.activation = activation
+        self.dropout = torch.nn.Dropout(dropout_rate)
+        self.w_2 = torch.nn.Linear(hidden_units, idim, bias=bias)
+
+    def forward(self, xs: torch.Tensor) -> torch.Tensor:
+        return self.w_2(self.dropout(self.activation(self.w_1(xs))))
