@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-sec/sec (1/RTF) of the long-form encode on MI355X.
+
+Metric (BASELINE.json / SURVEY.md 8(d)): sum(valid input frames)/100 / wall seconds over the timed region
+cmvn -> Conv2dSubsampling4 -> 12 bidirectional-RWKV Conformer layers -> after_norm -> CTC log-softmax, i.e. what
+wenet/bin/encoder-rtf.py:499-509 times, but with a device synchronize + barrier on both sides (the reference takes
+t1 without one, :510).  One "step" = one pass over one synthetic 30-minute file (config c3: 179 998 frames), run
+either as ONE sequence (default) or as the paper's window batches (--chunk-size / --batch-size,
+encoder-rtf.py:354-385).  Inputs are resident in HBM before the timed region.
+
+N > 1 (torchrun, one rank per GPU): every rank encodes its own file -- independent units, no data-path
+collective; value = all ranks' audio seconds / max-over-ranks time => "scaling": "weak".
+
+Prints ONE JSON line on rank 0 (schema in the task contract) with two extra objects:
+  roofline     -- the hand-written WKV-6 scan (its three kernels per launch), timed live with events on the launch
+                  stream; algorithmic bytes per DESIGN.md: B*T'*C*(4 reads + 1 write)*elem per direction.
+  cpu_baseline -- the CPU oracle (reference graph in torch CPU fp32 ops + oracle/wkv6_oracle.c) on a bounded sample
+                  of the same features, on this box's host cores (rank 0, N == 1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+AUDIO_SECONDS = 1800.0
+FRAMES = 1 + (int(AUDIO_SECONDS * 16000) - 400) // 160   # 179 998 (Kaldi snip_edges framing, 25 ms / 10 ms)
+VOCAB = 5000
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
+VALU_PEAK_TFLOPS = 157.3
+
+
+def encoder_conf():
+    # examples/gigaspeech/s0/conf/rwkv/giga.rwkvbi_ds4k31nc_12le.trans.shortform.yaml:4-25
+    return dict(output_size=512, attention_heads=8, linear_units=2048, num_blocks=12, dropout_rate=0.1,
+                positional_dropout_rate=0.1, attention_dropout_rate=0.0, input_layer="conv2d", normalize_before=True,
+                cnn_module_kernel=31, use_cnn_module=True, cnn_module_norm="layer_norm", activation_type="swish",
+                pos_enc_layer_type="rel_pos", selfattention_layer_type="rwkv_tmix60_bidirectional",
+                rnn_att_version="rwkv", rnn_att_direction="bi", rwkv_ctx_len=2048, rwkv_do_bfloat16=True)
+
+
+def synthetic_features(frames: int, seed: int, device) -> torch.Tensor:
+    """(1, frames, 80) log-mel-shaped features: band-limited noise under a slow amplitude envelope, so that the
+    CTC argmax is not constant.  (Synthetic 16 kHz audio -> fbank replaces this once the HIP fbank lands.)"""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    t = torch.arange(frames, dtype=torch.float32)
+    env = 1.0 + 0.8 * torch.sin(2 * math.pi * t / 700.0) * torch.sin(2 * math.pi * t / 9100.0)
+    x = torch.randn(frames, 80, generator=g)
+    x = (x + torch.roll(x, 1, 0) + torch.roll(x, 2, 0)) / math.sqrt(3.0)  # smooth along time
+    mel_tilt = torch.linspace(2.0, -2.0, 80)
+    return ((x * env[:, None]) * 2.0 + mel_tilt[None, :] + 8.0).unsqueeze(0).to(device)
+
+
+def windows(feats: torch.Tensor, chunk_size: int, batch_size: int):
+    """feats_batcher of encoder-rtf.py:354-385: cut (1, T, 80) into batches of `batch_size` windows of `chunk_size`
+    frames; the last window is zero-padded and its length shortened."""
+    T = feats.shape[1]
+    if chunk_size <= 0:
+        yield feats, torch.tensor([T], dtype=torch.int32, device=feats.device)
+        return
+    per = chunk_size * batch_size
+    for b in range(math.ceil(T / per)):
+        fb = feats[:, b * per:(b + 1) * per]
+        nb = math.ceil(fb.shape[1] / chunk_size)
+        lens = torch.full((nb,), chunk_size, dtype=torch.int32)
+        pad = nb * chunk_size - fb.shape[1]
+        if pad > 0:
+            lens[-1] -= pad
+            fb = torch.nn.functional.pad(fb, (0, 0, 0, pad))
+        yield fb.reshape(nb, chunk_size, 80), lens.to(feats.device)
+
+
+def build_model(dtype: str, device):
+    from paper_accurate_fast_cheap_amd.utils.init_model import init_model
+    torch.manual_seed(777)  # the trainer's seed, wenet/bin/train.py:71
+    configs = dict(encoder="conformer", encoder_conf=encoder_conf(), input_dim=80, output_dim=VOCAB, ctc="ctc",
+                   ctc_conf={"ctc_blank_id": 0}, model_conf={}, dataset_conf={})
+
+    class Args:
+        checkpoint = None
+
+    model, _ = init_model(Args(), configs)
+    model.eval()
+    if dtype == "bf16":
+        model = model.to(torch.bfloat16)   # encoder-rtf.py:424-426 (--bf16)
+    return model.to(device), configs
+
+
+def cpu_baseline(model, feats_cpu_f32, conf, sample_frames: int):
+    """Reference CPU path = same graph, torch CPU fp32 ops + the C restatement of the WKV op."""
+    from oracle import encoder_oracle as EO
+    sd = {k: v.detach().float().cpu() for k, v in model.encoder.state_dict().items()}
+    for k in list(sd):  # the slot stores bf16 parameters when rwkv_do_bfloat16 (rwkv_wrapper.py:53-54)
+        if ".tmix_block." in k and conf.get("rwkv_do_bfloat16", True):
+            sd[k] = sd[k].to(torch.bfloat16)
+    csd = {"ctc." + k: v.detach().float().cpu() for k, v in model.ctc.state_dict().items()}
+    xs = feats_cpu_f32[:, :sample_frames].contiguous()
+    lens = torch.tensor([sample_frames])
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.time()
+        out, _ = EO.encoder_forward(xs, lens, sd, conf, env={})
+        EO.ctc_log_softmax(out, csd)
+        dt = time.time() - t0
+    return {"value": round(sample_frames / 100.0 / dt, 3), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
+            "sample": f"first {sample_frames / 100:.0f} s of the same synthetic file, one sequence, fp32 graph with the "
+                      f"bf16 time-mix slot, {threads} torch/OpenMP threads, {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16slot"],
+                    help="bf16: whole model bf16 (BASELINE configs[1], encoder-rtf.py --bf16); "
+                         "bf16slot: fp32 model with the bf16 time-mix slot (the YAML default)")
+    ap.add_argument("--chunk-size", type=int, default=0, help="frames per window; 0 = the whole file as one sequence")
+    ap.add_argument("--batch-size", type=int, default=8)
+    ap.add_argument("--cpu-sample-frames", type=int, default=20000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")  # RCCL; only used for the timing barrier and the max-reduce
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from paper_accurate_fast_cheap_amd import _lib, profiling
+    _lib.lib()  # fail loudly, before anything else, if the HIP extension is missing
+
+    model, configs = build_model(args.dtype, device)
+    conf = configs["encoder_conf"]
+    feats32 = synthetic_features(FRAMES, 777 + rank, "cpu")
+    feats = feats32.to(device)
+    if args.dtype == "bf16":
+        feats = feats.to(torch.bfloat16)
+    batches = list(windows(feats, args.chunk_size, args.batch_size))   # resident in HBM before timing
+    frames_per_step = int(sum(int(l.sum()) for _, l in batches))
+
+    def step():
+        for fb, lens in batches:
+            enc, mask = model._forward_encoder(fb, lens)
+            logp = model.ctc_logprobs(enc)
+        return logp
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        profiling.enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    prof = profiling.summary()
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    audio_s = frames_per_step / 100.0 * args.steps * world
+    value = audio_s / elapsed
+
+    rec = prof.get("wkv6_fwd_bidir") or prof.get("wkv6_fwd")
+    roofline = None
+    if rec:
+        m = rec["meta"]
+        alg_bytes = m["B"] * m["T"] * m["C"] * 5 * m["elem_bytes"] * m["ndir"]
+        alg_flops = m["B"] * m["T"] * m["C"] * 448 * m["ndir"]
+        sec = rec["avg_ms"] * 1e-3
+        roofline = {"kernel": "wkv6 forward scan, both directions (chunk_state + state_scan + chunk_output kernels)",
+                    "bound": "hbm", "achieved": round(alg_bytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches": rec["n"], "avg_launch_us": round(rec["avg_ms"] * 1e3, 1),
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "valu_tflops": round(alg_flops / sec / 1e12, 2),
+                    "valu_frac": round(alg_flops / sec / 1e12 / VALU_PEAK_TFLOPS, 4)}
+
+    out = {
+        "metric": "audio-sec/sec (1/RTF) GigaSpeech long-form encode",
+        "value": round(value, 2), "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32+bf16-slot", "data": "synthetic",
+        "config": {"workload": "c3: 30-min synthetic file (179998 frames of 80-dim fbank-shaped features) per GPU, "
+                               + ("one sequence B=1" if args.chunk_size <= 0 else
+                                  f"windows chunk_size={args.chunk_size} x batch {args.batch_size}")
+                               + ", 12-layer bidirectional RWKV-v6 Conformer encoder (512d, 8x64 heads) + CTC(5000) "
+                                 "log-softmax; random-init weights (seed 777)",
+                   "frames_per_step": frames_per_step, "parallelism": f"dp{world} (independent files, no collective)"},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model, feats32, conf, min(args.cpu_sample_frames, FRAMES))
+    else:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+// Channels-last depthwise conv1d (+ optional fused GLU input and length mask) for gfx950.
+// See include/pafc_encoder_ops.h: pafc_dwconv1d_cl.
+//
+// HBM-bound: one read of x, one write of y.  A block is 256 threads = 4 waves = 512 channels... in general
+// C/2 lanes wide in chunks of 128 channels per wave; each lane owns 2 adjacent channels (one 4-byte bf16x2 or
+// 8-byte f32x2 access, so a wave touches 256/512 contiguous bytes of a row) and TO consecutive output frames.
+// The K taps of its two channels live in registers; every input row of the tile (+halo) is loaded once and
+// scattered into the <= K output accumulators it feeds, with all indices compile-time (full unroll).
+#include "pafc_common.h"
+#include "../../include/pafc_encoder_ops.h"
+
+namespace pafc {
+namespace {
+
+constexpr int KMAX = 31;
+constexpr int TO = 32;  // output frames per lane
+
+template <typename ET> struct Pair;
+template <> struct Pair<float> {
+    __device__ static __forceinline__ float2 load(const float *p) { return *reinterpret_cast<const float2 *>(p); }
+    __device__ static __forceinline__ void store(float *p, float2 v) { *reinterpret_cast<float2 *>(p) = v; }
+    __device__ static __forceinline__ float round(float v) { return v; }
+};
+template <> struct Pair<bf16_t> {
+    __device__ static __forceinline__ float2 load(const bf16_t *p) {
+        const uint32_t q = *reinterpret_cast<const uint32_t *>(p);
+        return make_float2(bf16_bits_to_f32(q & 0xffffu), __uint_as_float(q & 0xffff0000u));
+    }
+    __device__ static __forceinline__ void store(bf16_t *p, float2 v) {
+        *reinterpret_cast<uint32_t *>(p) = f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16);
+    }
+    __device__ static __forceinline__ float round(float v) { return round_bf16(v); }
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <typename ET, int K, bool GLU>
+__global__ __launch_bounds__(256) void dwconv_kernel(int T_in, int C, int left_pad, int T_out, const ET *__restrict__ x,
+                                                     const ET *__restrict__ w, const ET *__restrict__ bias,
+                                                     ET *__restrict__ y, const int32_t *__restrict__ lens) {
+    const int c = (blockIdx.y * 256 + threadIdx.x) * 2;
+    if (c >= C) return;
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * TO;
+    const int xc = GLU ? 2 * C : C;  // row stride of x in elements
+    const ET *xb = x + (size_t)b * T_in * xc;
+    const int valid = lens ? min(T_in, lens[b]) : T_in;
+
+    float w0[K], w1[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        w0[k] = Elem<ET>::load(w + (size_t)c * K + k);
+        w1[k] = Elem<ET>::load(w + (size_t)(c + 1) * K + k);
+    }
+    float2 bv = make_float2(0.f, 0.f);
+    if (bias) bv = Pair<ET>::load(bias + c);
+    float a0[TO], a1[TO];
+#pragma unroll
+    for (int o = 0; o < TO; ++o) { a0[o] = bv.x; a1[o] = bv.y; }
+
+    // input rows s = t0 - left_pad + q, q in [0, TO + K - 1); row q feeds output o with tap k = q - o
+#pragma unroll
+    for (int q = 0; q < TO + K - 1; ++q) {
+        const int s = t0 - left_pad + q;
+        float2 v = make_float2(0.f, 0.f);
+        if (s >= 0 && s < valid) {
+            v = Pair<ET>::load(xb + (size_t)s * xc + c);
+            if (GLU) {
+                const float2 g = Pair<ET>::load(xb + (size_t)s * xc + C + c);
+                v.x = Pair<ET>::round(v.x * sigmoidf_(g.x));  // torch computes glu in float, one rounding
+                v.y = Pair<ET>::round(v.y * sigmoidf_(g.y));
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < TO; ++o) {
+            const int k = q - o;
+            if (k >= 0 && k < K) {
+                a0[o] = fmaf(w0[k], v.x, a0[o]);
+                a1[o] = fmaf(w1[k], v.y, a1[o]);
+            }
+        }
+    }
+    ET *yb = y + (size_t)b * T_out * C + c;
+#pragma unroll
+    for (int o = 0; o < TO; ++o)
+        if (t0 + o < T_out) Pair<ET>::store(yb + (size_t)(t0 + o) * C, make_float2(a0[o], a1[o]));
+}
+
+template <typename ET, int K>
+int launch(int B, int T_in, int C, int left_pad, int T_out, const void *x, const void *w, const void *bias, void *y,
+           int glu, const int32_t *lens, hipStream_t s) {
+    dim3 grid((T_out + TO - 1) / TO, (C / 2 + 255) / 256, B), block(256);
+    if (glu)
+        hipLaunchKernelGGL((dwconv_kernel<ET, K, true>), grid, block, 0, s, T_in, C, left_pad, T_out, (const ET *)x,
+                           (const ET *)w, (const ET *)bias, (ET *)y, lens);
+    else
+        hipLaunchKernelGGL((dwconv_kernel<ET, K, false>), grid, block, 0, s, T_in, C, left_pad, T_out, (const ET *)x,
+                           (const ET *)w, (const ET *)bias, (ET *)y, lens);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+template <typename ET>
+int dispatch_k(int K, int B, int T_in, int C, int left_pad, int T_out, const void *x, const void *w, const void *bias,
+               void *y, int glu, const int32_t *lens, hipStream_t s) {
+    switch (K) {
+        case 31: return launch<ET, 31>(B, T_in, C, left_pad, T_out, x, w, bias, y, glu, lens, s);
+        case 15: return launch<ET, 15>(B, T_in, C, left_pad, T_out, x, w, bias, y, glu, lens, s);
+        case 7: return launch<ET, 7>(B, T_in, C, left_pad, T_out, x, w, bias, y, glu, lens, s);
+        case 3: return launch<ET, 3>(B, T_in, C, left_pad, T_out, x, w, bias, y, glu, lens, s);
+        default: return PAFC_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace
+}  // namespace pafc
+
+extern "C" int pafc_dwconv1d_cl(int dtype, int B, int T_in, int C, int K, int left_pad, int T_out, const void *x,
+                                const void *w, const void *bias, void *y, int glu, const int32_t *lens,
+                                pafc_stream_t stream) {
+    if (!x || !w || !y) return PAFC_ERR_NULL_POINTER;
+    if (B <= 0 || T_in <= 0 || T_out <= 0 || C <= 0 || (C % 2) || K <= 0 || K > pafc::KMAX || left_pad < 0 ||
+        B > 65535)
+        return PAFC_ERR_BAD_DIMS;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PAFC_BF16)
+        return pafc::dispatch_k<pafc::bf16_t>(K, B, T_in, C, left_pad, T_out, x, w, bias, y, glu, lens, s);
+    if (dtype == PAFC_F32) return pafc::dispatch_k<float>(K, B, T_in, C, left_pad, T_out, x, w, bias, y, glu, lens, s);
+    return PAFC_ERR_DTYPE;
+}

@@ -1,0 +1,40 @@
+"""Opt-in per-op device timing with events on the launch stream (used by bench.py for the roofline object).
+
+`with op_timer("wkv6_fwd") as t:` brackets a C-ABI call with two events recorded on torch's current stream --
+the stream the kernels are launched on -- when profiling is enabled, and is free otherwise."""
+import contextlib
+from collections import defaultdict
+
+import torch
+
+_enabled = False
+_records = defaultdict(list)
+
+
+def enable(flag: bool = True):
+    global _enabled
+    _enabled = flag
+    if flag:
+        _records.clear()
+
+
+@contextlib.contextmanager
+def op_timer(name: str, **meta):
+    if not _enabled:
+        yield
+        return
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    yield
+    b.record()
+    _records[name].append((a, b, meta))
+
+
+def summary():
+    """{name: {"n": launches, "avg_ms": mean device time, "meta": last meta}} -- call after a synchronize."""
+    out = {}
+    for name, recs in _records.items():
+        ms = [a.elapsed_time(b) for a, b, _ in recs]
+        out[name] = {"n": len(ms), "avg_ms": sum(ms) / len(ms), "meta": recs[-1][2]}
+    return out

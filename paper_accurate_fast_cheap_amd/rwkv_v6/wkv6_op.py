@@ -11,6 +11,7 @@ from typing import Optional, Tuple
 import torch
 
 from .. import _lib
+from ..profiling import op_timer
 
 HEAD_SIZE = 64
 
@@ -53,9 +54,10 @@ def wkv6_forward(r, k, v, w, u, *, reverse: bool = False, s_in: Optional[torch.T
     if s_in is not None and (s_in.dtype != torch.float32 or s_in.shape != (B, H, HEAD_SIZE, HEAD_SIZE)):
         raise _lib.PafcError("s_in must be float32 (B, H, 64, 64)")
     ws, nbytes = _workspace(B, T, C, H, 1, chunk_len, r.device)
-    rc = _lib.lib().pafc_wkv6_forward_state(code, B, T, C, H, _lib.ptr(r), _lib.ptr(k), _lib.ptr(v), _lib.ptr(w),
-                                            _lib.ptr(u), _lib.ptr(y), _lib.ptr(s_in), _lib.ptr(s_out), int(reverse),
-                                            chunk_len, _lib.ptr(ws), nbytes, _lib.stream_of(r))
+    with op_timer("wkv6_fwd", B=B, T=T, C=C, elem_bytes=r.element_size(), ndir=1):
+        rc = _lib.lib().pafc_wkv6_forward_state(code, B, T, C, H, _lib.ptr(r), _lib.ptr(k), _lib.ptr(v), _lib.ptr(w),
+                                                _lib.ptr(u), _lib.ptr(y), _lib.ptr(s_in), _lib.ptr(s_out),
+                                                int(reverse), chunk_len, _lib.ptr(ws), nbytes, _lib.stream_of(r))
     _lib.check(rc, "pafc_wkv6_forward_state")
     return (y, s_out) if want_state else y
 
@@ -76,8 +78,51 @@ def wkv6_forward_bidir(fwd: Tuple[torch.Tensor, ...], bwd: Tuple[torch.Tensor, .
     yf, yb = torch.empty_like(rf), torch.empty_like(rb)
     ws, nbytes = _workspace(B, T, C, H, 2, chunk_len, rf.device)
     P = _lib.ptr
-    rc = _lib.lib().pafc_wkv6_forward_bidir(code, B, T, C, H, P(rf), P(kf), P(vf), P(wf), P(uf), P(yf),
-                                            P(rb), P(kb), P(vb), P(wb), P(ub), P(yb),
-                                            chunk_len, P(ws), nbytes, _lib.stream_of(rf))
+    with op_timer("wkv6_fwd_bidir", B=B, T=T, C=C, elem_bytes=rf.element_size(), ndir=2):
+        rc = _lib.lib().pafc_wkv6_forward_bidir(code, B, T, C, H, P(rf), P(kf), P(vf), P(wf), P(uf), P(yf),
+                                                P(rb), P(kb), P(vb), P(wb), P(ub), P(yb),
+                                                chunk_len, P(ws), nbytes, _lib.stream_of(rf))
     _lib.check(rc, "pafc_wkv6_forward_bidir")
     return yf, yb
+
+
+def wkv6_backward(r, k, v, w, u, gy, *, reverse: bool = False, chunk_len: int = 0):
+    """(gr, gk, gv, gw, gu): what WKV_6.backward returns (model.py:135-152); gu already summed over the
+    batch and shaped (H, N)."""
+    _lib.require_gpu(r, k, v, w, u, gy)
+    B, T, C, H = _shape(r, u)
+    code = _same(r, k, v, w, u, gy)
+    gr, gk, gv, gw = (torch.empty_like(r) for _ in range(4))
+    gu = torch.empty(B, C, dtype=r.dtype, device=r.device)
+    L = _lib.lib()
+    nbytes = L.pafc_wkv6_bwd_workspace_bytes(B, T, C, H, chunk_len)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=r.device) if nbytes else None
+    P = _lib.ptr
+    rc = L.pafc_wkv6_backward(code, B, T, C, H, P(r), P(k), P(v), P(w), P(u), P(gy), P(gr), P(gk), P(gv), P(gw), P(gu),
+                              int(reverse), chunk_len, P(ws), nbytes, _lib.stream_of(r))
+    _lib.check(rc, "pafc_wkv6_backward")
+    return gr, gk, gv, gw, torch.sum(gu.float(), 0).to(r.dtype).view(H, C // H)
+
+
+class _WKV6(torch.autograd.Function):
+    """Autograd wrapper = the reference's WKV_6 / WKV_6_FP32 (model.py:108-214), plus the direction flag."""
+
+    @staticmethod
+    def forward(ctx, r, k, v, w, u, reverse):
+        ctx.save_for_backward(r, k, v, w, u)
+        ctx.reverse = reverse
+        return wkv6_forward(r, k, v, w, u, reverse=reverse)
+
+    @staticmethod
+    def backward(ctx, gy):
+        r, k, v, w, u = ctx.saved_tensors
+        gr, gk, gv, gw, gu = wkv6_backward(r, k, v, w, u, gy.contiguous(), reverse=ctx.reverse)
+        return gr, gk, gv, gw, gu, None
+
+
+def wkv6(r, k, v, w, u, reverse: bool = False):
+    """y = WKV6(...) with autograd when any operand needs a gradient."""
+    u = u.contiguous()
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (r, k, v, w, u)):
+        return _WKV6.apply(r, k, v, w, u, reverse)
+    return wkv6_forward(r, k, v, w, u, reverse=reverse)

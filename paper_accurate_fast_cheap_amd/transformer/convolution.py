@@ -40,7 +40,7 @@ class ConvolutionModule(nn.Module):
     def forward(self, x: torch.Tensor, mask_pad: torch.Tensor = torch.ones((0, 0, 0), dtype=torch.bool),
                 cache: torch.Tensor = torch.zeros((0, 0, 0))) -> Tuple[torch.Tensor, torch.Tensor]:
         """x (B, T, C), mask_pad (B, 1, T) or (0,0,0), cache (B, C, lorder) for causal -> (B, T, C), new_cache."""
-        from ..ops import depthwise_conv1d_cl
+        from ..hip_ops import depthwise_conv1d_cl
         keep = mask_pad.transpose(1, 2) if mask_pad.size(2) > 0 else None  # (B, T, 1)
         if keep is not None:
             x = x.masked_fill(~keep, 0.0)

@@ -1,0 +1,161 @@
+"""BaseEncoder / ConformerEncoder with the recurrent attention slot, on the MI355X.
+
+Reference: wenet/transformer/encoder.py:38-402 (BaseEncoder: forward, forward_chunk, forward_chunk_by_chunk)
+and :453-602 (ConformerEncoder: slot constructor arguments :545-569, layer list :589-602).  Same constructor
+keys as conf/rwkv/*.yaml `encoder_conf`, same sub-module names (embed, encoders.N, after_norm, global_cmvn),
+same return shapes.  Scope: num_langs == 0 and the recurrent slot keys; the MHA baseline, the LSL variant and
+the plain TransformerEncoder are not part of the accelerated path.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+
+from ..utils.class_utils import (WENET_ACTIVATION_CLASSES, WENET_ATTENTION_CLASSES, WENET_EMB_CLASSES,
+                                 WENET_SUBSAMPLE_CLASSES)
+from ..utils.mask import add_optional_chunk_mask, make_pad_mask
+from .convolution import ConvolutionModule
+from .encoder_layer import ConformerEncoderLayer
+from .positionwise_feed_forward import PositionwiseFeedForward
+
+
+class BaseEncoder(torch.nn.Module):
+    def __init__(self, input_size: int, output_size: int = 256, attention_heads: int = 4, linear_units: int = 2048,
+                 num_blocks: int = 6, dropout_rate: float = 0.1, positional_dropout_rate: float = 0.1,
+                 attention_dropout_rate: float = 0.0, input_layer: str = "conv2d", pos_enc_layer_type: str = "abs_pos",
+                 normalize_before: bool = True, static_chunk_size: int = 0, use_dynamic_chunk: bool = False,
+                 global_cmvn: torch.nn.Module = None, use_dynamic_left_chunk: bool = False,
+                 gradient_checkpointing: bool = False):
+        super().__init__()
+        self._output_size = output_size
+        self.global_cmvn = global_cmvn
+        self.embed = WENET_SUBSAMPLE_CLASSES[input_layer](
+            input_size, output_size, dropout_rate,
+            WENET_EMB_CLASSES[pos_enc_layer_type](output_size, positional_dropout_rate))
+        self.normalize_before = normalize_before
+        self.after_norm = torch.nn.LayerNorm(output_size, eps=1e-5)
+        self.static_chunk_size = static_chunk_size
+        self.use_dynamic_chunk = use_dynamic_chunk
+        self.use_dynamic_left_chunk = use_dynamic_left_chunk
+        self.gradient_checkpointing = gradient_checkpointing
+
+    def output_size(self) -> int:
+        return self._output_size
+
+    def forward(self, xs: torch.Tensor, xs_lens: torch.Tensor, decoding_chunk_size: int = 0,
+                num_decoding_left_chunks: int = -1, cat_embs: Optional[torch.Tensor] = None
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(B, T, F) padded features + (B,) lengths -> (B, T', C), (B, 1, T') bool mask.  encoder.py:117-149."""
+        xs, masks, _ = self.forward_return_layers(xs, xs_lens, decoding_chunk_size, num_decoding_left_chunks, cat_embs)
+        return xs, masks
+
+    def forward_return_layers(self, xs, xs_lens, decoding_chunk_size: int = 0, num_decoding_left_chunks: int = -1,
+                              cat_embs=None, want_layers: bool = False):
+        T = xs.size(1)
+        masks = ~make_pad_mask(xs_lens, T).unsqueeze(1)
+        if self.global_cmvn is not None:
+            xs = self.global_cmvn(xs)
+        xs, pos_emb, masks = self.embed(xs, masks)
+        mask_pad = masks
+        chunk_masks = add_optional_chunk_mask(xs, masks, self.use_dynamic_chunk, self.use_dynamic_left_chunk,
+                                              decoding_chunk_size, self.static_chunk_size, num_decoding_left_chunks)
+        layer_outs: List[torch.Tensor] = []
+        for layer in self.encoders:
+            xs, chunk_masks, _, _ = layer(xs, chunk_masks, pos_emb, mask_pad, cat_embs=cat_embs)
+            if want_layers:
+                layer_outs.append(xs)
+        if self.normalize_before:
+            xs = self.after_norm(xs)
+        return xs, masks, layer_outs
+
+    def forward_chunk(self, xs: torch.Tensor, offset: int, required_cache_size: int,
+                      att_cache: torch.Tensor = torch.zeros(0, 0, 0, 0),
+                      cnn_cache: torch.Tensor = torch.zeros(0, 0, 0, 0),
+                      att_mask: torch.Tensor = torch.ones((0, 0, 0), dtype=torch.bool),
+                      cat_embs: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """One chunk, reference semantics (encoder.py:231-339): B == 1; with the recurrent slot the wrappers hand
+        `cache` back untouched, so r_att_cache is (0,0,0,0) and, conv being non-causal in the paper's configs,
+        r_cnn_cache is (num_blocks,0,0,0): every chunk is an independent full-context pass over its own frames.
+        State-carrying streaming (what the reference lacks) is forward_chunk_carry()."""
+        assert xs.size(0) == 1
+        tmp_masks = torch.ones(1, 1, xs.size(1), device=xs.device, dtype=torch.bool)
+        if self.global_cmvn is not None:
+            xs = self.global_cmvn(xs)
+        xs, pos_emb, _ = self.embed(xs, tmp_masks, offset)
+        elayers = att_cache.size(0)
+        r_att_cache, r_cnn_cache = [], []
+        for i, layer in enumerate(self.encoders):
+            xs, _, new_att_cache, new_cnn_cache = layer(
+                xs, att_mask, pos_emb, cat_embs=cat_embs,
+                att_cache=att_cache[i:i + 1] if elayers > 0 else att_cache,
+                cnn_cache=cnn_cache[i] if cnn_cache.size(0) > 0 else cnn_cache)
+            r_att_cache.append(new_att_cache)
+            r_cnn_cache.append(new_cnn_cache.unsqueeze(0))
+        if self.normalize_before:
+            xs = self.after_norm(xs)
+        return xs, torch.cat(r_att_cache, dim=0), torch.cat(r_cnn_cache, dim=0)
+
+    def forward_chunk_by_chunk(self, xs: torch.Tensor, decoding_chunk_size: int, num_decoding_left_chunks: int = -1,
+                               cat_embs: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """encoder.py:341-402: overlapping input windows of (chunk-1)*4+7 frames, stride 4*chunk."""
+        assert decoding_chunk_size > 0
+        subsampling = self.embed.subsampling_rate
+        context = self.embed.right_context + 1
+        stride = subsampling * decoding_chunk_size
+        decoding_window = (decoding_chunk_size - 1) * subsampling + context
+        num_frames = xs.size(1)
+        att_cache = torch.zeros((0, 0, 0, 0), device=xs.device)
+        cnn_cache = torch.zeros((0, 0, 0, 0), device=xs.device)
+        outputs = []
+        offset = 0
+        required_cache_size = decoding_chunk_size * num_decoding_left_chunks
+        for cur in range(0, num_frames - context + 1, stride):
+            end = min(cur + decoding_window, num_frames)
+            y, att_cache, cnn_cache = self.forward_chunk(xs[:, cur:end, :], offset, required_cache_size, att_cache,
+                                                         cnn_cache, cat_embs=cat_embs)
+            outputs.append(y)
+            offset += y.size(1)
+        ys = torch.cat(outputs, 1)
+        return ys, torch.ones((1, 1, ys.size(1)), device=ys.device, dtype=torch.bool)
+
+
+class ConformerEncoder(BaseEncoder):
+    def __init__(self, input_size: int, output_size: int = 256, attention_heads: int = 4, linear_units: int = 2048,
+                 num_blocks: int = 6, dropout_rate: float = 0.1, positional_dropout_rate: float = 0.1,
+                 attention_dropout_rate: float = 0.0, input_layer: str = "conv2d", pos_enc_layer_type: str = "rel_pos",
+                 normalize_before: bool = True, static_chunk_size: int = 0, use_dynamic_chunk: bool = False,
+                 global_cmvn: torch.nn.Module = None, use_dynamic_left_chunk: bool = False,
+                 positionwise_conv_kernel_size: int = 1, macaron_style: bool = True,
+                 selfattention_layer_type: str = "rwkv_tmix60_bidirectional", activation_type: str = "swish",
+                 use_cnn_module: bool = True, cnn_module_kernel: int = 15, causal: bool = False,
+                 cnn_module_norm: str = "batch_norm", key_bias: bool = True, gradient_checkpointing: bool = False,
+                 lora_rank: int = 8, lora_alpha: int = 8, lora_dropout: float = 0.0, lora_list=None,
+                 num_langs: int = 0, rwkv_ctx_len: int = 2048, rwkv_do_bfloat16: bool = True,
+                 rnn_att_version: str = "", rnn_att_direction: str = "", att_context_size=(500, 500),
+                 global_tokens: int = 0, global_tokens_spacing: int = 1, global_attn_separate: bool = False):
+        super().__init__(input_size, output_size, attention_heads, linear_units, num_blocks, dropout_rate,
+                         positional_dropout_rate, attention_dropout_rate, input_layer, pos_enc_layer_type,
+                         normalize_before, static_chunk_size, use_dynamic_chunk, global_cmvn, use_dynamic_left_chunk,
+                         gradient_checkpointing)
+        if num_langs != 0:
+            raise NotImplementedError("language-specific layers (num_langs > 0) are outside the accelerated path")
+        if selfattention_layer_type not in WENET_ATTENTION_CLASSES:
+            raise NotImplementedError(
+                f"selfattention_layer_type={selfattention_layer_type!r}: only the recurrent slot keys "
+                f"{sorted(WENET_ATTENTION_CLASSES)} are implemented here (the MHA baseline is out of scope)")
+        activation = WENET_ACTIVATION_CLASSES[activation_type]()
+        self.num_langs = num_langs
+        # encoder.py:545-561: (head_size, dim_att, num_blocks, version, direction, ctx_len, do_bfloat16) + layer_id
+        slot_args = (output_size // attention_heads, output_size, num_blocks, rnn_att_version, rnn_att_direction,
+                     rwkv_ctx_len, rwkv_do_bfloat16)
+        ff_args = (output_size, linear_units, dropout_rate, activation)
+        conv_args = (output_size, cnn_module_kernel, activation, cnn_module_norm, causal)
+        self.encoders = torch.nn.ModuleList([
+            ConformerEncoderLayer(
+                output_size,
+                WENET_ATTENTION_CLASSES[selfattention_layer_type](*slot_args, layer_id),
+                PositionwiseFeedForward(*ff_args),
+                PositionwiseFeedForward(*ff_args) if macaron_style else None,
+                ConvolutionModule(*conv_args) if use_cnn_module else None,
+                dropout_rate, normalize_before,
+            ) for layer_id in range(num_blocks)
+        ])

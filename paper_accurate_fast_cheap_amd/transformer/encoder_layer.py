@@ -1,0 +1,76 @@
+"""ConformerEncoderLayer (reference: wenet/transformer/encoder_layer.py:112-261).
+
+x += 1/2 FFN_macaron(LN(x)); x += slot(LN(x)); x += conv(LN(x)); x += 1/2 FFN(LN(x)); x = LN_final(x), pre-norm
+(normalize_before) or post-norm, dropout identity in eval.  Sub-module and LayerNorm names are the reference's
+(feed_forward{,_macaron}, self_attn, conv_module, norm_{ff,mha,ff_macaron,conv,final})."""
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+
+class ConformerEncoderLayer(nn.Module):
+    def __init__(self, size: int, self_attn: nn.Module, feed_forward: Optional[nn.Module] = None,
+                 feed_forward_macaron: Optional[nn.Module] = None, conv_module: Optional[nn.Module] = None,
+                 dropout_rate: float = 0.1, normalize_before: bool = True):
+        super().__init__()
+        self.self_attn = self_attn
+        self.feed_forward = feed_forward
+        self.feed_forward_macaron = feed_forward_macaron
+        self.conv_module = conv_module
+        self.norm_ff = nn.LayerNorm(size, eps=1e-5)
+        self.norm_mha = nn.LayerNorm(size, eps=1e-5)
+        if feed_forward_macaron is not None:
+            self.norm_ff_macaron = nn.LayerNorm(size, eps=1e-5)
+            self.ff_scale = 0.5
+        else:
+            self.ff_scale = 1.0
+        if self.conv_module is not None:
+            self.norm_conv = nn.LayerNorm(size, eps=1e-5)
+            self.norm_final = nn.LayerNorm(size, eps=1e-5)
+        self.dropout = nn.Dropout(dropout_rate)
+        self.size = size
+        self.normalize_before = normalize_before
+
+    def forward(self, x: torch.Tensor, mask: torch.Tensor, pos_emb: torch.Tensor,
+                mask_pad: torch.Tensor = torch.ones((0, 0, 0), dtype=torch.bool),
+                att_cache: torch.Tensor = torch.zeros((0, 0, 0, 0)),
+                cnn_cache: torch.Tensor = torch.zeros((0, 0, 0, 0)),
+                cat_embs: Optional[torch.Tensor] = None
+                ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        if self.feed_forward_macaron is not None:
+            residual = x
+            if self.normalize_before:
+                x = self.norm_ff_macaron(x)
+            x = residual + self.ff_scale * self.dropout(self.feed_forward_macaron(x))
+            if not self.normalize_before:
+                x = self.norm_ff_macaron(x)
+
+        residual = x
+        if self.normalize_before:
+            x = self.norm_mha(x)
+        x_att, new_att_cache = self.self_attn(x, x, x, mask, pos_emb, att_cache)
+        x = residual + self.dropout(x_att)
+        if not self.normalize_before:
+            x = self.norm_mha(x)
+
+        new_cnn_cache = torch.zeros((0, 0, 0), dtype=x.dtype, device=x.device)
+        if self.conv_module is not None:
+            residual = x
+            if self.normalize_before:
+                x = self.norm_conv(x)
+            x, new_cnn_cache = self.conv_module(x, mask_pad, cnn_cache)
+            x = residual + self.dropout(x)
+            if not self.normalize_before:
+                x = self.norm_conv(x)
+
+        residual = x
+        if self.normalize_before:
+            x = self.norm_ff(x)
+        x = residual + self.ff_scale * self.dropout(self.feed_forward(x))
+        if not self.normalize_before:
+            x = self.norm_ff(x)
+
+        if self.conv_module is not None:
+            x = self.norm_final(x)
+        return x, mask, new_att_cache, new_cnn_cache

@@ -1,0 +1,36 @@
+"""Data-parallel sharding of independent units (utterances, long-form windows, files) over ranks.
+
+The path shards naturally: units are independent, so there is no data-path collective.
+Units are dealt by descending length round-robin (longest-processing-time first) so that every rank gets a
+similar number of frames; token lists are gathered to rank 0 on the host at the end."""
+from typing import List, Sequence
+
+import torch.distributed as dist
+
+
+def shard_units(lengths: Sequence[int], rank: int, world: int) -> List[int]:
+    """Indices of the units rank `rank` owns.  Greedy LPT: sort by length descending, give each next unit to
+    the currently lightest rank (ties -> lowest rank).  Deterministic, identical on every rank."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    load = [0] * world
+    owner = [0] * len(lengths)
+    for i in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[i] = r
+        load[r] += int(lengths[i])
+    return [i for i in range(len(lengths)) if owner[i] == rank]
+
+
+def gather_results(local: dict, world: int, dst: int = 0):
+    """{unit index: result} from every rank -> merged dict on rank `dst` (None elsewhere).  Host-side, after
+    the timed region; uses the default process group (RCCL on GPUs, gloo on CPU)."""
+    if world == 1:
+        return dict(local)
+    bucket = [None] * world if dist.get_rank() == dst else None
+    dist.gather_object(local, bucket, dst=dst)
+    if bucket is None:
+        return None
+    merged = {}
+    for part in bucket:
+        merged.update(part)
+    return merged

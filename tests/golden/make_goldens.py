@@ -154,6 +154,14 @@ def main():
                   logp_sample=logp[:, ::7, :].clone(), greedy=hyps, enc_lens=enc_lens))
         print(variant, "greedy lens", [len(h) for h in hyps], "params", sum(p.numel() for p in enc.parameters()))
 
+    # ---- closed-form initialisation of the time-mix parameters (src/model.py:232-260; no RNG involved) ----
+    init = {}
+    for layer_id in (0, 5, 11):
+        blk = RWKV_TmixWrapper(64, 512, 12, "rwkv", "uni", 2048, False, layer_id).tmix_block
+        init[layer_id] = {k: v.clone() for k, v in blk.state_dict().items()
+                          if k.startswith("time_maa_") and not k.startswith("time_maa_rkvw") or k in ("time_decay", "time_faaaa")}
+    save("tmix_init", dict(init=init, n_layers=12, n_embd=512, head_size=64))
+
     # ---- full-size encoder: parameter names/shapes only (state-dict compatibility contract) --
     conf = dict(cfg["encoder_conf"])
     enc = ConformerEncoder(80, **conf)

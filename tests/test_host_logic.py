@@ -1,0 +1,166 @@
+"""CPU-only tests of the host side: plugin surface, parameter names, initialisation, masks, loaders, sharding."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle import encoder_oracle as EO
+from tests.conftest import ROOT, load_golden
+
+
+def test_full_encoder_state_dict_equals_reference_spec():
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    from tests import synth
+    g = load_golden("encoder_full_spec")
+    enc = ConformerEncoder(80, **g["conf"])
+    assert synth.spec_of(enc.state_dict()) == g["spec"]          # names, shapes AND dtypes (bf16 slot parameters)
+    assert sum(p.numel() for p in enc.parameters()) == g["n_params"] == 97461248
+    assert enc.output_size() == 512 and enc.embed.subsampling_rate == 4 and enc.embed.right_context == 6
+
+
+def test_registry_keys_and_constructor_signature():
+    from paper_accurate_fast_cheap_amd.utils.class_utils import WENET_ATTENTION_CLASSES, install_into
+    want = {"rwkv_tmix60", "rwkv_tmix60_bidirectional", "rwkv_tmix60_bidirectional2", "rwkv_tmix60_dir_layer_drop",
+            "rwkv_tmix60_dir_layer_drop_both"}
+    assert want <= set(WENET_ATTENTION_CLASSES)
+    for k in want:  # positional ctor the reference encoder builds, encoder.py:553-561 + layer_id
+        m = WENET_ATTENTION_CLASSES[k](64, 128, 2, "rwkv", "bi", 2048, True, 1)
+        assert any(n.endswith("tmix_block.time_faaaa") for n, _ in m.named_parameters())
+
+    class FakeRef:
+        WENET_ATTENTION_CLASSES = {"selfattn": object}
+    install_into(FakeRef)
+    assert want <= set(FakeRef.WENET_ATTENTION_CLASSES) and "selfattn" in FakeRef.WENET_ATTENTION_CLASSES
+
+
+def test_unsupported_slots_fail_loudly():
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    with pytest.raises(NotImplementedError):
+        ConformerEncoder(80, output_size=128, attention_heads=2, selfattention_layer_type="rel_selfattn")
+    with pytest.raises(NotImplementedError):
+        ConformerEncoder(80, output_size=128, attention_heads=2, num_langs=3)
+
+
+def test_tmix_init_matches_reference_closed_form():
+    from paper_accurate_fast_cheap_amd.rwkv_v6.tmix import RWKV_Tmix_x060c
+    g = load_golden("tmix_init")
+    for layer_id, ref in g["init"].items():
+        blk = RWKV_Tmix_x060c(g["head_size"], g["n_layers"], g["n_embd"], g["n_embd"], layer_id)
+        sd = blk.state_dict()
+        for k, v in ref.items():
+            torch.testing.assert_close(sd[k], v, rtol=1e-6, atol=1e-6, msg=f"layer {layer_id} {k}")
+        assert float(sd["time_maa_rkvw_w1"].abs().max()) == 0 and float(sd["time_decay_w1"].abs().max()) == 0
+
+
+def test_masks_match_oracle():
+    from paper_accurate_fast_cheap_amd.utils.mask import make_pad_mask
+    lens = torch.tensor([5, 1, 9, 0])
+    assert torch.equal(make_pad_mask(lens, 9), EO.make_pad_mask(lens, 9))
+    assert torch.equal(make_pad_mask(lens), EO.make_pad_mask(lens))
+
+
+def test_greedy_collapse_matches_oracle():
+    from paper_accurate_fast_cheap_amd.transformer.search import remove_duplicates_and_blank
+    g = torch.Generator().manual_seed(3)
+    for _ in range(50):
+        hyp = torch.randint(0, 4, (int(torch.randint(0, 30, (1,), generator=g)),), generator=g).tolist()
+        assert remove_duplicates_and_blank(hyp, 0) == EO.remove_duplicates_and_blank(hyp, 0)
+    assert remove_duplicates_and_blank([], 0) == []
+    assert remove_duplicates_and_blank([0, 0, 3, 3, 0, 3, 2, 2], 0) == [3, 3, 2]
+
+
+def test_cmvn_loaders(tmp_path):
+    from paper_accurate_fast_cheap_amd.utils.cmvn import load_cmvn
+    sums, sumsq, n = [2.0, 4.0, 0.0], [6.0, 10.0, 0.0], 2
+    (tmp_path / "c.json").write_text(json.dumps({"mean_stat": sums, "var_stat": sumsq, "frame_num": n}))
+    (tmp_path / "c.kaldi").write_text("[ 2 4 0 2\n 6 10 0 0 ]\n")
+    for f, is_json in (("c.json", True), ("c.kaldi", False)):
+        mean, istd = load_cmvn(str(tmp_path / f), is_json)
+        assert mean.tolist() == [1.0, 2.0, 0.0]
+        assert istd[0] == pytest.approx(1 / (3 - 1) ** 0.5) and istd[1] == pytest.approx(1.0)
+        assert istd[2] == pytest.approx(1e10)  # variance floored at 1e-20 (utils/cmvn.py:38-39)
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    from paper_accurate_fast_cheap_amd.utils.checkpoint import load_checkpoint, save_checkpoint
+    from paper_accurate_fast_cheap_amd.utils.init_model import init_model
+    g = load_golden("encoder_reduced_bf16slot")
+    cfg = lambda: dict(encoder="conformer", encoder_conf=dict(g["conf"]), input_dim=80, output_dim=50, ctc="ctc",
+                       ctc_conf={"ctc_blank_id": 0}, model_conf={"ctc_weight": 0.3, "lsm_weight": 0.1}, dataset_conf={},
+                       tokenizer_conf={"special_tokens": {"<blank>": 0, "<sos>": 2, "<eos>": 2}})
+
+    class A:
+        checkpoint = None
+    m1, _ = init_model(A(), cfg())
+    save_checkpoint(m1, str(tmp_path / "m.pt"), {"step": 7, "num_seen_frames": 123})
+    blob = torch.load(str(tmp_path / "m.pt"), weights_only=False)
+    assert set(blob) == {"model0"} and any(k.startswith("encoder.encoders.0.self_attn.rwkv_wrapper_forward.") for k in blob["model0"])
+    A.checkpoint = str(tmp_path / "m.pt")
+    torch.manual_seed(1)
+    m2, c2 = init_model(A(), cfg())
+    assert c2["step"] == 7 and c2["num_seen_frames"] == 123 and c2["init_infos"]["step"] == 7
+    for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    assert m2.lsl_enc is False and m2.add_cat_embs is False and m2.cat_labels == [] and m2.sos == 2
+    assert isinstance(load_checkpoint(m2, A.checkpoint), dict)
+
+
+def test_bench_windows_follow_the_reference_batcher():
+    sys.path.insert(0, ROOT)
+    import bench
+    feats = torch.arange(1, 2 * 23 * 2 + 1, dtype=torch.float32).view(1, 46, 2).repeat(1, 1, 40)  # (1, 46, 80)
+    out = list(bench.windows(feats, 10, 2))
+    assert [tuple(f.shape) for f, _ in out] == [(2, 10, 80), (2, 10, 80), (1, 10, 80)]
+    assert [l.tolist() for _, l in out] == [[10, 10], [10, 10], [6]]
+    assert torch.equal(out[2][0][0, :6], feats[0, 40:46]) and float(out[2][0][0, 6:].abs().max()) == 0
+    assert bench.FRAMES == 179998
+    whole = list(bench.windows(feats, 0, 8))
+    assert len(whole) == 1 and whole[0][1].tolist() == [46]
+
+
+def test_shard_units_balanced_and_complete():
+    from paper_accurate_fast_cheap_amd.utils.sharding import shard_units
+    g = torch.Generator().manual_seed(0)
+    lens = torch.randint(100, 2001, (5715,), generator=g).tolist()   # GigaSpeech DEV size, segment filter range
+    for world in (1, 2, 4, 8):
+        parts = [shard_units(lens, r, world) for r in range(world)]
+        assert sorted(i for p in parts for i in p) == list(range(len(lens)))
+        loads = [sum(lens[i] for i in p) for p in parts]
+        assert max(loads) - min(loads) <= 2000
+    assert shard_units([], 0, 2) == [] and shard_units([5], 1, 2) == []
+
+
+_GLOO_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["PAFC_ROOT"])
+from paper_accurate_fast_cheap_amd.utils.sharding import shard_units, gather_results
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lens = [(7 * i) % 13 + 1 for i in range(29)]
+mine = shard_units(lens, rank, world)
+local = {i: [lens[i], i * i] for i in mine}          # stand-in for per-unit token lists
+t = torch.tensor([float(sum(lens[i] for i in mine))])
+dist.all_reduce(t, op=dist.ReduceOp.MAX)              # the bench's max-over-ranks reduction
+merged = gather_results(local, world)
+if rank == 0:
+    assert sorted(merged) == list(range(29)) and all(merged[i] == [lens[i], i * i] for i in merged)
+    assert t.item() >= sum(lens) / world
+    print("GLOO_OK")
+else:
+    assert merged is None
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_sharding_and_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, PAFC_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+                         env=env, capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "GLOO_OK" in out.stdout
