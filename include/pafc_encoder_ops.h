@@ -31,6 +31,33 @@ int pafc_dwconv1d_cl(int dtype, int B, int T_in, int C, int K, int left_pad, int
                      const void *w, const void *bias, void *y, int glu, const int32_t *lens,
                      pafc_stream_t stream);
 
+/* Residual add + LayerNorm (+ SiLU, + second LayerNorm, + padding masks) in one pass over (rows, C).
+ *   x_new = x + alpha * y            (y == NULL: x_new = x; mask_y: rows with t >= lens[b] of y count as zero)
+ *   out1  = LN(x_new; gamma1, beta1) (silu1: SiLU on top; zero1: rows with t >= lens[b] are written as zero)
+ *   out2  = LN(out1;  gamma2, beta2) (optional)
+ * Fuses the reference's `x = residual + ff_scale * dropout(branch(x))` followed by the next sub-block's pre-norm
+ * (ConformerEncoderLayer.forward, wenet/transformer/encoder_layer.py:201-259), the conv module's
+ * masked_fill / norm / activation (convolution.py:109-110,132-136,140-141), ln_x of the time-mix
+ * (src/model.py:323) and norm_final + the next layer's first pre-norm.  rows = B*T, row index = b*T + t.
+ * dtype: x, y, x_out, gamma*, beta*; dtype_out: out1/out2 (bf16 out of an fp32 stream = the slot's input cast,
+ * rwkv_wrapper_bidirectional.py:40-41).  ld1/ld2: row strides of out1/out2 in elements (a (rows, 2C) buffer can
+ * receive two LayerNorms side by side).  C % 8 == 0, C <= 1024.  eps as nn.LayerNorm (1e-5). */
+int pafc_add_layernorm(int dtype, int dtype_out, int rows, int C, const void *x, const void *y, float alpha,
+                       const int32_t *lens, int T, int mask_y, void *x_out, const void *gamma1, const void *beta1,
+                       void *out1, long ld1, int silu1, int zero1, const void *gamma2, const void *beta2, void *out2,
+                       long ld2, float eps, pafc_stream_t stream);
+
+/* Token shift + first lerp of the time-mix for ndir directions from one read of x (src/model.py:274-276):
+ *   xx_d = shift_d(x) - x,  out[d] = x + xx_d * maa_x_d;   shift_0 = x_{t-1} (or x_{t+1} when reverse0), shift_1 = x_{t+1}
+ * x: (B, T, C); maa_x0/1: (C); out: (ndir, B, T, C).  Zero beyond the sequence ends, like ZeroPad2d((0,0,1,-1)). */
+int pafc_tmix_shift_mix(int dtype, int B, int T, int C, int ndir, int reverse0, const void *x, const void *maa_x0,
+                        const void *maa_x1, void *out, pafc_stream_t stream);
+
+/* The four data-dependent lerps of the time-mix (src/model.py:280-284): z_q = x + xx * (maa_q + m_q), q = r,k,v,w.
+ * m: (ndir, 4, B*T, C) LoRA outputs; maa: (ndir, 4, C); z: (4, ndir, B*T, C). */
+int pafc_tmix_mix4(int dtype, int B, int T, int C, int ndir, int reverse0, const void *x, const void *m,
+                   const void *maa, void *z, pafc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

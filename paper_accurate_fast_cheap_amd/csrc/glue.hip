@@ -1,0 +1,294 @@
+// HBM-bound glue kernels of the Conformer layer and the RWKV time-mix for gfx950.
+// C ABI: include/pafc_encoder_ops.h.  In the reference every one of these is a chain of separate PyTorch
+// element-wise kernels, each a full (B,T,C) round trip; here each chain is one pass.  bf16 rounding points
+// are those of the op-by-op PyTorch chain (every intermediate that PyTorch would materialise in bf16 is
+// rounded to bf16 in registers), so the fused result tracks the reference's numerics, not a re-association.
+#include "pafc_common.h"
+#include "../../include/pafc_encoder_ops.h"
+
+namespace pafc {
+namespace {
+
+constexpr int VEC = 8;       // channels per lane per iteration
+constexpr int MAXIT = 2;     // => C <= 64 * 8 * 2 = 1024
+
+template <typename ET> __device__ __forceinline__ void load8(const ET *p, float *f);
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t *p, float *f) {
+    Elem<bf16_t>::unpack(*reinterpret_cast<const uint4 *>(p), f);
+}
+template <> __device__ __forceinline__ void load8<float>(const float *p, float *f) {
+    const float4 a = reinterpret_cast<const float4 *>(p)[0], b = reinterpret_cast<const float4 *>(p)[1];
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+template <typename ET> __device__ __forceinline__ void store8(ET *p, const float *f);
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t *p, const float *f) {
+    uint4 q;
+    q.x = f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16);
+    q.y = f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16);
+    q.z = f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16);
+    q.w = f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16);
+    *reinterpret_cast<uint4 *>(p) = q;
+}
+template <> __device__ __forceinline__ void store8<float>(float *p, const float *f) {
+    reinterpret_cast<float4 *>(p)[0] = make_float4(f[0], f[1], f[2], f[3]);
+    reinterpret_cast<float4 *>(p)[1] = make_float4(f[4], f[5], f[6], f[7]);
+}
+
+__device__ __forceinline__ float silu_(float x) { return x / (1.f + __expf(-x)); }
+
+struct LnArgs {
+    const void *x;        // (rows, C) residual stream
+    const void *y;        // (rows, C) branch output to add, or null
+    float alpha;          // x_new = x + alpha * y
+    const int32_t *lens;  // (B) valid frames per batch item, or null
+    int T;                // rows per batch item (for lens)
+    int mask_y;           // zero y rows with t >= lens[b] before the add (convolution.py:140-141)
+    void *x_out;          // (rows, C) x_new, or null
+    const void *g1, *b1;  // LayerNorm 1 (C)
+    void *o1;             // LN1 output, row stride ld1 (elements), or null
+    long ld1;
+    int silu1;            // o1 = silu(LN1(.))
+    int zero1;            // zero o1 rows with t >= lens[b] (the masked_fill on the conv-module input, convolution.py:109-110)
+    const void *g2, *b2;  // optional LayerNorm 2 applied to the (rounded) LN1 output
+    void *o2;
+    long ld2;
+    int rows, C;
+    float eps;
+};
+
+// One wave per row.  EX: residual / parameter dtype; EO: dtype of the LayerNorm outputs.
+template <typename EX, typename EO>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const LnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const int C = a.C;
+    const EX *x = (const EX *)a.x + (size_t)row * C;
+    bool beyond = false;
+    if (a.lens) beyond = (row % a.T) >= a.lens[row / a.T];
+
+    float v[MAXIT][VEC];
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = (it * 64 + lane) * VEC;
+        if (c < C) {
+            load8<EX>(x + c, v[it]);
+            if (a.y) {
+                float yv[VEC];
+                load8<EX>((const EX *)a.y + (size_t)row * C + c, yv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float t = (a.mask_y && beyond) ? 0.f : yv[e];
+                    if (a.alpha != 1.f) t = Elem<EX>::round(a.alpha * t);
+                    v[it][e] = Elem<EX>::round(v[it][e] + t);
+                }
+                if (a.x_out) store8<EX>((EX *)a.x_out + (size_t)row * C + c, v[it]);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sum += v[it][e];
+        }
+    }
+    if (!a.o1) return;
+    const float inv_c = 1.f / (float)C;
+    float mean = wave_sum(sum) * inv_c;
+    float sq = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = (it * 64 + lane) * VEC;
+        if (c < C) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = v[it][e] - mean; sq = fmaf(d, d, sq); }
+        }
+    }
+    float rstd = rsqrtf(wave_sum(sq) * inv_c + a.eps);
+    float sum2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = (it * 64 + lane) * VEC;
+        if (c < C) {
+            float g[VEC], b[VEC];
+            load8<EX>((const EX *)a.g1 + c, g);
+            load8<EX>((const EX *)a.b1 + c, b);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float o = Elem<EO>::round(fmaf((v[it][e] - mean) * rstd, g[e], b[e]));
+                if (a.silu1) o = Elem<EO>::round(silu_(o));
+                if (a.zero1 && beyond) o = 0.f;
+                v[it][e] = o;
+                sum2 += o;
+            }
+            store8<EO>((EO *)a.o1 + (size_t)row * a.ld1 + c, v[it]);
+        }
+    }
+    if (!a.o2) return;
+    mean = wave_sum(sum2) * inv_c;
+    sq = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = (it * 64 + lane) * VEC;
+        if (c < C) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = v[it][e] - mean; sq = fmaf(d, d, sq); }
+        }
+    }
+    rstd = rsqrtf(wave_sum(sq) * inv_c + a.eps);
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = (it * 64 + lane) * VEC;
+        if (c < C) {
+            float g[VEC], b[VEC], o[VEC];
+            load8<EX>((const EX *)a.g2 + c, g);
+            load8<EX>((const EX *)a.b2 + c, b);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = fmaf((v[it][e] - mean) * rstd, g[e], b[e]);
+            store8<EO>((EO *)a.o2 + (size_t)row * a.ld2 + c, o);
+        }
+    }
+}
+
+// ---- RWKV time-mix glue -----------------------------------------------------------------------------------------
+// token shift + first lerp, both directions from one read of x (src/model.py:274-276):
+//   xx_d = shift_d(x) - x;  xxx_d = x + xx_d * maa_x_d        d = 0: x_{t-1} (zero at t = 0), d = 1: x_{t+1} (zero at T-1)
+template <typename ET>
+__global__ __launch_bounds__(256) void tmix_shift_mix_kernel(int T, int C, long rows, int ndir, int rev0,
+                                                             const ET *__restrict__ x, const ET *__restrict__ maa0,
+                                                             const ET *__restrict__ maa1, ET *__restrict__ out) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cpr = C / VEC;  // lanes per row
+    const long row = gid / cpr;
+    if (row >= rows) return;
+    const int c = (int)(gid % cpr) * VEC;
+    const int t = (int)(row % T);
+    float xc[VEC], xp[VEC], xn[VEC];
+    load8<ET>(x + row * C + c, xc);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { xp[e] = 0.f; xn[e] = 0.f; }
+    if (t > 0) load8<ET>(x + (row - 1) * C + c, xp);
+    if (t < T - 1) load8<ET>(x + (row + 1) * C + c, xn);
+    for (int d = 0; d < ndir; ++d) {
+        const bool rev = (d == 0) ? (rev0 != 0) : true;
+        float m[VEC], o[VEC];
+        load8<ET>((d == 0 ? maa0 : maa1) + c, m);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float xx = Elem<ET>::round((rev ? xn[e] : xp[e]) - xc[e]);
+            o[e] = Elem<ET>::round(xc[e] + Elem<ET>::round(xx * m[e]));
+        }
+        store8<ET>(out + ((size_t)d * rows + row) * C + c, o);
+    }
+}
+
+// the four data-dependent lerps (src/model.py:280-284):  z_q = x + xx * (maa_q + m_q),  q in {r, k, v, w}
+//   m:   [ndir][4][rows][C]   (LoRA outputs, per direction)
+//   maa: [ndir][4][C]
+//   z:   [4][ndir][rows][C]   (q-major so that r,k,v of all directions are one contiguous batch of GEMM inputs)
+template <typename ET>
+__global__ __launch_bounds__(256) void tmix_mix4_kernel(int T, int C, long rows, int ndir, int rev0,
+                                                        const ET *__restrict__ x, const ET *__restrict__ m,
+                                                        const ET *__restrict__ maa, ET *__restrict__ z) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cpr = C / VEC;
+    const long row = gid / cpr;
+    if (row >= rows) return;
+    const int c = (int)(gid % cpr) * VEC;
+    const int t = (int)(row % T);
+    float xc[VEC], xp[VEC], xn[VEC];
+    load8<ET>(x + row * C + c, xc);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { xp[e] = 0.f; xn[e] = 0.f; }
+    if (t > 0) load8<ET>(x + (row - 1) * C + c, xp);
+    if (t < T - 1) load8<ET>(x + (row + 1) * C + c, xn);
+    for (int d = 0; d < ndir; ++d) {
+        const bool rev = (d == 0) ? (rev0 != 0) : true;
+        float xx[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) xx[e] = Elem<ET>::round((rev ? xn[e] : xp[e]) - xc[e]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float mv[VEC], av[VEC], o[VEC];
+            load8<ET>(m + (((size_t)d * 4 + q) * rows + row) * C + c, mv);
+            load8<ET>(maa + ((size_t)d * 4 + q) * C + c, av);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                o[e] = Elem<ET>::round(xc[e] + Elem<ET>::round(xx[e] * Elem<ET>::round(av[e] + mv[e])));
+            store8<ET>(z + (((size_t)q * ndir + d) * rows + row) * C + c, o);
+        }
+    }
+}
+
+template <typename EX>
+int launch_ln(int dtype_out, const LnArgs &a, hipStream_t s) {
+    dim3 grid((a.rows + 3) / 4), block(256);
+    if (dtype_out == PAFC_BF16)
+        hipLaunchKernelGGL((add_layernorm_kernel<EX, bf16_t>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((add_layernorm_kernel<EX, float>), grid, block, 0, s, a);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+}  // namespace
+}  // namespace pafc
+
+extern "C" {
+
+int pafc_add_layernorm(int dtype, int dtype_out, int rows, int C, const void *x, const void *y, float alpha,
+                       const int32_t *lens, int T, int mask_y, void *x_out, const void *gamma1, const void *beta1,
+                       void *out1, long ld1, int silu1, int zero1, const void *gamma2, const void *beta2, void *out2,
+                       long ld2, float eps, pafc_stream_t stream) {
+    if (!x) return PAFC_ERR_NULL_POINTER;
+    if (out1 && (!gamma1 || !beta1)) return PAFC_ERR_NULL_POINTER;
+    if (out2 && (!gamma2 || !beta2 || !out1)) return PAFC_ERR_NULL_POINTER;
+    if (rows <= 0 || C <= 0 || C % pafc::VEC || C > 64 * pafc::VEC * pafc::MAXIT || (lens && T <= 0))
+        return PAFC_ERR_BAD_DIMS;
+    if (ld1 % pafc::VEC || ld2 % pafc::VEC) return PAFC_ERR_BAD_DIMS;
+    if (dtype == PAFC_BF16 && dtype_out == PAFC_F32) return PAFC_ERR_DTYPE;
+    pafc::LnArgs a{x, y, alpha, lens, T, mask_y, x_out, gamma1, beta1, out1, ld1, silu1, zero1,
+                   gamma2, beta2, out2, ld2, rows, C, eps};
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PAFC_BF16) return pafc::launch_ln<pafc::bf16_t>(dtype_out, a, s);
+    if (dtype == PAFC_F32) return pafc::launch_ln<float>(dtype_out, a, s);
+    return PAFC_ERR_DTYPE;
+}
+
+int pafc_tmix_shift_mix(int dtype, int B, int T, int C, int ndir, int reverse0, const void *x, const void *maa_x0,
+                        const void *maa_x1, void *out, pafc_stream_t stream) {
+    if (!x || !maa_x0 || !out || (ndir == 2 && !maa_x1)) return PAFC_ERR_NULL_POINTER;
+    if (B <= 0 || T <= 0 || C <= 0 || C % pafc::VEC || ndir < 1 || ndir > 2) return PAFC_ERR_BAD_DIMS;
+    const long rows = (long)B * T;
+    const long threads = rows * (C / pafc::VEC);
+    dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PAFC_BF16)
+        hipLaunchKernelGGL(pafc::tmix_shift_mix_kernel<pafc::bf16_t>, grid, block, 0, s, T, C, rows, ndir, reverse0,
+                           (const pafc::bf16_t *)x, (const pafc::bf16_t *)maa_x0, (const pafc::bf16_t *)maa_x1,
+                           (pafc::bf16_t *)out);
+    else if (dtype == PAFC_F32)
+        hipLaunchKernelGGL(pafc::tmix_shift_mix_kernel<float>, grid, block, 0, s, T, C, rows, ndir, reverse0,
+                           (const float *)x, (const float *)maa_x0, (const float *)maa_x1, (float *)out);
+    else
+        return PAFC_ERR_DTYPE;
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+int pafc_tmix_mix4(int dtype, int B, int T, int C, int ndir, int reverse0, const void *x, const void *m,
+                   const void *maa, void *z, pafc_stream_t stream) {
+    if (!x || !m || !maa || !z) return PAFC_ERR_NULL_POINTER;
+    if (B <= 0 || T <= 0 || C <= 0 || C % pafc::VEC || ndir < 1 || ndir > 2) return PAFC_ERR_BAD_DIMS;
+    const long rows = (long)B * T;
+    const long threads = rows * (C / pafc::VEC);
+    dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PAFC_BF16)
+        hipLaunchKernelGGL(pafc::tmix_mix4_kernel<pafc::bf16_t>, grid, block, 0, s, T, C, rows, ndir, reverse0,
+                           (const pafc::bf16_t *)x, (const pafc::bf16_t *)m, (const pafc::bf16_t *)maa,
+                           (pafc::bf16_t *)z);
+    else if (dtype == PAFC_F32)
+        hipLaunchKernelGGL(pafc::tmix_mix4_kernel<float>, grid, block, 0, s, T, C, rows, ndir, reverse0,
+                           (const float *)x, (const float *)m, (const float *)maa, (float *)z);
+    else
+        return PAFC_ERR_DTYPE;
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -1,4 +1,4 @@
-// WKV-6 forward for gfx950: T-parallel three-pass chunked scan, both directions in one grid.
+// WKV-6 forward and backward for gfx950: T-parallel three-pass chunked scan, both directions in one grid.
 //
 // What it computes (per batch b, head h; j = key index, i = value index, d = exp(-exp(w))):
 //     y_t[i]  = sum_j r_t[j] * (u[j] k_t[j] v_t[i] + S[j][i])
@@ -319,6 +319,256 @@ int forward_impl(int dtype, int B, int T, int C, int H, int ndir, const DirArgs 
     return dtype == PAFC_BF16 ? launch_fwd<bf16_t>(p, ndir, any_final, s) : launch_fwd<float>(p, ndir, any_final, s);
 }
 
+
+// =====================================================================================================
+// Backward (replaces kernel_backward_101/102/103/201, wkv6_cuda.cu:65-263: five serial sweeps) as three
+// chunk-parallel sweeps plus a light epilogue.
+//
+// With S_t the state before step t (S_{t+1} = d_t S_t + k_t v_t^T) and G_t its adjoint
+// (G_t = d_t G_{t+1} + r_t gy_t^T, G_T = 0):
+//   P_t[j] = sum_i S_t[j][i]     gy_t[i]        "row sweep" in forward time   (a = k, p = v,  q = gy)
+//   Q_t[j] = sum_i G_{t+1}[j][i] v_t[i]         "row sweep" in reverse time   (a = r, p = gy, q = v)
+//   gv_t[i] = sum_j k_t[j] G_{t+1}[j][i] + (sum_j u r k) gy_t[i]
+//           = the FORWARD kernel with r<->k swapped, v := gy, run in reverse time  (pass C reused as is)
+//   c_t = v_t . gy_t,  e_t = v_{t-1} . gy_t
+//   gr_t = P_t + u k_t c_t        gk_t = Q_t + u r_t c_t        gu += r_t k_t c_t
+//   gw_t = Z_t * (-exp(w_t)),  Z_t = Z_{t-1} + k_{t-1} (Q_{t-1} - r_t e_t) - r_t (P_t - k_{t-1} e_t),  Z_0 = 0
+// (the last line is the reference's two-sweep sbbbb/sss recursion, wkv6_cuda.cu:211-261, rewritten so that it
+// needs only P and Q; gw_0 = gw_{T-1} = 0 as there).  Chunk states for S and G come from the forward's own
+// pass A / pass B (k,v,w in forward time; r,gy,w in reverse time).
+struct RowArgs {
+    const void *a, *p, *q, *w;
+    float *out;      // (B, T, C) fp32
+    int reverse;
+};
+
+struct RowParams {
+    RowArgs d[2];
+    int B, T, C, H, L, NC;
+    const float *ws_state;   // [2][B][H][NC][j][i]; entry c = state entering chunk c (after the scan)
+};
+
+// lane j owns ROW j of the state (64 VGPRs over i); a_j, d_j are per-lane, p_i and q_i are broadcast from LDS
+template <typename ET>
+__global__ __launch_bounds__(64, 3) void wkv6_row_kernel(const RowParams p) {
+    using G = TileGeom<ET>;
+    using E = Elem<ET>;
+    using GO = TileGeom<float>;
+    const int c = blockIdx.x;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int dir = blockIdx.z;
+    const int lane = threadIdx.x;
+    const RowArgs &D = p.d[dir];
+    const int T = p.T, C = p.C;
+
+    __shared__ __attribute__((aligned(16))) float s_a[TT][N];
+    __shared__ __attribute__((aligned(16))) float s_d[TT][N];
+    __shared__ __attribute__((aligned(16))) float s_p[TT][N];
+    __shared__ __attribute__((aligned(16))) float s_q[TT][N];
+    __shared__ __attribute__((aligned(16))) float s_o[TT][N];
+
+    const size_t head_off = (size_t)b * T * C + (size_t)h * N;
+    const ET *ga = (const ET *)D.a + head_off;
+    const ET *gp = (const ET *)D.p + head_off;
+    const ET *gq = (const ET *)D.q + head_off;
+    const ET *gw = (const ET *)D.w + head_off;
+    float *go = D.out + head_off;
+
+    float st[N];
+    if (p.NC > 1) {
+        const size_t seq = ((size_t)dir * p.B + b) * p.H + h;
+        const float4 *ws = reinterpret_cast<const float4 *>(p.ws_state + (seq * p.NC + c) * (size_t)(N * N) + lane * N);
+#pragma unroll
+        for (int i = 0; i < N; i += 4) {
+            const float4 v4 = ws[i / 4];
+            st[i] = v4.x; st[i + 1] = v4.y; st[i + 2] = v4.z; st[i + 3] = v4.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) st[i] = 0.f;
+    }
+    const int s_begin = c * p.L;
+    const int s_end = min(T, s_begin + p.L);
+
+    uint4 na[G::NLD], np[G::NLD], nq[G::NLD], nw[G::NLD];
+#pragma unroll
+    for (int q = 0; q < G::NLD; ++q) {
+        na[q] = tile_load<ET>(ga, q, lane, s_begin, s_end, T, C, D.reverse);
+        np[q] = tile_load<ET>(gp, q, lane, s_begin, s_end, T, C, D.reverse);
+        nq[q] = tile_load<ET>(gq, q, lane, s_begin, s_end, T, C, D.reverse);
+        nw[q] = tile_load<ET>(gw, q, lane, s_begin, s_end, T, C, D.reverse);
+    }
+    for (int s0 = s_begin; s0 < s_end; s0 += TT) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < G::NLD; ++q) {
+            const int tt = q * G::RPL + lane / G::LPR;
+            const int col = (lane % G::LPR) * G::EPL;
+            float f[G::EPL];
+            E::unpack(na[q], f);
+#pragma unroll
+            for (int e = 0; e < G::EPL; e += 4)
+                *reinterpret_cast<float4 *>(&s_a[tt][col + e]) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
+            E::unpack(np[q], f);
+#pragma unroll
+            for (int e = 0; e < G::EPL; e += 4)
+                *reinterpret_cast<float4 *>(&s_p[tt][col + e]) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
+            E::unpack(nq[q], f);
+#pragma unroll
+            for (int e = 0; e < G::EPL; e += 4)
+                *reinterpret_cast<float4 *>(&s_q[tt][col + e]) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
+            E::unpack(nw[q], f);
+#pragma unroll
+            for (int e = 0; e < G::EPL; ++e) f[e] = __expf(-__expf(f[e]));
+#pragma unroll
+            for (int e = 0; e < G::EPL; e += 4)
+                *reinterpret_cast<float4 *>(&s_d[tt][col + e]) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
+        }
+        const int s1 = s0 + TT;
+#pragma unroll
+        for (int q = 0; q < G::NLD; ++q) {
+            na[q] = tile_load<ET>(ga, q, lane, s1, s_end, T, C, D.reverse);
+            np[q] = tile_load<ET>(gp, q, lane, s1, s_end, T, C, D.reverse);
+            nq[q] = tile_load<ET>(gq, q, lane, s1, s_end, T, C, D.reverse);
+            nw[q] = tile_load<ET>(gw, q, lane, s1, s_end, T, C, D.reverse);
+        }
+        __syncthreads();
+        const int nt = min(TT, s_end - s0);
+#pragma unroll 1
+        for (int tt = 0; tt < nt; ++tt) {
+            const float aj = s_a[tt][lane], dj = s_d[tt][lane];
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+            for (int i = 0; i < N; i += 4) {
+                const float4 p4 = *reinterpret_cast<const float4 *>(&s_p[tt][i]);
+                const float4 q4 = *reinterpret_cast<const float4 *>(&s_q[tt][i]);
+                o0 = fmaf(q4.x, st[i], o0);
+                o1 = fmaf(q4.y, st[i + 1], o1);
+                o2 = fmaf(q4.z, st[i + 2], o2);
+                o3 = fmaf(q4.w, st[i + 3], o3);
+                st[i] = fmaf(st[i], dj, aj * p4.x);
+                st[i + 1] = fmaf(st[i + 1], dj, aj * p4.y);
+                st[i + 2] = fmaf(st[i + 2], dj, aj * p4.z);
+                st[i + 3] = fmaf(st[i + 3], dj, aj * p4.w);
+                if ((i & 15) == 12) __builtin_amdgcn_sched_barrier(0);
+            }
+            s_o[tt][lane] = (o0 + o1) + (o2 + o3);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < GO::NLD; ++q) {
+            const int tt = q * GO::RPL + lane / GO::LPR;
+            const int col = (lane % GO::LPR) * GO::EPL;
+            const int s = s0 + tt;
+            if (s < s_end) {
+                const int t = D.reverse ? (T - 1 - s) : s;
+                *reinterpret_cast<float4 *>(go + (size_t)t * C + col) = *reinterpret_cast<const float4 *>(&s_o[tt][col]);
+            }
+        }
+    }
+}
+
+struct EpiParams {
+    const void *r, *k, *v, *w, *u, *gy;
+    const float *P, *Q;
+    void *gr, *gk, *gw, *gu;
+    int B, T, C, H, reverse;
+};
+
+// one wave per (b, h), lane = channel; serial over time but only O(N) work per step
+template <typename ET>
+__global__ __launch_bounds__(64) void wkv6_bwd_epilogue_kernel(const EpiParams p) {
+    using E = Elem<ET>;
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int lane = threadIdx.x;
+    const int T = p.T, C = p.C;
+    const size_t base = (size_t)b * T * C + (size_t)h * N + lane;
+    const ET *r = (const ET *)p.r + base, *k = (const ET *)p.k + base, *v = (const ET *)p.v + base;
+    const ET *w = (const ET *)p.w + base, *gy = (const ET *)p.gy + base;
+    const float *P = p.P + base, *Q = p.Q + base;
+    ET *gr = (ET *)p.gr + base, *gk = (ET *)p.gk + base, *gw = (ET *)p.gw + base;
+    const float u = E::load((const ET *)p.u + h * N + lane);
+
+    float gu = 0.f, Z = 0.f;
+    float k_prev = 0.f, v_prev = 0.f, q_prev = 0.f;
+    auto at = [&](int s) { return (size_t)(p.reverse ? (T - 1 - s) : s) * C; };
+    // software pipeline: values of step s+1 are loaded while step s is reduced
+    float nr = E::load(r + at(0)), nk = E::load(k + at(0)), nv = E::load(v + at(0)), nw = E::load(w + at(0));
+    float ng = E::load(gy + at(0)), nP = P[at(0)], nQ = Q[at(0)];
+    for (int s = 0; s < T; ++s) {
+        const float rr = nr, kk = nk, vv = nv, ww = nw, gg = ng, Ps = nP, Qs = nQ;
+        const size_t o = at(s);
+        if (s + 1 < T) {
+            const size_t n = at(s + 1);
+            nr = E::load(r + n); nk = E::load(k + n); nv = E::load(v + n); nw = E::load(w + n);
+            ng = E::load(gy + n); nP = P[n]; nQ = Q[n];
+        }
+        const float c = wave_sum(vv * gg);
+        const float e = wave_sum(v_prev * gg);
+        E::store(gr + o, fmaf(u * kk, c, Ps));
+        E::store(gk + o, fmaf(u * rr, c, Qs));
+        gu = fmaf(rr * kk, c, gu);
+        if (s > 0) Z += k_prev * (q_prev - rr * e) - rr * (Ps - k_prev * e);
+        const float gwv = (s == 0 || s == T - 1) ? 0.f : Z * -__expf(ww);
+        E::store(gw + o, gwv);
+        k_prev = kk; v_prev = vv; q_prev = Qs;
+    }
+    E::store((ET *)p.gu + (size_t)b * C + h * N + lane, gu);
+}
+
+size_t bwd_ws_bytes(int B, int T, int C, int H, int L) {
+    size_t n = 2 * (size_t)B * T * C;                      // P, Q
+    if (L < T) {
+        const size_t NC = (T + L - 1) / L;
+        n += 2 * (size_t)B * H * NC * (N * N + N);          // chunk states + decays of S and G
+    }
+    return n * sizeof(float);
+}
+
+int bwd_chunk_len(int B, int T, int H, int chunk_len) {
+    int L = chunk_len > 0 ? chunk_len : pick_chunk_len(B, T, H, 2);
+    if (L < T) L = (L + TT - 1) / TT * TT;
+    return L >= T ? T : L;
+}
+
+template <typename ET>
+int launch_bwd(int B, int T, int C, int H, const void *r, const void *k, const void *v, const void *w, const void *u,
+               const void *gy, void *gr, void *gk, void *gv, void *gw, void *gu, int reverse, int L, float *ws,
+               hipStream_t stream) {
+    const int rev = reverse ? 1 : 0;
+    const int NC = (T + L - 1) / L;
+    float *P = ws, *Q = P + (size_t)B * T * C;
+    float *ws_state = Q + (size_t)B * T * C;
+    float *ws_decay = ws_state + 2 * (size_t)B * H * NC * (N * N);
+    // dir 0: S from (k, v, w) in forward time; dir 1: G from (r, gy, w) in reverse time, whose pass C is gv
+    FwdParams fp{};
+    fp.d[0] = DirArgs{k, k, v, w, u, gv, nullptr, nullptr, rev};            // r, y unused by pass A
+    fp.d[1] = DirArgs{k, r, gy, w, u, gv, nullptr, nullptr, 1 - rev};       // forward kernel with r<->k, v := gy
+    fp.B = B; fp.T = T; fp.C = C; fp.H = H; fp.L = L; fp.NC = NC;
+    fp.nc_local = NC - 1;
+    fp.ws_state = ws_state; fp.ws_decay = ws_decay;
+    if (NC > 1) {
+        hipLaunchKernelGGL((wkv6_chunk_kernel<ET, false>), dim3(NC - 1, B * H, 2), dim3(64), 0, stream, fp);
+        hipLaunchKernelGGL(wkv6_scan_kernel, dim3(16, B * H, 2), dim3(256), 0, stream, fp);
+    }
+    FwdParams fg = fp;  // pass C for direction 1 only: present it as direction 0 of a one-direction launch
+    fg.d[0] = fp.d[1];
+    fg.ws_state = ws_state + (size_t)B * H * NC * (N * N);
+    fg.ws_decay = ws_decay + (size_t)B * H * NC * N;
+    hipLaunchKernelGGL((wkv6_chunk_kernel<ET, true>), dim3(NC, B * H, 1), dim3(64), 0, stream, fg);
+
+    RowParams rp{};
+    rp.d[0] = RowArgs{k, v, gy, w, P, rev};
+    rp.d[1] = RowArgs{r, gy, v, w, Q, 1 - rev};
+    rp.B = B; rp.T = T; rp.C = C; rp.H = H; rp.L = L; rp.NC = NC;
+    rp.ws_state = ws_state;
+    hipLaunchKernelGGL(wkv6_row_kernel<ET>, dim3(NC, B * H, 2), dim3(64), 0, stream, rp);
+
+    EpiParams ep{r, k, v, w, u, gy, P, Q, gr, gk, gw, gu, B, T, C, H, rev};
+    hipLaunchKernelGGL(wkv6_bwd_epilogue_kernel<ET>, dim3(B * H), dim3(64), 0, stream, ep);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
 }  // namespace
 }  // namespace pafc
 
@@ -369,6 +619,32 @@ int pafc_wkv6_forward_bidir(int dtype, int B, int T, int C, int H, const void *r
                             void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
     DirArgs d[2] = {{r_f, k_f, v_f, w_f, u_f, y_f, nullptr, nullptr, 0}, {r_b, k_b, v_b, w_b, u_b, y_b, nullptr, nullptr, 1}};
     return pafc::forward_impl(dtype, B, T, C, H, 2, d, chunk_len, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"
+
+extern "C" {
+
+size_t pafc_wkv6_bwd_workspace_bytes(int B, int T, int C, int H, int chunk_len) {
+    if (B <= 0 || T <= 0 || C <= 0 || H <= 0) return 0;
+    return pafc::bwd_ws_bytes(B, T, C, H, pafc::bwd_chunk_len(B, T, H, chunk_len));
+}
+
+int pafc_wkv6_backward(int dtype, int B, int T, int C, int H, const void *r, const void *k, const void *v,
+                       const void *w, const void *u, const void *gy, void *gr, void *gk, void *gv, void *gw, void *gu,
+                       int reverse, int chunk_len, void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
+    if (B <= 0 || T <= 0 || C <= 0 || H <= 0 || C % H != 0 || (long)B * H > 65535) return PAFC_ERR_BAD_DIMS;
+    if (C / H != pafc::N) return PAFC_ERR_HEAD_SIZE;
+    if (!r || !k || !v || !w || !u || !gy || !gr || !gk || !gv || !gw || !gu || !workspace) return PAFC_ERR_NULL_POINTER;
+    const int L = pafc::bwd_chunk_len(B, T, H, chunk_len);
+    if (workspace_bytes < pafc::bwd_ws_bytes(B, T, C, H, L)) return PAFC_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PAFC_BF16)
+        return pafc::launch_bwd<pafc::bf16_t>(B, T, C, H, r, k, v, w, u, gy, gr, gk, gv, gw, gu, reverse, L,
+                                              (float *)workspace, s);
+    if (dtype == PAFC_F32)
+        return pafc::launch_bwd<float>(B, T, C, H, r, k, v, w, u, gy, gr, gk, gv, gw, gu, reverse, L, (float *)workspace, s);
+    return PAFC_ERR_DTYPE;
 }
 
 }  // extern "C"

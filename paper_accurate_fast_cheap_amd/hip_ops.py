@@ -34,3 +34,72 @@ def depthwise_conv1d_cl(x: torch.Tensor, weight: torch.Tensor, bias: Optional[to
                                   _lib.stream_of(x))
     _lib.check(rc, "pafc_dwconv1d_cl")
     return y
+
+
+def _bind2():
+    L = _bind()
+    if getattr(L, "_pafc_glue_bound", False):
+        return L
+    from ctypes import c_float, c_long
+    P, I = c_void_p, c_int
+    _lib._sig(L.pafc_add_layernorm, I, I, I, I, I, P, P, c_float, P, I, I, P, P, P, P, c_long, I, I, P, P, P, c_long,
+              c_float, P)
+    _lib._sig(L.pafc_tmix_shift_mix, I, I, I, I, I, I, P, P, P, P, P)
+    _lib._sig(L.pafc_tmix_mix4, I, I, I, I, I, I, P, P, P, P, P)
+    L._pafc_glue_bound = True
+    return L
+
+
+def add_layernorm(x: torch.Tensor, y: Optional[torch.Tensor], alpha: float, gamma1, beta1, *, out1: torch.Tensor = None,
+                  out_dtype: Optional[torch.dtype] = None, silu: bool = False, zero_rows: bool = False,
+                  lens: Optional[torch.Tensor] = None, T: int = 0, mask_y: bool = False, gamma2=None, beta2=None,
+                  want_ln: bool = True, want_x: bool = True, eps: float = 1e-5):
+    """x_new = x + alpha*y; out1 = LN1(x_new) [silu] [rows >= len zeroed]; out2 = LN2(out1).
+    Returns (x_new or x, out1 or None, out2 or None).  `out1` may be a pre-allocated (rows, ld) view (last-dim
+    slice of a wider buffer) so that two LayerNorms can land side by side."""
+    _lib.require_gpu(x, y, gamma1, beta1, gamma2, beta2, lens)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    out_dtype = out_dtype or x.dtype
+    x_out = torch.empty_like(x) if (y is not None and want_x) else None
+    o1 = None
+    ld1 = C
+    if want_ln:
+        if out1 is None:
+            o1 = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+        else:
+            o1 = out1
+            ld1 = out1.stride(-2)
+            if out1.stride(-1) != 1 or out1.dtype != out_dtype:
+                raise _lib.PafcError("out1 must be a unit-stride view in the output dtype")
+    o2 = torch.empty(x.shape, dtype=out_dtype, device=x.device) if gamma2 is not None else None
+    rc = _bind2().pafc_add_layernorm(
+        _lib.dtype_code(x.dtype), _lib.dtype_code(out_dtype), rows, C, _lib.ptr(x), _lib.ptr(y), float(alpha),
+        _lib.ptr(lens), int(T), int(mask_y), _lib.ptr(x_out), _lib.ptr(gamma1), _lib.ptr(beta1), _lib.ptr(o1), ld1,
+        int(silu), int(zero_rows), _lib.ptr(gamma2), _lib.ptr(beta2), _lib.ptr(o2), C, float(eps), _lib.stream_of(x))
+    _lib.check(rc, "pafc_add_layernorm")
+    return (x_out if y is not None else x), o1, o2  # first item is None when want_x=False
+
+
+def tmix_shift_mix(x: torch.Tensor, maa_x0: torch.Tensor, maa_x1: Optional[torch.Tensor], reverse0: bool = False):
+    """(B, T, C) -> (ndir, B, T, C): x + (shift_d(x) - x) * maa_x_d."""
+    _lib.require_gpu(x, maa_x0, maa_x1)
+    B, T, C = x.shape
+    ndir = 2 if maa_x1 is not None else 1
+    out = torch.empty((ndir, B, T, C), dtype=x.dtype, device=x.device)
+    rc = _bind2().pafc_tmix_shift_mix(_lib.dtype_code(x.dtype), B, T, C, ndir, int(reverse0), _lib.ptr(x),
+                                      _lib.ptr(maa_x0), _lib.ptr(maa_x1), _lib.ptr(out), _lib.stream_of(x))
+    _lib.check(rc, "pafc_tmix_shift_mix")
+    return out
+
+
+def tmix_mix4(x: torch.Tensor, m: torch.Tensor, maa: torch.Tensor, reverse0: bool = False):
+    """x (B,T,C), m (ndir,4,B*T,C), maa (ndir,4,C) -> z (4,ndir,B*T,C)."""
+    _lib.require_gpu(x, m, maa)
+    B, T, C = x.shape
+    ndir = m.shape[0]
+    z = torch.empty((4, ndir, B * T, C), dtype=x.dtype, device=x.device)
+    rc = _bind2().pafc_tmix_mix4(_lib.dtype_code(x.dtype), B, T, C, ndir, int(reverse0), _lib.ptr(x), _lib.ptr(m),
+                                 _lib.ptr(maa), _lib.ptr(z), _lib.stream_of(x))
+    _lib.check(rc, "pafc_tmix_mix4")
+    return z

@@ -6,6 +6,7 @@ keys as conf/rwkv/*.yaml `encoder_conf`, same sub-module names (embed, encoders.
 same return shapes.  Scope: num_langs == 0 and the recurrent slot keys; the MHA baseline, the LSL variant and
 the plain TransformerEncoder are not part of the accelerated path.
 """
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -37,6 +38,21 @@ class BaseEncoder(torch.nn.Module):
         self.use_dynamic_chunk = use_dynamic_chunk
         self.use_dynamic_left_chunk = use_dynamic_left_chunk
         self.gradient_checkpointing = gradient_checkpointing
+        # inference executor (transformer/fused.py); PAFC_DISABLE_FUSED=1 keeps the op-by-op module path
+        self.fused_inference = os.environ.get("PAFC_DISABLE_FUSED", "0") != "1"
+        self._fused_plan = None
+
+    def _fused(self, xs: torch.Tensor):
+        """The fused executor's plan when this call may use it (no autograd, GPU, eligible layers), else None."""
+        if not self.fused_inference or torch.is_grad_enabled() or not xs.is_cuda or self.training:
+            return None
+        from . import fused
+        if self._fused_plan is None:
+            if not (self.normalize_before and all(fused.eligible(l) for l in self.encoders)):
+                self.fused_inference = False
+                return None
+            self._fused_plan = fused.EncoderPlan(self.encoders)
+        return self._fused_plan
 
     def output_size(self) -> int:
         return self._output_size
@@ -58,6 +74,11 @@ class BaseEncoder(torch.nn.Module):
         mask_pad = masks
         chunk_masks = add_optional_chunk_mask(xs, masks, self.use_dynamic_chunk, self.use_dynamic_left_chunk,
                                               decoding_chunk_size, self.static_chunk_size, num_decoding_left_chunks)
+        plan = self._fused(xs)
+        if plan is not None:
+            from . import fused
+            xs, layer_outs = fused.encoder_layers_forward(plan, xs, mask_pad, self.after_norm, want_layers)
+            return xs, masks, layer_outs
         layer_outs: List[torch.Tensor] = []
         for layer in self.encoders:
             xs, chunk_masks, _, _ = layer(xs, chunk_masks, pos_emb, mask_pad, cat_embs=cat_embs)
@@ -82,6 +103,13 @@ class BaseEncoder(torch.nn.Module):
             xs = self.global_cmvn(xs)
         xs, pos_emb, _ = self.embed(xs, tmp_masks, offset)
         elayers = att_cache.size(0)
+        plan = self._fused(xs)
+        if plan is not None and elayers == 0 and cnn_cache.size(0) == 0:
+            from . import fused
+            xs, _ = fused.encoder_layers_forward(plan, xs, att_mask[:0], self.after_norm)
+            n = len(self.encoders)
+            return (xs, torch.zeros((0, 0, 0, 0), device=xs.device),
+                    torch.zeros((n, 0, 0, 0), dtype=xs.dtype, device=xs.device))
         r_att_cache, r_cnn_cache = [], []
         for i, layer in enumerate(self.encoders):
             xs, _, new_att_cache, new_cnn_cache = layer(

@@ -1,0 +1,167 @@
+"""Inference executor for a ConformerEncoderLayer with the recurrent slot: same modules, same parameters, same
+arithmetic as ConformerEncoderLayer.forward / RWKV_Tmix_x060c.forward (reference: wenet/transformer/encoder_layer.py:
+165-261, wenet/rwkv_v6/src/model.py:271-325, wenet/transformer/convolution.py:89-144), re-scheduled for HBM:
+
+  * every residual-add + pre-norm pair is ONE pass (pafc_add_layernorm), including norm_final + the next layer's
+    first pre-norm, the conv module's masked_fill / LayerNorm / SiLU, and the two ln_x of the slot, which land side
+    by side in one (M, 2C) buffer so that both output projections and the (a + b) / 2 become one GEMM with K = 2C;
+  * token shift and the five lerps are two passes for BOTH directions (pafc_tmix_shift_mix, pafc_tmix_mix4)
+    instead of ~17 element-wise kernels per direction, and nothing is flipped;
+  * r/k/v projections of both directions are one batched GEMM, the decay LoRA one batched GEMM pair;
+  * GLU is fused into the channels-last depthwise convolution.
+
+The GEMMs themselves stay with hipBLASLt via torch.  Used only under torch.no_grad() on GPU tensors; training
+goes through the plain module path (autograd)."""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import hip_ops
+from ..rwkv_v6.rwkv_wrapper import RWKV_TmixWrapper
+from ..rwkv_v6.rwkv_wrapper_bidirectional import RWKV_TmixWrapper_bidirectional
+from ..rwkv_v6.wkv6_op import wkv6_forward, wkv6_forward_bidir
+
+
+class LayerPlan:
+    """Stacked / pre-transposed views of one layer's parameters for the batched GEMMs (rebuilt when stale)."""
+
+    def __init__(self, layer: nn.Module):
+        self.layer = layer
+        slot = layer.self_attn
+        if isinstance(slot, RWKV_TmixWrapper_bidirectional):
+            self.blocks = [slot.rwkv_wrapper_forward.tmix_block, slot.rwkv_wrapper_backward.tmix_block]
+        else:
+            self.blocks = [slot.tmix_block]
+        self.ndir = len(self.blocks)
+        self.slot_bf16 = bool(slot.do_bfloat16)
+        self._stamp = None
+        self.refresh()
+
+    def _current_stamp(self):
+        ps = [p for b in self.blocks for p in b.parameters()]
+        return tuple((p.data_ptr(), p._version, p.dtype) for p in ps)
+
+    def refresh(self):
+        stamp = self._current_stamp()
+        if stamp == self._stamp:
+            return
+        bl = self.blocks
+        with torch.no_grad():
+            self.maa_x = [b.time_maa_x.reshape(-1).contiguous() for b in bl]
+            self.W1 = torch.stack([b.time_maa_rkvw_w1 for b in bl]).contiguous()           # (nd, C, 128)
+            self.W2 = [b.time_maa_rkvw_w2.contiguous() for b in bl]                        # (4, 32, C) each
+            self.maa4 = torch.stack([torch.stack([b.time_maa_r.reshape(-1), b.time_maa_k.reshape(-1),
+                                                  b.time_maa_v.reshape(-1), b.time_maa_w.reshape(-1)])
+                                     for b in bl]).contiguous()                             # (nd, 4, C)
+            # q-major, direction-minor: [r_0, r_1, k_0, k_1, v_0, v_1], each W^T (C_in, C_out)
+            self.Wrkv = torch.stack([getattr(b, n).weight.t() for n in ("receptance", "key", "value") for b in bl]
+                                    ).contiguous()
+            self.D1 = torch.stack([b.time_decay_w1 for b in bl]).contiguous()              # (nd, C, 64)
+            self.D2 = torch.stack([b.time_decay_w2 for b in bl]).contiguous()              # (nd, 64, C)
+            self.time_decay = torch.stack([b.time_decay.reshape(1, -1) for b in bl]).contiguous()  # (nd, 1, C)
+            self.u = [b.time_faaaa.contiguous() for b in bl]
+            wo = torch.cat([b.output.weight for b in bl], dim=1)                           # (C, nd*C)
+            self.Wo = (wo * 0.5 if self.ndir == 2 else wo).contiguous()                    # /2 is exact in bf16
+        self._stamp = stamp
+
+
+def eligible(layer: nn.Module) -> bool:
+    slot = layer.self_attn
+    if type(slot) not in (RWKV_TmixWrapper, RWKV_TmixWrapper_bidirectional):
+        return False
+    cm = layer.conv_module
+    return (layer.normalize_before and layer.feed_forward_macaron is not None and cm is not None
+            and cm.use_layer_norm and cm.lorder == 0 and isinstance(cm.activation, nn.SiLU)
+            and isinstance(layer.feed_forward.activation, nn.SiLU)
+            and isinstance(layer.feed_forward_macaron.activation, nn.SiLU) and cm.kernel_size in (3, 7, 15, 31)
+            and layer.size % 8 == 0 and layer.size <= 1024)
+
+
+def _ffn(ff: nn.Module, h: torch.Tensor) -> torch.Tensor:
+    return F.linear(F.silu(F.linear(h, ff.w_1.weight, ff.w_1.bias)), ff.w_2.weight, ff.w_2.bias)
+
+
+def slot_forward(plan: LayerPlan, h: torch.Tensor) -> torch.Tensor:
+    """h: (B, T, C) in the slot dtype -> slot output (B, T, C) in the slot dtype (both directions averaged)."""
+    B, T, C = h.shape
+    M, nd = B * T, plan.ndir
+    xxx = hip_ops.tmix_shift_mix(h, plan.maa_x[0], plan.maa_x[1] if nd == 2 else None)
+    t = torch.tanh(torch.bmm(xxx.view(nd, M, C), plan.W1))                                  # (nd, M, 128)
+    m = torch.empty((nd, 4, M, C), dtype=h.dtype, device=h.device)
+    for d in range(nd):
+        torch.bmm(t[d].view(M, 4, -1).transpose(0, 1), plan.W2[d], out=m[d])
+    z = hip_ops.tmix_mix4(h, m, plan.maa4)                                                  # (4, nd, M, C)
+    rkv = torch.bmm(z[:3].view(3 * nd, M, C), plan.Wrkv)                                    # (3nd, M, C)
+    w = torch.baddbmm(plan.time_decay, torch.tanh(torch.bmm(z[3], plan.D1)), plan.D2)       # (nd, M, C)
+    ycat = torch.empty((M, nd * C), dtype=h.dtype, device=h.device)
+    if nd == 2:
+        ys = wkv6_forward_bidir(
+            (rkv[0].view(B, T, C), rkv[2].view(B, T, C), rkv[4].view(B, T, C), w[0].view(B, T, C), plan.u[0]),
+            (rkv[1].view(B, T, C), rkv[3].view(B, T, C), rkv[5].view(B, T, C), w[1].view(B, T, C), plan.u[1]))
+    else:
+        ys = (wkv6_forward(rkv[0].view(B, T, C), rkv[1].view(B, T, C), rkv[2].view(B, T, C), w[0].view(B, T, C),
+                           plan.u[0]),)
+    for d, y in enumerate(ys):
+        ln = plan.blocks[d].ln_x
+        hip_ops.add_layernorm(y.view(M, C), None, 1.0, ln.weight, ln.bias, out1=ycat[:, d * C:(d + 1) * C], eps=ln.eps)
+    return F.linear(ycat, plan.Wo).view(B, T, C)
+
+
+def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optional[torch.Tensor],
+                  next_norm: Optional[nn.LayerNorm]) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """x: residual stream (B, T, C); h = norm_ff_macaron(x), already computed by the previous step.
+    Returns (layer output = norm_final(...), next_norm(layer output) or None)."""
+    L = plan.layer
+    B, T, C = x.shape
+    slot_dtype = torch.bfloat16 if plan.slot_bf16 else x.dtype
+    f = _ffn(L.feed_forward_macaron, h)
+    x, h, _ = hip_ops.add_layernorm(x, f, L.ff_scale, L.norm_mha.weight, L.norm_mha.bias, out_dtype=slot_dtype)
+    att = slot_forward(plan, h)
+    if att.dtype != x.dtype:
+        att = att.to(x.dtype)
+    masked = lens is not None
+    x, h, _ = hip_ops.add_layernorm(x, att, 1.0, L.norm_conv.weight, L.norm_conv.bias, zero_rows=masked, lens=lens, T=T)
+    cm = L.conv_module
+    p = F.linear(h, cm.pointwise_conv1.weight.squeeze(-1), cm.pointwise_conv1.bias)
+    dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, (cm.kernel_size - 1) // 2, T,
+                                     glu=True)
+    _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
+    c = F.linear(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias)
+    x, h, _ = hip_ops.add_layernorm(x, c, 1.0, L.norm_ff.weight, L.norm_ff.bias, lens=lens, T=T, mask_y=masked)
+    f = _ffn(L.feed_forward, h)
+    _, out, hn = hip_ops.add_layernorm(x, f, L.ff_scale, L.norm_final.weight, L.norm_final.bias, want_x=False,
+                                       gamma2=next_norm.weight if next_norm is not None else None,
+                                       beta2=next_norm.bias if next_norm is not None else None)
+    return out, hn
+
+
+class EncoderPlan:
+    def __init__(self, encoders: nn.ModuleList):
+        self.layers = [LayerPlan(l) for l in encoders]
+
+    def refresh(self):
+        for p in self.layers:
+            p.refresh()
+
+
+def encoder_layers_forward(plan: EncoderPlan, xs: torch.Tensor, masks: torch.Tensor, after_norm: Optional[nn.LayerNorm],
+                           want_layers: bool = False) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """The `for layer in self.encoders` loop of BaseEncoder.forward (+ after_norm), encoder.py:141-146.
+    masks: (B, 1, T') prefix masks from make_pad_mask, or a (0,0,0) fake mask (forward_chunk)."""
+    plan.refresh()
+    lens = masks.squeeze(1).sum(1).to(torch.int32) if masks.numel() > 0 else None
+    xs = xs.contiguous()
+    first = plan.layers[0].layer.norm_ff_macaron
+    _, h, _ = hip_ops.add_layernorm(xs, None, 1.0, first.weight, first.bias)
+    outs: List[torch.Tensor] = []
+    n = len(plan.layers)
+    for i, lp in enumerate(plan.layers):
+        nxt = plan.layers[i + 1].layer.norm_ff_macaron if i + 1 < n else after_norm
+        xs, h = layer_forward(lp, xs, h, lens, nxt)
+        if want_layers:
+            outs.append(xs)
+    if after_norm is not None:
+        xs = h
+    return xs, outs

@@ -151,7 +151,7 @@ def main():
              dict(spec=spec, seed=42, checksum=cs, conf=conf, ctc_spec=ctc_spec, ctc_seed=43, ctc_checksum=ctc_cs,
                   xs=xs, lens=lens, out=out, masks=masks, layer0=layer_outs[0], layer1=layer_outs[1],
                   chunk_x=xc, chunk_y=yc, att_cache_shape=tuple(att_cache.shape), cnn_cache_shape=tuple(cnn_cache.shape),
-                  logp_sample=logp[:, ::7, :].clone(), greedy=hyps, enc_lens=enc_lens))
+                  logp_sample=logp[:, ::7, :].clone(), logp_full=logp.clone(), greedy=hyps, enc_lens=enc_lens))
         print(variant, "greedy lens", [len(h) for h in hyps], "params", sum(p.numel() for p in enc.parameters()))
 
     # ---- closed-form initialisation of the time-mix parameters (src/model.py:232-260; no RNG involved) ----

@@ -1,0 +1,101 @@
+"""Fused inference executor (transformer/fused.py) and its glue kernels vs the op-by-op module path and fp32
+PyTorch references of the same ops.  GPU only."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import synth
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype,out_dtype", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                             (torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("C", [128, 512])
+def test_add_layernorm_matches_torch(hip, dtype, out_dtype, C):
+    from paper_accurate_fast_cheap_amd.hip_ops import add_layernorm
+    B, T = 3, 37
+    x = synth.randn((B, T, C), 1).to(dtype)
+    y = synth.randn((B, T, C), 2).to(dtype)
+    g1, b1, g2, b2 = (synth.randn((C,), s, 0.3).to(dtype) + (1 if s % 2 else 0) for s in (3, 4, 5, 6))
+    lens = torch.tensor([37, 20, 1], dtype=torch.int32)
+    keep = (torch.arange(T)[None, :] < lens[:, None]).unsqueeze(-1)
+    # op-by-op reference in the same dtype (what PyTorch would materialise), on CPU
+    xn = x + 0.5 * y.masked_fill(~keep, 0.0)
+    o1 = F.silu(F.layer_norm(xn, (C,), g1, b1, 1e-5).to(out_dtype)).masked_fill(~keep, 0.0)
+    o2 = F.layer_norm(o1.to(dtype), (C,), g2, b2, 1e-5).to(out_dtype)
+    gx, go1, go2 = add_layernorm(x.cuda(), y.cuda(), 0.5, g1.cuda(), b1.cuda(), out_dtype=out_dtype, silu=True,
+                                 zero_rows=True, lens=lens.cuda(), T=T, mask_y=True, gamma2=g2.cuda(), beta2=b2.cuda())
+    tol = dict(rtol=1e-4, atol=1e-5) if out_dtype == torch.float32 else dict(rtol=2 ** -7, atol=2 ** -7)
+    torch.testing.assert_close(gx.cpu().float(), xn.float(), rtol=1e-6 if dtype == torch.float32 else 2 ** -8, atol=1e-6)
+    torch.testing.assert_close(go1.cpu().float(), o1.float(), **tol)
+    torch.testing.assert_close(go2.cpu().float(), o2.float(), rtol=tol["rtol"] * 4, atol=tol["atol"] * 4)
+
+
+def test_add_layernorm_side_by_side_outputs(hip):
+    from paper_accurate_fast_cheap_amd.hip_ops import add_layernorm
+    M, C = 50, 128
+    ya, yb = synth.randn((M, C), 1), synth.randn((M, C), 2)
+    g, b = synth.randn((C,), 3) + 1, synth.randn((C,), 4)
+    cat = torch.zeros(M, 2 * C, device="cuda")
+    add_layernorm(ya.cuda(), None, 1.0, g.cuda(), b.cuda(), out1=cat[:, :C])
+    add_layernorm(yb.cuda(), None, 1.0, b.cuda(), g.cuda(), out1=cat[:, C:])
+    ref = torch.cat([F.layer_norm(ya, (C,), g, b), F.layer_norm(yb, (C,), b, g)], dim=1)
+    torch.testing.assert_close(cat.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_tmix_glue_matches_module_chain(hip, dtype):
+    """pafc_tmix_shift_mix / pafc_tmix_mix4 vs the reference's op chain (src/model.py:274-284) in the same dtype."""
+    from paper_accurate_fast_cheap_amd.hip_ops import tmix_mix4, tmix_shift_mix
+    B, T, C = 2, 19, 128
+    x = synth.randn((B, T, C), 1).to(dtype)
+    maa = [synth.randn((C,), 10 + i, 0.5).to(dtype) for i in range(2)]
+    maa4 = synth.randn((2, 4, C), 20, 0.5).to(dtype)
+    m = synth.randn((2, 4, B * T, C), 30, 0.3).to(dtype)
+    prev = [F.pad(x, (0, 0, 1, -1)), F.pad(x, (0, 0, -1, 1))]
+    got = tmix_shift_mix(x.cuda(), maa[0].cuda(), maa[1].cuda()).cpu()
+    z = tmix_mix4(x.cuda(), m.cuda(), maa4.cuda()).cpu()
+    # bf16: every intermediate is rounded where PyTorch rounds it -> bit-identical.  fp32: the compiler may
+    # contract x + xx * m into one fma (one rounding fewer than the op chain) -> 1 ulp
+    tol = dict(rtol=0, atol=0) if dtype == torch.bfloat16 else dict(rtol=1e-6, atol=1e-6)
+    for d in range(2):
+        xx = prev[d] - x
+        torch.testing.assert_close(got[d], x + xx * maa[d], **tol)
+        for q in range(4):
+            ref = x + xx * (maa4[d, q] + m[d, q].view(B, T, C))
+            torch.testing.assert_close(z[q, d].view(B, T, C), ref, **tol)
+    got1 = tmix_shift_mix(x.cuda(), maa[0].cuda(), None, reverse0=True).cpu()
+    torch.testing.assert_close(got1[0], x + (prev[1] - x) * maa[0], **tol)
+
+
+@pytest.mark.parametrize("variant", ["bf16slot", "f32", "uni_bf16slot", "uni_bf16model"])
+def test_fused_executor_equals_module_path(hip, variant):
+    """Same weights, same inputs: the fused executor against the op-by-op module path on the GPU (ragged batch)."""
+    from paper_accurate_fast_cheap_amd.transformer.cmvn import GlobalCMVN
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_reduced_" + variant)
+    enc = ConformerEncoder(80, global_cmvn=GlobalCMVN(torch.zeros(80), torch.ones(80)), **g["conf"])
+    enc.load_state_dict(synth.synth_state_dict(g["spec"], g["seed"]))
+    if variant == "uni_bf16model":
+        enc = enc.to(torch.bfloat16)
+    enc = enc.cuda().eval()
+    xs, lens = g["xs"].cuda(), g["lens"].cuda()
+    with torch.no_grad():
+        assert enc._fused(xs) is not None, "fused executor not eligible"
+        out_f, masks_f, layers_f = enc.forward_return_layers(xs, lens, want_layers=True)
+        yc_f, _, _ = enc.forward_chunk(g["chunk_x"].cuda(), 0, -1)
+        enc.fused_inference = False
+        out_p, masks_p, layers_p = enc.forward_return_layers(xs, lens, want_layers=True)
+        yc_p, _, _ = enc.forward_chunk(g["chunk_x"].cuda(), 0, -1)
+    assert torch.equal(masks_f, masks_p)
+    if variant == "f32":
+        tol = dict(rtol=1e-3, atol=1e-4)
+    elif variant == "uni_bf16model":
+        tol = dict(rtol=0.0, atol=0.4)
+    else:
+        tol = dict(rtol=0.0, atol=0.1)
+    for a, b in ((layers_f[0], layers_p[0]), (out_f, out_p), (yc_f, yc_p)):
+        torch.testing.assert_close(a.float(), b.float(), **tol)
+        assert float((a.float() - b.float()).abs().mean()) <= (1e-5 if variant == "f32" else 2e-2 if variant == "uni_bf16model" else 6e-3)
