@@ -45,16 +45,30 @@ def encoder_conf():
                 rnn_att_version="rwkv", rnn_att_direction="bi", rwkv_ctx_len=2048, rwkv_do_bfloat16=True)
 
 
-def synthetic_features(frames: int, seed: int, device) -> torch.Tensor:
-    """(1, frames, 80) log-mel-shaped features: band-limited noise under a slow amplitude envelope, so that the
-    CTC argmax is not constant.  (Synthetic 16 kHz audio -> fbank replaces this once the HIP fbank lands.)"""
+def synthetic_waveform(seconds: float, seed: int) -> torch.Tensor:
+    """(1, S) float32 in int16 range: seeded band-limited Gaussian noise under a slow amplitude envelope (so that
+    the CTC argmax is not constant), SURVEY.md 8(d) "Synthetic inputs"."""
+    S = int(seconds * 16000)
     g = torch.Generator(device="cpu").manual_seed(seed)
-    t = torch.arange(frames, dtype=torch.float32)
-    env = 1.0 + 0.8 * torch.sin(2 * math.pi * t / 700.0) * torch.sin(2 * math.pi * t / 9100.0)
-    x = torch.randn(frames, 80, generator=g)
-    x = (x + torch.roll(x, 1, 0) + torch.roll(x, 2, 0)) / math.sqrt(3.0)  # smooth along time
-    mel_tilt = torch.linspace(2.0, -2.0, 80)
-    return ((x * env[:, None]) * 2.0 + mel_tilt[None, :] + 8.0).unsqueeze(0).to(device)
+    x = torch.randn(S + 8, generator=g)
+    x = (x[:-8] + 2 * x[2:-6] + 3 * x[4:-4] + 2 * x[6:-2] + x[8:]) / 4.36   # low-pass FIR, unit variance
+    t = torch.arange(S, dtype=torch.float32)
+    env = 0.15 + 0.85 * (0.5 + 0.5 * torch.sin(2 * math.pi * t / (16000 * 3.1))) * (0.5 + 0.5 * torch.sin(2 * math.pi * t / (16000 * 41.0)))
+    return (x * env * 6000.0).round().clamp_(-32768, 32767).unsqueeze(0)
+
+
+def front_end(wave: torch.Tensor, device):
+    """HIP fbank of the whole file; returns ((1, T, 80) fp32 features on `device`, device milliseconds)."""
+    from paper_accurate_fast_cheap_amd.dataset.fbank import fbank
+    w = wave.to(device)
+    fbank(w, num_mel_bins=80)   # warm-up (tables, attributes)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    feats = fbank(w, num_mel_bins=80, frame_length=25.0, frame_shift=10.0, dither=0.0, energy_floor=0.0,
+                  sample_frequency=16000.0)
+    b.record()
+    torch.cuda.synchronize()
+    return feats.unsqueeze(0), a.elapsed_time(b)
 
 
 def windows(feats: torch.Tensor, chunk_size: int, batch_size: int):
@@ -141,8 +155,10 @@ def main():
 
     model, configs = build_model(args.dtype, device)
     conf = configs["encoder_conf"]
-    feats32 = synthetic_features(FRAMES, 777 + rank, "cpu")
-    feats = feats32.to(device)
+    wave = synthetic_waveform(AUDIO_SECONDS, 777 + rank)
+    feats, fbank_ms = front_end(wave, device)          # outside the timed region, as in encoder-rtf.py:347-353
+    assert feats.shape == (1, FRAMES, 80)
+    feats32 = feats.cpu()
     if args.dtype == "bf16":
         feats = feats.to(torch.bfloat16)
     batches = list(windows(feats, args.chunk_size, args.batch_size))   # resident in HBM before timing
@@ -200,13 +216,18 @@ def main():
         "value": round(value, 2), "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32+bf16-slot", "data": "synthetic",
-        "config": {"workload": "c3: 30-min synthetic file (179998 frames of 80-dim fbank-shaped features) per GPU, "
-                               + ("one sequence B=1" if args.chunk_size <= 0 else
+        "config": {"workload": "c3: 30-min synthetic 16 kHz file per GPU -> HIP fbank (179998 x 80, outside the timed "
+                               "region as in encoder-rtf.py) -> "
+                               + ("encoded as one sequence B=1" if args.chunk_size <= 0 else
                                   f"windows chunk_size={args.chunk_size} x batch {args.batch_size}")
                                + ", 12-layer bidirectional RWKV-v6 Conformer encoder (512d, 8x64 heads) + CTC(5000) "
                                  "log-softmax; random-init weights (seed 777)",
                    "frames_per_step": frames_per_step, "parallelism": f"dp{world} (independent files, no collective)"},
         "roofline": roofline,
+        "front_end": {"kernel": "fbank (HIP, fp32 MFMA DFT)", "ms_per_file": round(fbank_ms, 3),
+                      "audio_sec_per_sec": round(AUDIO_SECONDS / (fbank_ms * 1e-3), 1),
+                      "audio_sec_per_sec_encoder_plus_fbank": round(
+                          frames_per_step / 100.0 / (elapsed / args.steps + fbank_ms * 1e-3), 2)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, feats32, conf, min(args.cpu_sample_frames, FRAMES))

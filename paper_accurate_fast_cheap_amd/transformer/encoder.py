@@ -122,6 +122,28 @@ class BaseEncoder(torch.nn.Module):
             xs = self.after_norm(xs)
         return xs, torch.cat(r_att_cache, dim=0), torch.cat(r_cnn_cache, dim=0)
 
+    @torch.no_grad()
+    def forward_chunk_carry(self, xs: torch.Tensor, offset: int = 0, state: Optional[list] = None
+                            ) -> Tuple[torch.Tensor, list]:
+        """Streaming step with recurrent-state carry (BASELINE config c3 "recurrent-state carry, no KV cache").
+        xs: (B, time, F) input window -- windows overlap exactly as in forward_chunk_by_chunk (encoder.py:379-391,
+        window (chunk-1)*4+7, stride 4*chunk) because the subsampling convolutions keep no cache.  state: list of
+        per-layer carries from the previous call (None to start).  Uni-directional slot only; exact (chunked == full
+        sequence) when the conv module is causal, otherwise the conv sees zeros past the chunk edge like the
+        reference's forward_chunk does."""
+        masks = torch.ones(xs.size(0), 1, xs.size(1), device=xs.device, dtype=torch.bool)
+        if self.global_cmvn is not None:
+            xs = self.global_cmvn(xs)
+        xs, _, _ = self.embed(xs, masks, offset)
+        state = state or [None] * len(self.encoders)
+        new_state = []
+        for layer, carry in zip(self.encoders, state):
+            xs, c = layer.forward_carry(xs, carry)
+            new_state.append(c)
+        if self.normalize_before:
+            xs = self.after_norm(xs)
+        return xs, new_state
+
     def forward_chunk_by_chunk(self, xs: torch.Tensor, decoding_chunk_size: int, num_decoding_left_chunks: int = -1,
                                cat_embs: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """encoder.py:341-402: overlapping input windows of (chunk-1)*4+7 frames, stride 4*chunk."""

@@ -74,3 +74,33 @@ class ConformerEncoderLayer(nn.Module):
         if self.conv_module is not None:
             x = self.norm_final(x)
         return x, mask, new_att_cache, new_cnn_cache
+
+    def forward_carry(self, x: torch.Tensor, carry: Optional[dict]) -> Tuple[torch.Tensor, dict]:
+        """One chunk WITH recurrent-state carry (uni-directional slot only): what the reference's forward_chunk
+        lacks (its wrappers return `cache` untouched, rwkv_wrapper.py:81).  carry = {"shift": (B,1,C) last
+        normalised frame of the previous chunk, "wkv": float32 (B,H,N,N) scan state, "cnn": (B,C,lorder) causal-conv
+        left context} or None at the start of a stream.  With a causal conv module, chunked == full sequence."""
+        from ..rwkv_v6.rwkv_wrapper import RWKV_TmixWrapper
+        slot = self.self_attn
+        if type(slot) is not RWKV_TmixWrapper:
+            raise NotImplementedError("state carry is defined for the uni-directional slot (rwkv_tmix60)")
+        carry = carry or {}
+        if self.feed_forward_macaron is not None:
+            x = x + self.ff_scale * self.feed_forward_macaron(self.norm_ff_macaron(x))
+        h = self.norm_mha(x)
+        qd = h.dtype
+        if slot.do_bfloat16:
+            h = h.to(torch.bfloat16)
+        att, shift, wkv = slot.tmix_block.forward_state(h, carry.get("shift"), carry.get("wkv"))
+        x = x + att.to(qd)
+        new = {"shift": shift, "wkv": wkv}
+        if self.conv_module is not None:
+            empty_mask = torch.ones((0, 0, 0), dtype=torch.bool, device=x.device)
+            cnn = carry.get("cnn", torch.zeros((0, 0, 0), dtype=x.dtype, device=x.device))
+            c, new_cnn = self.conv_module(self.norm_conv(x), empty_mask, cnn)
+            x = x + c
+            new["cnn"] = new_cnn
+        x = x + self.ff_scale * self.feed_forward(self.norm_ff(x))
+        if self.conv_module is not None:
+            x = self.norm_final(x)
+        return x, new
