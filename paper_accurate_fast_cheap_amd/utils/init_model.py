@@ -4,8 +4,8 @@
 Reads the same config keys (cmvn, cmvn_conf, input_dim, output_dim, encoder, encoder_conf, ctc, ctc_conf,
 model, model_conf, tokenizer_conf, dataset_conf), honours args.checkpoint, and sets configs['init_infos'],
 ['num_seen_frames'], ['step'] and the model attributes lsl_enc / lsl_dec / add_cat_embs / cat_labels exactly like
-the reference (:242-268).  It builds encoder + CTC; `decoder`, `predictor`/`joint` sections of a reference YAML are
-accepted and skipped (a checkpoint's extra keys are ignored the way the reference's def_strict=False does, :243).
+the reference (:242-268).  It builds encoder + CTC (+ RNN predictor and joint for `model: transducer`); the `decoder` section of a reference
+YAML is accepted and skipped (a checkpoint's extra keys are ignored the way the reference's def_strict=False does, :243).
 """
 import logging
 
@@ -44,8 +44,20 @@ def init_model(args, configs):
         vocab_size, encoder.output_size(),
         blank_id=configs["ctc_conf"]["ctc_blank_id"] if "ctc_conf" in configs else 0)
     model_conf = dict(configs.get("model_conf", {}))
-    model = ASRModel(vocab_size=vocab_size, encoder=encoder, ctc=ctc,
-                     special_tokens=configs.get("tokenizer_conf", {}).get("special_tokens", None), **model_conf)
+    special = configs.get("tokenizer_conf", {}).get("special_tokens", None)
+    if configs.get("model", "asr_model") == "transducer" and "predictor_conf" in configs and "joint_conf" in configs:
+        # init_model.py:192-209: RNN predictor + joint around the same encoder / CTC (config c5)
+        from ..transducer.joint import TransducerJoint
+        from ..transducer.predictor import RNNPredictor
+        from ..transducer.transducer import Transducer
+        if configs.get("predictor", "rnn") != "rnn":
+            raise NotImplementedError("only the RNN predictor of the paper's configs is implemented")
+        predictor = RNNPredictor(vocab_size, **configs["predictor_conf"])
+        joint = TransducerJoint(vocab_size, **configs["joint_conf"])
+        model = Transducer(vocab_size=vocab_size, blank=0, encoder=encoder, predictor=predictor, joint=joint, ctc=ctc,
+                           special_tokens=special, **model_conf)
+    else:
+        model = ASRModel(vocab_size=vocab_size, encoder=encoder, ctc=ctc, special_tokens=special, **model_conf)
 
     if getattr(args, "checkpoint", None) is not None:
         infos = load_checkpoint(model, args.checkpoint, def_strict=False)

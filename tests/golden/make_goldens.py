@@ -154,6 +154,36 @@ def main():
                   logp_sample=logp[:, ::7, :].clone(), logp_full=logp.clone(), greedy=hyps, enc_lens=enc_lens))
         print(variant, "greedy lens", [len(h) for h in hyps], "params", sum(p.numel() for p in enc.parameters()))
 
+    # ---- config c5: CTC prefix beam search and the CTC-fused RNN-T prefix beam search ------------------------
+    from wenet.transformer.search import ctc_prefix_beam_search
+    from wenet.transducer.joint import TransducerJoint
+    from wenet.transducer.predictor import RNNPredictor
+    from wenet.transducer.search.prefix_beam_search import PrefixBeamSearch
+    V, D = 50, 128
+    enc_out = synth.randn((3, 37, D), 61)
+    enc_lens = torch.tensor([37, 30, 11])
+    ctc = CTC(V, D).eval()
+    ctc_spec, ctc_cs = load_synth(ctc, 62)
+    logp = ctc.log_softmax(enc_out)
+    cres = ctc_prefix_beam_search(logp, enc_lens, 8, None, 0)
+    pred = RNNPredictor(V, embed_size=64, output_size=64, embed_dropout=0.1, hidden_size=64, num_layers=2, bias=True,
+                        rnn_type="lstm", dropout=0.1).eval()
+    pred_spec, pred_cs = load_synth(pred, 63)
+    joint = TransducerJoint(V, enc_output_size=D, pred_output_size=64, join_dim=64, prejoin_linear=True,
+                            postjoin_linear=False, joint_mode="add", activation="tanh").eval()
+    joint_spec, joint_cs = load_synth(joint, 64)
+    bs = PrefixBeamSearch(None, pred, joint, ctc, 0)
+    tres = bs.prefix_beam_search_decode(enc_out, enc_lens, logp, beam_size=8, ctc_weight=0.3, transducer_weight=0.7)
+    jt = joint(enc_out[:, :5], pred(torch.tensor([[0, 3, 7], [0, 9, 9], [0, 1, 2]])))
+    save("search_c5", dict(
+        enc_out=enc_out, enc_lens=enc_lens, ctc_spec=ctc_spec, ctc_seed=62, ctc_checksum=ctc_cs, logp=logp,
+        pred_spec=pred_spec, pred_seed=63, joint_spec=joint_spec, joint_seed=64, joint_sample=jt,
+        ctc_prefix=[dict(tokens=list(r.tokens), score=r.score, nbest=[list(n) for n in r.nbest],
+                         nbest_scores=list(r.nbest_scores)) for r in cres],
+        rnnt=[dict(tokens=list(r.tokens), score=r.score, nbest=[list(n) for n in r.nbest],
+                   nbest_scores=list(r.nbest_scores)) for r in tres]))
+    print("c5 ctc prefix best", [len(r.tokens) for r in cres], "rnnt best", [len(r.tokens) for r in tres])
+
     # ---- closed-form initialisation of the time-mix parameters (src/model.py:232-260; no RNG involved) ----
     init = {}
     for layer_id in (0, 5, 11):
