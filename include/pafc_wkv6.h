@@ -54,6 +54,11 @@ enum { PAFC_F32 = 0, PAFC_BF16 = 1 };
 /* Library/ABI version, bumped when a signature changes. */
 int pafc_abi_version(void);
 
+/* Hardware self-check of the in-row lane exchanges the matrix-core kernel relies on (DPP control codes): writes,
+ * for x = lane + 1, 12 results per lane [xor1, xor2, xor4, xor8, up1, up2, up4, up8, dn1, dn2, dn4, dn8] into
+ * out_64x12 (device, 768 floats); tests compare them with the definitions. */
+int pafc_selftest_lane_ops(float *out_64x12, pafc_stream_t stream);
+
 /* ---- workspace sizing -------------------------------------------------------------------- */
 /* Chunk length the library would pick for this shape (fills the 256 CUs; returns T when the
  * B*H*ndir sequences alone already do, in which case no workspace is needed). */

@@ -13,6 +13,7 @@
 // global loads are issued before the current tile is consumed.  y goes back through LDS so that it is
 // also stored 16 B per lane.  The bonus term sum_j r u k is a per-step wave reduction, which takes u out
 // of the inner loop: 3 VALU ops per (j, i, t).
+#include <stdlib.h>
 #include "pafc_common.h"
 #include "../../include/pafc_wkv6.h"
 
@@ -21,6 +22,7 @@ namespace {
 
 constexpr int N = 64;   // head size
 constexpr int TT = 8;   // time steps per LDS tile
+constexpr int CHUNK_ALIGN = 16;  // chunk lengths are multiples of the MFMA kernel's block (and of TT)
 
 struct DirArgs {
     const void *r, *k, *v, *w, *u;
@@ -256,6 +258,8 @@ __global__ __launch_bounds__(256) void wkv6_scan_kernel(const FwdParams p) {
     if (D.s_out) D.s_out[sidx] = run;  // only reached with nc_local == NC
 }
 
+#include "wkv6_mfma.inc"
+
 int pick_chunk_len(int B, int T, int H, int ndir) {
     const long seqs = (long)B * H * ndir;
     const long target_waves = 2048;  // 256 CUs x 4 SIMDs x 2 waves
@@ -263,7 +267,7 @@ int pick_chunk_len(int B, int T, int H, int ndir) {
     long nc = (target_waves + seqs - 1) / seqs;
     long L = (T + nc - 1) / nc;
     if (L < 64) L = 64;                      // below this the 64 KB of state traffic per chunk dominates
-    L = (L + TT - 1) / TT * TT;
+    L = (L + CHUNK_ALIGN - 1) / CHUNK_ALIGN * CHUNK_ALIGN;
     return L >= T ? T : (int)L;
 }
 
@@ -273,18 +277,27 @@ size_t ws_bytes(int B, int T, int H, int ndir, int L) {
     return sizeof(float) * (size_t)ndir * B * H * NC * (N * N + N);
 }
 
+// PAFC_WKV6_IMPL=valu selects the register/LDS formulation (wkv6_chunk_kernel); default is the matrix-core one.
+// Read per call (no global state); only meant for A/B measurements and tests.
+bool use_mfma() {
+    const char *e = getenv("PAFC_WKV6_IMPL");
+    return !(e && e[0] == 'v');
+}
+
 template <typename ET>
 int launch_fwd(FwdParams &p, int ndir, bool any_final, hipStream_t stream) {
-    const dim3 grid_bh(1, p.B * p.H, ndir);
+    const bool mfma = use_mfma();
     if (p.NC > 1) {
         p.nc_local = any_final ? p.NC : p.NC - 1;
         dim3 ga(p.nc_local, p.B * p.H, ndir);
-        hipLaunchKernelGGL((wkv6_chunk_kernel<ET, false>), ga, dim3(64), 0, stream, p);
+        if (mfma) hipLaunchKernelGGL((wkv6_mfma_kernel<ET, false>), ga, dim3(64), 0, stream, p);
+        else hipLaunchKernelGGL((wkv6_chunk_kernel<ET, false>), ga, dim3(64), 0, stream, p);
         dim3 gb(16, p.B * p.H, ndir);
         hipLaunchKernelGGL(wkv6_scan_kernel, gb, dim3(256), 0, stream, p);
     }
     dim3 gc(p.NC, p.B * p.H, ndir);
-    hipLaunchKernelGGL((wkv6_chunk_kernel<ET, true>), gc, dim3(64), 0, stream, p);
+    if (mfma) hipLaunchKernelGGL((wkv6_mfma_kernel<ET, true>), gc, dim3(64), 0, stream, p);
+    else hipLaunchKernelGGL((wkv6_chunk_kernel<ET, true>), gc, dim3(64), 0, stream, p);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 
@@ -302,7 +315,7 @@ int forward_impl(int dtype, int B, int T, int C, int H, int ndir, const DirArgs 
     }
     int L = chunk_len > 0 ? chunk_len : pick_chunk_len(B, T, H, ndir);
     if (workspace == nullptr) L = T;
-    if (L < T) L = (L + TT - 1) / TT * TT;
+    if (L < T) L = (L + CHUNK_ALIGN - 1) / CHUNK_ALIGN * CHUNK_ALIGN;
     if (L >= T) L = T;
     FwdParams p{};
     for (int d = 0; d < ndir; ++d) p.d[d] = dirs[d];
@@ -527,7 +540,7 @@ size_t bwd_ws_bytes(int B, int T, int C, int H, int L) {
 
 int bwd_chunk_len(int B, int T, int H, int chunk_len) {
     int L = chunk_len > 0 ? chunk_len : pick_chunk_len(B, T, H, 2);
-    if (L < T) L = (L + TT - 1) / TT * TT;
+    if (L < T) L = (L + CHUNK_ALIGN - 1) / CHUNK_ALIGN * CHUNK_ALIGN;
     return L >= T ? T : L;
 }
 
@@ -578,6 +591,12 @@ extern "C" {
 
 int pafc_abi_version(void) { return 1; }
 
+int pafc_selftest_lane_ops(float *out_64x12, pafc_stream_t stream) {
+    if (!out_64x12) return PAFC_ERR_NULL_POINTER;
+    hipLaunchKernelGGL(pafc::lane_ops_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_64x12);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
 int pafc_wkv6_pick_chunk_len(int B, int T, int C, int H, int ndir) {
     if (B <= 0 || T <= 0 || H <= 0 || ndir <= 0) return 0;
     (void)C;
@@ -588,7 +607,7 @@ size_t pafc_wkv6_fwd_workspace_bytes(int B, int T, int C, int H, int ndir, int c
     if (B <= 0 || T <= 0 || H <= 0 || ndir <= 0) return 0;
     (void)C;
     int L = chunk_len > 0 ? chunk_len : pafc::pick_chunk_len(B, T, H, ndir);
-    if (L < T) L = (L + pafc::TT - 1) / pafc::TT * pafc::TT;
+    if (L < T) L = (L + pafc::CHUNK_ALIGN - 1) / pafc::CHUNK_ALIGN * pafc::CHUNK_ALIGN;
     return pafc::ws_bytes(B, T, H, ndir, L);
 }
 

@@ -54,9 +54,14 @@ class ConvolutionModule(nn.Module):
             new_cache = torch.zeros((0, 0, 0), dtype=x.dtype, device=x.device)
         x = F.linear(x, self.pointwise_conv1.weight.squeeze(-1), self.pointwise_conv1.bias)
         x = F.glu(x, dim=-1)
-        x = depthwise_conv1d_cl(x, self.depthwise_conv.weight, self.depthwise_conv.bias,
-                                left_pad=0 if self.lorder > 0 else (self.kernel_size - 1) // 2,
-                                out_len=x.size(1) - self.lorder if self.lorder > 0 else x.size(1))
+        if torch.is_grad_enabled() and (x.requires_grad or self.depthwise_conv.weight.requires_grad):
+            # training: the channels-last kernel is forward-only, autograd goes through the library convolution
+            x = self.depthwise_conv._conv_forward(x.transpose(1, 2), self.depthwise_conv.weight,
+                                                  self.depthwise_conv.bias).transpose(1, 2)
+        else:
+            x = depthwise_conv1d_cl(x, self.depthwise_conv.weight, self.depthwise_conv.bias,
+                                    left_pad=0 if self.lorder > 0 else (self.kernel_size - 1) // 2,
+                                    out_len=x.size(1) - self.lorder if self.lorder > 0 else x.size(1))
         if self.use_layer_norm:
             x = self.activation(self.norm(x))
         else:

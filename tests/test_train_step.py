@@ -1,0 +1,170 @@
+"""Config c4: the training step.  GPU: autograd through the HIP WKV backward inside the whole encoder equals the CPU
+oracle's gradients.  CPU (gloo, 2 ranks): the DDP step semantics -- averaged gradients equal the single-process
+gradients of the concatenated batch, clipping, skip-on-nonfinite."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle import encoder_oracle as EO
+from oracle import wkv6_oracle as WO
+from tests import synth
+from tests.conftest import ROOT, load_golden
+
+
+_ORIG_FORWARD = WO.forward
+
+
+class _OracleWKV(torch.autograd.Function):
+    """Autograd wrapper around the C restatement (forward wkv6_cuda.cu:8-63, backward :65-263) for reference grads."""
+
+    @staticmethod
+    def forward(ctx, r, k, v, w, u):
+        ctx.save_for_backward(r, k, v, w, u)
+        return _ORIG_FORWARD(r.contiguous(), k.contiguous(), v.contiguous(), w.contiguous(), u.contiguous())
+
+    @staticmethod
+    def backward(ctx, gy):
+        r, k, v, w, u = ctx.saved_tensors
+        return WO.backward(r.contiguous(), k.contiguous(), v.contiguous(), w.contiguous(), u.contiguous(), gy.contiguous())
+
+
+@pytest.mark.gpu
+def test_encoder_ctc_gradients_match_oracle(hip, monkeypatch):
+    from paper_accurate_fast_cheap_amd.transformer.asr_model import ASRModel
+    from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_reduced_f32")
+    conf = dict(g["conf"], dropout_rate=0.0, positional_dropout_rate=0.0)
+    sd = {k: v for k, v in synth.synth_state_dict(g["spec"], g["seed"]).items() if not k.startswith("global_cmvn")}
+    csd = synth.synth_state_dict(g["ctc_spec"], g["ctc_seed"])
+    xs = synth.randn((2, 83, 80), 5, 2.0)
+    lens = torch.tensor([83, 61])
+    ys = torch.tensor([[3, 7, 7, 9, 1], [4, 2, 8, 0, 0]])
+    ylens = torch.tensor([5, 3])
+
+    # reference gradients on CPU: oracle graph with autograd through the C backward
+    leaves = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    cleaves = {"ctc." + k: v.clone().requires_grad_() for k, v in csd.items()}
+    monkeypatch.setattr(EO.wkv6_oracle, "forward", lambda r, k, v, w, u: _OracleWKV.apply(r, k, v, w, u))
+    out, masks = EO.encoder_forward(xs, lens, leaves, conf, env={})
+    logp = EO.ctc_log_softmax(out, cleaves).transpose(0, 1)
+    enc_lens = masks.squeeze(1).sum(1)
+    ref_loss = torch.nn.functional.ctc_loss(logp, ys, enc_lens, ylens, blank=0, reduction="sum", zero_infinity=True) / 2
+    ref_loss.backward()
+
+    enc = ConformerEncoder(80, **conf)
+    enc.load_state_dict(sd)
+    ctc = CTC(50, 128)
+    ctc.load_state_dict(csd)
+    model = ASRModel(50, enc, ctc).cuda().train()
+    batch = {"feats": xs, "feats_lengths": lens, "target": ys, "target_lengths": ylens}
+    loss = model(batch, torch.device("cuda"))["loss"]
+    loss.backward()
+    assert float(loss) == pytest.approx(float(ref_loss), rel=1e-4)
+    checked = 0
+    for name, p in model.encoder.named_parameters():
+        rg = leaves[name].grad
+        assert p.grad is not None, name
+        scale = max(float(rg.abs().max()), 1e-3)
+        err = float((p.grad.cpu() - rg).abs().max())
+        assert err <= 2e-3 * scale, f"{name}: {err:.3e} vs scale {scale:.3e}"
+        checked += 1
+    assert checked == len(list(model.encoder.parameters())) and checked > 100
+
+
+@pytest.mark.gpu
+def test_train_step_updates_and_skips_nonfinite(hip):
+    from paper_accurate_fast_cheap_amd.utils.init_model import init_model
+    from paper_accurate_fast_cheap_amd.utils.train_utils import train_step
+    g = load_golden("encoder_reduced_f32")   # fp32 slot parameters: an Adam step of 1e-4 is below bf16 resolution
+    cfg = dict(encoder="conformer", encoder_conf=dict(g["conf"]), input_dim=80, output_dim=50, ctc="ctc",
+               ctc_conf={"ctc_blank_id": 0}, model_conf={}, dataset_conf={})
+
+    class A:
+        checkpoint = None
+    torch.manual_seed(3)
+    model, _ = init_model(A(), cfg)
+    model = model.cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    batch = {"feats": synth.randn((4, 120, 80), 1, 2.0), "feats_lengths": torch.tensor([120, 100, 90, 64]),
+             "target": torch.randint(1, 50, (4, 6), generator=torch.Generator().manual_seed(2)),
+             "target_lengths": torch.tensor([6, 5, 4, 3])}
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    info = train_step(model, batch, opt, torch.device("cuda"), grad_clip=0.1)
+    assert info["updated"] and torch.isfinite(info["loss"]) and torch.isfinite(info["grad_norm"])
+    same = [n for n, p in model.named_parameters() if torch.equal(before[n], p.detach())]
+    # the LoRA output matrices see tanh(x @ 0) = 0 at the reference's init (src/model.py:244,251): zero gradient;
+    # time_maa_* start at 1 - (i/C)^p with entries exactly 1.0 / near 1 where an Adam step of 1e-4 can round away
+    assert all(n.endswith(("time_maa_rkvw_w2", "time_decay_w2")) or ".time_maa_" in n for n in same), same
+    for d in ("rwkv_wrapper_forward", "rwkv_wrapper_backward"):      # both directions of the slot are trained
+        assert not any(d in n and n.endswith(("receptance.weight", "time_faaaa", "time_decay")) for n in same)
+    bad = dict(batch, feats=batch["feats"] * float("nan"))
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    info = train_step(model, bad, opt, torch.device("cuda"), grad_clip=0.1)
+    assert not info["updated"]
+    assert all(torch.equal(before[n], p.detach()) for n, p in model.named_parameters())
+
+
+_DDP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["PAFC_ROOT"])
+from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+from paper_accurate_fast_cheap_amd.transformer.positionwise_feed_forward import PositionwiseFeedForward
+from paper_accurate_fast_cheap_amd.utils.train_utils import train_step, wrap_model_ddp, reduce_seen_frames
+
+class Tiny(torch.nn.Module):          # the CPU-runnable tail of the path: FFN + CTC head (the WKV slot is GPU-only)
+    def __init__(self):
+        super().__init__()
+        self.ff = PositionwiseFeedForward(16, 32, 0.0, torch.nn.SiLU())
+        self.ctc = CTC(11, 16)
+    def forward(self, batch, device):
+        h = self.ff(batch["feats"])
+        loss, _ = self.ctc(h, batch["feats_lengths"], batch["target"], batch["target_lengths"])
+        return {"loss": loss}
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(0)
+ref = Tiny()
+model = Tiny(); model.load_state_dict(ref.state_dict())
+ddp = wrap_model_ddp(model)
+g = torch.Generator().manual_seed(1)
+feats = torch.randn(4, 12, 16, generator=g); lens = torch.tensor([12, 10, 9, 7])
+tgt = torch.randint(1, 11, (4, 3), generator=g); tl = torch.tensor([3, 2, 3, 1])
+sl = slice(rank * 2, rank * 2 + 2)
+batch = {"feats": feats[sl], "feats_lengths": lens[sl], "target": tgt[sl], "target_lengths": tl[sl]}
+opt = torch.optim.SGD(ddp.parameters(), lr=0.0)      # lr 0: look at the gradients themselves
+ddp.train(); out = ddp(batch, torch.device("cpu")); out["loss"].backward()
+# single-process reference: mean over ranks of per-rank (sum / B_rank) losses
+tot = 0.0
+for r in range(world):
+    s2 = slice(r * 2, r * 2 + 2)
+    tot = tot + ref({"feats": feats[s2], "feats_lengths": lens[s2], "target": tgt[s2], "target_lengths": tl[s2]}, None)["loss"]
+(tot / world).backward()
+for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+    assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6), n
+opt.zero_grad()
+info = train_step(ddp, batch, torch.optim.Adam(ddp.parameters(), lr=1e-3), torch.device("cpu"), grad_clip=0.1)
+assert info["updated"] and float(info["grad_norm"]) > 0
+w = [p.detach().clone() for p in model.parameters()]
+flat = torch.cat([x.flatten() for x in w]); gathered = [torch.empty_like(flat) for _ in range(world)]
+dist.all_gather(gathered, flat)
+assert all(torch.equal(gathered[0], t) for t in gathered)      # replicas stay identical after the step
+assert reduce_seen_frames(int(lens[sl].sum()), torch.device("cpu")) == (int(lens.sum()) if rank == 0 else int(lens[sl].sum()))
+if rank == 0: print("DDP_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_ddp_step(tmp_path):
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(_DDP_WORKER)
+    env = dict(os.environ, PAFC_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29627", str(script)],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "DDP_OK" in out.stdout

@@ -135,3 +135,40 @@ def test_backward_reverse_direction_and_autograd(hip):
     ref_f = WO.backward(*a, gy)
     for leaf, rf in zip(leaves, ref_f):
         torch.testing.assert_close(leaf.grad.cpu(), rf, rtol=1e-3, atol=2e-4 * max(1.0, float(rf.abs().max())))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_matrix_core_and_valu_kernels_agree(hip, dtype, monkeypatch):
+    """The two formulations of the chunk kernel (PAFC_WKV6_IMPL=valu / default matrix-core) on the same inputs,
+    ragged T (tail block), strong decays included."""
+    from paper_accurate_fast_cheap_amd.rwkv_v6.wkv6_op import wkv6_forward
+    a = _inputs(2, 333, 128, 2, 4242, dtype, wshift=-1.0)
+    g = [t.cuda() for t in a]
+    y_m, s_m = wkv6_forward(*g, want_state=True, chunk_len=48)
+    monkeypatch.setenv("PAFC_WKV6_IMPL", "valu")
+    y_v, s_v = wkv6_forward(*g, want_state=True, chunk_len=48)
+    ref, s_ref = WO.forward(*a, want_state=True)
+    torch.testing.assert_close(y_m.float(), y_v.float(), **_tol(dtype))
+    torch.testing.assert_close(y_m.cpu().float(), ref.float(), **_tol(dtype))
+    torch.testing.assert_close(s_m.cpu(), s_ref, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(s_v.cpu(), s_ref, rtol=1e-3, atol=1e-4)
+
+
+def test_lane_ops_selftest(hip):
+    """The in-row lane exchanges of the matrix-core kernel (DPP control codes) do what their names say."""
+    import ctypes
+    out = torch.zeros(64, 12, device="cuda")
+    hip.pafc_selftest_lane_ops.restype = ctypes.c_int
+    rc = hip.pafc_selftest_lane_ops(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    o = out.cpu()
+    for lane in range(64):
+        t = lane & 15
+        x = lambda l: float(l + 1)
+        exp = [x(lane ^ 1), x(lane ^ 2), x(lane ^ 4), x(lane ^ 8),
+               1.0 if t & 1 else x(lane + 1), 1.0 if t & 2 else x(lane + 2), 1.0 if t & 4 else x(lane + 4),
+               1.0 if t & 8 else x(lane + 8),
+               x(lane - 1) if t & 1 else 1.0, x(lane - 2) if t & 2 else 1.0, x(lane - 4) if t & 4 else 1.0,
+               x(lane - 8) if t & 8 else 1.0]
+        assert o[lane].tolist() == exp, (lane, o[lane].tolist(), exp)
