@@ -97,6 +97,14 @@ int pafc_wkv6_forward_bidir(int dtype, int B, int T, int C, int H, const void *r
                             const void *u_b, void *y_b, int chunk_len, void *workspace,
                             size_t workspace_bytes, pafc_stream_t stream);
 
+/* As above with the decay bias fused: the scan uses w + wb (rounded to the element type, as the reference's
+ * `self.time_decay + lora` does, src/model.py:289), wb_f / wb_b: (H, N) or NULL.  Saves one (B,T,C) pass per direction. */
+int pafc_wkv6_forward_bidir_wbias(int dtype, int B, int T, int C, int H, const void *r_f, const void *k_f,
+                                  const void *v_f, const void *w_f, const void *u_f, const void *wb_f, void *y_f,
+                                  const void *r_b, const void *k_b, const void *v_b, const void *w_b, const void *u_b,
+                                  const void *wb_b, void *y_b, int chunk_len, void *workspace, size_t workspace_bytes,
+                                  pafc_stream_t stream);
+
 /* ---- backward ---------------------------------------------------------------------------- */
 /* Replaces torch.ops.wkv6.backward / backward_fp32 (wkv6_op.cpp:12-14,21-23; kernel_backward_101/102/103/201
  * wkv6_cuda.cu:65-263).  gu is the (B, C) per-batch partial.  reverse as above. */

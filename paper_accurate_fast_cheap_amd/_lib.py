@@ -50,6 +50,7 @@ def lib():
     _sig(L.pafc_wkv6_forward_f32, I, I, I, I, I, P, P, P, P, P, P, I, P, Z, P)
     _sig(L.pafc_wkv6_forward_state, I, I, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, Z, P)
     _sig(L.pafc_wkv6_forward_bidir, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, I, P, Z, P)
+    _sig(L.pafc_wkv6_forward_bidir_wbias, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, P, Z, P)
     _sig(L.pafc_wkv6_bwd_workspace_bytes, Z, I, I, I, I, I)
     _sig(L.pafc_wkv6_backward, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, I, I, P, Z, P)
     _lib = L

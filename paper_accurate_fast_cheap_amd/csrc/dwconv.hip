@@ -13,7 +13,7 @@ namespace pafc {
 namespace {
 
 constexpr int KMAX = 31;
-constexpr int TO = 32;  // output frames per lane
+constexpr int TO = 16;  // output frames per lane
 
 template <typename ET> struct Pair;
 template <> struct Pair<float> {
@@ -58,19 +58,28 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int T_in, int C, int left_p
 #pragma unroll
     for (int o = 0; o < TO; ++o) { a0[o] = bv.x; a1[o] = bv.y; }
 
-    // input rows s = t0 - left_pad + q, q in [0, TO + K - 1); row q feeds output o with tap k = q - o
+    // input rows s = t0 - left_pad + q, q in [0, TO + K - 1); row q feeds output o with tap k = q - o.
+    // All rows are fetched first, branch-free (clamped address + select), so that the loads are in flight
+    // together instead of one exposed HBM round trip per row; then the taps are applied from registers.
+    constexpr int NR = TO + K - 1;
+    float2 in[NR];
+    float2 gate[GLU ? NR : 1];
 #pragma unroll
-    for (int q = 0; q < TO + K - 1; ++q) {
+    for (int q = 0; q < NR; ++q) {
         const int s = t0 - left_pad + q;
-        float2 v = make_float2(0.f, 0.f);
-        if (s >= 0 && s < valid) {
-            v = Pair<ET>::load(xb + (size_t)s * xc + c);
-            if (GLU) {
-                const float2 g = Pair<ET>::load(xb + (size_t)s * xc + C + c);
-                v.x = Pair<ET>::round(v.x * sigmoidf_(g.x));  // torch computes glu in float, one rounding
-                v.y = Pair<ET>::round(v.y * sigmoidf_(g.y));
-            }
+        const int sc = min(max(s, 0), T_in - 1);
+        in[q] = Pair<ET>::load(xb + (size_t)sc * xc + c);
+        if (GLU) gate[q] = Pair<ET>::load(xb + (size_t)sc * xc + C + c);
+    }
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const int s = t0 - left_pad + q;
+        float2 v = in[q];
+        if (GLU) {
+            v.x = Pair<ET>::round(v.x * sigmoidf_(gate[q].x));  // torch computes glu in float, one rounding
+            v.y = Pair<ET>::round(v.y * sigmoidf_(gate[q].y));
         }
+        if (!(s >= 0 && s < valid)) v = make_float2(0.f, 0.f);
 #pragma unroll
         for (int o = 0; o < TO; ++o) {
             const int k = q - o;

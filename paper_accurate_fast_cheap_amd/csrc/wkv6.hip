@@ -30,6 +30,7 @@ struct DirArgs {
     const float *s_in;
     float *s_out;
     int reverse;
+    const void *wb;   // optional per-channel bias added to w (time_decay), (H * N) in the element type, or null
 };
 
 struct FwdParams {
@@ -147,6 +148,10 @@ __global__ __launch_bounds__(64, WRITE_Y ? 3 : 4) void wkv6_chunk_kernel(const F
             for (int e = 0; e < G::EPL; e += 4)
                 *reinterpret_cast<float4 *>(&s_v[tt][col + e]) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
             E::unpack(nw[q], f);
+            if (D.wb != nullptr) {
+#pragma unroll
+                for (int e = 0; e < G::EPL; ++e) f[e] = E::round(f[e] + E::load((const ET *)D.wb + h * N + col + e));
+            }
 #pragma unroll
             for (int e = 0; e < G::EPL; ++e) f[e] = __expf(-__expf(f[e]));
 #pragma unroll
@@ -555,8 +560,8 @@ int launch_bwd(int B, int T, int C, int H, const void *r, const void *k, const v
     float *ws_decay = ws_state + 2 * (size_t)B * H * NC * (N * N);
     // dir 0: S from (k, v, w) in forward time; dir 1: G from (r, gy, w) in reverse time, whose pass C is gv
     FwdParams fp{};
-    fp.d[0] = DirArgs{k, k, v, w, u, gv, nullptr, nullptr, rev};            // r, y unused by pass A
-    fp.d[1] = DirArgs{k, r, gy, w, u, gv, nullptr, nullptr, 1 - rev};       // forward kernel with r<->k, v := gy
+    fp.d[0] = DirArgs{k, k, v, w, u, gv, nullptr, nullptr, rev, nullptr};            // r, y unused by pass A
+    fp.d[1] = DirArgs{k, r, gy, w, u, gv, nullptr, nullptr, 1 - rev, nullptr};       // forward kernel with r<->k, v := gy
     fp.B = B; fp.T = T; fp.C = C; fp.H = H; fp.L = L; fp.NC = NC;
     fp.nc_local = NC - 1;
     fp.ws_state = ws_state; fp.ws_decay = ws_decay;
@@ -614,7 +619,7 @@ size_t pafc_wkv6_fwd_workspace_bytes(int B, int T, int C, int H, int ndir, int c
 int pafc_wkv6_forward_state(int dtype, int B, int T, int C, int H, const void *r, const void *k, const void *v,
                             const void *w, const void *u, void *y, const float *s_in, float *s_out, int reverse,
                             int chunk_len, void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
-    DirArgs d{r, k, v, w, u, y, s_in, s_out, reverse ? 1 : 0};
+    DirArgs d{r, k, v, w, u, y, s_in, s_out, reverse ? 1 : 0, nullptr};
     return pafc::forward_impl(dtype, B, T, C, H, 1, &d, chunk_len, workspace, workspace_bytes, stream);
 }
 
@@ -632,11 +637,26 @@ int pafc_wkv6_forward_f32(int B, int T, int C, int H, const void *r, const void 
                                    workspace_bytes, stream);
 }
 
+int pafc_wkv6_forward_bidir_wbias(int dtype, int B, int T, int C, int H, const void *r_f, const void *k_f,
+                                  const void *v_f, const void *w_f, const void *u_f, const void *wb_f, void *y_f,
+                                  const void *r_b, const void *k_b, const void *v_b, const void *w_b, const void *u_b,
+                                  const void *wb_b, void *y_b, int chunk_len, void *workspace, size_t workspace_bytes,
+                                  pafc_stream_t stream);
+
 int pafc_wkv6_forward_bidir(int dtype, int B, int T, int C, int H, const void *r_f, const void *k_f, const void *v_f,
                             const void *w_f, const void *u_f, void *y_f, const void *r_b, const void *k_b,
                             const void *v_b, const void *w_b, const void *u_b, void *y_b, int chunk_len,
                             void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
-    DirArgs d[2] = {{r_f, k_f, v_f, w_f, u_f, y_f, nullptr, nullptr, 0}, {r_b, k_b, v_b, w_b, u_b, y_b, nullptr, nullptr, 1}};
+    return pafc_wkv6_forward_bidir_wbias(dtype, B, T, C, H, r_f, k_f, v_f, w_f, u_f, nullptr, y_f, r_b, k_b, v_b, w_b,
+                                         u_b, nullptr, y_b, chunk_len, workspace, workspace_bytes, stream);
+}
+
+int pafc_wkv6_forward_bidir_wbias(int dtype, int B, int T, int C, int H, const void *r_f, const void *k_f,
+                                  const void *v_f, const void *w_f, const void *u_f, const void *wb_f, void *y_f,
+                                  const void *r_b, const void *k_b, const void *v_b, const void *w_b, const void *u_b,
+                                  const void *wb_b, void *y_b, int chunk_len, void *workspace, size_t workspace_bytes,
+                                  pafc_stream_t stream) {
+    DirArgs d[2] = {{r_f, k_f, v_f, w_f, u_f, y_f, nullptr, nullptr, 0, wb_f}, {r_b, k_b, v_b, w_b, u_b, y_b, nullptr, nullptr, 1, wb_b}};
     return pafc::forward_impl(dtype, B, T, C, H, 2, d, chunk_len, workspace, workspace_bytes, stream);
 }
 

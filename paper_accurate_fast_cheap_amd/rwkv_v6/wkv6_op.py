@@ -62,7 +62,8 @@ def wkv6_forward(r, k, v, w, u, *, reverse: bool = False, s_in: Optional[torch.T
     return (y, s_out) if want_state else y
 
 
-def wkv6_forward_bidir(fwd: Tuple[torch.Tensor, ...], bwd: Tuple[torch.Tensor, ...], *, chunk_len: int = 0):
+def wkv6_forward_bidir(fwd: Tuple[torch.Tensor, ...], bwd: Tuple[torch.Tensor, ...], *, chunk_len: int = 0,
+                       w_bias: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """Both directions of the bidirectional wrapper in one launch.
 
     fwd / bwd = (r, k, v, w, u) produced by the left-to-right / right-to-left parameter sets on the SAME,
@@ -78,11 +79,13 @@ def wkv6_forward_bidir(fwd: Tuple[torch.Tensor, ...], bwd: Tuple[torch.Tensor, .
     yf, yb = torch.empty_like(rf), torch.empty_like(rb)
     ws, nbytes = _workspace(B, T, C, H, 2, chunk_len, rf.device)
     P = _lib.ptr
+    wbf, wbb = w_bias if w_bias is not None else (None, None)   # (H*N,) each: time_decay, added to w in-kernel
+    _lib.require_gpu(wbf, wbb)
     with op_timer("wkv6_fwd_bidir", B=B, T=T, C=C, elem_bytes=rf.element_size(), ndir=2):
-        rc = _lib.lib().pafc_wkv6_forward_bidir(code, B, T, C, H, P(rf), P(kf), P(vf), P(wf), P(uf), P(yf),
-                                                P(rb), P(kb), P(vb), P(wb), P(ub), P(yb),
-                                                chunk_len, P(ws), nbytes, _lib.stream_of(rf))
-    _lib.check(rc, "pafc_wkv6_forward_bidir")
+        rc = _lib.lib().pafc_wkv6_forward_bidir_wbias(code, B, T, C, H, P(rf), P(kf), P(vf), P(wf), P(uf), P(wbf), P(yf),
+                                                      P(rb), P(kb), P(vb), P(wb), P(ub), P(wbb), P(yb),
+                                                      chunk_len, P(ws), nbytes, _lib.stream_of(rf))
+    _lib.check(rc, "pafc_wkv6_forward_bidir_wbias")
     return yf, yb
 
 

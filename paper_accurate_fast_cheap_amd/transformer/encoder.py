@@ -197,6 +197,8 @@ class ConformerEncoder(BaseEncoder):
         # encoder.py:545-561: (head_size, dim_att, num_blocks, version, direction, ctx_len, do_bfloat16) + layer_id
         slot_args = (output_size // attention_heads, output_size, num_blocks, rnn_att_version, rnn_att_direction,
                      rwkv_ctx_len, rwkv_do_bfloat16)
+        if selfattention_layer_type == "mamba_att":   # encoder.py:563-569
+            slot_args = (output_size // attention_heads, output_size, num_blocks, rnn_att_version, rnn_att_direction)
         ff_args = (output_size, linear_units, dropout_rate, activation)
         conv_args = (output_size, cnn_module_kernel, activation, cnn_module_norm, causal)
         self.encoders = torch.nn.ModuleList([

@@ -94,12 +94,15 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor) -> torch.Tensor:
         torch.bmm(t[d].view(M, 4, -1).transpose(0, 1), plan.W2[d], out=m[d])
     z = hip_ops.tmix_mix4(h, m, plan.maa4)                                                  # (4, nd, M, C)
     rkv = torch.bmm(z[:3].view(3 * nd, M, C), plan.Wrkv)                                    # (3nd, M, C)
-    w = torch.baddbmm(plan.time_decay, torch.tanh(torch.bmm(z[3], plan.D1)), plan.D2)       # (nd, M, C)
+    w = torch.bmm(torch.tanh(torch.bmm(z[3], plan.D1)), plan.D2)                            # (nd, M, C) decay LoRA
+    if nd == 1:
+        w = w + plan.time_decay            # uni: one extra pass; bi: time_decay is added inside the scan kernel
     ycat = torch.empty((M, nd * C), dtype=h.dtype, device=h.device)
     if nd == 2:
         ys = wkv6_forward_bidir(
             (rkv[0].view(B, T, C), rkv[2].view(B, T, C), rkv[4].view(B, T, C), w[0].view(B, T, C), plan.u[0]),
-            (rkv[1].view(B, T, C), rkv[3].view(B, T, C), rkv[5].view(B, T, C), w[1].view(B, T, C), plan.u[1]))
+            (rkv[1].view(B, T, C), rkv[3].view(B, T, C), rkv[5].view(B, T, C), w[1].view(B, T, C), plan.u[1]),
+            w_bias=(plan.time_decay[0].view(-1), plan.time_decay[1].view(-1)))
     else:
         ys = (wkv6_forward(rkv[0].view(B, T, C), rkv[1].view(B, T, C), rkv[2].view(B, T, C), w[0].view(B, T, C),
                            plan.u[0]),)

@@ -1,0 +1,123 @@
+"""Mamba-2 in the attention slot (registry key `mamba_att`).
+
+Reference: wenet/transformer/mamba_att_wrapper.py:6-52 and wenet/transformer/mamba2_bidirectional.py:38-145, which
+only ADAPT the third-party `mamba_ssm.modules.mamba2.Mamba2` (Rev fork, unpinned: requirements.txt:32, path.sh:10;
++ causal-conv1d >= 1.4.0): constructed as Mamba(dim_att, headdim=head_size) with every other argument at its default
+(d_state 128, d_conv 4, expand 2, ngroups 1, rmsnorm, norm_before_gate False, conv_bias True, bias False, chunk 256).
+The package is absent from the reference tree and from this image -> *** parity unpinned ***: what follows restates
+the PUBLISHED Mamba-2 block (Dao & Gu 2024, "Transformers are SSMs", and mamba_ssm 2.x's module layout, whose
+parameter names it keeps so that `self_attn.mamba[.mamba_forward|.mamba_backward].*` checkpoints have a home):
+
+    z, xBC, dt = split(in_proj(u));  xBC = silu(causal_depthwise_conv1d_k4(xBC));  x, B, C = split(xBC)
+    dt = softplus(dt + dt_bias);  a_t = exp(dt_t A),  A = -exp(A_log)                       (scalar per head)
+    h_t = a_t h_{t-1} + dt_t B_t (x) x_t ;  y_t = C_t . h_t + D x_t                          (state 64 x 128 per head)
+    out = out_proj( RMSNorm(y * silu(z)) * norm.weight )
+
+The selective scan runs on the SAME chunked gfx950 scan kernel as RWKV-6: with S_t := a_t h_{t-1} the recurrence is
+S_{t+1} = a_{t+1} S_t + (a_{t+1} B_t)(dt_t x_t)^T and y_t = C_t . S_t + (C_t . B_t) dt_t x_t, i.e. WKV-6 with
+r = C, k = a_{t+1} B, v = dt x, per-head scalar decay, no bonus (u = 0); d_state 128 is two 64-wide halves."""
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..rwkv_v6.wkv6_op import wkv6_forward
+
+_EMPTY_CACHE = torch.zeros((0, 0, 0, 0))
+
+
+class RMSNormGated(nn.Module):
+    def __init__(self, d: int, eps: float = 1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(d))
+
+    def forward(self, x: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+        x = (x * F.silu(z)).float()          # norm_before_gate = False: gate first
+        x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.eps)
+        return (x * self.weight.float()).to(z.dtype)
+
+
+class Mamba2(nn.Module):
+    def __init__(self, d_model: int, d_state: int = 128, d_conv: int = 4, expand: int = 2, headdim: int = 64,
+                 ngroups: int = 1, A_init_range=(1, 16), dt_min: float = 0.001, dt_max: float = 0.1,
+                 dt_init_floor: float = 1e-4, bias: bool = False, conv_bias: bool = True, chunk_size: int = 256):
+        super().__init__()
+        if headdim != 64 or d_state % 64 or ngroups != 1:
+            raise NotImplementedError("scan kernel: headdim 64, d_state a multiple of 64, ngroups 1 (the paper's config)")
+        self.d_model, self.d_state, self.d_conv, self.headdim, self.ngroups = d_model, d_state, d_conv, headdim, ngroups
+        self.d_inner = expand * d_model
+        self.nheads = self.d_inner // headdim
+        d_in_proj = 2 * self.d_inner + 2 * ngroups * d_state + self.nheads
+        self.in_proj = nn.Linear(d_model, d_in_proj, bias=bias)
+        conv_dim = self.d_inner + 2 * ngroups * d_state
+        self.conv1d = nn.Conv1d(conv_dim, conv_dim, d_conv, groups=conv_dim, padding=d_conv - 1, bias=conv_bias)
+        dt = torch.exp(torch.rand(self.nheads) * (math.log(dt_max) - math.log(dt_min)) + math.log(dt_min))
+        dt = torch.clamp(dt, min=dt_init_floor)
+        self.dt_bias = nn.Parameter(dt + torch.log(-torch.expm1(-dt)))      # inverse softplus
+        self.A_log = nn.Parameter(torch.log(torch.empty(self.nheads).uniform_(*A_init_range)))
+        self.D = nn.Parameter(torch.ones(self.nheads))
+        self.norm = RMSNormGated(self.d_inner, eps=1e-5)
+        self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias)
+
+    def forward(self, u: torch.Tensor) -> torch.Tensor:
+        Bsz, L, _ = u.shape
+        H, P, N = self.nheads, self.headdim, self.d_state
+        zxbcdt = self.in_proj(u)
+        z, xBC, dt = torch.split(zxbcdt, [self.d_inner, self.d_inner + 2 * N, H], dim=-1)
+        xBC = F.silu(self.conv1d(xBC.transpose(1, 2))[..., :L].transpose(1, 2))        # causal: keep the first L
+        x, Bm, Cm = torch.split(xBC, [self.d_inner, N, N], dim=-1)
+        dt = F.softplus(dt.float() + self.dt_bias.float())                            # (B, L, H)
+        A = -torch.exp(self.A_log.float())                                             # (H,)
+        logdec = dt * A                                                                # log a_t  (< 0)
+        # shifted decay a_{t+1}; the last step's value never reaches an output
+        nxt = torch.cat([logdec[:, 1:], torch.zeros_like(logdec[:, :1])], dim=1)       # (B, L, H)
+        a_next = torch.exp(nxt)
+        w = torch.log((-nxt).clamp_min(1e-30))                                         # exp(-exp(w)) = a_{t+1}
+        xf = x.float().view(Bsz, L, H, P)
+        v = (xf * dt.unsqueeze(-1)).reshape(Bsz, L, H * P).contiguous()                # dt_t x_t
+        wk = w.unsqueeze(-1).expand(Bsz, L, H, 64).reshape(Bsz, L, H * 64).contiguous()
+        u0 = torch.zeros(H, 64, dtype=torch.float32, device=u.device)
+        y = torch.zeros(Bsz, L, H * P, dtype=torch.float32, device=u.device)
+        for half in range(N // 64):
+            Bh = Bm[..., half * 64:(half + 1) * 64].float()                            # (B, L, 64) shared by all heads
+            Ch = Cm[..., half * 64:(half + 1) * 64].float()
+            k = (a_next.unsqueeze(-1) * Bh.unsqueeze(2)).reshape(Bsz, L, H * 64).contiguous()
+            r = Ch.unsqueeze(2).expand(Bsz, L, H, 64).reshape(Bsz, L, H * 64).contiguous()
+            y = y + wkv6_forward(r, k, v, wk, u0)
+            y = y + ((Bh * Ch).sum(-1, keepdim=True).unsqueeze(-1) * v.view(Bsz, L, H, P)).reshape(Bsz, L, H * P)
+        y = y + (xf * self.D.float().view(1, 1, H, 1)).reshape(Bsz, L, H * P)
+        y = self.norm(y.to(z.dtype), z)
+        return self.out_proj(y)
+
+
+class Mamba2Bidirectional(nn.Module):
+    """mamba2_bidirectional.py:38-145: (Mamba2_f(u) + flip(Mamba2_b(flip(u)))) / 2."""
+
+    def __init__(self, d_model: int, headdim: int = 32, **kw):
+        super().__init__()
+        self.mamba_forward = Mamba2(d_model, headdim=headdim, **kw)
+        self.mamba_backward = Mamba2(d_model, headdim=headdim, **kw)
+
+    def forward(self, u: torch.Tensor) -> torch.Tensor:
+        out_b = torch.flip(self.mamba_backward(torch.flip(u, [1])), [1])
+        return (self.mamba_forward(u) + out_b) / 2
+
+
+class MambaAttWrapper(nn.Module):
+    """mamba_att_wrapper.py:6-52: same MHA-shaped forward as the RWKV wrappers; `cache` handed back untouched."""
+
+    def __init__(self, head_size: int, dim_att: int, num_blocks: int, rnn_att_version: str = "mamba2",
+                 rnn_att_direction: str = "bi", layer_id: int = 1):
+        super().__init__()
+        self.head_size, self.dim_att, self.num_blocks = head_size, dim_att, num_blocks
+        self.rnn_att_version, self.rnn_att_direction, self.layer_id = rnn_att_version, rnn_att_direction, layer_id
+        if rnn_att_version != "mamba2":
+            raise NotImplementedError("only rnn_att_version: mamba2 (the paper's conf/mamba YAMLs)")
+        self.mamba = (Mamba2Bidirectional if rnn_att_direction == "bi" else Mamba2)(dim_att, headdim=head_size)
+
+    def forward(self, query: torch.Tensor, key=None, value=None, mask=None, pos_emb=None,
+                cache: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self.mamba(query), (cache if cache is not None else _EMPTY_CACHE.to(query.device))

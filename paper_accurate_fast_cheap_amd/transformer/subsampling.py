@@ -48,7 +48,8 @@ class Conv2dSubsampling4(BaseSubsampling):
             self._w_c2 = c2.weight.detach().contiguous(memory_format=torch.channels_last)
             self._nhwc_stamp = stamp
         p = x.unsqueeze(1).unfold(2, 3, 2).unfold(3, 3, 2).reshape(B, T1 * F1, 9)
-        y = F.relu(F.linear(p, c1.weight.view(C, 9), c1.bias))                # (B, T1*F1, C)
+        # relu(bias + p W^T) in one GEMM epilogue: the conv1 output is the largest tensor of the whole pass
+        y = torch._addmm_activation(c1.bias, p.view(B * T1 * F1, 9), c1.weight.view(C, 9).t(), use_gelu=False)
         y = y.view(B, T1, F1, C).permute(0, 3, 1, 2)                            # NCHW view of NHWC memory
         y = F.relu(F.conv2d(y, self._w_c2, c2.bias, stride=2))
         b, c, t, f = y.shape

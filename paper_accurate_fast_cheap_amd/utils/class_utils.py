@@ -10,6 +10,7 @@ from ..rwkv_v6.rwkv_wrapper import RWKV_TmixWrapper
 from ..rwkv_v6.rwkv_wrapper_bidirectional import RWKV_TmixWrapper_bidirectional
 from ..rwkv_v6.rwkv_wrapper_bidirectional_direction_dropout import (
     RWKV_TmixWrapper_bidirectional_direction_dropout, RWKV_TmixWrapper_bidirectional_direction_dropout_both)
+from ..transformer.mamba2 import MambaAttWrapper
 from ..transformer.embedding import NoPositionalEncoding, PositionalEncoding, RelPositionalEncoding
 from ..transformer.subsampling import Conv2dSubsampling4, LinearNoSubsampling
 
@@ -40,6 +41,7 @@ WENET_ATTENTION_CLASSES = {
     "rwkv_tmix60_bidirectional2": RWKV_TmixWrapper_bidirectional,  # same arithmetic (bidirectional2.py:95-150)
     "rwkv_tmix60_dir_layer_drop": RWKV_TmixWrapper_bidirectional_direction_dropout,
     "rwkv_tmix60_dir_layer_drop_both": RWKV_TmixWrapper_bidirectional_direction_dropout_both,
+    "mamba_att": MambaAttWrapper,   # Mamba-2 on the same scan kernel; arithmetic third-party -> parity unpinned
 }
 
 
