@@ -144,6 +144,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.workload == "c2":
+        # ~90 distinct (B, T) shapes: MIOpen's default exhaustive per-shape search costs seconds each; the
+        # immediate-mode heuristic is the production setting for ragged batches
+        os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -51,7 +51,7 @@ def test_state_carry(hip, dtype, chunk):
     y1, s1 = wkv6_forward(*(cut(t, 0, 61) for t in g[:4]), g[4], want_state=True, chunk_len=chunk)
     y2, s2 = wkv6_forward(*(cut(t, 61, T) for t in g[:4]), g[4], s_in=s1, want_state=True, chunk_len=chunk)
     torch.testing.assert_close(torch.cat([y1, y2], 1).float(), y.float(), **_tol(dtype))
-    torch.testing.assert_close(s2, s, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(s2, s, rtol=1e-3, atol=1e-4)   # state update runs on 16-bit split bf16 MFMA operands
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
