@@ -203,3 +203,44 @@ def test_state_carry_chunked_equals_full(hip, dtype):
     ys = torch.cat(outs, 1)
     assert ys.shape == full.shape
     torch.testing.assert_close(ys, full, rtol=1e-3, atol=2e-4)
+
+
+def test_minimal_and_ragged_edge_inputs(hip):
+    """Shortest input the subsampling accepts (7 frames -> T' = 1), a batch whose shortest member is that short, and
+    lengths that are not multiples of anything: fused executor == module path, masks exact, outputs finite."""
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_reduced_f32")
+    sd = {k: v for k, v in _sd(g).items() if not k.startswith("global_cmvn")}
+    enc = ConformerEncoder(80, **g["conf"])
+    enc.load_state_dict(sd)
+    enc = enc.cuda().eval()
+    for xs, lens in ((synth.randn((1, 7, 80), 1), torch.tensor([7])),
+                     (synth.randn((3, 45, 80), 2), torch.tensor([45, 7, 23]))):
+        ref, ref_masks = EO.encoder_forward(xs, lens, sd, g["conf"], env={})
+        with torch.no_grad():
+            out, masks = enc(xs.cuda(), lens.cuda())
+        assert torch.equal(masks.cpu(), ref_masks) and torch.isfinite(out).all()
+        _assert_close(out, ref, False, "edge")
+
+
+def test_full_size_encoder_properties(hip):
+    """BASELINE sizes (12 layers x 512, bf16 model, 5-minute and 30-minute files): the fused executor agrees with
+    the op-by-op module path on the 5-minute file (bf16 tolerance), and the 30-minute single-sequence pass (T' =
+    44 998, the bench workload) is finite with the expected shape."""
+    import bench
+    model, configs = bench.build_model("bf16", torch.device("cuda"))
+    enc = model.encoder
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x5 = (torch.randn(1, 30000, 80, device="cuda", generator=g) * 2 + 8).to(torch.bfloat16)
+    lens5 = torch.tensor([30000], device="cuda")
+    with torch.no_grad():
+        a, ma = enc(x5, lens5)
+        enc.fused_inference = False
+        b, mb = enc(x5, lens5)
+        enc.fused_inference = True
+        assert a.shape == (1, 7499, 512) and torch.equal(ma, mb)
+        d = (a.float() - b.float()).abs()
+        assert float(d.mean()) < 2e-2 and float(d.max()) < 0.6, (float(d.mean()), float(d.max()))
+        x30 = (torch.randn(1, 179998, 80, device="cuda", generator=g) * 2 + 8).to(torch.bfloat16)
+        out, m = enc(x30, torch.tensor([179998], device="cuda"))
+        assert out.shape == (1, 44998, 512) and int(m.sum()) == 44998 and bool(torch.isfinite(out).all())
