@@ -58,6 +58,21 @@ int pafc_tmix_shift_mix(int dtype, int B, int T, int C, int ndir, int reverse0, 
 int pafc_tmix_mix4(int dtype, int B, int T, int C, int ndir, int reverse0, const void *x, const void *m,
                    const void *maa, void *z, pafc_stream_t stream);
 
+/* pafc_tmix_mix4 with the LoRA up-projection fused in (bf16): m_q = bf16(t[:, 32q:32q+32] . W2[q]) is computed on the
+ * matrix cores inside the pass, so the 4 x ndir LoRA maps never touch HBM (the K = 32 `torch.bmm` of src/model.py:278).
+ * t: (ndir, B*T, 128) = tanh(xxx W1); w2t: (ndir, 4, C, 32) = time_maa_rkvw_w2 with K innermost. C % 32 == 0. */
+int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const void *x, const void *t, const void *w2t,
+                             const void *maa, void *z, pafc_stream_t stream);
+
+/* out (rows, N) = act(x (rows, K) . weight (N, K)^T + bias (N)) as one hipBLASLt GEMM with a fused epilogue; act 0 =
+ * identity, 1 = SiLU.  Replaces `activation(w_1(x))` of PositionwiseFeedForward.forward
+ * (wenet/transformer/positionwise_feed_forward.py:47-55): the separate SiLU pass over the (rows, 2048) hidden tensor
+ * disappears and bias + SiLU see the fp32 accumulator (one rounding instead of two).  workspace: caller-owned,
+ * pafc_linear_act_workspace_bytes() bytes are always enough.  A library GEMM, not a hand-written kernel. */
+size_t pafc_linear_act_workspace_bytes(void);
+int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, const void *weight, const void *bias,
+                         void *out, int act, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

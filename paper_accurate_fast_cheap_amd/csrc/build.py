@@ -21,7 +21,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-Wa
 
 
 def sources():
-    return sorted(glob.glob(os.path.join(HERE, "*.hip")))
+    return sorted(glob.glob(os.path.join(HERE, "*.hip"))) + sorted(glob.glob(os.path.join(HERE, "*.cpp")))
 
 
 def stale():
@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", OUT + ".tmp"] + sources()
+    cmd = [hipcc] + FLAGS + ["-o", OUT + ".tmp"] + sources() + ["-L/opt/rocm/lib", "-lhipblaslt", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

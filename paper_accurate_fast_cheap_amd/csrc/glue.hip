@@ -217,6 +217,64 @@ __global__ __launch_bounds__(256) void tmix_mix4_kernel(int T, int C, long rows,
     }
 }
 
+// LoRA up-projection + the four lerps in one pass (bf16):
+//   m_q = bf16( tanh(xxx W1)[:, 32q:32q+32] . W2[q] )   (src/model.py:277-278, a K = 32 batched GEMM in the reference)
+//   z_q = x + xx * (maa_q + m_q)                         (src/model.py:280-284)
+// The K = 32 product is exactly one v_mfma_f32_16x16x32_bf16 per 16x16 tile, so the (rows, C) x 4 x ndir LoRA maps
+// are never written to or read from HBM (368 MB per layer at the 30-minute shape).  One wave = 16 time rows x all
+// columns; the MFMA is issued with M = output column, N = time row, so each lane ends up with 4 consecutive columns
+// of ITS row per MFMA and, with the column slots of two MFMAs interleaved, 8 = one 16-byte store.
+//   x: (rows, C); t: (ndir, rows, 128); w2t: (ndir, 4, C, 32) (W2 with K innermost); maa: (ndir, 4, C); z: (4, ndir, rows, C)
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8g __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long rows, int ndir, int rev0,
+                                                             const bf16_t *__restrict__ x, const bf16_t *__restrict__ t,
+                                                             const bf16_t *__restrict__ w2t,
+                                                             const bf16_t *__restrict__ maa, bf16_t *__restrict__ z) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, qq = lane >> 4;
+    const long row = ((long)blockIdx.x * 4 + wave) * 16 + r16;
+    const long rowc = row < rows ? row : rows - 1;     // clamp (every lane takes part in the MFMAs), skip the store
+    const int tt = (int)(rowc % T);
+    const f32x4g zero = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < ndir; ++d) {
+        const bool rev = (d == 0) ? (rev0 != 0) : true;
+        const bool has_nb = rev ? (tt < T - 1) : (tt > 0);
+        const long nb = rev ? rowc + 1 : rowc - 1;
+        uint4 tb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            tb[q] = *reinterpret_cast<const uint4 *>(t + ((size_t)d * rows + rowc) * 128 + 32 * q + 8 * qq);
+        for (int cb = 0; cb < C / 32; ++cb) {
+            const int col = cb * 32 + 8 * qq;                       // this lane's 8 output columns
+            const int colA = cb * 32 + 8 * (r16 >> 2) + (r16 & 3);  // column whose W2 row this lane feeds (slot r16)
+            float xc[VEC], xn[VEC], xx[VEC];
+            load8<bf16_t>(x + rowc * C + col, xc);
+            load8<bf16_t>(x + (has_nb ? nb : rowc) * C + col, xn);   // branch-free: select after the load
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) xx[e] = round_bf16((has_nb ? xn[e] : 0.f) - xc[e]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf16_t *wq = w2t + ((size_t)(d * 4 + q) * C) * 32 + 8 * qq;
+                const uint4 a1 = *reinterpret_cast<const uint4 *>(wq + (size_t)colA * 32);
+                const uint4 a2 = *reinterpret_cast<const uint4 *>(wq + (size_t)(colA + 4) * 32);
+                const f32x4g m1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8g, a1),
+                                                                         __builtin_bit_cast(bf16x8g, tb[q]), zero, 0, 0, 0);
+                const f32x4g m2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8g, a2),
+                                                                         __builtin_bit_cast(bf16x8g, tb[q]), zero, 0, 0, 0);
+                float av[VEC], o[VEC];
+                load8<bf16_t>(maa + ((size_t)d * 4 + q) * C + col, av);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float mv = round_bf16(e < 4 ? m1[e] : m2[e - 4]);
+                    o[e] = round_bf16(xc[e] + round_bf16(xx[e] * round_bf16(av[e] + mv)));
+                }
+                if (row < rows) store8<bf16_t>(z + (((size_t)q * ndir + d) * rows + row) * C + col, o);
+            }
+        }
+    }
+}
+
 template <typename EX>
 int launch_ln(int dtype_out, const LnArgs &a, hipStream_t s) {
     dim3 grid((a.rows + 3) / 4), block(256);
@@ -288,6 +346,19 @@ int pafc_tmix_mix4(int dtype, int B, int T, int C, int ndir, int reverse0, const
                            (const float *)x, (const float *)m, (const float *)maa, (float *)z);
     else
         return PAFC_ERR_DTYPE;
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+
+int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const void *x, const void *t, const void *w2t,
+                             const void *maa, void *z, pafc_stream_t stream) {
+    if (!x || !t || !w2t || !maa || !z) return PAFC_ERR_NULL_POINTER;
+    if (B <= 0 || T <= 0 || C <= 0 || C % 32 || ndir < 1 || ndir > 2) return PAFC_ERR_BAD_DIMS;
+    const long rows = (long)B * T;
+    dim3 grid((unsigned)((rows + 63) / 64)), block(256);
+    hipLaunchKernelGGL(pafc::tmix_lora_mix4_kernel, grid, block, 0, (hipStream_t)stream, T, C, rows, ndir, reverse0,
+                       (const pafc::bf16_t *)x, (const pafc::bf16_t *)t, (const pafc::bf16_t *)w2t,
+                       (const pafc::bf16_t *)maa, (pafc::bf16_t *)z);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 

@@ -46,6 +46,7 @@ def _bind2():
               c_float, P)
     _lib._sig(L.pafc_tmix_shift_mix, I, I, I, I, I, I, P, P, P, P, P)
     _lib._sig(L.pafc_tmix_mix4, I, I, I, I, I, I, P, P, P, P, P)
+    _lib._sig(L.pafc_tmix_lora_mix4_bf16, I, I, I, I, I, I, P, P, P, P, P, P)
     L._pafc_glue_bound = True
     return L
 
@@ -102,4 +103,45 @@ def tmix_mix4(x: torch.Tensor, m: torch.Tensor, maa: torch.Tensor, reverse0: boo
     rc = _bind2().pafc_tmix_mix4(_lib.dtype_code(x.dtype), B, T, C, ndir, int(reverse0), _lib.ptr(x), _lib.ptr(m),
                                  _lib.ptr(maa), _lib.ptr(z), _lib.stream_of(x))
     _lib.check(rc, "pafc_tmix_mix4")
+    return z
+
+
+_gemm_ws = {}
+
+
+def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: str = "silu"):
+    """act(x @ weight.T + bias) as one hipBLASLt GEMM with fused epilogue (act: 'silu' or 'none')."""
+    _lib.require_gpu(x, weight, bias)
+    L = _bind2()
+    if not getattr(L, "_pafc_gemm_bound", False):
+        from ctypes import c_long, c_size_t
+        _lib._sig(L.pafc_linear_act_workspace_bytes, c_size_t)
+        _lib._sig(L.pafc_linear_bias_act, c_int, c_int, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                  c_void_p, c_size_t, c_void_p)
+        L._pafc_gemm_bound = True
+    N, K = weight.shape
+    rows = x.numel() // K
+    if x.shape[-1] != K or weight.dtype != x.dtype:
+        raise _lib.PafcError("linear_bias_act: shape/dtype mismatch")
+    ws = _gemm_ws.get(x.device)
+    if ws is None:
+        ws = _gemm_ws[x.device] = torch.empty(L.pafc_linear_act_workspace_bytes(), dtype=torch.uint8, device=x.device)
+    out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+    rc = L.pafc_linear_bias_act(_lib.dtype_code(x.dtype), rows, N, K, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias),
+                                _lib.ptr(out), 1 if act == "silu" else 0, _lib.ptr(ws), ws.numel(), _lib.stream_of(x))
+    _lib.check(rc, "pafc_linear_bias_act")
+    return out
+
+
+def tmix_lora_mix4(x: torch.Tensor, t: torch.Tensor, w2t: torch.Tensor, maa: torch.Tensor, reverse0: bool = False):
+    """bf16: x (B,T,C), t (ndir,B*T,128) = tanh(xxx W1), w2t (ndir,4,C,32), maa (ndir,4,C) -> z (4,ndir,B*T,C)."""
+    _lib.require_gpu(x, t, w2t, maa)
+    B, T, C = x.shape
+    ndir = t.shape[0]
+    if x.dtype != torch.bfloat16 or t.shape != (ndir, B * T, 128) or w2t.shape != (ndir, 4, C, 32):
+        raise _lib.PafcError("tmix_lora_mix4: bf16 only, t (ndir, B*T, 128), w2t (ndir, 4, C, 32)")
+    z = torch.empty((4, ndir, B * T, C), dtype=x.dtype, device=x.device)
+    rc = _bind2().pafc_tmix_lora_mix4_bf16(B, T, C, ndir, int(reverse0), _lib.ptr(x), _lib.ptr(t), _lib.ptr(w2t),
+                                           _lib.ptr(maa), _lib.ptr(z), _lib.stream_of(x))
+    _lib.check(rc, "pafc_tmix_lora_mix4_bf16")
     return z

@@ -52,6 +52,7 @@ class LayerPlan:
             self.maa_x = [b.time_maa_x.reshape(-1).contiguous() for b in bl]
             self.W1 = torch.stack([b.time_maa_rkvw_w1 for b in bl]).contiguous()           # (nd, C, 128)
             self.W2 = [b.time_maa_rkvw_w2.contiguous() for b in bl]                        # (4, 32, C) each
+            self.W2t = torch.stack([b.time_maa_rkvw_w2.transpose(1, 2) for b in bl]).contiguous()  # (nd, 4, C, 32)
             self.maa4 = torch.stack([torch.stack([b.time_maa_r.reshape(-1), b.time_maa_k.reshape(-1),
                                                   b.time_maa_v.reshape(-1), b.time_maa_w.reshape(-1)])
                                      for b in bl]).contiguous()                             # (nd, 4, C)
@@ -80,7 +81,8 @@ def eligible(layer: nn.Module) -> bool:
 
 
 def _ffn(ff: nn.Module, h: torch.Tensor) -> torch.Tensor:
-    return F.linear(F.silu(F.linear(h, ff.w_1.weight, ff.w_1.bias)), ff.w_2.weight, ff.w_2.bias)
+    # w_1 + bias + SiLU is one GEMM with a fused epilogue (no separate pass over the (rows, 2048) hidden tensor)
+    return F.linear(hip_ops.linear_bias_act(h, ff.w_1.weight, ff.w_1.bias, "silu"), ff.w_2.weight, ff.w_2.bias)
 
 
 def slot_forward(plan: LayerPlan, h: torch.Tensor) -> torch.Tensor:
@@ -89,10 +91,13 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor) -> torch.Tensor:
     M, nd = B * T, plan.ndir
     xxx = hip_ops.tmix_shift_mix(h, plan.maa_x[0], plan.maa_x[1] if nd == 2 else None)
     t = torch.tanh(torch.bmm(xxx.view(nd, M, C), plan.W1))                                  # (nd, M, 128)
-    m = torch.empty((nd, 4, M, C), dtype=h.dtype, device=h.device)
-    for d in range(nd):
-        torch.bmm(t[d].view(M, 4, -1).transpose(0, 1), plan.W2[d], out=m[d])
-    z = hip_ops.tmix_mix4(h, m, plan.maa4)                                                  # (4, nd, M, C)
+    if h.dtype == torch.bfloat16 and t.shape[-1] == 128 and C % 32 == 0:
+        z = hip_ops.tmix_lora_mix4(h, t, plan.W2t, plan.maa4)      # LoRA up-projection on MFMA inside the lerp pass
+    else:
+        m = torch.empty((nd, 4, M, C), dtype=h.dtype, device=h.device)
+        for d in range(nd):
+            torch.bmm(t[d].view(M, 4, -1).transpose(0, 1), plan.W2[d], out=m[d])
+        z = hip_ops.tmix_mix4(h, m, plan.maa4)                                              # (4, nd, M, C)
     rkv = torch.bmm(z[:3].view(3 * nd, M, C), plan.Wrkv)                                    # (3nd, M, C)
     w = torch.bmm(torch.tanh(torch.bmm(z[3], plan.D1)), plan.D2)                            # (nd, M, C) decay LoRA
     if nd == 1:

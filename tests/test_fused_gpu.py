@@ -99,3 +99,33 @@ def test_fused_executor_equals_module_path(hip, variant):
     for a, b in ((layers_f[0], layers_p[0]), (out_f, out_p), (yc_f, yc_p)):
         torch.testing.assert_close(a.float(), b.float(), **tol)
         assert float((a.float() - b.float()).abs().mean()) <= (1e-5 if variant == "f32" else 2e-2 if variant == "uni_bf16model" else 6e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_linear_bias_silu_epilogue(hip, dtype):
+    from paper_accurate_fast_cheap_amd.hip_ops import linear_bias_act
+    x = synth.randn((3, 41, 128), 1).to(dtype)
+    w = synth.randn((256, 128), 2, 0.1).to(dtype)
+    b = synth.randn((256,), 3, 0.2).to(dtype)
+    ref = F.silu(F.linear(x.float(), w.float(), b.float()))
+    got = linear_bias_act(x.cuda(), w.cuda(), b.cuda(), "silu").cpu()
+    got_id = linear_bias_act(x.cuda(), w.cuda(), b.cuda(), "none").cpu()
+    tol = dict(rtol=2 ** -7, atol=1e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(got.float(), ref, **tol)
+    torch.testing.assert_close(got_id.float(), F.linear(x.float(), w.float(), b.float()), **tol)
+
+
+def test_lora_mix4_fused_equals_two_step(hip):
+    """pafc_tmix_lora_mix4_bf16 (LoRA up-projection on MFMA inside the lerp pass) vs bmm + pafc_tmix_mix4."""
+    from paper_accurate_fast_cheap_amd.hip_ops import tmix_lora_mix4, tmix_mix4
+    B, T, C, nd = 2, 37, 128, 2
+    x = synth.randn((B, T, C), 1).bfloat16().cuda()
+    t = torch.tanh(synth.randn((nd, B * T, 128), 2)).bfloat16().cuda()
+    w2 = (synth.randn((nd, 4, 32, C), 3) * 0.2).bfloat16().cuda()
+    maa = synth.randn((nd, 4, C), 4, 0.5).bfloat16().cuda()
+    m = torch.stack([torch.bmm(t[d].view(B * T, 4, 32).transpose(0, 1), w2[d]) for d in range(nd)])   # (nd,4,M,C)
+    ref = tmix_mix4(x, m.contiguous(), maa)
+    got = tmix_lora_mix4(x, t, w2.transpose(2, 3).contiguous(), maa)
+    # identical op chain; the only freedom is the K = 32 summation order inside the MFMA vs the library GEMM
+    torch.testing.assert_close(got.float(), ref.float(), rtol=2 ** -7, atol=2 ** -7)
+    assert float((got.float() - ref.float()).abs().mean()) < 1e-3
