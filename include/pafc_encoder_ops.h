@@ -60,7 +60,7 @@ int pafc_tmix_mix4(int dtype, int B, int T, int C, int ndir, int reverse0, const
 
 /* pafc_tmix_mix4 with the LoRA up-projection fused in (bf16): m_q = bf16(t[:, 32q:32q+32] . W2[q]) is computed on the
  * matrix cores inside the pass, so the 4 x ndir LoRA maps never touch HBM (the K = 32 `torch.bmm` of src/model.py:278).
- * t: (ndir, B*T, 128) = tanh(xxx W1); w2t: (ndir, 4, C, 32) = time_maa_rkvw_w2 with K innermost. C % 32 == 0. */
+ * t: (ndir, B*T, 128) = tanh(xxx W1); w2t: (ndir, 4, C, 32) = time_maa_rkvw_w2 with K innermost. C % 64 == 0. */
 int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const void *x, const void *t, const void *w2t,
                              const void *maa, void *z, pafc_stream_t stream);
 

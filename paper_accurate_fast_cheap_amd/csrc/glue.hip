@@ -237,6 +237,10 @@ __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long 
     const long rowc = row < rows ? row : rows - 1;     // clamp (every lane takes part in the MFMAs), skip the store
     const int tt = (int)(rowc % T);
     const f32x4g zero = {0.f, 0.f, 0.f, 0.f};
+    // the MFMA leaves a lane with 8 columns of ITS row; through LDS the tile goes back to whole 128-byte row
+    // segments per 8 lanes, so z is stored in full lines
+    constexpr int LDZ = 64 + 8;
+    __shared__ __attribute__((aligned(16))) bf16_t s_z[4][4][16][LDZ];   // [wave][q][row][col]
     for (int d = 0; d < ndir; ++d) {
         const bool rev = (d == 0) ? (rev0 != 0) : true;
         const bool has_nb = rev ? (tt < T - 1) : (tt > 0);
@@ -245,7 +249,11 @@ __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long 
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             tb[q] = *reinterpret_cast<const uint4 *>(t + ((size_t)d * rows + rowc) * 128 + 32 * q + 8 * qq);
-        for (int cb = 0; cb < C / 32; ++cb) {
+        // a wave covers CBW = 2 column blocks of 32 (blockIdx.y picks which): 8x more waves than one wave per
+        // 16 rows, short fully unrolled bodies -> the loads of a body are all in flight together
+#pragma unroll
+        for (int cbi = 0; cbi < 2; ++cbi) {
+            const int cb = blockIdx.y * 2 + cbi;
             const int col = cb * 32 + 8 * qq;                       // this lane's 8 output columns
             const int colA = cb * 32 + 8 * (r16 >> 2) + (r16 & 3);  // column whose W2 row this lane feeds (slot r16)
             float xc[VEC], xn[VEC], xx[VEC];
@@ -269,9 +277,21 @@ __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long 
                     const float mv = round_bf16(e < 4 ? m1[e] : m2[e - 4]);
                     o[e] = round_bf16(xc[e] + round_bf16(xx[e] * round_bf16(av[e] + mv)));
                 }
-                if (row < rows) store8<bf16_t>(z + (((size_t)q * ndir + d) * rows + row) * C + col, o);
+                store8<bf16_t>(&s_z[wave][q][r16][cbi * 32 + 8 * qq], o);
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int rr = half * 8 + (lane >> 3), cc = (lane & 7) * 8;
+                const long orow = ((long)blockIdx.x * 4 + wave) * 16 + rr;
+                if (orow < rows)
+                    *reinterpret_cast<uint4 *>(z + (((size_t)q * ndir + d) * rows + orow) * C + blockIdx.y * 64 + cc) =
+                        *reinterpret_cast<const uint4 *>(&s_z[wave][q][rr][cc]);
+            }
+        __syncthreads();
     }
 }
 
@@ -353,9 +373,9 @@ int pafc_tmix_mix4(int dtype, int B, int T, int C, int ndir, int reverse0, const
 int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const void *x, const void *t, const void *w2t,
                              const void *maa, void *z, pafc_stream_t stream) {
     if (!x || !t || !w2t || !maa || !z) return PAFC_ERR_NULL_POINTER;
-    if (B <= 0 || T <= 0 || C <= 0 || C % 32 || ndir < 1 || ndir > 2) return PAFC_ERR_BAD_DIMS;
+    if (B <= 0 || T <= 0 || C <= 0 || C % 64 || ndir < 1 || ndir > 2) return PAFC_ERR_BAD_DIMS;
     const long rows = (long)B * T;
-    dim3 grid((unsigned)((rows + 63) / 64)), block(256);
+    dim3 grid((unsigned)((rows + 63) / 64), C / 64), block(256);
     hipLaunchKernelGGL(pafc::tmix_lora_mix4_kernel, grid, block, 0, (hipStream_t)stream, T, C, rows, ndir, reverse0,
                        (const pafc::bf16_t *)x, (const pafc::bf16_t *)t, (const pafc::bf16_t *)w2t,
                        (const pafc::bf16_t *)maa, (pafc::bf16_t *)z);

@@ -91,7 +91,7 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor) -> torch.Tensor:
     M, nd = B * T, plan.ndir
     xxx = hip_ops.tmix_shift_mix(h, plan.maa_x[0], plan.maa_x[1] if nd == 2 else None)
     t = torch.tanh(torch.bmm(xxx.view(nd, M, C), plan.W1))                                  # (nd, M, 128)
-    if h.dtype == torch.bfloat16 and t.shape[-1] == 128 and C % 32 == 0:
+    if h.dtype == torch.bfloat16 and t.shape[-1] == 128 and C % 64 == 0:
         z = hip_ops.tmix_lora_mix4(h, t, plan.W2t, plan.maa4)      # LoRA up-projection on MFMA inside the lerp pass
     else:
         m = torch.empty((nd, 4, M, C), dtype=h.dtype, device=h.device)
