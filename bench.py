@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--batch-size", type=int, default=8)
     ap.add_argument("--cpu-sample-frames", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     args = ap.parse_args()
 
     if args.workload == "c2":
@@ -153,7 +154,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")  # RCCL; only used for the timing barrier and the max-reduce
+        dist.init_process_group(args.dist_backend)  # RCCL; only used for the timing barrier and the max-reduce
+    if os.environ.get("PAFC_BENCH_ONE_GPU") == "1":   # rehearsal of the N > 1 code path on a single-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -219,12 +222,14 @@ def main():
     prof = profiling.summary()
 
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        rdev = device if args.dist_backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if world > 1 and args.workload == "c2":   # ranks hold different shards: total frames = sum over ranks
-        t = torch.tensor([frames_per_step], device=device, dtype=torch.float64)
+        t = torch.tensor([frames_per_step], device=device if args.dist_backend == "nccl" else torch.device("cpu"),
+                         dtype=torch.float64)
         dist.all_reduce(t)
         total_frames = float(t.item())
     else:

@@ -64,6 +64,15 @@ int pafc_tmix_mix4(int dtype, int B, int T, int C, int ndir, int reverse0, const
 int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const void *x, const void *t, const void *w2t,
                              const void *maa, void *z, pafc_stream_t stream);
 
+/* 3x3 stride-2 convolution + bias (+ ReLU), NHWC, bf16, as an implicit GEMM on the matrix cores:
+ *   out[b][t2][f2][co] = act(bias[co] + sum_{kh,kw,ci} w[co][ci][kh][kw] in[b][2 t2 + kh][2 f2 + kw][ci]),
+ *   T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1.
+ * Replaces the second Conv2d + ReLU of Conv2dSubsampling4 (wenet/transformer/subsampling.py:187-192).
+ * in: (B, T1, F1, Ci); w_tap_co_ci: the Conv2d weight re-laid out as (9, Co, Ci) = weight.permute(2,3,0,1);
+ * bias: (Co) or NULL; out: (B, T2, F2, Co).  Ci % 64 == 0, Co % 128 == 0. */
+int pafc_conv3x3s2_nhwc_bf16(int B, int T1, int F1, int Ci, int Co, const void *in, const void *w_tap_co_ci,
+                             const void *bias, void *out, int relu, pafc_stream_t stream);
+
 /* out (rows, N) = act(x (rows, K) . weight (N, K)^T + bias (N)) as one hipBLASLt GEMM with a fused epilogue; act 0 =
  * identity, 1 = SiLU.  Replaces `activation(w_1(x))` of PositionwiseFeedForward.forward
  * (wenet/transformer/positionwise_feed_forward.py:47-55): the separate SiLU pass over the (rows, 2048) hidden tensor

@@ -145,3 +145,22 @@ def tmix_lora_mix4(x: torch.Tensor, t: torch.Tensor, w2t: torch.Tensor, maa: tor
                                            _lib.ptr(maa), _lib.ptr(z), _lib.stream_of(x))
     _lib.check(rc, "pafc_tmix_lora_mix4_bf16")
     return z
+
+
+def conv3x3s2_nhwc(x: torch.Tensor, w_tap_co_ci: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = True):
+    """x (B, T1, F1, Ci) bf16 NHWC, w (9, Co, Ci) -> (B, T2, F2, Co) = relu(conv3x3 stride 2 + bias)."""
+    _lib.require_gpu(x, w_tap_co_ci, bias)
+    L = _bind2()
+    if not getattr(L, "_pafc_conv_bound", False):
+        _lib._sig(L.pafc_conv3x3s2_nhwc_bf16, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                  c_void_p, c_int, c_void_p)
+        L._pafc_conv_bound = True
+    B, T1, F1, Ci = x.shape
+    Co = w_tap_co_ci.shape[1]
+    if x.dtype != torch.bfloat16 or w_tap_co_ci.shape != (9, Co, Ci) or w_tap_co_ci.dtype != x.dtype:
+        raise _lib.PafcError("conv3x3s2_nhwc: bf16 NHWC input and a (9, Co, Ci) weight")
+    out = torch.empty((B, (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1, Co), dtype=x.dtype, device=x.device)
+    rc = L.pafc_conv3x3s2_nhwc_bf16(B, T1, F1, Ci, Co, _lib.ptr(x), _lib.ptr(w_tap_co_ci), _lib.ptr(bias), _lib.ptr(out),
+                                    int(relu), _lib.stream_of(x))
+    _lib.check(rc, "pafc_conv3x3s2_nhwc_bf16")
+    return out

@@ -129,3 +129,17 @@ def test_lora_mix4_fused_equals_two_step(hip):
     # identical op chain; the only freedom is the K = 32 summation order inside the MFMA vs the library GEMM
     torch.testing.assert_close(got.float(), ref.float(), rtol=2 ** -7, atol=2 ** -7)
     assert float((got.float() - ref.float()).abs().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("B,T1,F1,C", [(1, 9, 39, 128), (2, 37, 39, 128), (1, 201, 39, 512), (3, 5, 7, 256)])
+def test_conv3x3s2_implicit_gemm(hip, B, T1, F1, C):
+    """pafc_conv3x3s2_nhwc_bf16 vs torch conv2d (fp32 reference of the same op on bf16 inputs)."""
+    from paper_accurate_fast_cheap_amd.hip_ops import conv3x3s2_nhwc
+    x = synth.randn((B, T1, F1, C), 1).bfloat16()
+    w = (synth.randn((C, C, 3, 3), 2) / (3 * C ** 0.5)).bfloat16()
+    b = synth.randn((C,), 3, 0.1).bfloat16()
+    ref = F.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), b.float(), stride=2)).permute(0, 2, 3, 1)
+    got = conv3x3s2_nhwc(x.cuda(), w.permute(2, 3, 0, 1).reshape(9, C, C).contiguous().cuda(), b.cuda(), relu=True).cpu()
+    assert got.shape == ref.shape
+    torch.testing.assert_close(got.float(), ref, rtol=2 ** -7, atol=2e-2)
+    assert float((got.float() - ref).abs().mean()) < 3e-3
