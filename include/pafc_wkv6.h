@@ -46,7 +46,8 @@ enum {
     PAFC_ERR_WORKSPACE = -4,     /* workspace too small for the requested chunk_len */
     PAFC_ERR_LAUNCH = -5,        /* hipLaunchKernel failed */
     PAFC_ERR_DTYPE = -6,
-    PAFC_ERR_UNSUPPORTED = -7
+    PAFC_ERR_UNSUPPORTED = -7,
+    PAFC_ERR_ALIGNMENT = -8      /* r, k, v, w, y must be 16-byte aligned (torch allocations and (B,T,C) views are) */
 };
 
 enum { PAFC_F32 = 0, PAFC_BF16 = 1 };
@@ -54,10 +55,10 @@ enum { PAFC_F32 = 0, PAFC_BF16 = 1 };
 /* Library/ABI version, bumped when a signature changes. */
 int pafc_abi_version(void);
 
-/* Hardware self-check of the in-row lane exchanges the matrix-core kernel relies on (DPP control codes): writes,
- * for x = lane + 1, 12 results per lane [xor1, xor2, xor4, xor8, up1, up2, up4, up8, dn1, dn2, dn4, dn8] into
- * out_64x12 (device, 768 floats); tests compare them with the definitions. */
-int pafc_selftest_lane_ops(float *out_64x12, pafc_stream_t stream);
+/* Hardware self-check of the in-row lane permutations the matrix-core kernel relies on (DPP control codes): writes,
+ * for x = lane + 1, 4 results per lane [lane^1, lane^2, mirror in the 8-lane half (i -> 7-i), mirror in the 16-lane
+ * row (i -> 15-i)] into out_64x4 (device, 256 floats); tests compare them with the definitions. */
+int pafc_selftest_lane_ops(float *out_64x4, pafc_stream_t stream);
 
 /* ---- workspace sizing -------------------------------------------------------------------- */
 /* Chunk length the library would pick for this shape (fills the 256 CUs; returns T when the

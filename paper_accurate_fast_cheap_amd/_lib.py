@@ -17,6 +17,7 @@ PAFC_F32, PAFC_BF16 = 0, 1
 _ERRORS = {
     -1: "null pointer", -2: "bad dims (B, T, C, H must be positive and C == H * 64)", -3: "head size must be 64",
     -4: "workspace too small", -5: "kernel launch failed", -6: "unsupported dtype", -7: "unsupported",
+    -8: "r, k, v, w, y must be 16-byte aligned",
 }
 
 

@@ -316,6 +316,8 @@ int forward_impl(int dtype, int B, int T, int C, int H, int ndir, const DirArgs 
     for (int d = 0; d < ndir; ++d) {
         const DirArgs &a = dirs[d];
         if (!a.r || !a.k || !a.v || !a.w || !a.u || !a.y) return PAFC_ERR_NULL_POINTER;
+        if ((((uintptr_t)a.r | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.w | (uintptr_t)a.y) & 15) != 0)
+            return PAFC_ERR_ALIGNMENT;
         any_final |= a.s_out != nullptr;
     }
     int L = chunk_len > 0 ? chunk_len : pick_chunk_len(B, T, H, ndir);
@@ -596,9 +598,9 @@ extern "C" {
 
 int pafc_abi_version(void) { return 1; }
 
-int pafc_selftest_lane_ops(float *out_64x12, pafc_stream_t stream) {
-    if (!out_64x12) return PAFC_ERR_NULL_POINTER;
-    hipLaunchKernelGGL(pafc::lane_ops_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_64x12);
+int pafc_selftest_lane_ops(float *out_64x4, pafc_stream_t stream) {
+    if (!out_64x4) return PAFC_ERR_NULL_POINTER;
+    hipLaunchKernelGGL(pafc::lane_ops_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_64x4);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 

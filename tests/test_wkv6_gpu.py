@@ -157,18 +157,14 @@ def test_matrix_core_and_valu_kernels_agree(hip, dtype, monkeypatch):
 def test_lane_ops_selftest(hip):
     """The in-row lane exchanges of the matrix-core kernel (DPP control codes) do what their names say."""
     import ctypes
-    out = torch.zeros(64, 12, device="cuda")
+    out = torch.zeros(64, 4, device="cuda")
     hip.pafc_selftest_lane_ops.restype = ctypes.c_int
     rc = hip.pafc_selftest_lane_ops(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     torch.cuda.synchronize()
     o = out.cpu()
     for lane in range(64):
-        t = lane & 15
+        row, t = lane & ~15, lane & 15
         x = lambda l: float(l + 1)
-        exp = [x(lane ^ 1), x(lane ^ 2), x(lane ^ 4), x(lane ^ 8),
-               1.0 if t & 1 else x(lane + 1), 1.0 if t & 2 else x(lane + 2), 1.0 if t & 4 else x(lane + 4),
-               1.0 if t & 8 else x(lane + 8),
-               x(lane - 1) if t & 1 else 1.0, x(lane - 2) if t & 2 else 1.0, x(lane - 4) if t & 4 else 1.0,
-               x(lane - 8) if t & 8 else 1.0]
+        exp = [x(lane ^ 1), x(lane ^ 2), x(row + (t & 8) + 7 - (t & 7)), x(row + 15 - t)]
         assert o[lane].tolist() == exp, (lane, o[lane].tolist(), exp)
