@@ -73,14 +73,18 @@ int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const 
 int pafc_conv3x3s2_nhwc_bf16(int B, int T1, int F1, int Ci, int Co, const void *in, const void *w_tap_co_ci,
                              const void *bias, void *out, int relu, pafc_stream_t stream);
 
-/* out (rows, N) = act(x (rows, K) . weight (N, K)^T + bias (N)) as one hipBLASLt GEMM with a fused epilogue; act 0 =
- * identity, 1 = SiLU.  Replaces `activation(w_1(x))` of PositionwiseFeedForward.forward
+/* out (rows, N) = act(alpha * x (rows, K) . weight (N, K)^T + residual (rows, N) + bias (N)) as one hipBLASLt GEMM
+ * with a fused epilogue; act 0 = identity, 1 = SiLU; bias and residual may be NULL; residual may alias out; bias is
+ * added as given (not scaled by alpha).  Replaces `activation(w_1(x))` of PositionwiseFeedForward.forward
  * (wenet/transformer/positionwise_feed_forward.py:47-55): the separate SiLU pass over the (rows, 2048) hidden tensor
- * disappears and bias + SiLU see the fp32 accumulator (one rounding instead of two).  workspace: caller-owned,
- * pafc_linear_act_workspace_bytes() bytes are always enough.  A library GEMM, not a hand-written kernel. */
+ * disappears and bias + SiLU see the fp32 accumulator (one rounding instead of two); and, with residual, the
+ * `x = residual + ff_scale * ff(x)` / `x = residual + branch(x)` adds of ConformerEncoderLayer.forward
+ * (wenet/transformer/encoder_layer.py:201-259).  workspace: caller-owned, pafc_linear_act_workspace_bytes() bytes are
+ * always enough.  A library GEMM, not a hand-written kernel. */
 size_t pafc_linear_act_workspace_bytes(void);
 int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, const void *weight, const void *bias,
-                         void *out, int act, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
+                         void *out, int act, float alpha, const void *residual, void *workspace, size_t workspace_bytes,
+                         pafc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,31 @@
+/*
+ * pafc_search.h -- C ABI of the GPU-resident part of the decode step.
+ *
+ * CTC greedy search of the reference (wenet/transformer/search.py:106-121 + remove_duplicates_and_blank,
+ * wenet/utils/ctc_utils.py:22-32): argmax over the vocabulary per frame, frames beyond the utterance length count as
+ * blank, runs of equal ids collapse to one, blanks are dropped.  There: topk on the device, a (B, T) copy to the
+ * host and a Python loop per frame.  Here: two kernels; only the collapsed token lists leave the device.
+ * Conventions as in pafc_wkv6.h.
+ */
+#ifndef PAFC_SEARCH_H
+#define PAFC_SEARCH_H
+
+#include "pafc_wkv6.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* scores: (B, T, V) contiguous, PAFC_F32 or PAFC_BF16 -- log-probabilities or logits (same argmax).
+ * lens: (B) int64 valid frames per utterance, or NULL (all T frames valid).
+ * best: (B, T) int32 scratch that receives the per-frame argmax (ties: lowest index, like torch.topk / argmax;
+ *       padded frames: blank_id).
+ * tokens: (B, T) int32, row b holds ntok[b] collapsed token ids; ntok: (B) int32.
+ * frames: (B, T) int32 or NULL: frame index of the FIRST frame of each emitted token (for time stamps). */
+int pafc_ctc_greedy(int dtype, int B, int T, int V, const void *scores, const int64_t *lens, int blank_id,
+                    int32_t *best, int32_t *tokens, int32_t *ntok, int32_t *frames, pafc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

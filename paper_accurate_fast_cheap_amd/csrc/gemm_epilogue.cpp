@@ -1,10 +1,15 @@
-// Linear + bias + SiLU as ONE library GEMM with a fused epilogue (C ABI: include/pafc_encoder_ops.h).
+// Linear + bias (+ SiLU) (+ residual) as ONE library GEMM with a fused epilogue (C ABI: include/pafc_encoder_ops.h).
 //
 // Replaces `activation(w_1(x))` of PositionwiseFeedForward.forward (wenet/transformer/positionwise_feed_forward.py:47-55,
 // activation swish = SiLU): in the reference (and through torch) that is a GEMM+bias kernel followed by an
 // element-wise SiLU kernel over the (rows, 2048) hidden tensor -- its largest per-layer activation, read and
 // written once more.  hipBLASLt's SWISH_BIAS epilogue applies bias and x*sigmoid(x) to the fp32 accumulator before
 // the single bf16 rounding.  This is a plain library GEMM (no hand-written tiling here), so it lives in a .cpp.
+//
+// With `residual` the same call computes  out = residual + alpha * x.W^T + bias  (beta = 1, C = residual): the
+// `x = residual + ff_scale * ff(x)` / `x = residual + branch(x)` adds of ConformerEncoderLayer.forward
+// (wenet/transformer/encoder_layer.py:201-259) happen on the fp32 accumulator, and the pre-norm pass that follows
+// reads one tensor instead of two.
 //
 // The hipBLASLt handle and the heuristic's algorithm choice per (rows, N, K) are cached per process and device: they
 // are library objects, not state of the computation (results never depend on them).
@@ -29,7 +34,7 @@ struct Plan {
 
 std::mutex g_mu;
 std::map<int, hipblasLtHandle_t> g_handles;                                   // per device
-std::map<std::tuple<int, int, long, int, int, int>, Plan> g_plans;            // (device, dtype, rows, N, K, act)
+std::map<std::tuple<int, int, long, int, int, int>, Plan> g_plans;   // (device, dtype, rows, N, K, act | bias | residual)
 
 constexpr size_t kMaxWorkspace = 64u << 20;
 
@@ -40,7 +45,8 @@ extern "C" {
 size_t pafc_linear_act_workspace_bytes(void) { return kMaxWorkspace; }
 
 int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, const void *weight, const void *bias,
-                         void *out, int act, void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
+                         void *out, int act, float alpha, const void *residual, void *workspace,
+                         size_t workspace_bytes, pafc_stream_t stream) {
     if (!x || !weight || !out) return PAFC_ERR_NULL_POINTER;
     if (rows <= 0 || N <= 0 || K <= 0) return PAFC_ERR_BAD_DIMS;
     if (dtype != PAFC_BF16 && dtype != PAFC_F32) return PAFC_ERR_DTYPE;
@@ -52,7 +58,7 @@ int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, cons
     std::lock_guard<std::mutex> lock(g_mu);
     hipblasLtHandle_t &handle = g_handles[dev];
     if (!handle && hipblasLtCreate(&handle) != HIPBLAS_STATUS_SUCCESS) return PAFC_ERR_LAUNCH;
-    Plan &p = g_plans[std::make_tuple(dev, dtype, rows, N, K, act)];
+    Plan &p = g_plans[std::make_tuple(dev, dtype, rows, N, K, act | (bias ? 2 : 0) | (residual ? 4 : 0))];
     if (!p.ok) {
         // row-major out (rows, N) = x (rows, K) . W(N, K)^T   <=>   column-major D (N, rows) = W_cm(K, N)^T . x_cm(K, rows)
         if (hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return PAFC_ERR_LAUNCH;
@@ -90,8 +96,9 @@ int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, cons
     }
     if (p.ws > 0 && (!workspace || workspace_bytes < p.ws)) return PAFC_ERR_WORKSPACE;
     if (bias) hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
-    const float alpha = 1.f, beta = 0.f;
-    const hipblasStatus_t st = hipblasLtMatmul(handle, p.desc, &alpha, weight, p.a, x, p.b, &beta, out, p.d, out, p.d,
+    const float beta = residual ? 1.f : 0.f;
+    const void *c = residual ? residual : out;
+    const hipblasStatus_t st = hipblasLtMatmul(handle, p.desc, &alpha, weight, p.a, x, p.b, &beta, c, p.d, out, p.d,
                                                &p.algo, workspace, p.ws, (hipStream_t)stream);
     return st == HIPBLAS_STATUS_SUCCESS ? PAFC_OK : PAFC_ERR_LAUNCH;
 }

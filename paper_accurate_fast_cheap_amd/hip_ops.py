@@ -109,26 +109,34 @@ def tmix_mix4(x: torch.Tensor, m: torch.Tensor, maa: torch.Tensor, reverse0: boo
 _gemm_ws = {}
 
 
-def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: str = "silu"):
-    """act(x @ weight.T + bias) as one hipBLASLt GEMM with fused epilogue (act: 'silu' or 'none')."""
-    _lib.require_gpu(x, weight, bias)
+def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: str = "silu",
+                    alpha: float = 1.0, residual: Optional[torch.Tensor] = None, inplace: bool = False):
+    """act(alpha * x @ weight.T + residual + bias) as one hipBLASLt GEMM with fused epilogue (act: 'silu' or 'none').
+    bias is added as given (not scaled by alpha).  inplace: write the result over ``residual``."""
+    _lib.require_gpu(x, weight, bias, residual)
     L = _bind2()
     if not getattr(L, "_pafc_gemm_bound", False):
-        from ctypes import c_long, c_size_t
+        from ctypes import c_float, c_long, c_size_t
         _lib._sig(L.pafc_linear_act_workspace_bytes, c_size_t)
         _lib._sig(L.pafc_linear_bias_act, c_int, c_int, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                  c_void_p, c_size_t, c_void_p)
+                  c_float, c_void_p, c_void_p, c_size_t, c_void_p)
         L._pafc_gemm_bound = True
     N, K = weight.shape
     rows = x.numel() // K
-    if x.shape[-1] != K or weight.dtype != x.dtype:
+    if x.shape[-1] != K or weight.dtype != x.dtype or (bias is not None and bias.dtype != x.dtype):
         raise _lib.PafcError("linear_bias_act: shape/dtype mismatch")
+    if residual is not None and (residual.dtype != x.dtype or residual.numel() != rows * N):
+        raise _lib.PafcError("linear_bias_act: residual must be (rows, N) in the activation dtype")
     ws = _gemm_ws.get(x.device)
     if ws is None:
         ws = _gemm_ws[x.device] = torch.empty(L.pafc_linear_act_workspace_bytes(), dtype=torch.uint8, device=x.device)
-    out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+    if inplace and residual is not None:
+        out = residual
+    else:
+        out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
     rc = L.pafc_linear_bias_act(_lib.dtype_code(x.dtype), rows, N, K, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias),
-                                _lib.ptr(out), 1 if act == "silu" else 0, _lib.ptr(ws), ws.numel(), _lib.stream_of(x))
+                                _lib.ptr(out), 1 if act == "silu" else 0, float(alpha), _lib.ptr(residual), _lib.ptr(ws),
+                                ws.numel(), _lib.stream_of(x))
     _lib.check(rc, "pafc_linear_bias_act")
     return out
 
@@ -164,3 +172,22 @@ def conv3x3s2_nhwc(x: torch.Tensor, w_tap_co_ci: torch.Tensor, bias: Optional[to
                                     int(relu), _lib.stream_of(x))
     _lib.check(rc, "pafc_conv3x3s2_nhwc_bf16")
     return out
+
+
+def ctc_greedy(scores: torch.Tensor, lens: Optional[torch.Tensor], blank_id: int = 0, want_frames: bool = False):
+    """GPU-resident CTC greedy search (include/pafc_search.h): (B, T, V) scores -> (tokens (B, T) int32, ntok (B) int32
+    [, first-frame index per token]).  Row b of ``tokens`` holds ``ntok[b]`` collapsed ids."""
+    _lib.require_gpu(scores, lens)
+    if scores.dim() != 3:
+        raise _lib.PafcError("ctc_greedy wants (B, T, V) scores")
+    L = _bind()
+    B, T, V = scores.shape
+    lens64 = None if lens is None else lens.to(torch.int64).contiguous()
+    best = torch.empty(B, T, dtype=torch.int32, device=scores.device)
+    tokens = torch.empty(B, T, dtype=torch.int32, device=scores.device)
+    ntok = torch.empty(B, dtype=torch.int32, device=scores.device)
+    frames = torch.empty(B, T, dtype=torch.int32, device=scores.device) if want_frames else None
+    _lib.check(L.pafc_ctc_greedy(_lib.dtype_code(scores.dtype), B, T, V, _lib.ptr(scores), _lib.ptr(lens64), int(blank_id),
+                                 _lib.ptr(best), _lib.ptr(tokens), _lib.ptr(ntok), _lib.ptr(frames),
+                                 _lib.stream_of(scores)), "pafc_ctc_greedy")
+    return (tokens, ntok, frames) if want_frames else (tokens, ntok)

@@ -40,7 +40,8 @@ class LayerPlan:
         self.refresh()
 
     def _current_stamp(self):
-        ps = [p for b in self.blocks for p in b.parameters()]
+        L = self.layer
+        ps = [p for b in self.blocks for p in b.parameters()] + [L.feed_forward_macaron.w_2.bias, L.feed_forward.w_2.bias]
         return tuple((p.data_ptr(), p._version, p.dtype) for p in ps)
 
     def refresh(self):
@@ -65,6 +66,11 @@ class LayerPlan:
             self.u = [b.time_faaaa.contiguous() for b in bl]
             wo = torch.cat([b.output.weight for b in bl], dim=1)                           # (C, nd*C)
             self.Wo = (wo * 0.5 if self.ndir == 2 else wo).contiguous()                    # /2 is exact in bf16
+            # biases of the two FFN output projections, pre-multiplied by ff_scale: the residual-fused GEMM computes
+            # x + ff_scale * (h W2^T) + (ff_scale * b2)
+            L = self.layer
+            self.b2_macaron = (L.feed_forward_macaron.w_2.bias * L.ff_scale).contiguous()
+            self.b2 = (L.feed_forward.w_2.bias * L.ff_scale).contiguous()
         self._stamp = stamp
 
 
@@ -85,8 +91,16 @@ def _ffn(ff: nn.Module, h: torch.Tensor) -> torch.Tensor:
     return F.linear(hip_ops.linear_bias_act(h, ff.w_1.weight, ff.w_1.bias, "silu"), ff.w_2.weight, ff.w_2.bias)
 
 
-def slot_forward(plan: LayerPlan, h: torch.Tensor) -> torch.Tensor:
-    """h: (B, T, C) in the slot dtype -> slot output (B, T, C) in the slot dtype (both directions averaged)."""
+def _ffn_residual(ff: nn.Module, h: torch.Tensor, x: torch.Tensor, scale: float, b2_scaled: torch.Tensor,
+                  inplace: bool) -> torch.Tensor:
+    """x + scale * ff(h): the add rides on the w_2 GEMM (beta = 1), so the pre-norm that follows reads ONE tensor."""
+    hid = hip_ops.linear_bias_act(h, ff.w_1.weight, ff.w_1.bias, "silu")
+    return hip_ops.linear_bias_act(hid, ff.w_2.weight, b2_scaled, "none", alpha=scale, residual=x, inplace=inplace)
+
+
+def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """h: (B, T, C) in the slot dtype -> slot output (B, T, C) in the slot dtype (both directions averaged).
+    With ``residual`` (same dtype) the result is residual + slot output, written over ``residual``."""
     B, T, C = h.shape
     M, nd = B * T, plan.ndir
     xxx = hip_ops.tmix_shift_mix(h, plan.maa_x[0], plan.maa_x[1] if nd == 2 else None)
@@ -114,6 +128,8 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor) -> torch.Tensor:
     for d, y in enumerate(ys):
         ln = plan.blocks[d].ln_x
         hip_ops.add_layernorm(y.view(M, C), None, 1.0, ln.weight, ln.bias, out1=ycat[:, d * C:(d + 1) * C], eps=ln.eps)
+    if residual is not None:
+        return hip_ops.linear_bias_act(ycat, plan.Wo, None, "none", residual=residual.view(M, C), inplace=True).view(B, T, C)
     return F.linear(ycat, plan.Wo).view(B, T, C)
 
 
@@ -124,22 +140,33 @@ def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optio
     L = plan.layer
     B, T, C = x.shape
     slot_dtype = torch.bfloat16 if plan.slot_bf16 else x.dtype
-    f = _ffn(L.feed_forward_macaron, h)
-    x, h, _ = hip_ops.add_layernorm(x, f, L.ff_scale, L.norm_mha.weight, L.norm_mha.bias, out_dtype=slot_dtype)
-    att = slot_forward(plan, h)
-    if att.dtype != x.dtype:
-        att = att.to(x.dtype)
     masked = lens is not None
-    x, h, _ = hip_ops.add_layernorm(x, att, 1.0, L.norm_conv.weight, L.norm_conv.bias, zero_rows=masked, lens=lens, T=T)
     cm = L.conv_module
+    # Residual adds ride on the GEMM that produces the branch output whenever branch and stream share a dtype.  The
+    # first add of a layer writes a fresh tensor (the incoming stream may be a caller-visible layer output), the
+    # later ones update the layer-private stream in place.
+    x = _ffn_residual(L.feed_forward_macaron, h, x, L.ff_scale, plan.b2_macaron, inplace=False)
+    _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_mha.weight, L.norm_mha.bias, out_dtype=slot_dtype, want_x=False)
+    if slot_dtype == x.dtype:
+        x = slot_forward(plan, h, residual=x)
+        _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_conv.weight, L.norm_conv.bias, zero_rows=masked, lens=lens,
+                                        T=T, want_x=False)
+    else:
+        att = slot_forward(plan, h).to(x.dtype)
+        x, h, _ = hip_ops.add_layernorm(x, att, 1.0, L.norm_conv.weight, L.norm_conv.bias, zero_rows=masked, lens=lens, T=T)
     p = F.linear(h, cm.pointwise_conv1.weight.squeeze(-1), cm.pointwise_conv1.bias)
     dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, (cm.kernel_size - 1) // 2, T,
                                      glu=True)
     _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
-    c = F.linear(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias)
-    x, h, _ = hip_ops.add_layernorm(x, c, 1.0, L.norm_ff.weight, L.norm_ff.bias, lens=lens, T=T, mask_y=masked)
-    f = _ffn(L.feed_forward, h)
-    _, out, hn = hip_ops.add_layernorm(x, f, L.ff_scale, L.norm_final.weight, L.norm_final.bias, want_x=False,
+    if not masked:
+        x = hip_ops.linear_bias_act(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none",
+                                    residual=x, inplace=True)
+        _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff.weight, L.norm_ff.bias, want_x=False)
+    else:   # padded frames of the conv branch count as zero (convolution.py:140-141): the add stays in the norm pass
+        c = F.linear(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias)
+        x, h, _ = hip_ops.add_layernorm(x, c, 1.0, L.norm_ff.weight, L.norm_ff.bias, lens=lens, T=T, mask_y=True)
+    x = _ffn_residual(L.feed_forward, h, x, L.ff_scale, plan.b2, inplace=True)
+    _, out, hn = hip_ops.add_layernorm(x, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False,
                                        gamma2=next_norm.weight if next_norm is not None else None,
                                        beta2=next_norm.bias if next_norm is not None else None)
     return out, hn

@@ -44,6 +44,20 @@ def remove_duplicates_and_blank(hyp: List[int], blank_id: int = 0) -> List[int]:
 
 
 def ctc_greedy_search(ctc_probs: torch.Tensor, ctc_lens: torch.Tensor, blank_id: int = 0) -> List[DecodeResult]:
+    """search.py:106-121.  On the GPU the argmax, the padding rule and the collapse run in two kernels
+    (``pafc_ctc_greedy``) and only the collapsed ids come back -- two small copies for the whole batch instead of a
+    (B, T) copy and a Python loop per frame.  Host tensors take the reference's own steps below."""
+    if ctc_probs.is_cuda:
+        from ..hip_ops import ctc_greedy
+        tokens, ntok = ctc_greedy(ctc_probs.contiguous(), ctc_lens.to(ctc_probs.device), blank_id)
+        keep = torch.arange(tokens.shape[1], device=tokens.device)[None, :] < ntok[:, None]
+        flat = tokens[keep].tolist()          # all utterances back to back
+        counts = ntok.tolist()
+        out, pos = [], 0
+        for n in counts:
+            out.append(DecodeResult(flat[pos:pos + n]))
+            pos += n
+        return out
     batch_size, maxlen = ctc_probs.shape[:2]
     topk_index = ctc_probs.argmax(dim=2)  # == topk(1): ties resolve to the lowest index in both
     mask = make_pad_mask(ctc_lens, maxlen)

@@ -113,6 +113,15 @@ def test_linear_bias_silu_epilogue(hip, dtype):
     tol = dict(rtol=2 ** -7, atol=1e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(got.float(), ref, **tol)
     torch.testing.assert_close(got_id.float(), F.linear(x.float(), w.float(), b.float()), **tol)
+    # residual-fused form: res + alpha * x W^T + bias, out of place and over the residual
+    res = synth.randn((3, 41, 256), 4).to(dtype)
+    want = res.float() + 0.5 * F.linear(x.float(), w.float()) + b.float()
+    got_r = linear_bias_act(x.cuda(), w.cuda(), b.cuda(), "none", alpha=0.5, residual=res.cuda())
+    torch.testing.assert_close(got_r.cpu().float(), want, **tol)
+    buf = res.cuda().clone()
+    same = linear_bias_act(x.cuda(), w.cuda(), None, "none", residual=buf, inplace=True)
+    assert same.data_ptr() == buf.data_ptr()
+    torch.testing.assert_close(buf.cpu().float(), res.float() + F.linear(x.float(), w.float()), **tol)
 
 
 def test_lora_mix4_fused_equals_two_step(hip):

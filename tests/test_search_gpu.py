@@ -1,0 +1,84 @@
+"""GPU-resident CTC greedy search (include/pafc_search.h) against the oracle's restatement of the reference steps
+(topk(1) -> padded frames = blank -> remove_duplicates_and_blank).  Bit-exact bar: token ids."""
+import pytest
+import torch
+
+from oracle import encoder_oracle as EO
+
+pytestmark = pytest.mark.gpu
+
+
+def _scores(B, T, V, dtype, seed, peaky=True):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, T, V, generator=g)
+    if peaky:   # long runs of the same id and many blanks, like real CTC posteriors
+        ids = torch.randint(0, V, (B, (T + 6) // 7), generator=g).repeat_interleave(7, dim=1)[:, :T]
+        ids[torch.rand(B, T, generator=g) < 0.5] = 0
+        x.scatter_(2, ids[..., None], 6.0)
+    return x.log_softmax(-1).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,V", [(1, 1, 2), (3, 17, 50), (8, 499, 5000), (2, 300, 4999), (5, 64, 7)])
+def test_greedy_kernel_matches_oracle(hip, dtype, B, T, V):
+    from paper_accurate_fast_cheap_amd.hip_ops import ctc_greedy
+    from paper_accurate_fast_cheap_amd.transformer.search import ctc_greedy_search
+    x = _scores(B, T, V, dtype, seed=B * 1000 + T)
+    lens = torch.randint(1, T + 1, (B,), generator=torch.Generator().manual_seed(T))
+    lens[0] = T
+    want = EO.ctc_greedy_search(x.float(), lens, 0)
+    xd = x.cuda()
+    got = [r.tokens for r in ctc_greedy_search(xd, lens.cuda(), 0)]
+    assert got == want
+    # raw kernel outputs: counts, first-frame indices, untouched tail
+    tokens, ntok, frames = ctc_greedy(xd, lens.cuda(), 0, want_frames=True)
+    best = xd.float().argmax(-1).cpu()
+    for b in range(B):
+        n = int(ntok[b])
+        assert tokens[b, :n].tolist() == want[b]
+        fr = frames[b, :n].tolist()
+        assert all(int(best[b, f]) == tok for f, tok in zip(fr, want[b]))
+        assert fr == sorted(fr) and all(f < int(lens[b]) for f in fr)
+
+
+def test_greedy_ties_resolve_to_lowest_index_and_all_blank(hip):
+    from paper_accurate_fast_cheap_amd.transformer.search import ctc_greedy_search
+    x = torch.full((2, 6, 300), -5.0)
+    x[0, :, 0] = -1.0                          # utterance 0: blank everywhere -> no tokens
+    x[1, 0, [7, 130, 299]] = -0.5              # three-way tie -> 7
+    x[1, 1, [130, 299]] = -0.5                 # tie -> 130
+    x[1, 2, 130] = -0.5                        # repeat of 130: collapsed
+    x[1, 3, 0] = -0.1                          # blank separates
+    x[1, 4, 130] = -0.5                        # 130 again: emitted again
+    x[1, 5, 5] = -0.2                          # beyond lens -> ignored
+    lens = torch.tensor([6, 5])
+    for dt in (torch.float32, torch.bfloat16):
+        got = [r.tokens for r in ctc_greedy_search(x.to(dt).cuda(), lens.cuda(), 0)]
+        # ties: first maximal index (torch.argmax's documented rule; topk(1) leaves ties unspecified)
+        assert got == [[], [7, 130, 130]]
+    allneg = torch.full((1, 3, 40), float("-inf"))   # degenerate rows resolve to index 0 = blank -> nothing emitted
+    assert [r.tokens for r in ctc_greedy_search(allneg.cuda(), torch.tensor([3]).cuda(), 0)] == [[]]
+
+
+def test_greedy_long_form_sequence(hip):
+    """c3 size: one 30-minute sequence (T' = 44 998, V = 5000, bf16): tile-crossing runs and offsets."""
+    from paper_accurate_fast_cheap_amd.transformer.search import ctc_greedy_search
+    T, V = 44998, 5000
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, V, ((T + 4) // 5,), generator=g).repeat_interleave(5)[:T]
+    ids[torch.rand(T, generator=g) < 0.4] = 0
+    x = torch.full((1, T, V), -9.0, dtype=torch.bfloat16, device="cuda")
+    x[0, torch.arange(T), ids.cuda()] = -0.01
+    got = ctc_greedy_search(x, torch.tensor([T], device="cuda"), 0)[0].tokens
+    assert got == EO.remove_duplicates_and_blank(ids.tolist(), 0)
+
+
+def test_greedy_bad_arguments(hip):
+    from paper_accurate_fast_cheap_amd._lib import PafcError
+    from paper_accurate_fast_cheap_amd.hip_ops import ctc_greedy
+    with pytest.raises(PafcError):
+        ctc_greedy(torch.zeros(2, 3, 4), None)            # host tensor
+    with pytest.raises(PafcError):
+        ctc_greedy(torch.zeros(2, 3, 4, device="cuda"), None, blank_id=9)
+    with pytest.raises(PafcError):
+        ctc_greedy(torch.zeros(2, 3, 4, device="cuda", dtype=torch.float16), None)
