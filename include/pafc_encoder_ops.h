@@ -86,6 +86,19 @@ int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, cons
                          void *out, int act, float alpha, const void *residual, void *workspace, size_t workspace_bytes,
                          pafc_stream_t stream);
 
+/* Hand-written bf16 GEMM with fused epilogue (csrc/gemm_bf16.hip), batched:
+ *   out[z][m][n] = act(alpha * sum_k A[z][m][k] * W[z][n][k] + bias[z][n] + residual[z][m][n]),   z < batch
+ * A: (M, K) rows lda apart; W: (N, K) = nn.Linear.weight layout, rows ldw apart; out / residual: (M, N), rows ldo / ldr
+ * apart; stride*: elements between consecutive batch entries (strideBias = 0 shares one bias); bias, residual may be
+ * NULL; residual may alias out.  act: 0 none, 1 SiLU, 2 tanh, 3 ReLU.  bias is added as given (not scaled by alpha);
+ * everything is applied to the fp32 accumulator, one rounding to bf16.  N % 8 == 0 (tiles are 128 wide), K % 64 == 0, all leading
+ * dimensions / strides multiples of 8 elements, pointers 16-byte aligned.  Replaces the Linear / 1x1-Conv1d calls of
+ * PositionwiseFeedForward, ConvolutionModule, RWKV_Tmix_x060c and the residual adds of ConformerEncoderLayer.forward
+ * (positionwise_feed_forward.py:47-55, convolution.py:118-141, rwkv_v6/src/model.py:286-324, encoder_layer.py:201-259). */
+int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, long lda, long strideA, const void *W, long ldw,
+                   long strideW, const void *bias, long strideBias, const void *residual, long ldr, long strideR,
+                   void *out, long ldo, long strideO, float alpha, int act, pafc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,236 @@
+// Dense projections of the encoder as a hand-written bf16 GEMM with fused epilogues (gfx950).
+// C ABI: include/pafc_encoder_ops.h: pafc_gemm_bf16.
+//
+//   out[z][m][n] = act(alpha * sum_k A[z][m][k] * W[z][n][k] + bias[z][n] + residual[z][m][n])
+// i.e. nn.Linear (weight stored (N, K), K contiguous) with the bias, the activation (SiLU / tanh / ReLU), the
+// ff_scale and the residual add applied to the fp32 accumulator before the single rounding to bf16.  Replaces the
+// FFN / 1x1-conv / r,k,v / output projections of ConformerEncoderLayer, ConvolutionModule and RWKV_Tmix_x060c
+// (wenet/transformer/positionwise_feed_forward.py:47-55, convolution.py:118-141, rwkv_v6/src/model.py:286-324,
+// encoder_layer.py:201-259) -- 55 % of the encoder pass.  z = batch (grid.z) for the stacked projections of the two
+// directions.
+//
+// Same skeleton as the subsampling convolution (conv_sub.hip): block = 256 threads (2 x 2 waves), tile 128 x 128 x 64,
+// each wave 4 x 4 MFMA 16x16x32 tiles; A and W tiles go global -> LDS by LDS-DMA with the XOR swizzle on the source
+// side, two LDS stages; tiles are numbered so that the N-tiles of one M-tile run on one XCD (they share the A tile
+// in that XCD's L2).  Epilogue: the accumulators (+ bias, activation) are staged through LDS -- as fp32 when a
+// residual has to be added (the residual is then read with full 16-byte rows and added before the rounding), as
+// bf16 otherwise -- and leave as whole 256-byte rows.
+#include "pafc_common.h"
+#include "../../include/pafc_encoder_ops.h"
+
+namespace pafc {
+namespace {
+
+constexpr int GBM = 128, GBN = 128, GBK = 64;
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8g __attribute__((ext_vector_type(8)));
+
+struct GemmParams {
+    const bf16_t *A, *W, *bias, *res;
+    bf16_t *out;
+    long M;
+    int N, K;
+    long lda, ldw, ldo, ldr;          // row strides (elements)
+    long sA, sW, sO, sB, sR;          // batch strides (elements); sB = 0 shares the bias
+    float alpha;
+    int act;                          // 0 none, 1 SiLU, 2 tanh, 3 ReLU
+    int mtiles, ntiles;
+};
+
+__device__ __forceinline__ void gdma16(const bf16_t *src, bf16_t *lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
+    if (act == 2) {   // tanh(v) = 1 - 2 / (exp(2v) + 1); saturates correctly at +-inf
+        return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * v) + 1.f);
+    }
+    if (act == 3) return fmaxf(v, 0.f);
+    return v;
+}
+
+template <bool HAS_RES>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];   // [2 stages][A 128x64 | W 128x64] (64 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.y;
+
+    const long nblk = (long)p.mtiles * p.ntiles;
+    long bid = blockIdx.x;
+    const long per = nblk / 8;
+    if (bid < per * 8) bid = (bid % 8) * per + bid / 8;   // XCD-aware order; the tail keeps its id
+    const int mt0 = (int)(bid / p.ntiles), nt0 = (int)(bid % p.ntiles);
+    const long m0 = (long)mt0 * GBM;
+    const int n0 = nt0 * GBN;
+
+    const bf16_t *Az = p.A + z * p.sA, *Wz = p.W + z * p.sW;
+    const int sub = lane >> 3, pch = lane & 7;
+    const bf16_t *a_src[4];
+    const bf16_t *w_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wave * 32 + j * 8 + sub;
+        const int c = pch ^ (row & 7);
+        long m = m0 + row;
+        if (m >= p.M) m = p.M - 1;                          // clamp: the row is computed but never stored
+        a_src[j] = Az + m * p.lda + 8 * c;
+        const int n = min(n0 + row, p.N - 1);               // N tail: clamped rows feed columns that are never stored
+        w_src[j] = Wz + (long)n * p.ldw + 8 * c;
+    }
+    const int iters = p.K / GBK;
+
+    auto issue = [&](int it, int buf) {
+        bf16_t *A = lds + buf * (2 * GBM * GBK);
+        bf16_t *Wt = A + GBM * GBK;
+        const int koff = it * GBK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rowbase = (wave * 32 + j * 8) * GBK;
+            gdma16(a_src[j] + koff, A + rowbase);
+            gdma16(w_src[j] + koff, Wt + rowbase);
+        }
+    };
+
+    f32x4g acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4g{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, kq = lane >> 4;
+    issue(0, 0);
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it + 1 < iters) issue(it + 1, (it + 1) & 1);
+        const bf16_t *A = lds + (it & 1) * (2 * GBM * GBK);
+        const bf16_t *Wt = A + GBM * GBK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8g af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + i * 16 + fr;
+                af[i] = *reinterpret_cast<const bf16x8g *>(A + row * GBK + (((ks * 4 + kq) ^ (row & 7)) * 8));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wn * 64 + j * 16 + fr;
+                wf[j] = *reinterpret_cast<const bf16x8g *>(Wt + row * GBK + (((ks * 4 + kq) ^ (row & 7)) * 8));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();   // operand buffers are free: reuse them to stage the output tile
+
+    // ---- epilogue: C/D layout col = lane & 15 (n), row = 4 (lane >> 4) + reg (m) --------------------------------
+    const bf16_t *bz = p.bias ? p.bias + z * p.sB : nullptr;
+    bf16_t *Oz = p.out + z * p.sO;
+    if constexpr (HAS_RES) {
+        constexpr int LDF = GBN + 4;   // fp32 staging [128][132] = 66 KiB
+        float *O = reinterpret_cast<float *>(lds);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = wn * 64 + j * 16 + fr;
+            const float bv = bz ? bf16_bits_to_f32(bz[min(n0 + col, p.N - 1)]) : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    O[(wm * 64 + i * 16 + 4 * kq + g) * LDF + col] = apply_act(fmaf(acc[i][j][g], p.alpha, bv), p.act);
+        }
+        __syncthreads();
+        const bf16_t *Rz = p.res + z * p.sR;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = q * 16 + (tid >> 4), c8 = (tid & 15) * 8;
+            const long m = m0 + row;
+            if (m < p.M && n0 + c8 < p.N) {
+                const uint4 rq = *reinterpret_cast<const uint4 *>(Rz + m * p.ldr + n0 + c8);
+                float r[8];
+                Elem<bf16_t>::unpack(rq, r);
+                const float4 o0 = *reinterpret_cast<const float4 *>(O + row * LDF + c8);
+                const float4 o1 = *reinterpret_cast<const float4 *>(O + row * LDF + c8 + 4);
+                uint4 w;
+                w.x = f32_to_bf16_bits(o0.x + r[0]) | (f32_to_bf16_bits(o0.y + r[1]) << 16);
+                w.y = f32_to_bf16_bits(o0.z + r[2]) | (f32_to_bf16_bits(o0.w + r[3]) << 16);
+                w.z = f32_to_bf16_bits(o1.x + r[4]) | (f32_to_bf16_bits(o1.y + r[5]) << 16);
+                w.w = f32_to_bf16_bits(o1.z + r[6]) | (f32_to_bf16_bits(o1.w + r[7]) << 16);
+                *reinterpret_cast<uint4 *>(Oz + m * p.ldo + n0 + c8) = w;
+            }
+        }
+    } else {
+        constexpr int LDO = GBN + 8;
+        bf16_t *O = lds;   // [128][136] bf16 = 34 KiB
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = wn * 64 + j * 16 + fr;
+            const float bv = bz ? bf16_bits_to_f32(bz[min(n0 + col, p.N - 1)]) : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    O[(wm * 64 + i * 16 + 4 * kq + g) * LDO + col] =
+                        (bf16_t)f32_to_bf16_bits(apply_act(fmaf(acc[i][j][g], p.alpha, bv), p.act));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = q * 16 + (tid >> 4), c8 = (tid & 15) * 8;
+            const long m = m0 + row;
+            if (m < p.M && n0 + c8 < p.N)
+                *reinterpret_cast<uint4 *>(Oz + m * p.ldo + n0 + c8) = *reinterpret_cast<const uint4 *>(O + row * LDO + c8);
+        }
+    }
+}
+
+}  // namespace
+}  // namespace pafc
+
+extern "C" int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, long lda, long strideA, const void *W,
+                              long ldw, long strideW, const void *bias, long strideBias, const void *residual, long ldr,
+                              long strideR, void *out, long ldo, long strideO, float alpha, int act,
+                              pafc_stream_t stream) {
+    if (!A || !W || !out) return PAFC_ERR_NULL_POINTER;
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535) return PAFC_ERR_BAD_DIMS;
+    if (N % 8 || K % pafc::GBK) return PAFC_ERR_UNSUPPORTED;
+    if (act < 0 || act > 3) return PAFC_ERR_UNSUPPORTED;
+    if (lda < K || ldw < K || ldo < N || (residual && ldr < N)) return PAFC_ERR_BAD_DIMS;
+    // 16-byte row segments everywhere (LDS-DMA sources, vector stores)
+    if ((lda | ldw | ldo | strideA | strideW | strideO) % 8 || (residual && ((ldr | strideR) % 8))) return PAFC_ERR_ALIGNMENT;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)residual) & 15) != 0) return PAFC_ERR_ALIGNMENT;
+    pafc::GemmParams p{};
+    p.A = (const pafc::bf16_t *)A; p.W = (const pafc::bf16_t *)W; p.bias = (const pafc::bf16_t *)bias;
+    p.res = (const pafc::bf16_t *)residual; p.out = (pafc::bf16_t *)out;
+    p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr;
+    p.sA = strideA; p.sW = strideW; p.sO = strideO; p.sB = strideBias; p.sR = strideR;
+    p.alpha = alpha; p.act = act;
+    p.mtiles = (int)((M + pafc::GBM - 1) / pafc::GBM);
+    p.ntiles = (N + pafc::GBN - 1) / pafc::GBN;
+    const long nblk = (long)p.mtiles * p.ntiles;
+    if (nblk > 0x7fffffffL) return PAFC_ERR_BAD_DIMS;
+    const dim3 grid((unsigned)nblk, (unsigned)batch);
+    hipStream_t s = (hipStream_t)stream;
+    if (residual) {
+        const size_t lds = (size_t)pafc::GBM * (pafc::GBN + 4) * sizeof(float);   // 66 KiB (>= the 64 KiB of the stages)
+        if (hipFuncSetAttribute((const void *)pafc::gemm_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return PAFC_ERR_LAUNCH;
+        hipLaunchKernelGGL(pafc::gemm_bf16_kernel<true>, grid, dim3(256), lds, s, p);
+    } else {
+        const size_t lds = 2 * 2 * pafc::GBM * pafc::GBK * sizeof(pafc::bf16_t);       // 64 KiB
+        if (hipFuncSetAttribute((const void *)pafc::gemm_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return PAFC_ERR_LAUNCH;
+        hipLaunchKernelGGL(pafc::gemm_bf16_kernel<false>, grid, dim3(256), lds, s, p);
+    }
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}

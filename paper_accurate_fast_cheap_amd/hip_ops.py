@@ -191,3 +191,44 @@ def ctc_greedy(scores: torch.Tensor, lens: Optional[torch.Tensor], blank_id: int
                                  _lib.ptr(best), _lib.ptr(tokens), _lib.ptr(ntok), _lib.ptr(frames),
                                  _lib.stream_of(scores)), "pafc_ctc_greedy")
     return (tokens, ntok, frames) if want_frames else (tokens, ntok)
+
+
+_ACTS = {"none": 0, "silu": 1, "tanh": 2, "relu": 3}
+
+
+def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
+              alpha: float = 1.0, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """Hand-written bf16 GEMM with fused epilogue (include/pafc_encoder_ops.h: pafc_gemm_bf16).
+    a: (M, K) or (Z, M, K); w: (N, K) or (Z, N, K) in nn.Linear layout; bias: (N) or (Z, N); residual / out:
+    (M, N) or (Z, M, N), ``out`` may be ``residual``.  Rows may be strided views (unit stride in the last dim)."""
+    _lib.require_gpu(bias)
+    for t in (a, w, residual, out):
+        if t is not None and (not t.is_cuda or t.dtype != torch.bfloat16 or t.stride(-1) != 1):
+            raise _lib.PafcError("gemm_bf16: bf16 GPU tensors with unit stride in the last dimension")
+    L = _bind2()
+    if not getattr(L, "_pafc_gemm2_bound", False):
+        from ctypes import c_float, c_long
+        P, I, G = c_void_p, c_int, c_long
+        _lib._sig(L.pafc_gemm_bf16, I, G, I, I, I, P, G, G, P, G, G, P, G, P, G, G, P, G, G, c_float, I, P)
+        L._pafc_gemm2_bound = True
+    batched = a.dim() == 3
+    Z = a.shape[0] if batched else 1
+    M, K = a.shape[-2], a.shape[-1]
+    N = w.shape[-2]
+    if w.shape[-1] != K or (batched and (w.dim() != 3 or w.shape[0] != Z)) or (not batched and (a.dim() != 2 or w.dim() != 2)):
+        raise _lib.PafcError("gemm_bf16: a (M, K) x w (N, K), or both with a leading batch")
+    if out is None:
+        out = torch.empty((Z, M, N) if batched else (M, N), dtype=a.dtype, device=a.device)
+    for t in (residual, out):
+        if t is not None and tuple(t.shape) != ((Z, M, N) if batched else (M, N)):
+            raise _lib.PafcError("gemm_bf16: residual / out must be (M, N) per batch entry")
+    if bias is not None and (bias.dtype != a.dtype or bias.shape[-1] != N):
+        raise _lib.PafcError("gemm_bf16: bias must be (N) or (Z, N) bf16")
+    sb = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
+    bs = lambda t: t.stride(0) if batched else 0
+    rc = L.pafc_gemm_bf16(M, N, K, Z, _lib.ptr(a), a.stride(-2), bs(a), _lib.ptr(w), w.stride(-2), bs(w),
+                          _lib.ptr(bias), sb, _lib.ptr(residual), residual.stride(-2) if residual is not None else 0,
+                          bs(residual) if residual is not None else 0, _lib.ptr(out), out.stride(-2), bs(out),
+                          float(alpha), _ACTS[act], _lib.stream_of(a))
+    _lib.check(rc, "pafc_gemm_bf16")
+    return out

@@ -52,6 +52,8 @@ class LayerPlan:
         with torch.no_grad():
             self.maa_x = [b.time_maa_x.reshape(-1).contiguous() for b in bl]
             self.W1 = torch.stack([b.time_maa_rkvw_w1 for b in bl]).contiguous()           # (nd, C, 128)
+            self.W1n = torch.stack([b.time_maa_rkvw_w1.t() for b in bl]).contiguous()      # (nd, 128, C): Linear layout
+            self.D1n = torch.stack([b.time_decay_w1.t() for b in bl]).contiguous()         # (nd, 64, C)
             self.W2 = [b.time_maa_rkvw_w2.contiguous() for b in bl]                        # (4, 32, C) each
             self.W2t = torch.stack([b.time_maa_rkvw_w2.transpose(1, 2) for b in bl]).contiguous()  # (nd, 4, C, 32)
             self.maa4 = torch.stack([torch.stack([b.time_maa_r.reshape(-1), b.time_maa_k.reshape(-1),
@@ -104,7 +106,11 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
     B, T, C = h.shape
     M, nd = B * T, plan.ndir
     xxx = hip_ops.tmix_shift_mix(h, plan.maa_x[0], plan.maa_x[1] if nd == 2 else None)
-    t = torch.tanh(torch.bmm(xxx.view(nd, M, C), plan.W1))                                  # (nd, M, 128)
+    own_gemm = h.dtype == torch.bfloat16 and C % 64 == 0
+    if own_gemm:   # tanh rides on the down-projection (hand-written GEMM, one rounding)
+        t = hip_ops.gemm_bf16(xxx.view(nd, M, C), plan.W1n, act="tanh")                     # (nd, M, 128)
+    else:
+        t = torch.tanh(torch.bmm(xxx.view(nd, M, C), plan.W1))
     if h.dtype == torch.bfloat16 and t.shape[-1] == 128 and C % 64 == 0:
         z = hip_ops.tmix_lora_mix4(h, t, plan.W2t, plan.maa4)      # LoRA up-projection on MFMA inside the lerp pass
     else:
@@ -113,7 +119,8 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
             torch.bmm(t[d].view(M, 4, -1).transpose(0, 1), plan.W2[d], out=m[d])
         z = hip_ops.tmix_mix4(h, m, plan.maa4)                                              # (4, nd, M, C)
     rkv = torch.bmm(z[:3].view(3 * nd, M, C), plan.Wrkv)                                    # (3nd, M, C)
-    w = torch.bmm(torch.tanh(torch.bmm(z[3], plan.D1)), plan.D2)                            # (nd, M, C) decay LoRA
+    td = hip_ops.gemm_bf16(z[3], plan.D1n, act="tanh") if own_gemm else torch.tanh(torch.bmm(z[3], plan.D1))
+    w = torch.bmm(td, plan.D2)                                                              # (nd, M, C) decay LoRA
     if nd == 1:
         w = w + plan.time_decay            # uni: one extra pass; bi: time_decay is added inside the scan kernel
     ycat = torch.empty((M, nd * C), dtype=h.dtype, device=h.device)
@@ -159,8 +166,13 @@ def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optio
                                      glu=True)
     _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
     if not masked:
-        x = hip_ops.linear_bias_act(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none",
-                                    residual=x, inplace=True)
+        if g.dtype == torch.bfloat16 and C % 64 == 0:
+            x2 = x.view(B * T, C)
+            hip_ops.gemm_bf16(g.view(B * T, C), cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias,
+                              residual=x2, out=x2)
+        else:
+            x = hip_ops.linear_bias_act(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none",
+                                        residual=x, inplace=True)
         _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff.weight, L.norm_ff.bias, want_x=False)
     else:   # padded frames of the conv branch count as zero (convolution.py:140-141): the add stays in the norm pass
         c = F.linear(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias)

@@ -152,3 +152,47 @@ def test_conv3x3s2_implicit_gemm(hip, B, T1, F1, C):
     assert got.shape == ref.shape
     torch.testing.assert_close(got.float(), ref, rtol=2 ** -7, atol=2e-2)
     assert float((got.float() - ref).abs().mean()) < 3e-3
+
+
+@pytest.mark.parametrize("M,N,K,Z", [(300, 128, 64, 1), (129, 256, 512, 1), (1000, 64, 512, 2), (257, 2048, 512, 1),
+                                     (128, 512, 2048, 1), (77, 512, 512, 6), (5, 8, 64, 1)])
+@pytest.mark.parametrize("act", ["none", "silu", "tanh", "relu"])
+def test_gemm_bf16_hand_written(hip, M, N, K, Z, act):
+    """pafc_gemm_bf16 (hand-written MFMA GEMM) vs fp32 torch: tails in M and N, batching, every epilogue."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_bf16
+    bf = torch.bfloat16
+    shp = (lambda *s: (Z,) + s) if Z > 1 else (lambda *s: s)
+    a = synth.randn(shp(M, K), 1).to(bf)
+    w = synth.randn(shp(N, K), 2, 0.05).to(bf)
+    b = synth.randn(shp(N), 3, 0.2).to(bf)
+    r = synth.randn(shp(M, N), 4).to(bf)
+    f = {"none": lambda t: t, "silu": F.silu, "tanh": torch.tanh, "relu": F.relu}[act]
+    lin = torch.matmul(a.float(), w.float().transpose(-1, -2))
+    bb = b.float().unsqueeze(-2) if Z > 1 else b.float()
+    tol = dict(rtol=2 ** -7, atol=2e-2)
+    got = gemm_bf16(a.cuda(), w.cuda(), b.cuda(), act)
+    torch.testing.assert_close(got.cpu().float(), f(lin + bb), **tol)
+    got = gemm_bf16(a.cuda(), w.cuda(), None, act, alpha=0.5, residual=r.cuda())
+    torch.testing.assert_close(got.cpu().float(), f(0.5 * lin) + r.float(), **tol)
+    buf = r.cuda().clone()
+    assert gemm_bf16(a.cuda(), w.cuda(), b.cuda(), "none", residual=buf, out=buf).data_ptr() == buf.data_ptr()
+    torch.testing.assert_close(buf.cpu().float(), lin + bb + r.float(), **tol)
+
+
+def test_gemm_bf16_strided_rows_and_errors(hip):
+    from paper_accurate_fast_cheap_amd._lib import PafcError
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_bf16
+    bf = torch.bfloat16
+    wide = synth.randn((200, 256), 5).to(bf).cuda()
+    a = wide[:, 64:192]                                   # row stride 256, offset 128 B: still 16-byte aligned rows
+    w = synth.randn((128, 128), 6, 0.05).to(bf).cuda()
+    outw = torch.zeros(200, 384, dtype=bf, device="cuda")
+    gemm_bf16(a, w, out=outw[:, 128:256])
+    torch.testing.assert_close(outw[:, 128:256].cpu().float(), a.cpu().float() @ w.cpu().float().t(), rtol=2 ** -7, atol=2e-2)
+    assert float(outw[:, :128].abs().max()) == 0 and float(outw[:, 256:].abs().max()) == 0
+    with pytest.raises(PafcError):
+        gemm_bf16(a, synth.randn((128, 100), 7).to(bf).cuda())          # K mismatch
+    with pytest.raises(PafcError):
+        gemm_bf16(wide[:, :96], synth.randn((128, 96), 7).to(bf).cuda())  # K % 64
+    with pytest.raises(PafcError):
+        gemm_bf16(a.float(), w.float())

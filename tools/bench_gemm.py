@@ -1,17 +1,46 @@
-import torch, time
+"""Hand-written GEMM (pafc_gemm_bf16) vs the library paths on the encoder's shapes (30-minute sequence)."""
+import sys, time
+import torch
 import torch.nn.functional as F
-from paper_accurate_fast_cheap_amd.hip_ops import linear_bias_act
-M=44998
+from paper_accurate_fast_cheap_amd.hip_ops import gemm_bf16, linear_bias_act
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 44998
+dev, bf = "cuda", torch.bfloat16
+
+
 def bench(fn, name, flops):
     for _ in range(3): fn()
-    torch.cuda.synchronize(); t0=time.time(); n=20
+    torch.cuda.synchronize(); t0 = time.time(); n = 20
     for _ in range(n): fn()
-    torch.cuda.synchronize(); dt=(time.time()-t0)/n
-    print(f"{name}: {dt*1e6:.1f} us  {flops/dt/1e12:.0f} TF/s", flush=True)
-for (K,N) in [(512,2048),(2048,512),(512,1024),(512,512),(1024,512)]:
-    x=torch.randn(M,K,device='cuda',dtype=torch.bfloat16); w=torch.randn(N,K,device='cuda',dtype=torch.bfloat16)*0.05; b=torch.randn(N,device='cuda',dtype=torch.bfloat16)
-    fl=2*M*K*N
-    bench(lambda: F.linear(x,w,b), f"torch linear {K}->{N}", fl)
-    bench(lambda: F.silu(F.linear(x,w,b)), f"torch linear+silu {K}->{N}", fl)
-    bench(lambda: linear_bias_act(x,w,b,"silu"), f"pafc linear_bias_silu {K}->{N}", fl)
-    bench(lambda: linear_bias_act(x,w,b,"none"), f"pafc linear_bias {K}->{N}", fl)
+    torch.cuda.synchronize(); dt = (time.time() - t0) / n
+    print(f"  {name:34s} {dt*1e6:8.1f} us  {flops/dt/1e12:6.0f} TF/s", flush=True)
+
+
+def check(got, want, what):
+    err = (got.float() - want.float()).abs().max().item()
+    ref = want.float().abs().max().item()
+    print(f"  check {what}: max err {err:.3g} (max |ref| {ref:.3g})", flush=True)
+
+
+for (K, N, act, res, name) in [(512, 2048, "silu", False, "ffn w_1 + SiLU"), (2048, 512, "none", True, "ffn w_2 + residual"),
+                               (512, 1024, "none", False, "pointwise_conv1"), (512, 512, "none", True, "pointwise_conv2 + residual"),
+                               (1024, 512, "none", True, "slot output + residual"), (512, 128, "tanh", False, "maa LoRA down + tanh")]:
+    print(f"{name}: M={M} K={K} N={N}")
+    x = torch.randn(M, K, device=dev, dtype=bf); w = torch.randn(N, K, device=dev, dtype=bf) * 0.05
+    b = torch.randn(N, device=dev, dtype=bf); r = torch.randn(M, N, device=dev, dtype=bf) if res else None
+    fl = 2 * M * K * N
+    a = {"silu": F.silu, "tanh": torch.tanh, "none": lambda t: t}[act]
+    want = a(F.linear(x.float(), w.float(), b.float())) * 1.0
+    if res: want = r.float() + 0.5 * F.linear(x.float(), w.float()) + b.float()
+    got = gemm_bf16(x, w, b, act, alpha=0.5 if res else 1.0, residual=r)
+    check(got, want, "gemm_bf16")
+    bench(lambda: gemm_bf16(x, w, b, act, alpha=0.5 if res else 1.0, residual=r), "pafc gemm_bf16 (hand-written)", fl)
+    if act in ("silu", "none"):
+        bench(lambda: linear_bias_act(x, w, b, act, alpha=0.5 if res else 1.0, residual=r), "hipBLASLt fused epilogue", fl)
+    bench(lambda: a(F.linear(x, w, b)), "torch linear (+act)", fl)
+
+print("batched r,k,v of both directions: 6 x (M, 512) x (512, 512)")
+z = torch.randn(6, M, 512, device=dev, dtype=bf); w6 = torch.randn(6, 512, 512, device=dev, dtype=bf) * 0.05
+check(gemm_bf16(z, w6), torch.bmm(z.float(), w6.float().transpose(1, 2)), "batched")
+bench(lambda: gemm_bf16(z, w6), "pafc gemm_bf16 batched", 6 * 2 * M * 512 * 512)
+w6t = w6.transpose(1, 2).contiguous()
+bench(lambda: torch.bmm(z, w6t), "torch bmm", 6 * 2 * M * 512 * 512)
