@@ -11,20 +11,24 @@
 // as a GEMM  M = B*T2*F2 output positions,  N = Co,  K = 9 * Ci, NHWC in and out (so every A row segment of one tap is
 // 64 contiguous channels = 128 B, and the output needs no transpose before the Linear that follows).
 //
-// Block = 256 threads (4 waves, 2 x 2), tile 128 (M) x 128 (N) x 64 (K); each wave owns 64 x 64 = 4 x 4 MFMA
-// 16x16x32 tiles (64 accumulator VGPRs).  A and B tiles go global -> LDS by LDS-DMA (global_load_lds, 16 B per lane,
-// no VGPRs): the LDS image is lane-linear, so the XOR swizzle that makes the ds_read_b128 fragment reads
-// conflict-free is applied to the per-lane SOURCE address (chunk p of row r holds source chunk p ^ (r & 7)).  Two LDS
-// buffers: the loads of K-step i+1 are in flight while step i is multiplied.  Epilogue: bias + ReLU on the fp32
-// accumulators, one rounding to bf16, staged through LDS and stored as whole 256-byte rows.
+// Block = 256 threads (4 waves, 2 x 2); each wave owns (16 WM) x (16 WN) outputs = WM x WN MFMA 16x16x32 tiles, K
+// step 64.  A and B tiles go global -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPRs): the LDS image is
+// lane-linear, so the XOR swizzle that makes the ds_read_b128 fragment reads conflict-free is applied to the per-lane
+// SOURCE address (chunk p of row r holds source chunk p ^ (r & 7)).  STAGES LDS buffers: the loads of K-step
+// i + STAGES - 1 are in flight while step i is multiplied.
+// Tile shape is the lever against the real limit of this loop, LDS bandwidth: a 64 x 64 wave tile reads 512 B of LDS
+// per MFMA = the CU's whole 128 B/clk at full MFMA rate; 128 x 64 reads 384 B, 128 x 128 256 B (and then needs
+// the 512-register budget of one wave per SIMD).
+// Epilogue: bias + ReLU on the fp32 accumulators, one rounding to bf16, staged through LDS and stored as whole rows.
 // Blocks are numbered so that the N-tiles of one M-tile run on one XCD (they share the A tile in that XCD's L2).
+#include <stdlib.h>
 #include "pafc_common.h"
 #include "../../include/pafc_encoder_ops.h"
 
 namespace pafc {
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
 typedef float f32x4c __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
 
@@ -44,8 +48,12 @@ __device__ __forceinline__ void dma16(const bf16_t *src, bf16_t *lds_base) {
                                      (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void conv3x3s2_kernel(const ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];   // [2 buffers][A 128x64 | B 128x64]
+template <int WM, int WN, int STAGES, int BLOCKS_PER_CU>
+__global__ __launch_bounds__(256, BLOCKS_PER_CU) void conv3x3s2_kernel(const ConvParams p) {
+    constexpr int BM = 32 * WM, BN = 32 * WN;          // block tile (2 x 2 waves)
+    constexpr int STAGE = (BM + BN) * BK;              // elements per stage: A rows then B rows
+    constexpr int AJ = BM / 32, BJ = BN / 32;          // DMA instructions (8 rows each) per wave for A / B
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -58,13 +66,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_kernel(const ConvParams p) {
     const long m0 = (long)mt0 * BM;
     const int n0 = nt0 * BN;
 
-    // ---- per-lane DMA sources: wave w fills rows [32 w, 32 w + 32) of A and of B, 4 instructions of 8 rows each ----
+    // ---- per-lane DMA sources: wave w fills rows [w BM/4, (w+1) BM/4) of A and the same share of B ---------------
     const int sub = lane >> 3, pch = lane & 7;             // row within the 8-row group, LDS chunk position
-    const bf16_t *a_src[4];
-    const bf16_t *b_src[4];
+    const bf16_t *a_src[AJ];
+    const bf16_t *b_src[BJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wave * 32 + j * 8 + sub;
+    for (int j = 0; j < AJ; ++j) {
+        const int row = wave * (BM / 4) + j * 8 + sub;
         const int c = pch ^ (row & 7);                      // source chunk that lands at position pch
         long m = m0 + row;
         if (m >= p.M) m = p.M - 1;                          // clamp: the row is computed but never stored
@@ -73,7 +81,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_kernel(const ConvParams p) {
         const int t2 = (int)(bt % p.T2);
         const int b = (int)(bt / p.T2);
         a_src[j] = p.in + (((long)b * p.T1 + 2 * t2) * p.F1 + 2 * f2) * p.Ci + 8 * c;
-        b_src[j] = p.wt + (long)(n0 + row) * p.Ci + 8 * c;
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int row = wave * (BN / 4) + j * 8 + sub;
+        b_src[j] = p.wt + (long)(n0 + row) * p.Ci + 8 * (pch ^ (row & 7));
     }
     const int kblocks = p.Ci / BK;
     const int iters = 9 * kblocks;
@@ -84,78 +96,107 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_kernel(const ConvParams p) {
         const int kh = tap / 3, kw = tap - 3 * kh;
         const long aoff = ((long)kh * p.F1 + kw) * p.Ci + kb * BK;
         const long boff = tap * tap_stride_b + kb * BK;
-        bf16_t *A = lds + buf * (2 * BM * BK);
+        bf16_t *A = lds + buf * STAGE;
         bf16_t *Bt = A + BM * BK;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rowbase = (wave * 32 + j * 8) * BK;   // wave-uniform LDS base of this 8-row group (1 KiB)
-            dma16(a_src[j] + aoff, A + rowbase);
-            dma16(b_src[j] + boff, Bt + rowbase);
-        }
+        for (int j = 0; j < AJ; ++j) dma16(a_src[j] + aoff, A + (wave * (BM / 4) + j * 8) * BK);
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) dma16(b_src[j] + boff, Bt + (wave * (BN / 4) + j * 8) * BK);
     };
 
-    f32x4c acc[4][4];
+    f32x4c acc[WM][WN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < WN; ++j) acc[i][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, kq = lane >> 4;
-    issue(0, 0);
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < iters) issue(s, s);
     for (int it = 0; it < iters; ++it) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                    // buffer it&1 landed; everyone left buffer (it+1)&1
-        if (it + 1 < iters) issue(it + 1, (it + 1) & 1);
-        const bf16_t *A = lds + (it & 1) * (2 * BM * BK);
+        // the stage of iteration `it` has landed when at most the (STAGES - 2) younger stages are still in flight
+        if (STAGES == 2 || it + STAGES - 2 >= iters) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (AJ + BJ)) : "memory");
+        __syncthreads();                                    // stage it % STAGES landed; everyone left the stage refilled next
+        if (it + STAGES - 1 < iters) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
+        const bf16_t *A = lds + (it % STAGES) * STAGE;
         const bf16_t *Bt = A + BM * BK;
+        // LDS -> register reads are software-pipelined one unit (= one A fragment x WN B fragments = WN MFMAs) ahead,
+        // B fragments of the second k-step double-buffered and fetched a few per unit: with one or two waves per SIMD
+        // nobody else hides the ds_read latency, and left alone the compiler waits for every fragment it just asked for
+        auto ldA = [&](int ks, int i) {
+            const int row = wm * (16 * WM) + i * 16 + fr;
+            return *reinterpret_cast<const bf16x8c *>(A + row * BK + (((ks * 4 + kq) ^ (row & 7)) * 8));
+        };
+        auto ldB = [&](int ks, int j) {
+            const int row = wn * (16 * WN) + j * 16 + fr;
+            return *reinterpret_cast<const bf16x8c *>(Bt + row * BK + (((ks * 4 + kq) ^ (row & 7)) * 8));
+        };
+        bf16x8c bq[2][WN], aq[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8c af[4], bfr[4];
+        for (int j = 0; j < WN; ++j) bq[0][j] = ldB(0, j);
+        aq[0] = ldA(0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wm * 64 + i * 16 + fr;
-                const int pos = (ks * 4 + kq) ^ (row & 7);
-                af[i] = *reinterpret_cast<const bf16x8c *>(A + row * BK + pos * 8);
+        for (int u = 0; u < 2 * WM; ++u) {
+            const int ks = u / WM, i = u % WM;
+            if (u + 1 < 2 * WM) aq[(u + 1) & 1] = ldA((u + 1) / WM, (u + 1) % WM);
+            if (ks == 0) {
+#pragma unroll
+                for (int j = (i * WN) / WM; j < ((i + 1) * WN) / WM; ++j) bq[1][j] = ldB(1, j);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wn * 64 + j * 16 + fr;
-                const int pos = (ks * 4 + kq) ^ (row & 7);
-                bfr[j] = *reinterpret_cast<const bf16x8c *>(Bt + row * BK + pos * 8);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[u & 1], bq[ks][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();   // all waves done with the operand buffers: reuse them to stage the output tile
 
     // ---- epilogue: C/D layout col = lane & 15 (n), row = 4 (lane >> 4) + reg (m) --------------------------------
     constexpr int LDO = BN + 8;
-    bf16_t *O = lds;   // [128][136] bf16 = 34 KiB <= 64 KiB
+    bf16_t *O = lds;   // [BM][BN + 8] bf16 (the launch sizes the LDS for the larger of stages and staging)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = wn * 64 + j * 16 + fr;
+    for (int j = 0; j < WN; ++j) {
+        const int col = wn * (16 * WN) + j * 16 + fr;
         const float bv = p.bias ? bf16_bits_to_f32(p.bias[n0 + col]) : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float v = acc[i][j][g] + bv;
                 if (p.relu) v = fmaxf(v, 0.f);
-                O[(wm * 64 + i * 16 + 4 * kq + g) * LDO + col] = (bf16_t)f32_to_bf16_bits(v);
+                O[(wm * (16 * WM) + i * 16 + 4 * kq + g) * LDO + col] = (bf16_t)f32_to_bf16_bits(v);
             }
     }
     __syncthreads();
+    constexpr int CPR = BN / 8;            // 16-byte chunks per output row
+    constexpr int RPP = 256 / CPR;         // rows per pass of the block
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int row = q * 16 + (tid >> 4), c8 = (tid & 15) * 8;
+    for (int q = 0; q < BM / RPP; ++q) {
+        const int row = q * RPP + tid / CPR, c8 = (tid % CPR) * 8;
         const long m = m0 + row;
         if (m < p.M)
             *reinterpret_cast<uint4 *>(p.out + m * p.Co + n0 + c8) = *reinterpret_cast<const uint4 *>(O + row * LDO + c8);
     }
+}
+
+template <int WM, int WN, int STAGES, int BPC>
+int launch_conv(ConvParams &p, hipStream_t stream) {
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    if (p.Co % BN) return PAFC_ERR_BAD_DIMS;
+    p.mtiles = (int)((p.M + BM - 1) / BM);
+    p.ntiles = p.Co / BN;
+    constexpr size_t stage_bytes = (size_t)STAGES * (BM + BN) * BK * sizeof(bf16_t);
+    constexpr size_t out_bytes = (size_t)BM * (BN + 8) * sizeof(bf16_t);
+    const size_t lds = stage_bytes > out_bytes ? stage_bytes : out_bytes;
+    auto kern = conv3x3s2_kernel<WM, WN, STAGES, BPC>;
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PAFC_ERR_LAUNCH;
+    const long nblk = (long)p.mtiles * p.ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 
 }  // namespace
@@ -164,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_kernel(const ConvParams p) {
 extern "C" int pafc_conv3x3s2_nhwc_bf16(int B, int T1, int F1, int Ci, int Co, const void *in, const void *w_tap_co_ci,
                                         const void *bias, void *out, int relu, pafc_stream_t stream) {
     if (!in || !w_tap_co_ci || !out) return PAFC_ERR_NULL_POINTER;
-    if (B <= 0 || T1 < 3 || F1 < 3 || Ci <= 0 || Co <= 0 || Ci % pafc::BK || Co % pafc::BN) return PAFC_ERR_BAD_DIMS;
+    if (B <= 0 || T1 < 3 || F1 < 3 || Ci <= 0 || Co <= 0 || Ci % pafc::BK || Co % 128) return PAFC_ERR_BAD_DIMS;
     pafc::ConvParams p{};
     p.in = (const pafc::bf16_t *)in; p.wt = (const pafc::bf16_t *)w_tap_co_ci; p.bias = (const pafc::bf16_t *)bias;
     p.out = (pafc::bf16_t *)out;
@@ -172,13 +213,16 @@ extern "C" int pafc_conv3x3s2_nhwc_bf16(int B, int T1, int F1, int Ci, int Co, c
     p.T2 = (T1 - 3) / 2 + 1; p.F2 = (F1 - 3) / 2 + 1;
     p.M = (long)B * p.T2 * p.F2;
     p.relu = relu;
-    p.mtiles = (int)((p.M + pafc::BM - 1) / pafc::BM);
-    p.ntiles = Co / pafc::BN;
-    const size_t lds = 2 * 2 * pafc::BM * pafc::BK * sizeof(pafc::bf16_t);   // 64 KiB
-    if (hipFuncSetAttribute((const void *)pafc::conv3x3s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
-        return PAFC_ERR_LAUNCH;
-    const long nblk = (long)p.mtiles * p.ntiles;
-    hipLaunchKernelGGL(pafc::conv3x3s2_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, p);
-    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+    // PAFC_CONV_TILE selects the tile shape for A/B measurements (read per call, no global state); default below.
+    const char *e = getenv("PAFC_CONV_TILE");
+    const int v = e ? atoi(e) : 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (v == 1) return pafc::launch_conv<4, 4, 2, 2>(p, s);     // 128 x 128 block, 64 x 64 wave tiles, 2 blocks per CU
+    if (v == 2) return pafc::launch_conv<8, 4, 3, 1>(p, s);     // 256 x 128 block, 128 x 64 wave tiles, 3 stages
+    if (v == 3) return pafc::launch_conv<8, 4, 2, 1>(p, s);     // 256 x 128 block, 2 stages
+    if (v == 4 && Co % 256 == 0) return pafc::launch_conv<8, 8, 2, 1>(p, s);   // 256 x 256 block, 128 x 128 wave tiles
+    // default: 256 x 256 tiles when there are enough of them to fill the chip several times over (the tail of a 1-block-
+    // per-CU grid costs a whole tile time), 128 x 128 otherwise
+    if (Co % 256 == 0 && ((p.M + 255) / 256) * (Co / 256) >= 8 * 256) return pafc::launch_conv<8, 8, 2, 1>(p, s);
+    return pafc::launch_conv<4, 4, 2, 2>(p, s);
 }

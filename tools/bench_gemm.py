@@ -1,5 +1,5 @@
 """Hand-written GEMM (pafc_gemm_bf16) vs the library paths on the encoder's shapes (30-minute sequence)."""
-import sys, time
+import os, sys, time
 import torch
 import torch.nn.functional as F
 from paper_accurate_fast_cheap_amd.hip_ops import gemm_bf16, linear_bias_act
