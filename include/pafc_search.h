@@ -25,6 +25,12 @@ extern "C" {
 int pafc_ctc_greedy(int dtype, int B, int T, int V, const void *scores, const int64_t *lens, int blank_id,
                     int32_t *best, int32_t *tokens, int32_t *ntok, int32_t *frames, pafc_stream_t stream);
 
+/* Row-wise log-softmax over the vocabulary: out[r][v] = x[r][v] - max_v x[r] - log sum_v exp(x[r][v] - max), fp32
+ * arithmetic, one rounding to the element type (CTC.log_softmax, wenet/transformer/ctc.py:106-114, behind
+ * ASRModel.ctc_logprobs, asr_model.py:324-335).  x, out: (rows, V) contiguous, may alias.  One pass over HBM: a wave
+ * keeps its row in registers (V <= 8192 elements in bf16, 4096 in fp32; longer rows are re-read from cache). */
+int pafc_log_softmax_rows(int dtype, long rows, int V, const void *x, void *out, pafc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

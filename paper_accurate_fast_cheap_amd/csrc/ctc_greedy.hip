@@ -90,6 +90,82 @@ __global__ __launch_bounds__(256) void ctc_collapse_kernel(int T, int blank, con
     if (tid == 0) ntok[b] = s_base;
 }
 
+// log-softmax of one row per wave.  RC 16-byte chunks per lane live in registers between the reduction and the write
+// (one read of HBM); rows longer than 64 * RC chunks (or not 16-byte aligned) take the three-sweep path, whose second
+// and third sweeps hit the cache.
+template <typename ET, int RC>
+__global__ __launch_bounds__(256) void log_softmax_kernel(long rows, int V, const ET *x, ET *out) {
+    using E = Elem<ET>;
+    constexpr int EPL = E::kPerLane;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const ET *p = x + row * (long)V;
+    ET *o = out + row * (long)V;
+    const int nvec = V / EPL;
+    const bool fast = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(o)) & 15) == 0 && nvec <= 64 * RC;
+    float mx = -INFINITY, sum = 0.f;
+    if (fast) {
+        uint4 q[RC];
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            const int idx = c * 64 + lane;
+            if (idx < nvec) {
+                q[c] = *reinterpret_cast<const uint4 *>(p + (long)idx * EPL);
+                float f[EPL];
+                E::unpack(q[c], f);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) mx = fmaxf(mx, f[e]);
+            }
+        }
+        float tail = -INFINITY;
+        const int ti = nvec * EPL + lane;
+        if (ti < V) { tail = E::load(p + ti); mx = fmaxf(mx, tail); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            if (c * 64 + lane < nvec) {
+                float f[EPL];
+                E::unpack(q[c], f);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) sum += __expf(f[e] - mx);
+            }
+        }
+        if (ti < V) sum += __expf(tail - mx);
+        sum = wave_sum(sum);
+        const float lse = __logf(sum);
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            const int idx = c * 64 + lane;
+            if (idx < nvec) {
+                float f[EPL];
+                E::unpack(q[c], f);
+                if constexpr (EPL == 8) {
+                    uint4 w;
+                    w.x = f32_to_bf16_bits(f[0] - mx - lse) | (f32_to_bf16_bits(f[1] - mx - lse) << 16);
+                    w.y = f32_to_bf16_bits(f[2] - mx - lse) | (f32_to_bf16_bits(f[3] - mx - lse) << 16);
+                    w.z = f32_to_bf16_bits(f[4] - mx - lse) | (f32_to_bf16_bits(f[5] - mx - lse) << 16);
+                    w.w = f32_to_bf16_bits(f[6] - mx - lse) | (f32_to_bf16_bits(f[7] - mx - lse) << 16);
+                    *reinterpret_cast<uint4 *>(o + (long)idx * EPL) = w;
+                } else {
+                    const float4 w = {f[0] - mx - lse, f[1] - mx - lse, f[2] - mx - lse, f[3] - mx - lse};
+                    *reinterpret_cast<float4 *>(o + (long)idx * EPL) = w;
+                }
+            }
+        }
+        if (ti < V) E::store(o + ti, tail - mx - lse);
+        return;
+    }
+    for (int i = lane; i < V; i += 64) mx = fmaxf(mx, E::load(p + i));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    for (int i = lane; i < V; i += 64) sum += __expf(E::load(p + i) - mx);
+    sum = wave_sum(sum);
+    const float lse = __logf(sum);
+    for (int i = lane; i < V; i += 64) E::store(o + i, E::load(p + i) - mx - lse);
+}
+
 }  // namespace
 }  // namespace pafc
 
@@ -109,5 +185,21 @@ extern "C" int pafc_ctc_greedy(int dtype, int B, int T, int V, const void *score
         hipLaunchKernelGGL((pafc::ctc_argmax_kernel<float>), dim3((unsigned)nblk), dim3(256), 0, s, rows, T, V,
                            (const float *)scores, lens, blank_id, best);
     hipLaunchKernelGGL(pafc::ctc_collapse_kernel, dim3(B), dim3(256), 0, s, T, blank_id, best, tokens, ntok, frames);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+extern "C" int pafc_log_softmax_rows(int dtype, long rows, int V, const void *x, void *out, pafc_stream_t stream) {
+    if (!x || !out) return PAFC_ERR_NULL_POINTER;
+    if (rows <= 0 || V <= 0) return PAFC_ERR_BAD_DIMS;
+    if (dtype != PAFC_F32 && dtype != PAFC_BF16) return PAFC_ERR_DTYPE;
+    const long nblk = (rows + 3) / 4;
+    if (nblk > 0x7fffffffL) return PAFC_ERR_BAD_DIMS;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PAFC_BF16)
+        hipLaunchKernelGGL((pafc::log_softmax_kernel<pafc::bf16_t, 16>), dim3((unsigned)nblk), dim3(256), 0, s, rows, V,
+                           (const pafc::bf16_t *)x, (pafc::bf16_t *)out);
+    else
+        hipLaunchKernelGGL((pafc::log_softmax_kernel<float, 16>), dim3((unsigned)nblk), dim3(256), 0, s, rows, V,
+                           (const float *)x, (float *)out);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }

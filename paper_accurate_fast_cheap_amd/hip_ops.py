@@ -232,3 +232,18 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
                           float(alpha), _ACTS[act], _lib.stream_of(a))
     _lib.check(rc, "pafc_gemm_bf16")
     return out
+
+
+def log_softmax_rows(x: torch.Tensor, inplace: bool = False) -> torch.Tensor:
+    """log_softmax over the last dimension in one pass over HBM (include/pafc_search.h: pafc_log_softmax_rows)."""
+    _lib.require_gpu(x)
+    L = _bind()
+    if not getattr(L, "_pafc_lsm_bound", False):
+        from ctypes import c_long
+        _lib._sig(L.pafc_log_softmax_rows, c_int, c_int, c_long, c_int, c_void_p, c_void_p, c_void_p)
+        L._pafc_lsm_bound = True
+    V = x.shape[-1]
+    out = x if inplace else torch.empty_like(x)
+    _lib.check(L.pafc_log_softmax_rows(_lib.dtype_code(x.dtype), x.numel() // V, V, _lib.ptr(x), _lib.ptr(out),
+                                       _lib.stream_of(x)), "pafc_log_softmax_rows")
+    return out

@@ -22,7 +22,13 @@ class CTC(torch.nn.Module):
         return loss, ys_hat.transpose(0, 1)
 
     def log_softmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
-        return F.log_softmax(self.ctc_lo(hs_pad), dim=2)
+        """ctc.py:106-114.  Inference on the GPU: the (B, T', V) logits -- the largest activation of the pass -- are
+        normalised in place by one kernel that reads them once; with autograd (training) the framework op is used."""
+        logits = self.ctc_lo(hs_pad)
+        if logits.is_cuda and not torch.is_grad_enabled() and logits.dtype in (torch.float32, torch.bfloat16):
+            from ..hip_ops import log_softmax_rows
+            return log_softmax_rows(logits.contiguous(), inplace=True)
+        return F.log_softmax(logits, dim=2)
 
     def argmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
         return torch.argmax(self.ctc_lo(hs_pad), dim=2)

@@ -82,3 +82,24 @@ def test_greedy_bad_arguments(hip):
         ctc_greedy(torch.zeros(2, 3, 4, device="cuda"), None, blank_id=9)
     with pytest.raises(PafcError):
         ctc_greedy(torch.zeros(2, 3, 4, device="cuda", dtype=torch.float16), None)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,V", [(1, 1), (7, 50), (300, 5000), (33, 4999), (5, 9000), (3, 70000)])
+def test_log_softmax_rows(hip, dtype, rows, V):
+    """One-pass log-softmax vs the fp32 definition: register path, unaligned rows, rows too long for registers."""
+    from paper_accurate_fast_cheap_amd.hip_ops import log_softmax_rows
+    x = (torch.randn(rows, V, generator=torch.Generator().manual_seed(V)) * 4).to(dtype)
+    x[0, 0] = 30.0                                           # a dominant entry: log-prob ~ 0, the others ~ -30
+    want = x.float().log_softmax(-1)
+    got = log_softmax_rows(x.cuda())
+    tol = dict(rtol=2 ** -7, atol=2 ** -6) if dtype == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(got.cpu().float(), want, **tol)
+    assert got.dtype == dtype
+    if dtype == torch.float32:
+        assert torch.allclose(got.exp().sum(-1).cpu(), torch.ones(rows), atol=1e-4)
+    buf = x.cuda().clone()
+    assert log_softmax_rows(buf, inplace=True).data_ptr() == buf.data_ptr()
+    assert torch.equal(buf, got)
+    if dtype == torch.float32:   # same argmax as the input (greedy search may run on either)
+        assert torch.equal(got.argmax(-1).cpu(), x.argmax(-1))
