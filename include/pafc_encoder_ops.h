@@ -90,7 +90,10 @@ int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, cons
  *   out[z][m][n] = act(alpha * sum_k A[z][m][k] * W[z][n][k] + bias[z][n] + residual[z][m][n]),   z < batch
  * A: (M, K) rows lda apart; W: (N, K) = nn.Linear.weight layout, rows ldw apart; out / residual: (M, N), rows ldo / ldr
  * apart; stride*: elements between consecutive batch entries (strideBias = 0 shares one bias); bias, residual may be
- * NULL; residual may alias out.  act: 0 none, 1 SiLU, 2 tanh, 3 ReLU.  bias is added as given (not scaled by alpha);
+ * NULL; residual may alias out.  act: 0 none, 1 SiLU, 2 tanh, 3 ReLU, 4 GLU (out has N / 2 columns: within every block of
+ * 128 weight rows the first 64 are the value rows and the last 64 the gate rows of the same 64 output channels,
+ * out[m][64 t + c] = a * sigmoid(b) with a, b = columns 128 t + c, 128 t + 64 + c; N % 128 == 0, no residual -- F.glu
+ * after pointwise_conv1, convolution.py:118-128, with the weight rows interleaved by the caller).  bias is added as given (not scaled by alpha);
  * everything is applied to the fp32 accumulator, one rounding to bf16.  N % 8 == 0 (tiles are 128 wide), K % 64 == 0, all leading
  * dimensions / strides multiples of 8 elements, pointers 16-byte aligned.  Replaces the Linear / 1x1-Conv1d calls of
  * PositionwiseFeedForward, ConvolutionModule, RWKV_Tmix_x060c and the residual adds of ConformerEncoderLayer.forward

@@ -53,8 +53,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-template <bool HAS_RES>
+// EPI: 0 = plain (bf16 staging), 1 = residual (fp32 staging), 2 = GLU (the tile's columns [0, 64) are values, [64, 128)
+// the gates of the same 64 output channels; the output has N / 2 columns)
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
+    constexpr bool HAS_RES = EPI == 1;
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];   // [2 stages][A 128x64 | W 128x64] (64 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -168,6 +171,52 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
                 *reinterpret_cast<uint4 *>(Oz + m * p.ldo + n0 + c8) = w;
             }
         }
+    } else if constexpr (EPI == 2) {
+        // waves wn = 1 hold the gates of exactly the elements waves wn = 0 hold (same lane, same register): the gate
+        // passes through LDS as fp32 in the accumulator layout, the product a * sigmoid(b) is rounded once
+        constexpr int LDG = 64 + 4;
+        float *G = reinterpret_cast<float *>(lds);               // [128][68] fp32 = 34 KiB
+        constexpr int LDH = 64 + 8;
+        bf16_t *O = lds + 128 * LDG * 2 + 512;                    // behind the gates: [128][72] bf16 = 18 KiB
+        if (wn == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = j * 16 + fr;
+                const float bv = bz ? bf16_bits_to_f32(bz[n0 + 64 + col]) : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float b = fmaf(acc[i][j][g], p.alpha, bv);
+                        G[(wm * 64 + i * 16 + 4 * kq + g) * LDG + col] = __builtin_amdgcn_rcpf(1.f + __expf(-b));
+                    }
+            }
+        }
+        __syncthreads();
+        if (wn == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = j * 16 + fr;
+                const float bv = bz ? bf16_bits_to_f32(bz[n0 + col]) : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = wm * 64 + i * 16 + 4 * kq + g;
+                        const float a = fmaf(acc[i][j][g], p.alpha, bv);
+                        O[row * LDH + col] = (bf16_t)f32_to_bf16_bits(a * G[row * LDG + col]);
+                    }
+            }
+        }
+        __syncthreads();
+        const int oc0 = n0 / 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = q * 32 + (tid >> 3), c8 = (tid & 7) * 8;
+            const long m = m0 + row;
+            if (m < p.M)
+                *reinterpret_cast<uint4 *>(Oz + m * p.ldo + oc0 + c8) = *reinterpret_cast<const uint4 *>(O + row * LDH + c8);
+        }
     } else {
         constexpr int LDO = GBN + 8;
         bf16_t *O = lds;   // [128][136] bf16 = 34 KiB
@@ -203,8 +252,10 @@ extern "C" int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, lo
     if (!A || !W || !out) return PAFC_ERR_NULL_POINTER;
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535) return PAFC_ERR_BAD_DIMS;
     if (N % 8 || K % pafc::GBK) return PAFC_ERR_UNSUPPORTED;
-    if (act < 0 || act > 3) return PAFC_ERR_UNSUPPORTED;
-    if (lda < K || ldw < K || ldo < N || (residual && ldr < N)) return PAFC_ERR_BAD_DIMS;
+    if (act < 0 || act > 4) return PAFC_ERR_UNSUPPORTED;
+    const bool glu = act == 4;
+    if (glu && (N % pafc::GBN || residual)) return PAFC_ERR_UNSUPPORTED;
+    if (lda < K || ldw < K || ldo < (glu ? N / 2 : N) || (residual && ldr < N)) return PAFC_ERR_BAD_DIMS;
     // 16-byte row segments everywhere (LDS-DMA sources, vector stores)
     if ((lda | ldw | ldo | strideA | strideW | strideO) % 8 || (residual && ((ldr | strideR) % 8))) return PAFC_ERR_ALIGNMENT;
     if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)residual) & 15) != 0) return PAFC_ERR_ALIGNMENT;
@@ -223,16 +274,16 @@ extern "C" int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, lo
     hipStream_t s = (hipStream_t)stream;
     if (residual) {
         const size_t lds = (size_t)pafc::GBM * (pafc::GBN + 4) * sizeof(float);   // 66 KiB (>= the 64 KiB of the stages)
-        if (hipFuncSetAttribute((const void *)pafc::gemm_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)pafc::gemm_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return PAFC_ERR_LAUNCH;
-        hipLaunchKernelGGL(pafc::gemm_bf16_kernel<true>, grid, dim3(256), lds, s, p);
+        hipLaunchKernelGGL(pafc::gemm_bf16_kernel<1>, grid, dim3(256), lds, s, p);
     } else {
         const size_t lds = 2 * 2 * pafc::GBM * pafc::GBK * sizeof(pafc::bf16_t);       // 64 KiB
-        if (hipFuncSetAttribute((const void *)pafc::gemm_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
+        auto kern = glu ? pafc::gemm_bf16_kernel<2> : pafc::gemm_bf16_kernel<0>;
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PAFC_ERR_LAUNCH;
-        hipLaunchKernelGGL(pafc::gemm_bf16_kernel<false>, grid, dim3(256), lds, s, p);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     }
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }

@@ -193,14 +193,16 @@ def ctc_greedy(scores: torch.Tensor, lens: Optional[torch.Tensor], blank_id: int
     return (tokens, ntok, frames) if want_frames else (tokens, ntok)
 
 
-_ACTS = {"none": 0, "silu": 1, "tanh": 2, "relu": 3}
+_ACTS = {"none": 0, "silu": 1, "tanh": 2, "relu": 3, "glu": 4}
 
 
 def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
               alpha: float = 1.0, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
     """Hand-written bf16 GEMM with fused epilogue (include/pafc_encoder_ops.h: pafc_gemm_bf16).
     a: (M, K) or (Z, M, K); w: (N, K) or (Z, N, K) in nn.Linear layout; bias: (N) or (Z, N); residual / out:
-    (M, N) or (Z, M, N), ``out`` may be ``residual``.  Rows may be strided views (unit stride in the last dim)."""
+    (M, N) or (Z, M, N), ``out`` may be ``residual``.  Rows may be strided views (unit stride in the last dim).
+    act "glu": w / bias rows come in blocks of 128 = 64 value rows + the 64 gate rows of the same channels
+    (``glu_interleave``); out is (M, N / 2)."""
     _lib.require_gpu(bias)
     for t in (a, w, residual, out):
         if t is not None and (not t.is_cuda or t.dtype != torch.bfloat16 or t.stride(-1) != 1):
@@ -217,10 +219,11 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
     N = w.shape[-2]
     if w.shape[-1] != K or (batched and (w.dim() != 3 or w.shape[0] != Z)) or (not batched and (a.dim() != 2 or w.dim() != 2)):
         raise _lib.PafcError("gemm_bf16: a (M, K) x w (N, K), or both with a leading batch")
+    No = N // 2 if act == "glu" else N
     if out is None:
-        out = torch.empty((Z, M, N) if batched else (M, N), dtype=a.dtype, device=a.device)
+        out = torch.empty((Z, M, No) if batched else (M, No), dtype=a.dtype, device=a.device)
     for t in (residual, out):
-        if t is not None and tuple(t.shape) != ((Z, M, N) if batched else (M, N)):
+        if t is not None and tuple(t.shape) != ((Z, M, No) if batched else (M, No)):
             raise _lib.PafcError("gemm_bf16: residual / out must be (M, N) per batch entry")
     if bias is not None and (bias.dtype != a.dtype or bias.shape[-1] != N):
         raise _lib.PafcError("gemm_bf16: bias must be (N) or (Z, N) bf16")
@@ -247,3 +250,14 @@ def log_softmax_rows(x: torch.Tensor, inplace: bool = False) -> torch.Tensor:
     _lib.check(L.pafc_log_softmax_rows(_lib.dtype_code(x.dtype), x.numel() // V, V, _lib.ptr(x), _lib.ptr(out),
                                        _lib.stream_of(x)), "pafc_log_softmax_rows")
     return out
+
+
+def glu_interleave(t: torch.Tensor) -> torch.Tensor:
+    """(2C, ...) parameter of a Linear followed by F.glu (values = rows [0, C), gates = rows [C, 2C)) -> the row order
+    pafc_gemm_bf16 wants for act "glu": blocks of 64 value rows followed by the 64 gate rows of the same channels."""
+    C = t.shape[0] // 2
+    if C % 64:
+        raise _lib.PafcError("glu_interleave: channels must be a multiple of 64")
+    v = t[:C].reshape(C // 64, 64, *t.shape[1:])
+    g = t[C:].reshape(C // 64, 64, *t.shape[1:])
+    return torch.cat([v, g], dim=1).reshape(t.shape).contiguous()

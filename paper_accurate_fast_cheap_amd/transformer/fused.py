@@ -41,7 +41,9 @@ class LayerPlan:
 
     def _current_stamp(self):
         L = self.layer
-        ps = [p for b in self.blocks for p in b.parameters()] + [L.feed_forward_macaron.w_2.bias, L.feed_forward.w_2.bias]
+        ps = [p for b in self.blocks for p in b.parameters()] + [L.feed_forward_macaron.w_2.bias, L.feed_forward.w_2.bias,
+                                                                    L.conv_module.pointwise_conv1.weight,
+                                                                    L.conv_module.pointwise_conv1.bias]
         return tuple((p.data_ptr(), p._version, p.dtype) for p in ps)
 
     def refresh(self):
@@ -73,6 +75,13 @@ class LayerPlan:
             L = self.layer
             self.b2_macaron = (L.feed_forward_macaron.w_2.bias * L.ff_scale).contiguous()
             self.b2 = (L.feed_forward.w_2.bias * L.ff_scale).contiguous()
+            # pointwise_conv1 with its rows interleaved (64 values, 64 gates, ...) so that F.glu is a GEMM epilogue
+            pw1 = L.conv_module.pointwise_conv1
+            self.pw1_glu = None
+            if pw1.weight.dtype == torch.bfloat16 and pw1.weight.is_cuda and pw1.weight.shape[0] % 128 == 0 \
+                    and pw1.weight.shape[1] % 64 == 0:
+                self.pw1_glu = (hip_ops.glu_interleave(pw1.weight.squeeze(-1)),
+                                hip_ops.glu_interleave(pw1.bias) if pw1.bias is not None else None)
         self._stamp = stamp
 
 
@@ -161,9 +170,14 @@ def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optio
     else:
         att = slot_forward(plan, h).to(x.dtype)
         x, h, _ = hip_ops.add_layernorm(x, att, 1.0, L.norm_conv.weight, L.norm_conv.bias, zero_rows=masked, lens=lens, T=T)
-    p = F.linear(h, cm.pointwise_conv1.weight.squeeze(-1), cm.pointwise_conv1.bias)
-    dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, (cm.kernel_size - 1) // 2, T,
-                                     glu=True)
+    if plan.pw1_glu is not None and h.dtype == torch.bfloat16:
+        # F.glu rides on pointwise_conv1 (half the write, and the depthwise kernel no longer recomputes sigmoids)
+        p = hip_ops.gemm_bf16(h.view(B * T, C), plan.pw1_glu[0], plan.pw1_glu[1], act="glu").view(B, T, C)
+        dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, (cm.kernel_size - 1) // 2, T)
+    else:
+        p = F.linear(h, cm.pointwise_conv1.weight.squeeze(-1), cm.pointwise_conv1.bias)
+        dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, (cm.kernel_size - 1) // 2, T,
+                                         glu=True)
     _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
     if not masked:
         if g.dtype == torch.bfloat16 and C % 64 == 0:

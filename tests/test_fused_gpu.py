@@ -196,3 +196,19 @@ def test_gemm_bf16_strided_rows_and_errors(hip):
         gemm_bf16(wide[:, :96], synth.randn((128, 96), 7).to(bf).cuda())  # K % 64
     with pytest.raises(PafcError):
         gemm_bf16(a.float(), w.float())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (129, 1024, 512), (64, 256, 128)])
+def test_gemm_bf16_glu_epilogue(hip, M, N, K):
+    """act "glu": Linear -> F.glu as one GEMM, with the caller interleaving value / gate rows (glu_interleave)."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_bf16, glu_interleave
+    bf = torch.bfloat16
+    a = synth.randn((M, K), 1).to(bf)
+    w = synth.randn((N, K), 2, 0.08).to(bf)
+    b = synth.randn((N,), 3, 0.3).to(bf)
+    want = F.glu(F.linear(a.float(), w.float(), b.float()), dim=-1)
+    got = gemm_bf16(a.cuda(), glu_interleave(w.cuda()), glu_interleave(b.cuda()), act="glu")
+    assert got.shape == (M, N // 2)
+    torch.testing.assert_close(got.cpu().float(), want, rtol=2 ** -7, atol=1e-2)
+    got = gemm_bf16(a.cuda(), glu_interleave(w.cuda()), None, act="glu")
+    torch.testing.assert_close(got.cpu().float(), F.glu(F.linear(a.float(), w.float()), dim=-1), rtol=2 ** -7, atol=1e-2)
