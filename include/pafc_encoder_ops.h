@@ -73,6 +73,13 @@ int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const 
 int pafc_conv3x3s2_nhwc_bf16(int B, int T1, int F1, int Ci, int Co, const void *in, const void *w_tap_co_ci,
                              const void *bias, void *out, int relu, pafc_stream_t stream);
 
+/* out[b][t1][f1][c] = relu(bias[c] + sum_{kh,kw} w[c][kh][kw] * x[b][2 t1 + kh][2 f1 + kw]): the first Conv2d(1, C, 3, 2)
+ * + ReLU of Conv2dSubsampling4 (wenet/transformer/subsampling.py:185-186) written NHWC, the layout the second
+ * convolution reads.  x: (B, T, F) bf16 features; w_c_9: the Conv2d weight (C, 1, 3, 3) as stored; out: (B, T1, F1, C) with
+ * T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1.  fp32 accumulation, one rounding.  C % 8 == 0 and 256 % (C / 8) == 0. */
+int pafc_conv3x3s2_c1_nhwc_bf16(int B, int T, int F, int C, const void *x, const void *w_c_9, const void *bias, void *out,
+                                int relu, pafc_stream_t stream);
+
 /* out (rows, N) = act(alpha * x (rows, K) . weight (N, K)^T + residual (rows, N) + bias (N)) as one hipBLASLt GEMM
  * with a fused epilogue; act 0 = identity, 1 = SiLU; bias and residual may be NULL; residual may alias out; bias is
  * added as given (not scaled by alpha).  Replaces `activation(w_1(x))` of PositionwiseFeedForward.forward

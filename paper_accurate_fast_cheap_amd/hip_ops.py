@@ -261,3 +261,21 @@ def glu_interleave(t: torch.Tensor) -> torch.Tensor:
     v = t[:C].reshape(C // 64, 64, *t.shape[1:])
     g = t[C:].reshape(C // 64, 64, *t.shape[1:])
     return torch.cat([v, g], dim=1).reshape(t.shape).contiguous()
+
+
+def conv3x3s2_c1_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = True):
+    """First subsampling convolution (1 input channel): x (B, T, F) bf16, weight (C, 1, 3, 3) -> (B, T1, F1, C)."""
+    _lib.require_gpu(x, weight, bias)
+    if x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16 or x.dim() != 3 or weight.shape[1:] != (1, 3, 3):
+        raise _lib.PafcError("conv3x3s2_c1_nhwc: bf16 x (B, T, F) and weight (C, 1, 3, 3)")
+    L = _bind()
+    if not getattr(L, "_pafc_c1_bound", False):
+        _lib._sig(L.pafc_conv3x3s2_c1_nhwc_bf16, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                  c_int, c_void_p)
+        L._pafc_c1_bound = True
+    B, T, Fd = x.shape
+    C = weight.shape[0]
+    out = torch.empty((B, (T - 3) // 2 + 1, (Fd - 3) // 2 + 1, C), dtype=x.dtype, device=x.device)
+    _lib.check(L.pafc_conv3x3s2_c1_nhwc_bf16(B, T, Fd, C, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out),
+                                             int(relu), _lib.stream_of(x)), "pafc_conv3x3s2_c1_nhwc_bf16")
+    return out

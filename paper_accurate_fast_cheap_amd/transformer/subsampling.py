@@ -48,15 +48,17 @@ class Conv2dSubsampling4(BaseSubsampling):
             self._w_c2 = c2.weight.detach().contiguous(memory_format=torch.channels_last)
             self._w_c2_taps = c2.weight.detach().permute(2, 3, 0, 1).reshape(9, C, C).contiguous()   # (tap, co, ci)
             self._nhwc_stamp = stamp
-        p = x.unsqueeze(1).unfold(2, 3, 2).unfold(3, 3, 2).reshape(B, T1 * F1, 9)
-        # relu(bias + p W^T) in one GEMM epilogue: the conv1 output is the largest tensor of the whole pass
-        y = torch._addmm_activation(c1.bias, p.view(B * T1 * F1, 9), c1.weight.view(C, 9).t(), use_gelu=False)
-        if x.dtype == torch.bfloat16 and C % 128 == 0:
-            # conv2 + ReLU: hand-written implicit GEMM on the matrix cores, NHWC in and out
-            from ..hip_ops import conv3x3s2_nhwc
-            y = conv3x3s2_nhwc(y.view(B, T1, F1, C), self._w_c2_taps, c2.bias, relu=True)    # (B, T', F', C)
+        if x.dtype == torch.bfloat16 and C % 128 == 0 and 256 % (C // 8) == 0:
+            # conv1 + ReLU: write-bound direct kernel (its output is the largest tensor of the whole pass);
+            # conv2 + ReLU: hand-written implicit GEMM on the matrix cores; NHWC in and out
+            from ..hip_ops import conv3x3s2_c1_nhwc, conv3x3s2_nhwc
+            y = conv3x3s2_c1_nhwc(x.contiguous(), c1.weight, c1.bias, relu=True)            # (B, T1, F1, C)
+            y = conv3x3s2_nhwc(y, self._w_c2_taps, c2.bias, relu=True)                       # (B, T', F', C)
             b, t, f, c = y.shape
             return F.linear(y.view(b, t, f * c), self._w_lin, lin.bias)
+        p = x.unsqueeze(1).unfold(2, 3, 2).unfold(3, 3, 2).reshape(B, T1 * F1, 9)
+        # relu(bias + p W^T) in one GEMM epilogue
+        y = torch._addmm_activation(c1.bias, p.view(B * T1 * F1, 9), c1.weight.view(C, 9).t(), use_gelu=False)
         y = y.view(B, T1, F1, C).permute(0, 3, 1, 2)                            # NCHW view of NHWC memory
         y = F.relu(F.conv2d(y, self._w_c2, c2.bias, stride=2))
         b, c, t, f = y.shape

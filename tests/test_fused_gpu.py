@@ -212,3 +212,20 @@ def test_gemm_bf16_glu_epilogue(hip, M, N, K):
     torch.testing.assert_close(got.cpu().float(), want, rtol=2 ** -7, atol=1e-2)
     got = gemm_bf16(a.cuda(), glu_interleave(w.cuda()), None, act="glu")
     torch.testing.assert_close(got.cpu().float(), F.glu(F.linear(a.float(), w.float()), dim=-1), rtol=2 ** -7, atol=1e-2)
+
+
+@pytest.mark.parametrize("B,T,Fd,C", [(1, 7, 80, 512), (3, 64, 80, 256), (2, 33, 23, 128), (1, 1003, 80, 512)])
+def test_conv3x3s2_c1_nhwc(hip, B, T, Fd, C):
+    """First subsampling convolution (1 channel in) as the direct NHWC kernel vs F.conv2d in fp32."""
+    from paper_accurate_fast_cheap_amd.hip_ops import conv3x3s2_c1_nhwc
+    bf = torch.bfloat16
+    x = synth.randn((B, T, Fd), 1).to(bf)
+    w = synth.randn((C, 1, 3, 3), 2, 0.3).to(bf)
+    b = synth.randn((C,), 3, 0.2).to(bf)
+    want = F.relu(F.conv2d(x.float().unsqueeze(1), w.float(), b.float(), stride=2)).permute(0, 2, 3, 1)
+    got = conv3x3s2_c1_nhwc(x.cuda(), w.cuda(), b.cuda(), relu=True)
+    assert got.shape == want.shape
+    torch.testing.assert_close(got.cpu().float(), want, rtol=2 ** -7, atol=1e-2)
+    got = conv3x3s2_c1_nhwc(x.cuda(), w.cuda(), None, relu=False)
+    want = F.conv2d(x.float().unsqueeze(1), w.float(), None, stride=2).permute(0, 2, 3, 1)
+    torch.testing.assert_close(got.cpu().float(), want, rtol=2 ** -7, atol=1e-2)

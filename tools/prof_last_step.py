@@ -13,7 +13,7 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    ends = [r for r in rows if "SoftMaxForward" in r["Kernel_Name"]]
+    ends = [r for r in rows if "SoftMaxForward" in r["Kernel_Name"] or "log_softmax_kernel" in r["Kernel_Name"]]
     t0 = int(ends[-2]["End_Timestamp"]) if len(ends) >= 2 else 0
     last = [r for r in rows if int(r["Start_Timestamp"]) > t0]
     agg = collections.defaultdict(lambda: [0, 0])
