@@ -31,6 +31,19 @@ int pafc_ctc_greedy(int dtype, int B, int T, int V, const void *scores, const in
  * keeps its row in registers (V <= 8192 elements in bf16, 4096 in fp32; longer rows are re-read from cache). */
 int pafc_log_softmax_rows(int dtype, long rows, int V, const void *x, void *out, pafc_stream_t stream);
 
+/* CTC prefix beam search (ctc_prefix_beam_search, wenet/transformer/search.py:124-248, without context graph and time
+ * stamps), one wave per utterance, frames walked on the device.
+ * top_logp / top_idx: (B, T, K) the K best log-probabilities and token ids per frame, best first (torch.topk of the CTC
+ *   log-probs, as the reference takes them per frame); K <= 16, beam <= 16.  lens: (B) int64 valid frames, or NULL.
+ * out_tokens: (B, beam, T) int32, entry (b, n) holds out_len[b][n] ids of the n-th best prefix (best first);
+ * out_len: (B, beam) int32, -1 for unused entries (fewer prefixes than beam); out_score: (B, beam) float64 total
+ * log-probabilities (arithmetic in float64 like the reference's Python floats).
+ * workspace: pafc_ctc_prefix_beam_workspace_bytes(B, T, beam) bytes (the per-utterance prefix tries). */
+size_t pafc_ctc_prefix_beam_workspace_bytes(int B, int T, int beam);
+int pafc_ctc_prefix_beam_search(int B, int T, int K, const float *top_logp, const int32_t *top_idx, const int64_t *lens,
+                                int beam, int blank_id, int32_t *out_tokens, int32_t *out_len, double *out_score,
+                                void *workspace, size_t workspace_bytes, pafc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

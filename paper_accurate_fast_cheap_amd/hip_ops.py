@@ -279,3 +279,33 @@ def conv3x3s2_c1_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
     _lib.check(L.pafc_conv3x3s2_c1_nhwc_bf16(B, T, Fd, C, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out),
                                              int(relu), _lib.stream_of(x)), "pafc_conv3x3s2_c1_nhwc_bf16")
     return out
+
+
+def ctc_prefix_beam(top_logp: torch.Tensor, top_idx: torch.Tensor, lens: Optional[torch.Tensor], beam: int,
+                    blank_id: int = 0):
+    """GPU-resident CTC prefix beam search (include/pafc_search.h).  top_logp (B, T, K) float32 / top_idx (B, T, K) =
+    torch.topk of the CTC log-probs.  Returns (tokens (B, beam, T) int32, lengths (B, beam) int32 [-1 = unused],
+    scores (B, beam) float64), best first."""
+    _lib.require_gpu(top_logp, top_idx, lens)
+    from ctypes import c_size_t
+    L = _bind()
+    if not getattr(L, "_pafc_beam_bound", False):
+        P, I = c_void_p, c_int
+        _lib._sig(L.pafc_ctc_prefix_beam_workspace_bytes, c_size_t, I, I, I)
+        _lib._sig(L.pafc_ctc_prefix_beam_search, I, I, I, I, P, P, P, I, I, P, P, P, P, c_size_t, P)
+        L._pafc_beam_bound = True
+    if top_logp.dtype != torch.float32 or top_logp.shape != top_idx.shape or top_logp.dim() != 3:
+        raise _lib.PafcError("ctc_prefix_beam: top_logp float32 (B, T, K) and top_idx of the same shape")
+    B, T, K = top_logp.shape
+    idx32 = top_idx.to(torch.int32).contiguous()
+    lens64 = None if lens is None else lens.to(torch.int64).contiguous()
+    dev = top_logp.device
+    nws = L.pafc_ctc_prefix_beam_workspace_bytes(B, T, beam)
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=dev)
+    tokens = torch.empty(B, beam, T, dtype=torch.int32, device=dev)
+    lengths = torch.empty(B, beam, dtype=torch.int32, device=dev)
+    scores = torch.empty(B, beam, dtype=torch.float64, device=dev)
+    _lib.check(L.pafc_ctc_prefix_beam_search(B, T, K, _lib.ptr(top_logp), _lib.ptr(idx32), _lib.ptr(lens64), int(beam),
+                                             int(blank_id), _lib.ptr(tokens), _lib.ptr(lengths), _lib.ptr(scores),
+                                             _lib.ptr(ws), nws, _lib.stream_of(top_logp)), "pafc_ctc_prefix_beam_search")
+    return tokens, lengths, scores

@@ -89,6 +89,22 @@ def ctc_prefix_beam_search(ctc_probs: torch.Tensor, ctc_lens: torch.Tensor, beam
     B = ctc_probs.shape[0]
     k = min(beam_size, ctc_probs.shape[-1])
     top_p, top_i = ctc_probs.float().topk(k, dim=-1)          # (B, T, k)
+    if ctc_probs.is_cuda and beam_size <= 16:
+        # GPU-resident: one wave per utterance walks the frames (pafc_ctc_prefix_beam_search); only the n-best lists
+        # come back.  Same candidates, merges and tie order as the loop below; float64 scores from the device's
+        # exp / log agree with the host's to a few ulps.
+        from ..hip_ops import ctc_prefix_beam
+        toks, lens_n, scores = ctc_prefix_beam(top_p.contiguous(), top_i.contiguous(), ctc_lens.to(ctc_probs.device),
+                                               beam_size, blank_id)
+        lens_h, scores_h = lens_n.tolist(), scores.tolist()
+        maxlen = max(1, int(lens_n.max()))
+        toks_h = toks[:, :, :maxlen].tolist()
+        results = []
+        for b in range(B):
+            nbest = [tuple(toks_h[b][n][:lens_h[b][n]]) for n in range(beam_size) if lens_h[b][n] >= 0]
+            nsc = [scores_h[b][n] for n in range(beam_size) if lens_h[b][n] >= 0]
+            results.append(DecodeResult(tokens=nbest[0], score=nsc[0], nbest=nbest, nbest_scores=nsc))
+        return results
     top_p, top_i, lens = top_p.cpu().tolist(), top_i.cpu().tolist(), [int(v) for v in ctc_lens.tolist()]
     results = []
     for b in range(B):

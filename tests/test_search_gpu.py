@@ -103,3 +103,55 @@ def test_log_softmax_rows(hip, dtype, rows, V):
     assert torch.equal(buf, got)
     if dtype == torch.float32:   # same argmax as the input (greedy search may run on either)
         assert torch.equal(got.argmax(-1).cpu(), x.argmax(-1))
+
+
+def _host_beam(logp, lens, beam):
+    """the product's host bookkeeping on CPU tensors (itself pinned to the reference by tests/test_search.py)"""
+    from paper_accurate_fast_cheap_amd.transformer.search import ctc_prefix_beam_search
+    return ctc_prefix_beam_search(logp.cpu(), lens.cpu(), beam)
+
+
+@pytest.mark.parametrize("B,T,V,beam", [(1, 1, 5, 3), (4, 37, 50, 10), (3, 120, 5000, 8), (2, 60, 12, 16), (5, 25, 7, 10)])
+def test_gpu_prefix_beam_search_matches_host(hip, B, T, V, beam):
+    """GPU-resident CTC prefix beam search: n-best token lists identical to the host loop (= the reference's), scores
+    equal to float64 round-off; ragged lengths, beams wider than the vocabulary, peaky and flat posteriors."""
+    from paper_accurate_fast_cheap_amd.transformer.search import ctc_prefix_beam_search
+    for peaky in (True, False):
+        logp = _scores(B, T, V, torch.float32, seed=B * 100 + T + int(peaky), peaky=peaky)
+        lens = torch.randint(1, T + 1, (B,), generator=torch.Generator().manual_seed(T + 3))
+        lens[0] = T
+        want = _host_beam(logp, lens, beam)
+        got = ctc_prefix_beam_search(logp.cuda(), lens.cuda(), beam)
+        for w, g in zip(want, got):
+            assert [tuple(n) for n in g.nbest] == [tuple(n) for n in w.nbest]
+            assert tuple(g.tokens) == tuple(w.tokens)
+            assert g.nbest_scores == pytest.approx(w.nbest_scores, rel=1e-12, abs=1e-9)
+
+
+def test_gpu_prefix_beam_search_golden_c5(hip):
+    """The reference's own output for config c5's CTC search (tests/golden, captured from wenet/transformer/search.py)."""
+    from paper_accurate_fast_cheap_amd.transformer.search import ctc_prefix_beam_search
+    from tests.conftest import load_golden
+    g = load_golden("search_c5")
+    res = ctc_prefix_beam_search(g["logp"].cuda(), g["enc_lens"].cuda(), 8)
+    for r, want in zip(res, g["ctc_prefix"]):
+        assert list(r.tokens) == want["tokens"]
+        assert [list(n) for n in r.nbest] == want["nbest"]
+        assert r.nbest_scores == pytest.approx(want["nbest_scores"], rel=1e-12, abs=1e-9)
+
+
+def test_gpu_prefix_beam_search_edge_cases(hip):
+    from paper_accurate_fast_cheap_amd._lib import PafcError
+    from paper_accurate_fast_cheap_amd.hip_ops import ctc_prefix_beam
+    from paper_accurate_fast_cheap_amd.transformer.search import ctc_prefix_beam_search
+    logp = torch.log_softmax(torch.randn(2, 6, 7, generator=torch.Generator().manual_seed(3)), -1)
+    lens = torch.tensor([6, 0])
+    r = ctc_prefix_beam_search(logp.cuda(), lens.cuda(), 3)
+    h = _host_beam(logp, lens, 3)
+    assert list(r[1].tokens) == [] and r[1].nbest == [()] and r[1].score == 0.0      # empty utterance
+    assert [tuple(n) for n in r[0].nbest] == [tuple(n) for n in h[0].nbest] and len(r[0].nbest) == 3
+    allblank = torch.full((1, 5, 4), -20.0)
+    allblank[..., 0] = 0.0
+    assert list(ctc_prefix_beam_search(allblank.cuda(), torch.tensor([5]).cuda(), 2)[0].tokens) == []
+    with pytest.raises(PafcError):   # beam beyond the kernel's limit is refused, not truncated
+        ctc_prefix_beam(torch.zeros(1, 2, 17, device="cuda"), torch.zeros(1, 2, 17, dtype=torch.int64, device="cuda"), None, 17)

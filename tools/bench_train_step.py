@@ -1,0 +1,71 @@
+"""Config c4: the DDP training step -- 32 utterances per GPU, T <= 2000 frames, fp32 master weights with
+the bf16 time-mix slot (the YAML default), CTC objective, forward + backward (WKV-6 backward kernels) + gradient
+all-reduce (RCCL when launched with torch.distributed.run) + clip + Adam.  Not the headline metric: a measurement of
+the training path, printed as one JSON line.
+
+  python tools/bench_train_step.py [--steps 5 --warmup 2 --batch 32]
+  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train_step.py
+"""
+import argparse, json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as B   # noqa: E402  (model / waveform helpers of the headline bench)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    args = ap.parse_args()
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    from paper_accurate_fast_cheap_amd import _lib
+    from paper_accurate_fast_cheap_amd.utils.train_utils import train_step, wrap_model_ddp
+    _lib.lib()
+    model, _ = B.build_model("fp32", device)          # fp32 parameters, bf16 slot: conf/rwkv/*.yaml as shipped
+    if world > 1:
+        model = wrap_model_ddp(model, device)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    g = torch.Generator().manual_seed(777 + rank)
+    lens = torch.randint(100, 2001, (args.batch,), generator=g)
+    feats, _ = B.front_end(B.synthetic_waveform(60.0, 777 + rank), device)
+    src = feats[0]
+    fb = torch.zeros(args.batch, int(lens.max()), 80, device=device)
+    for j, n in enumerate(lens.tolist()):
+        off = (j * 7919) % (src.shape[0] - 2001)
+        fb[j, :n] = src[off:off + n]
+    tl = torch.randint(1, 161, (args.batch,), generator=g)
+    tl = torch.minimum(tl, ((lens - 1) // 2 - 1) // 2 // 2).clamp(min=1)
+    tgt = torch.randint(1, B.VOCAB, (args.batch, int(tl.max())), generator=g)
+    batch = {"feats": fb, "feats_lengths": lens.to(device), "target": tgt.to(device), "target_lengths": tl.to(device)}
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(); torch.cuda.synchronize()
+    info = None
+    for i in range(args.warmup):
+        info = train_step(model, batch, opt, device, step_index=i)
+    sync(); t0 = time.perf_counter()
+    for i in range(args.steps):
+        info = train_step(model, batch, opt, device, step_index=i)
+    sync(); dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t)
+    frames = int(lens.sum()) * world * args.steps
+    if rank == 0:
+        print(json.dumps({"metric": "training audio-sec/sec (c4: fwd + bwd + all-reduce + clip + Adam, CTC objective)",
+                          "value": round(frames / 100.0 / dt, 1), "unit": "audio-sec/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+                          "utts_per_gpu": args.batch, "frames_per_gpu_step": int(lens.sum()),
+                          "loss": float(info["loss"]), "grad_norm": float(info["grad_norm"]), "dtype": "fp32 + bf16 slot",
+                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
+
+
+if __name__ == "__main__":
+    main()
