@@ -87,11 +87,18 @@ int pafc_conv3x3s2_c1_nhwc_bf16(int B, int T, int F, int C, const void *x, const
  * disappears and bias + SiLU see the fp32 accumulator (one rounding instead of two); and, with residual, the
  * `x = residual + ff_scale * ff(x)` / `x = residual + branch(x)` adds of ConformerEncoderLayer.forward
  * (wenet/transformer/encoder_layer.py:201-259).  workspace: caller-owned, pafc_linear_act_workspace_bytes() bytes are
- * always enough.  A library GEMM, not a hand-written kernel. */
+ * always enough.  A library GEMM, not a hand-written kernel; for large problems the library's candidate kernels are timed
+ * once per shape on the call's own operands and the fastest is cached (PAFC_GEMM_TUNE=0: the heuristic's first pick). */
 size_t pafc_linear_act_workspace_bytes(void);
 int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, const void *weight, const void *bias,
                          void *out, int act, float alpha, const void *residual, void *workspace, size_t workspace_bytes,
                          pafc_stream_t stream);
+
+/* out[z] (rows, N) = alpha * x[z] (rows, K) . weight[z] (N, K)^T for z < batch on contiguous stacks -- the stacked r, k, v
+ * (and decay LoRA) projections of both directions (wenet/rwkv_v6/src/model.py:286-290), one library GEMM call, algorithm
+ * measured once per shape like pafc_linear_bias_act. */
+int pafc_linear_batched(int dtype, int batch, long rows, int N, int K, const void *x, const void *weight, void *out,
+                        float alpha, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
 
 /* Hand-written bf16 GEMM with fused epilogue (csrc/gemm_bf16.hip), batched:
  *   out[z][m][n] = act(alpha * sum_k A[z][m][k] * W[z][n][k] + bias[z][n] + residual[z][m][n]),   z < batch

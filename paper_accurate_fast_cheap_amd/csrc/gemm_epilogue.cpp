@@ -11,10 +11,15 @@
 // (wenet/transformer/encoder_layer.py:201-259) happen on the fp32 accumulator, and the pre-norm pass that follows
 // reads one tensor instead of two.
 //
-// The hipBLASLt handle and the heuristic's algorithm choice per (rows, N, K) are cached per process and device: they
-// are library objects, not state of the computation (results never depend on them).
+// The hipBLASLt handle and the algorithm choice per (rows, N, K, epilogue) are cached per process and device: they are
+// library objects, not state of the computation.  For large problems the choice is MEASURED once (the library's
+// heuristic ranks its kernels without running them and its first pick is often not the fastest on this shape): up to
+// 16 candidates run on the call's own operands (into a scratch output when the call is in place) and the fastest is
+// kept -- what MIOpen's "find" does for convolutions.  PAFC_GEMM_TUNE=0 keeps the heuristic's first pick.
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
+
+#include <stdlib.h>
 
 #include <map>
 #include <mutex>
@@ -34,7 +39,7 @@ struct Plan {
 
 std::mutex g_mu;
 std::map<int, hipblasLtHandle_t> g_handles;                                   // per device
-std::map<std::tuple<int, int, long, int, int, int>, Plan> g_plans;   // (device, dtype, rows, N, K, act | bias | residual)
+std::map<std::tuple<int, int, long, int, int, int, int>, Plan> g_plans;   // (device, dtype, rows, N, K, act | bias | residual, batch)
 
 constexpr size_t kMaxWorkspace = 64u << 20;
 
@@ -44,11 +49,12 @@ extern "C" {
 
 size_t pafc_linear_act_workspace_bytes(void) { return kMaxWorkspace; }
 
-int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, const void *weight, const void *bias,
-                         void *out, int act, float alpha, const void *residual, void *workspace,
-                         size_t workspace_bytes, pafc_stream_t stream) {
+static int linear_impl(int dtype, int batch, long rows, int N, int K, const void *x, const void *weight, const void *bias,
+                       void *out, int act, float alpha, const void *residual, void *workspace, size_t workspace_bytes,
+                       pafc_stream_t stream) {
     if (!x || !weight || !out) return PAFC_ERR_NULL_POINTER;
-    if (rows <= 0 || N <= 0 || K <= 0) return PAFC_ERR_BAD_DIMS;
+    if (rows <= 0 || N <= 0 || K <= 0 || batch <= 0) return PAFC_ERR_BAD_DIMS;
+    if (batch > 1 && bias) return PAFC_ERR_UNSUPPORTED;
     if (dtype != PAFC_BF16 && dtype != PAFC_F32) return PAFC_ERR_DTYPE;
     if (act != 0 && act != 1) return PAFC_ERR_UNSUPPORTED;   // 0: identity, 1: SiLU
     int dev = 0;
@@ -58,7 +64,7 @@ int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, cons
     std::lock_guard<std::mutex> lock(g_mu);
     hipblasLtHandle_t &handle = g_handles[dev];
     if (!handle && hipblasLtCreate(&handle) != HIPBLAS_STATUS_SUCCESS) return PAFC_ERR_LAUNCH;
-    Plan &p = g_plans[std::make_tuple(dev, dtype, rows, N, K, act | (bias ? 2 : 0) | (residual ? 4 : 0))];
+    Plan &p = g_plans[std::make_tuple(dev, dtype, rows, N, K, act | (bias ? 2 : 0) | (residual ? 4 : 0), batch)];
     if (!p.ok) {
         // row-major out (rows, N) = x (rows, K) . W(N, K)^T   <=>   column-major D (N, rows) = W_cm(K, N)^T . x_cm(K, rows)
         if (hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return PAFC_ERR_LAUNCH;
@@ -79,19 +85,74 @@ int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, cons
         hipblasLtMatrixLayoutCreate(&p.a, dt, K, N, K);       // W as column-major (K, N), ld K
         hipblasLtMatrixLayoutCreate(&p.b, dt, K, rows, K);    // x as column-major (K, rows)
         hipblasLtMatrixLayoutCreate(&p.d, dt, N, rows, N);    // out as column-major (N, rows)
+        if (batch > 1) {   // contiguous stacks: weight (batch, N, K), x (batch, rows, K), out / residual (batch, rows, N)
+            const int32_t bc = batch;
+            const int64_t sa = (int64_t)N * K, sb = (int64_t)rows * K, sd = (int64_t)rows * N;
+            hipblasLtMatrixLayoutSetAttribute(p.a, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc));
+            hipblasLtMatrixLayoutSetAttribute(p.b, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc));
+            hipblasLtMatrixLayoutSetAttribute(p.d, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc));
+            hipblasLtMatrixLayoutSetAttribute(p.a, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &sa, sizeof(sa));
+            hipblasLtMatrixLayoutSetAttribute(p.b, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &sb, sizeof(sb));
+            hipblasLtMatrixLayoutSetAttribute(p.d, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &sd, sizeof(sd));
+        }
         hipblasLtMatmulPreference_t pref;
         hipblasLtMatmulPreferenceCreate(&pref);
         const uint64_t maxws = kMaxWorkspace;
         hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &maxws, sizeof(maxws));
         // the bias pointer takes part in the heuristic's validity check
         if (bias) hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
-        hipblasLtMatmulHeuristicResult_t res[1];
+        constexpr int kMaxAlgos = 16;
+        hipblasLtMatmulHeuristicResult_t res[kMaxAlgos];
         int found = 0;
-        const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.a, p.b, p.d, p.d, pref, 1, res, &found);
+        const char *te = getenv("PAFC_GEMM_TUNE");
+        // batched problems keep the heuristic's first pick: one of the library's lower-ranked strided-batched candidates
+        // faulted on this GPU (memory access fault at (6, 44998, 512) x (6, 512, 512)); only candidates that need no
+        // workspace (no split-K / stream-K bookkeeping) are ever timed
+        // and only long-form problems (rows >= 32768) are measured at all: that is where the first pick was seen to lose
+        // (FFN w_1 at 44 998 rows: 176 -> 140 us), and it keeps the set of library kernels ever launched small
+        const bool tune = !(te && te[0] == '0') && batch == 1 && rows >= 32768 && workspace &&
+                          workspace_bytes >= kMaxWorkspace;
+        const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.a, p.b, p.d, p.d, pref, tune ? kMaxAlgos : 1,
+                                                                   res, &found);
         hipblasLtMatmulPreferenceDestroy(pref);
         if (st != HIPBLAS_STATUS_SUCCESS || found < 1) return PAFC_ERR_UNSUPPORTED;
-        p.algo = res[0].algo;
-        p.ws = res[0].workspaceSize;
+        int best = 0;
+        if (tune && found > 1) {
+            // time every candidate on the real operands; an in-place call (out == residual, beta = 1) writes to a scratch
+            // output meanwhile so that the residual is not accumulated into more than once
+            hipStream_t hs = (hipStream_t)stream;
+            void *scratch = nullptr;
+            void *dst = out;
+            const size_t esz = dtype == PAFC_BF16 ? 2 : 4;
+            if (residual == out && hipMalloc(&scratch, (size_t)batch * rows * N * esz) == hipSuccess) dst = scratch;
+            if (residual != out || scratch) {
+                hipEvent_t e0, e1;
+                hipEventCreate(&e0); hipEventCreate(&e1);
+                const float tbeta = residual ? 1.f : 0.f;
+                const void *tc = residual ? residual : dst;
+                float best_ms = 1e30f, first_ms = 1e30f;
+                for (int i = 0; i < found; ++i) {
+                    if (i > 0 && res[i].workspaceSize > 0) continue;
+                    bool ok = true;
+                    for (int rep = 0; rep < 7 && ok; ++rep) {       // first run warms the code object, the other six are timed
+                        if (rep == 1) hipEventRecord(e0, hs);
+                        ok = hipblasLtMatmul(handle, p.desc, &alpha, weight, p.a, x, p.b, &tbeta, tc, p.d, dst, p.d, &res[i].algo,
+                                             workspace, res[i].workspaceSize, hs) == HIPBLAS_STATUS_SUCCESS;
+                    }
+                    hipEventRecord(e1, hs);
+                    hipEventSynchronize(e1);
+                    float ms = 0.f;
+                    hipEventElapsedTime(&ms, e0, e1);
+                    if (ok && i == 0) first_ms = ms;
+                    if (ok && ms < best_ms) { best_ms = ms; best = i; }
+                }
+                if (best_ms > 0.95f * first_ms) best = 0;           // leave the heuristic's pick unless clearly beaten
+                hipEventDestroy(e0); hipEventDestroy(e1);
+            }
+            if (scratch) hipFree(scratch);
+        }
+        p.algo = res[best].algo;
+        p.ws = res[best].workspaceSize;
         p.ok = true;
     }
     if (p.ws > 0 && (!workspace || workspace_bytes < p.ws)) return PAFC_ERR_WORKSPACE;
@@ -101,6 +162,17 @@ int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, cons
     const hipblasStatus_t st = hipblasLtMatmul(handle, p.desc, &alpha, weight, p.a, x, p.b, &beta, c, p.d, out, p.d,
                                                &p.algo, workspace, p.ws, (hipStream_t)stream);
     return st == HIPBLAS_STATUS_SUCCESS ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, const void *weight, const void *bias,
+                         void *out, int act, float alpha, const void *residual, void *workspace,
+                         size_t workspace_bytes, pafc_stream_t stream) {
+    return linear_impl(dtype, 1, rows, N, K, x, weight, bias, out, act, alpha, residual, workspace, workspace_bytes, stream);
+}
+
+int pafc_linear_batched(int dtype, int batch, long rows, int N, int K, const void *x, const void *weight, void *out,
+                        float alpha, void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
+    return linear_impl(dtype, batch, rows, N, K, x, weight, nullptr, out, 0, alpha, nullptr, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

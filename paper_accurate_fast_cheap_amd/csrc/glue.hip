@@ -280,7 +280,10 @@ __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long 
                 store8<bf16_t>(&s_z[wave][q][r16][cbi * 32 + 8 * qq], o);
             }
         }
-        __syncthreads();
+        // s_z[wave] is private to this wave and LDS operations of one wave complete in order: a compiler fence is all
+        // the synchronisation the re-layout needs (no block barrier: the four waves run independently)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -291,7 +294,8 @@ __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long 
                     *reinterpret_cast<uint4 *>(z + (((size_t)q * ndir + d) * rows + orow) * C + blockIdx.y * 64 + cc) =
                         *reinterpret_cast<const uint4 *>(&s_z[wave][q][rr][cc]);
             }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -24,11 +24,12 @@ class CTC(torch.nn.Module):
     def log_softmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
         """ctc.py:106-114.  Inference on the GPU: the (B, T', V) logits -- the largest activation of the pass -- are
         normalised in place by one kernel that reads them once; with autograd (training) the framework op is used."""
-        logits = self.ctc_lo(hs_pad)
-        if logits.is_cuda and not torch.is_grad_enabled() and logits.dtype in (torch.float32, torch.bfloat16):
-            from ..hip_ops import log_softmax_rows
-            return log_softmax_rows(logits.contiguous(), inplace=True)
-        return F.log_softmax(logits, dim=2)
+        if hs_pad.is_cuda and not torch.is_grad_enabled() and hs_pad.dtype in (torch.float32, torch.bfloat16) \
+                and hs_pad.dtype == self.ctc_lo.weight.dtype:
+            from ..hip_ops import linear_bias_act, log_softmax_rows
+            logits = linear_bias_act(hs_pad.contiguous(), self.ctc_lo.weight, self.ctc_lo.bias, "none")
+            return log_softmax_rows(logits, inplace=True)
+        return F.log_softmax(self.ctc_lo(hs_pad), dim=2)
 
     def argmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
         return torch.argmax(self.ctc_lo(hs_pad), dim=2)

@@ -180,13 +180,8 @@ def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optio
                                          glu=True)
     _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
     if not masked:
-        if g.dtype == torch.bfloat16 and C % 64 == 0:
-            x2 = x.view(B * T, C)
-            hip_ops.gemm_bf16(g.view(B * T, C), cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias,
-                              residual=x2, out=x2)
-        else:
-            x = hip_ops.linear_bias_act(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none",
-                                        residual=x, inplace=True)
+        x = hip_ops.linear_bias_act(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none",
+                                    residual=x, inplace=True)
         _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff.weight, L.norm_ff.bias, want_x=False)
     else:   # padded frames of the conv branch count as zero (convolution.py:140-141): the add stays in the norm pass
         c = F.linear(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias)

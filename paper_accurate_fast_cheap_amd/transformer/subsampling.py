@@ -55,7 +55,8 @@ class Conv2dSubsampling4(BaseSubsampling):
             y = conv3x3s2_c1_nhwc(x.contiguous(), c1.weight, c1.bias, relu=True)            # (B, T1, F1, C)
             y = conv3x3s2_nhwc(y, self._w_c2_taps, c2.bias, relu=True)                       # (B, T', F', C)
             b, t, f, c = y.shape
-            return F.linear(y.view(b, t, f * c), self._w_lin, lin.bias)
+            from ..hip_ops import linear_bias_act
+            return linear_bias_act(y.view(b, t, f * c), self._w_lin, lin.bias, "none")
         p = x.unsqueeze(1).unfold(2, 3, 2).unfold(3, 3, 2).reshape(B, T1 * F1, 9)
         # relu(bias + p W^T) in one GEMM epilogue
         y = torch._addmm_activation(c1.bias, p.view(B * T1 * F1, 9), c1.weight.view(C, 9).t(), use_gelu=False)
