@@ -94,12 +94,6 @@ int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, cons
                          void *out, int act, float alpha, const void *residual, void *workspace, size_t workspace_bytes,
                          pafc_stream_t stream);
 
-/* out[z] (rows, N) = alpha * x[z] (rows, K) . weight[z] (N, K)^T for z < batch on contiguous stacks -- the stacked r, k, v
- * (and decay LoRA) projections of both directions (wenet/rwkv_v6/src/model.py:286-290), one library GEMM call, algorithm
- * measured once per shape like pafc_linear_bias_act. */
-int pafc_linear_batched(int dtype, int batch, long rows, int N, int K, const void *x, const void *weight, void *out,
-                        float alpha, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
-
 /* Hand-written bf16 GEMM with fused epilogue (csrc/gemm_bf16.hip), batched:
  *   out[z][m][n] = act(alpha * sum_k A[z][m][k] * W[z][n][k] + bias[z][n] + residual[z][m][n]),   z < batch
  * A: (M, K) rows lda apart; W: (N, K) = nn.Linear.weight layout, rows ldw apart; out / residual: (M, N), rows ldo / ldr

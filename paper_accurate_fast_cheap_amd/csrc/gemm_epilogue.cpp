@@ -170,9 +170,4 @@ int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, cons
     return linear_impl(dtype, 1, rows, N, K, x, weight, bias, out, act, alpha, residual, workspace, workspace_bytes, stream);
 }
 
-int pafc_linear_batched(int dtype, int batch, long rows, int N, int K, const void *x, const void *weight, void *out,
-                        float alpha, void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
-    return linear_impl(dtype, batch, rows, N, K, x, weight, nullptr, out, 0, alpha, nullptr, workspace, workspace_bytes, stream);
-}
-
 }  // extern "C"

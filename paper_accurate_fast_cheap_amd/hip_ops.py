@@ -310,26 +310,3 @@ def ctc_prefix_beam(top_logp: torch.Tensor, top_idx: torch.Tensor, lens: Optiona
                                              _lib.ptr(ws), nws, _lib.stream_of(top_logp)), "pafc_ctc_prefix_beam_search")
     return tokens, lengths, scores
 
-
-def linear_batched(x: torch.Tensor, weight: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
-    """x (Z, M, K) @ weight (Z, N, K)^T -> (Z, M, N): one hipBLASLt strided-batched GEMM with a measured algorithm."""
-    _lib.require_gpu(x, weight)
-    L = _bind2()
-    if not getattr(L, "_pafc_lb_bound", False):
-        from ctypes import c_float, c_long, c_size_t
-        _lib._sig(L.pafc_linear_act_workspace_bytes, c_size_t)
-        _lib._sig(L.pafc_linear_batched, c_int, c_int, c_int, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
-                  c_void_p, c_size_t, c_void_p)
-        L._pafc_lb_bound = True
-    if x.dim() != 3 or weight.dim() != 3 or x.shape[0] != weight.shape[0] or x.shape[2] != weight.shape[2] \
-            or x.dtype != weight.dtype:
-        raise _lib.PafcError("linear_batched: x (Z, M, K), weight (Z, N, K), same dtype")
-    Z, M, K = x.shape
-    N = weight.shape[1]
-    ws = _gemm_ws.get(x.device)
-    if ws is None:
-        ws = _gemm_ws[x.device] = torch.empty(L.pafc_linear_act_workspace_bytes(), dtype=torch.uint8, device=x.device)
-    out = torch.empty((Z, M, N), dtype=x.dtype, device=x.device)
-    _lib.check(L.pafc_linear_batched(_lib.dtype_code(x.dtype), Z, M, N, K, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(out),
-                                     float(alpha), _lib.ptr(ws), ws.numel(), _lib.stream_of(x)), "pafc_linear_batched")
-    return out
