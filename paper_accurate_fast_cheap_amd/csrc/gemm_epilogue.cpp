@@ -127,7 +127,7 @@ static int linear_impl(int dtype, int batch, long rows, int N, int K, const void
             if (residual == out && hipMalloc(&scratch, (size_t)batch * rows * N * esz) == hipSuccess) dst = scratch;
             if (residual != out || scratch) {
                 hipEvent_t e0, e1;
-                hipEventCreate(&e0); hipEventCreate(&e1);
+                (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
                 const float tbeta = residual ? 1.f : 0.f;
                 const void *tc = residual ? residual : dst;
                 float best_ms = 1e30f, first_ms = 1e30f;
@@ -135,21 +135,21 @@ static int linear_impl(int dtype, int batch, long rows, int N, int K, const void
                     if (i > 0 && res[i].workspaceSize > 0) continue;
                     bool ok = true;
                     for (int rep = 0; rep < 7 && ok; ++rep) {       // first run warms the code object, the other six are timed
-                        if (rep == 1) hipEventRecord(e0, hs);
+                        if (rep == 1) (void)hipEventRecord(e0, hs);
                         ok = hipblasLtMatmul(handle, p.desc, &alpha, weight, p.a, x, p.b, &tbeta, tc, p.d, dst, p.d, &res[i].algo,
                                              workspace, res[i].workspaceSize, hs) == HIPBLAS_STATUS_SUCCESS;
                     }
-                    hipEventRecord(e1, hs);
-                    hipEventSynchronize(e1);
+                    (void)hipEventRecord(e1, hs);
+                    (void)hipEventSynchronize(e1);
                     float ms = 0.f;
-                    hipEventElapsedTime(&ms, e0, e1);
+                    (void)hipEventElapsedTime(&ms, e0, e1);
                     if (ok && i == 0) first_ms = ms;
                     if (ok && ms < best_ms) { best_ms = ms; best = i; }
                 }
                 if (best_ms > 0.95f * first_ms) best = 0;           // leave the heuristic's pick unless clearly beaten
-                hipEventDestroy(e0); hipEventDestroy(e1);
+                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
             }
-            if (scratch) hipFree(scratch);
+            if (scratch) (void)hipFree(scratch);
         }
         p.algo = res[best].algo;
         p.ws = res[best].workspaceSize;
