@@ -310,3 +310,46 @@ def ctc_prefix_beam(top_logp: torch.Tensor, top_idx: torch.Tensor, lens: Optiona
                                              _lib.ptr(ws), nws, _lib.stream_of(top_logp)), "pafc_ctc_prefix_beam_search")
     return tokens, lengths, scores
 
+
+
+class RnntBeamState:
+    """Device-side beams of the CTC-fused RNN-T prefix beam search (include/pafc_search.h: pafc_rnnt_beam_*)."""
+
+    def __init__(self, B: int, T: int, beam: int, blank: int, device):
+        from ctypes import c_size_t
+        L = _bind()
+        if not getattr(L, "_pafc_rnnt_bound", False):
+            P, I = c_void_p, c_int
+            _lib._sig(L.pafc_rnnt_beam_workspace_bytes, c_size_t, I, I, I)
+            _lib._sig(L.pafc_rnnt_beam_init, I, I, I, I, I, P, c_size_t, P, P, P)
+            _lib._sig(L.pafc_rnnt_beam_step, I, I, I, I, I, I, P, P, P, P, c_size_t, P, P, P)
+            _lib._sig(L.pafc_rnnt_beam_finish, I, I, I, I, P, c_size_t, P, P, P, P)
+            L._pafc_rnnt_bound = True
+        self.L, self.B, self.T, self.beam, self.blank = L, B, T, beam, blank
+        self.nws = L.pafc_rnnt_beam_workspace_bytes(B, T, beam)
+        if self.nws == 0:
+            raise _lib.PafcError("rnnt beam search: B, T, beam must be positive")
+        self.ws = torch.empty(self.nws, dtype=torch.uint8, device=device)
+        self.next_idx = torch.empty(B * beam, dtype=torch.int64, device=device)
+        self.last_tok = torch.empty(B * beam, dtype=torch.int64, device=device)
+        self.stream = _lib.stream_of(self.ws)
+        _lib.check(L.pafc_rnnt_beam_init(B, T, beam, blank, _lib.ptr(self.ws), self.nws, _lib.ptr(self.next_idx),
+                                         _lib.ptr(self.last_tok), self.stream), "pafc_rnnt_beam_init")
+
+    def step(self, t: int, lens64: Optional[torch.Tensor], top_val: torch.Tensor, top_idx: torch.Tensor):
+        _lib.require_gpu(top_val, top_idx, lens64)
+        if top_val.dtype != torch.float32 or top_idx.dtype != torch.int64 or top_val.numel() != self.B * self.beam * self.beam:
+            raise _lib.PafcError("rnnt beam step: top_val float32 / top_idx int64 of (B, beam, beam)")
+        _lib.check(self.L.pafc_rnnt_beam_step(self.B, self.T, self.beam, self.blank, int(t), _lib.ptr(lens64),
+                                              _lib.ptr(top_val), _lib.ptr(top_idx), _lib.ptr(self.ws), self.nws,
+                                              _lib.ptr(self.next_idx), _lib.ptr(self.last_tok), self.stream),
+                   "pafc_rnnt_beam_step")
+
+    def finish(self):
+        dev = self.ws.device
+        tokens = torch.empty(self.B, self.beam, self.T, dtype=torch.int32, device=dev)
+        lengths = torch.empty(self.B, self.beam, dtype=torch.int32, device=dev)
+        scores = torch.empty(self.B, self.beam, dtype=torch.float64, device=dev)
+        _lib.check(self.L.pafc_rnnt_beam_finish(self.B, self.T, self.beam, _lib.ptr(self.ws), self.nws, _lib.ptr(tokens),
+                                                _lib.ptr(lengths), _lib.ptr(scores), self.stream), "pafc_rnnt_beam_finish")
+        return tokens, lengths, scores

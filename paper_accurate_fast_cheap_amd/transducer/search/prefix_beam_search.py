@@ -35,6 +35,7 @@ class PrefixBeamSearch:
         self.joint = joint
         self.ctc = ctc
         self.blank = blank
+        self.device_resident = True   # GPU tensors: keep the beams on the device (False: host bookkeeping, one copy per frame)
 
     def forward_decoder_one_step(self, encoder_x: torch.Tensor, pre_t: torch.Tensor, cache: List[torch.Tensor]):
         padding = torch.zeros(pre_t.size(0), 1, device=encoder_x.device, dtype=cache[0].dtype)
@@ -59,6 +60,9 @@ class PrefixBeamSearch:
                                         transducer_weight: float = 0.7, cat_embs: Optional[torch.Tensor] = None):
         device = encoder_outs.device
         B = encoder_outs.shape[0]
+        if self.device_resident and encoder_outs.is_cuda and beam_size <= 16 and B > 0 and encoder_outs.shape[1] > 0:
+            return self._decode_batch_resident(encoder_outs, encoder_lens, ctc_probs, beam_size, ctc_weight,
+                                               transducer_weight)
         lens = [int(v) for v in encoder_lens.tolist()]
         max_len = max(lens) if lens else 0
         state = self.predictor.init_state(B, method="zero", device=device)
@@ -126,4 +130,39 @@ class PrefixBeamSearch:
             nbest = [b.hyp[1:] for b in bs]
             nbest_scores = [b.score for b in bs]
             results.append(DecodeResult(tokens=nbest[0], score=nbest_scores[0], nbest=nbest, nbest_scores=nbest_scores))
+        return results
+
+    @torch.no_grad()
+    def _decode_batch_resident(self, encoder_outs, encoder_lens, ctc_probs, beam_size: int, ctc_weight: float,
+                               transducer_weight: float):
+        """The same search with the beams on the device (pafc_rnnt_beam_*): B x beam fixed slots, predictor step,
+        joint, fusion and top-k as batched ops over all slots, the candidate walk in a kernel, LSTM states re-indexed
+        by the kernel's output -- no host synchronisation until the n-best lists are read back."""
+        from ...hip_ops import RnntBeamState
+        device = encoder_outs.device
+        B, T, _ = encoder_outs.shape
+        n = B * beam_size
+        lens64 = encoder_lens.to(device=device, dtype=torch.int64).contiguous()
+        st = RnntBeamState(B, T, beam_size, self.blank, device)
+        state = self.predictor.init_state(n, method="zero", device=device)
+        cache = [s.to(encoder_outs.dtype) for s in state]
+        for t in range(T):
+            enc = encoder_outs[:, t, :].repeat_interleave(beam_size, dim=0).unsqueeze(1)            # (n, 1, D)
+            logp, new_cache = self.forward_decoder_one_step(enc, st.last_tok, cache)
+            logp = logp.squeeze(1).squeeze(1)                                                        # (n, V)
+            ctc_t = ctc_probs[:, t, :].repeat_interleave(beam_size, dim=0)
+            logp = torch.log(torch.add(transducer_weight * torch.exp(logp), ctc_weight * torch.exp(ctc_t)))
+            top_val, top_idx = logp.topk(beam_size)
+            st.step(t, lens64, top_val.float().contiguous(), top_idx.contiguous())
+            cache = [torch.cat([cache[0], new_cache[0]], dim=1).index_select(1, st.next_idx),
+                     torch.cat([cache[1], new_cache[1]], dim=1).index_select(1, st.next_idx)]
+        toks, lens_n, scores = st.finish()
+        lens_h, scores_h = lens_n.tolist(), scores.tolist()
+        maxlen = max(1, int(lens_n.max()))
+        toks_h = toks[:, :, :maxlen].tolist()
+        results = []
+        for b in range(B):
+            nbest = [toks_h[b][k][:lens_h[b][k]] for k in range(beam_size) if lens_h[b][k] >= 0]
+            nsc = [scores_h[b][k] for k in range(beam_size) if lens_h[b][k] >= 0]
+            results.append(DecodeResult(tokens=nbest[0], score=nsc[0], nbest=nbest, nbest_scores=nsc))
         return results
