@@ -134,9 +134,11 @@ def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
         out = residual
     else:
         out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
-    rc = L.pafc_linear_bias_act(_lib.dtype_code(x.dtype), rows, N, K, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias),
-                                _lib.ptr(out), 1 if act == "silu" else 0, float(alpha), _lib.ptr(residual), _lib.ptr(ws),
-                                ws.numel(), _lib.stream_of(x))
+    from .profiling import op_timer
+    with op_timer("linear_%dx%d" % (K, N), sample=12, flops=2.0 * rows * N * K):
+        rc = L.pafc_linear_bias_act(_lib.dtype_code(x.dtype), rows, N, K, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias),
+                                    _lib.ptr(out), 1 if act == "silu" else 0, float(alpha), _lib.ptr(residual),
+                                    _lib.ptr(ws), ws.numel(), _lib.stream_of(x))
     _lib.check(rc, "pafc_linear_bias_act")
     return out
 
@@ -168,8 +170,10 @@ def conv3x3s2_nhwc(x: torch.Tensor, w_tap_co_ci: torch.Tensor, bias: Optional[to
     if x.dtype != torch.bfloat16 or w_tap_co_ci.shape != (9, Co, Ci) or w_tap_co_ci.dtype != x.dtype:
         raise _lib.PafcError("conv3x3s2_nhwc: bf16 NHWC input and a (9, Co, Ci) weight")
     out = torch.empty((B, (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1, Co), dtype=x.dtype, device=x.device)
-    rc = L.pafc_conv3x3s2_nhwc_bf16(B, T1, F1, Ci, Co, _lib.ptr(x), _lib.ptr(w_tap_co_ci), _lib.ptr(bias), _lib.ptr(out),
-                                    int(relu), _lib.stream_of(x))
+    from .profiling import op_timer
+    with op_timer("conv3x3s2", flops=2.0 * out.numel() * 9 * Ci):
+        rc = L.pafc_conv3x3s2_nhwc_bf16(B, T1, F1, Ci, Co, _lib.ptr(x), _lib.ptr(w_tap_co_ci), _lib.ptr(bias),
+                                        _lib.ptr(out), int(relu), _lib.stream_of(x))
     _lib.check(rc, "pafc_conv3x3s2_nhwc_bf16")
     return out
 

@@ -9,6 +9,7 @@ import torch
 
 _enabled = False
 _records = defaultdict(list)
+_calls = defaultdict(int)
 
 
 def enable(flag: bool = True):
@@ -16,11 +17,17 @@ def enable(flag: bool = True):
     _enabled = flag
     if flag:
         _records.clear()
+        _calls.clear()
 
 
 @contextlib.contextmanager
-def op_timer(name: str, **meta):
+def op_timer(name: str, sample: int = 1, **meta):
+    """sample = n: time only every n-th call of this name (frequent ops: the events themselves cost ~2 us each)."""
     if not _enabled:
+        yield
+        return
+    _calls[name] += 1
+    if sample > 1 and (_calls[name] - 1) % sample:
         yield
         return
     a = torch.cuda.Event(enable_timing=True)
