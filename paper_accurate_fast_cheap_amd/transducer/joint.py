@@ -44,3 +44,20 @@ class TransducerJoint(nn.Module):
         if self.postjoin_linear:
             out = self.post_ffn(out)
         return self.ffn_out(self.activatoin(out))
+
+    def forward_optimized(self, enc_out: torch.Tensor, pred_out: torch.Tensor, enc_out_len: torch.Tensor,
+                          pred_out_len: torch.Tensor, pre_project: bool = True) -> torch.Tensor:
+        """joint.py:111-149: the layout the optimized transducer loss wants -- per utterance only the valid
+        (T_n, U_n + 1) lattice, flattened and concatenated: (sum_n T_n (U_n + 1), V).  enc_out (B, T, E), pred_out
+        (B, U + 1, P) (predictor over the blank-prepended targets)."""
+        if not (pre_project and self.prejoin_linear):
+            raise NotImplementedError("forward_optimized needs the pre-join projections (as in the reference)")
+        rows = []
+        for i in range(enc_out.size(0)):
+            e = self.enc_ffn(enc_out[i, :int(enc_out_len[i])]).unsqueeze(1)          # (T_n, 1, J)
+            d = self.pred_ffn(pred_out[i, :int(pred_out_len[i]) + 1]).unsqueeze(0)   # (1, U_n + 1, J)
+            rows.append((e + d).reshape(-1, self.join_dim))
+        out = torch.cat(rows)
+        if self.postjoin_linear:
+            out = self.post_ffn(out)
+        return self.ffn_out(self.activatoin(out))
