@@ -50,14 +50,16 @@ int pafc_ctc_prefix_beam_search(int B, int T, int K, const float *top_logp, cons
  * framework ops and hands the (B, beam, beam) values / token ids to pafc_rnnt_beam_step, which updates the beams in
  * `workspace` and returns, per slot, where the survivor's LSTM state comes from -- next_idx[slot] indexes the
  * concatenation [old states (B*beam) | new states (B*beam)] -- and the token to feed the predictor next (last_tok).
- * No host synchronisation between frames.  beam <= 16.  lens: (B) int64 valid frames or NULL.
+ * No host synchronisation between frames.  beam <= 16.  lens: (B) int64 valid frames or NULL.  t_dev (device int64, or
+ * NULL): when given, the frame index is read from it instead of `t`, so the whole frame body can be captured once in a
+ * hipGraph and replayed (the caller increments it); frames t >= T are no-ops.
  * pafc_rnnt_beam_finish writes the n-best lists like pafc_ctc_prefix_beam_search (the leading blank is not included). */
 size_t pafc_rnnt_beam_workspace_bytes(int B, int T, int beam);
 int pafc_rnnt_beam_init(int B, int T, int beam, int blank_id, void *workspace, size_t workspace_bytes, int64_t *next_idx,
                         int64_t *last_tok, pafc_stream_t stream);
-int pafc_rnnt_beam_step(int B, int T, int beam, int blank_id, int t, const int64_t *lens, const float *top_val,
-                        const int64_t *top_idx, void *workspace, size_t workspace_bytes, int64_t *next_idx,
-                        int64_t *last_tok, pafc_stream_t stream);
+int pafc_rnnt_beam_step(int B, int T, int beam, int blank_id, int t, const int64_t *t_dev, const int64_t *lens,
+                        const float *top_val, const int64_t *top_idx, void *workspace, size_t workspace_bytes,
+                        int64_t *next_idx, int64_t *last_tok, pafc_stream_t stream);
 int pafc_rnnt_beam_finish(int B, int T, int beam, void *workspace, size_t workspace_bytes, int32_t *out_tokens,
                           int32_t *out_len, double *out_score, pafc_stream_t stream);
 

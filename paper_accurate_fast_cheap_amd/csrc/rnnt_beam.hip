@@ -63,9 +63,12 @@ __global__ void rnnt_beam_init_kernel(void *ws, int B, int T, int beam, int blan
     }
 }
 
-__global__ __launch_bounds__(64) void rnnt_beam_step_kernel(void *ws, int B, int T, int beam, int blank, int t,
-                                                            const int64_t *lens, const float *top_val,
-                                                            const int64_t *top_idx, int64_t *next_idx, int64_t *last_tok) {
+__global__ __launch_bounds__(64) void rnnt_beam_step_kernel(void *ws, int B, int T, int beam, int blank, int t_host,
+                                                            const int64_t *t_dev, const int64_t *lens,
+                                                            const float *top_val, const int64_t *top_idx,
+                                                            int64_t *next_idx, int64_t *last_tok) {
+    // the frame index comes from device memory when the frame body is replayed from a captured graph
+    const int t = t_dev != nullptr ? (int)*t_dev : t_host;
     __shared__ float c_val[RB * RB];
     __shared__ int c_tok[RB * RB], c_order[RB * RB];
     __shared__ int m_node[RB], m_parent[RB], m_last[RB];
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(64) void rnnt_beam_step_kernel(void *ws, int B, int
     const RnntState s = carve(ws, B, T, beam);
     const int b = blockIdx.x, lane = threadIdx.x;
     const int base = b * beam;
-    if (lens != nullptr && t >= lens[b]) {          // finished utterance: every slot keeps its state and its beam
+    if (t >= T || (lens != nullptr && t >= lens[b])) {   // finished utterance: every slot keeps its state and its beam
         if (lane < beam) next_idx[base + lane] = base + lane;
         return;
     }
@@ -210,15 +213,15 @@ extern "C" int pafc_rnnt_beam_init(int B, int T, int beam, int blank_id, void *w
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 
-extern "C" int pafc_rnnt_beam_step(int B, int T, int beam, int blank_id, int t, const int64_t *lens, const float *top_val,
-                                   const int64_t *top_idx, void *workspace, size_t workspace_bytes, int64_t *next_idx,
-                                   int64_t *last_tok, pafc_stream_t stream) {
+extern "C" int pafc_rnnt_beam_step(int B, int T, int beam, int blank_id, int t, const int64_t *t_dev, const int64_t *lens,
+                                   const float *top_val, const int64_t *top_idx, void *workspace, size_t workspace_bytes,
+                                   int64_t *next_idx, int64_t *last_tok, pafc_stream_t stream) {
     const int rc = rnnt_check(B, T, beam, workspace, workspace_bytes);
     if (rc) return rc;
     if (!top_val || !top_idx || !next_idx || !last_tok) return PAFC_ERR_NULL_POINTER;
-    if (t < 0 || t >= T) return PAFC_ERR_BAD_DIMS;
+    if (!t_dev && (t < 0 || t >= T)) return PAFC_ERR_BAD_DIMS;
     hipLaunchKernelGGL(pafc::rnnt_beam_step_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, workspace, B, T, beam, blank_id, t,
-                       lens, top_val, top_idx, next_idx, last_tok);
+                       t_dev, lens, top_val, top_idx, next_idx, last_tok);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 

@@ -326,7 +326,7 @@ class RnntBeamState:
             P, I = c_void_p, c_int
             _lib._sig(L.pafc_rnnt_beam_workspace_bytes, c_size_t, I, I, I)
             _lib._sig(L.pafc_rnnt_beam_init, I, I, I, I, I, P, c_size_t, P, P, P)
-            _lib._sig(L.pafc_rnnt_beam_step, I, I, I, I, I, I, P, P, P, P, c_size_t, P, P, P)
+            _lib._sig(L.pafc_rnnt_beam_step, I, I, I, I, I, I, P, P, P, P, P, c_size_t, P, P, P)
             _lib._sig(L.pafc_rnnt_beam_finish, I, I, I, I, P, c_size_t, P, P, P, P)
             L._pafc_rnnt_bound = True
         self.L, self.B, self.T, self.beam, self.blank = L, B, T, beam, blank
@@ -340,14 +340,16 @@ class RnntBeamState:
         _lib.check(L.pafc_rnnt_beam_init(B, T, beam, blank, _lib.ptr(self.ws), self.nws, _lib.ptr(self.next_idx),
                                          _lib.ptr(self.last_tok), self.stream), "pafc_rnnt_beam_init")
 
-    def step(self, t: int, lens64: Optional[torch.Tensor], top_val: torch.Tensor, top_idx: torch.Tensor):
-        _lib.require_gpu(top_val, top_idx, lens64)
+    def step(self, t: int, lens64: Optional[torch.Tensor], top_val: torch.Tensor, top_idx: torch.Tensor,
+             t_dev: Optional[torch.Tensor] = None):
+        """t_dev: device int64 scalar holding the frame index (graph replay); otherwise ``t``."""
+        _lib.require_gpu(top_val, top_idx, lens64, t_dev)
         if top_val.dtype != torch.float32 or top_idx.dtype != torch.int64 or top_val.numel() != self.B * self.beam * self.beam:
             raise _lib.PafcError("rnnt beam step: top_val float32 / top_idx int64 of (B, beam, beam)")
-        _lib.check(self.L.pafc_rnnt_beam_step(self.B, self.T, self.beam, self.blank, int(t), _lib.ptr(lens64),
-                                              _lib.ptr(top_val), _lib.ptr(top_idx), _lib.ptr(self.ws), self.nws,
-                                              _lib.ptr(self.next_idx), _lib.ptr(self.last_tok), self.stream),
-                   "pafc_rnnt_beam_step")
+        _lib.check(self.L.pafc_rnnt_beam_step(self.B, self.T, self.beam, self.blank, int(t), _lib.ptr(t_dev),
+                                              _lib.ptr(lens64), _lib.ptr(top_val), _lib.ptr(top_idx), _lib.ptr(self.ws),
+                                              self.nws, _lib.ptr(self.next_idx), _lib.ptr(self.last_tok),
+                                              _lib.stream_of(top_val)), "pafc_rnnt_beam_step")
 
     def finish(self):
         dev = self.ws.device

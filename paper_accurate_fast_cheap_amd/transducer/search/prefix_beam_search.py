@@ -36,6 +36,7 @@ class PrefixBeamSearch:
         self.ctc = ctc
         self.blank = blank
         self.device_resident = True   # GPU tensors: keep the beams on the device (False: host bookkeeping, one copy per frame)
+        self.use_graph = True         # device-resident path: replay the frame body from a captured hipGraph
 
     def forward_decoder_one_step(self, encoder_x: torch.Tensor, pre_t: torch.Tensor, cache: List[torch.Tensor]):
         padding = torch.zeros(pre_t.size(0), 1, device=encoder_x.device, dtype=cache[0].dtype)
@@ -145,17 +146,49 @@ class PrefixBeamSearch:
         lens64 = encoder_lens.to(device=device, dtype=torch.int64).contiguous()
         st = RnntBeamState(B, T, beam_size, self.blank, device)
         state = self.predictor.init_state(n, method="zero", device=device)
-        cache = [s.to(encoder_outs.dtype) for s in state]
-        for t in range(T):
-            enc = encoder_outs[:, t, :].repeat_interleave(beam_size, dim=0).unsqueeze(1)            # (n, 1, D)
+        cache = [s.to(encoder_outs.dtype).contiguous() for s in state]        # static buffers, updated in place
+        t_dev = torch.zeros(1, dtype=torch.int64, device=device)
+        ctc_probs = ctc_probs.contiguous()
+
+        def frame():
+            # one frame for all B x beam slots; every tensor it touches has a fixed address and shape, and the frame
+            # index lives on the device (t_dev), so the body can be captured once and replayed
+            enc = encoder_outs.index_select(1, t_dev.clamp(max=T - 1)).squeeze(1)
+            enc = enc.repeat_interleave(beam_size, dim=0).unsqueeze(1)                              # (n, 1, D)
             logp, new_cache = self.forward_decoder_one_step(enc, st.last_tok, cache)
             logp = logp.squeeze(1).squeeze(1)                                                        # (n, V)
-            ctc_t = ctc_probs[:, t, :].repeat_interleave(beam_size, dim=0)
+            ctc_t = ctc_probs.index_select(1, t_dev.clamp(max=T - 1)).squeeze(1).repeat_interleave(beam_size, dim=0)
             logp = torch.log(torch.add(transducer_weight * torch.exp(logp), ctc_weight * torch.exp(ctc_t)))
             top_val, top_idx = logp.topk(beam_size)
-            st.step(t, lens64, top_val.float().contiguous(), top_idx.contiguous())
-            cache = [torch.cat([cache[0], new_cache[0]], dim=1).index_select(1, st.next_idx),
-                     torch.cat([cache[1], new_cache[1]], dim=1).index_select(1, st.next_idx)]
+            st.step(0, lens64, top_val.float().contiguous(), top_idx.contiguous(), t_dev=t_dev)
+            cache[0].copy_(torch.cat([cache[0], new_cache[0]], dim=1).index_select(1, st.next_idx))
+            cache[1].copy_(torch.cat([cache[1], new_cache[1]], dim=1).index_select(1, st.next_idx))
+            t_dev.add_(1)
+
+        done = 0
+        if self.use_graph and T >= 8:
+            # launch-bound loop (~25 small kernels per frame): two eager frames warm every library handle, then the
+            # body is captured into a hipGraph and replayed for the remaining frames.  MIOpen's RNN call is not
+            # capturable (it sizes its workspace inside the call), so the LSTM runs through the framework's own cell.
+            try:
+                with torch.backends.cudnn.flags(enabled=False):
+                    side = torch.cuda.Stream(device=device)
+                    side.wait_stream(torch.cuda.current_stream(device))
+                    with torch.cuda.stream(side):
+                        frame(); frame()
+                    torch.cuda.current_stream(device).wait_stream(side)
+                    done = 2
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        frame()
+                    for _ in range(T - done):
+                        graph.replay()
+                    done = T
+            except Exception:   # capture unsupported in this build: finish eagerly from wherever t_dev stands
+                torch.cuda.synchronize(device)
+                done = int(t_dev.item())
+        for _ in range(T - done):
+            frame()
         toks, lens_n, scores = st.finish()
         lens_h, scores_h = lens_n.tolist(), scores.tolist()
         maxlen = max(1, int(lens_n.max()))
