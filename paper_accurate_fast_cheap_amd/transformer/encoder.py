@@ -144,6 +144,59 @@ class BaseEncoder(torch.nn.Module):
             xs = self.after_norm(xs)
         return xs, new_state
 
+    @torch.no_grad()
+    def stream_chunks(self, xs: torch.Tensor, decoding_chunk_size: int, use_graph: bool = True) -> torch.Tensor:
+        """A whole utterance (B, T, F) through forward_chunk_carry, window by window (the windows of
+        forward_chunk_by_chunk), returning the concatenated outputs (B, T', D).  A chunk step is ~25 small kernels per
+        layer -- launch-bound -- and every full window has the same shape, so on the GPU the step is captured once into
+        a hipGraph over fixed input / state / output buffers and replayed per window; the first windows (which also
+        let the causal-conv cache reach its final length) and a shorter last window run eagerly."""
+        assert decoding_chunk_size > 0
+        sub, ctx = self.embed.subsampling_rate, self.embed.right_context + 1
+        stride, window = sub * decoding_chunk_size, (decoding_chunk_size - 1) * sub + ctx
+        T = xs.size(1)
+        starts = list(range(0, T - ctx + 1, stride))
+        full = [c for c in starts if c + window <= T]
+        outs: List[torch.Tensor] = []
+        state: Optional[list] = None
+
+        def eager(c):
+            nonlocal state
+            y, state = self.forward_chunk_carry(xs[:, c:min(c + window, T)], 0, state)
+            outs.append(y)
+
+        lorder = max([getattr(l.conv_module, "lorder", 0) or 0 for l in self.encoders if l.conv_module is not None] + [0])
+        warm = max(2, -(-lorder // decoding_chunk_size) + 1)
+        done = 0
+        if use_graph and xs.is_cuda and len(full) >= warm + 4:
+            try:
+                side = torch.cuda.Stream(device=xs.device)
+                side.wait_stream(torch.cuda.current_stream(xs.device))
+                with torch.cuda.stream(side):
+                    for c in full[:warm]:
+                        eager(c)
+                torch.cuda.current_stream(xs.device).wait_stream(side)
+                done = warm
+                static_in = xs[:, full[warm]:full[warm] + window].clone()
+                static_state = [{k: v.clone() for k, v in st.items()} for st in state]
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    y_static, new_state = self.forward_chunk_carry(static_in, 0, static_state)
+                    for st, nw in zip(static_state, new_state):
+                        for k in st:
+                            st[k].copy_(nw[k])
+                for c in full[warm:]:
+                    static_in.copy_(xs[:, c:c + window])
+                    graph.replay()
+                    outs.append(y_static.clone())
+                    done += 1
+                state = static_state
+            except Exception:   # capture unsupported here: the remaining windows run eagerly from the current state
+                torch.cuda.synchronize(xs.device)
+        for c in starts[done:]:
+            eager(c)
+        return torch.cat(outs, 1)
+
     def forward_chunk_by_chunk(self, xs: torch.Tensor, decoding_chunk_size: int, num_decoding_left_chunks: int = -1,
                                cat_embs: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """encoder.py:341-402: overlapping input windows of (chunk-1)*4+7 frames, stride 4*chunk."""

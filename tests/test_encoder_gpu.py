@@ -203,6 +203,16 @@ def test_state_carry_chunked_equals_full(hip, dtype):
     ys = torch.cat(outs, 1)
     assert ys.shape == full.shape
     torch.testing.assert_close(ys, full, rtol=1e-3, atol=2e-4)
+    # stream_chunks = the same windows, the chunk step replayed from a captured hipGraph: equal to the eager loop up to
+    # fp32 round-off (under capture the GEMM library may pick another algorithm) and to the full-sequence pass
+    long = synth.randn((1, 4 * 8 * 14 + 3, 80), 78, 2.0).cuda()
+    with torch.no_grad():
+        eager = enc.stream_chunks(long, 8, use_graph=False)
+        replayed = enc.stream_chunks(long, 8, use_graph=True)
+        whole, _ = enc(long, torch.tensor([long.size(1)], device="cuda"))
+    assert replayed.shape == eager.shape == whole.shape
+    torch.testing.assert_close(replayed, eager, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(replayed, whole, rtol=1e-3, atol=2e-4)
 
 
 def test_minimal_and_ragged_edge_inputs(hip):
