@@ -49,10 +49,10 @@ class BaseEncoder(torch.nn.Module):
         from . import fused
         if self._fused_plan is None:
             if not (self.normalize_before and all(fused.eligible(l) for l in self.encoders)):
-                self.fused_inference = False
+                self._fused_plan = False           # remembered: these layers take the module path in forward()
                 return None
             self._fused_plan = fused.EncoderPlan(self.encoders)
-        return self._fused_plan
+        return self._fused_plan or None
 
     def output_size(self) -> int:
         return self._output_size
@@ -137,8 +137,19 @@ class BaseEncoder(torch.nn.Module):
         xs, _, _ = self.embed(xs, masks, offset)
         state = state or [None] * len(self.encoders)
         new_state = []
-        for layer, carry in zip(self.encoders, state):
-            xs, c = layer.forward_carry(xs, carry)
+        plans = None
+        if self.fused_inference and not torch.is_grad_enabled() and not self.training and xs.is_cuda:
+            from . import fused
+            if all(fused.carry_eligible(l, xs) for l in self.encoders):     # one bf16 stream, causal conv: fused kernels
+                if getattr(self, "_carry_plans", None) is None:
+                    self._carry_plans = [fused.LayerPlan(l) for l in self.encoders]
+                plans = self._carry_plans
+        for i, (layer, carry) in enumerate(zip(self.encoders, state)):
+            if plans is not None:
+                plans[i].refresh()
+                xs, c = fused.layer_forward_carry(plans[i], xs, carry)
+            else:
+                xs, c = layer.forward_carry(xs, carry)
             new_state.append(c)
         if self.normalize_before:
             xs = self.after_norm(xs)

@@ -215,6 +215,42 @@ def test_state_carry_chunked_equals_full(hip, dtype):
     torch.testing.assert_close(replayed, whole, rtol=1e-3, atol=2e-4)
 
 
+def test_fused_state_carry_step_matches_module_path(hip):
+    """bf16 stream (B = 1, causal conv): the chunk step on the fused kernels (fused.layer_forward_carry) carries the
+    same three states and produces the module path's outputs to bf16 round-off; carried scan state to fp32 round-off."""
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_reduced_uni_bf16model")
+    conf = dict(g["conf"], causal=True, cnn_module_kernel=15)
+    torch.manual_seed(6)
+    enc = ConformerEncoder(80, **conf)
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.05)
+    enc = enc.to(torch.bfloat16).cuda().eval()
+    xs = synth.randn((1, 4 * 8 * 9 + 3, 80), 79, 2.0).to(torch.bfloat16).cuda()
+    with torch.no_grad():
+        enc.fused_inference = True
+        a = enc.stream_chunks(xs, 8, use_graph=False)
+        assert getattr(enc, "_carry_plans", None) is not None        # the fused step really ran
+        _, st_f = enc.forward_chunk_carry(xs[:, :35], 0, None)
+        enc.fused_inference = False
+        b = enc.stream_chunks(xs, 8, use_graph=False)
+        _, st_m = enc.forward_chunk_carry(xs[:, :35], 0, None)
+        enc.fused_inference = True
+        c = enc.stream_chunks(xs, 8, use_graph=True)
+    assert a.shape == b.shape == c.shape
+    d = (a.float() - b.float()).abs()
+    assert float(d.mean()) < 2e-2 and float(d.max()) < 0.4, (float(d.mean()), float(d.max()))
+    d = (a.float() - c.float()).abs()
+    assert float(d.mean()) < 2e-2 and float(d.max()) < 0.4
+    for f, m in zip(st_f, st_m):
+        assert set(f) == set(m) == {"shift", "wkv", "cnn"}
+        assert f["cnn"].shape == m["cnn"].shape and f["shift"].shape == m["shift"].shape
+    torch.testing.assert_close(st_f[0]["wkv"], st_m[0]["wkv"], rtol=5e-2, atol=5e-2)
+    torch.testing.assert_close(st_f[0]["cnn"].float(), st_m[0]["cnn"].float(), rtol=5e-2, atol=5e-2)
+
+
 def test_minimal_and_ragged_edge_inputs(hip):
     """Shortest input the subsampling accepts (7 frames -> T' = 1), a batch whose shortest member is that short, and
     lengths that are not multiples of anything: fused executor == module path, masks exact, outputs finite."""
