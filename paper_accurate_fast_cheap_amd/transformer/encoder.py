@@ -41,6 +41,11 @@ class BaseEncoder(torch.nn.Module):
         # inference executor (transformer/fused.py); PAFC_DISABLE_FUSED=1 keeps the op-by-op module path
         self.fused_inference = os.environ.get("PAFC_DISABLE_FUSED", "0") != "1"
         self._fused_plan = None
+        # opt-in hipGraph cache for inference batches of a recurring (B, T) shape (windowed long-form decoding runs dozens
+        # of identical batches whose ~300 short kernels are launch-bound): the N most recent shapes keep a captured
+        # graph of the whole forward; 0 = off.  Each graph pins its activations, hence opt-in and bounded.
+        self.graph_cache_size = 0
+        self._graphs = {}
 
     def _fused(self, xs: torch.Tensor):
         """The fused executor's plan when this call may use it (no autograd, GPU, eligible layers), else None."""
@@ -61,8 +66,52 @@ class BaseEncoder(torch.nn.Module):
                 num_decoding_left_chunks: int = -1, cat_embs: Optional[torch.Tensor] = None
                 ) -> Tuple[torch.Tensor, torch.Tensor]:
         """(B, T, F) padded features + (B,) lengths -> (B, T', C), (B, 1, T') bool mask.  encoder.py:117-149."""
+        if (self.graph_cache_size > 0 and xs.is_cuda and not torch.is_grad_enabled() and not self.training
+                and cat_embs is None and decoding_chunk_size <= 0):
+            out = self._forward_graphed(xs, xs_lens)
+            if out is not None:
+                return out
         xs, masks, _ = self.forward_return_layers(xs, xs_lens, decoding_chunk_size, num_decoding_left_chunks, cat_embs)
         return xs, masks
+
+    def _forward_graphed(self, xs: torch.Tensor, xs_lens: torch.Tensor):
+        """Replay the forward of this (B, T, dtype) shape from a captured hipGraph; the first sighting of a shape runs
+        eagerly (returns None), the second one captures.  Outputs are copies: the graph's own buffers are reused."""
+        key = (tuple(xs.shape), xs.dtype, xs_lens.dtype)
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._graphs[key] = "seen"
+            self._trim_graphs()
+            return None
+        if ent == "seen":
+            try:
+                sx, sl = xs.clone(), xs_lens.clone()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    oy, om, _ = self.forward_return_layers(sx, sl)
+                ent = self._graphs[key] = (graph, sx, sl, oy, om)
+                self._graphs[key] = self._graphs.pop(key)     # newest last, then drop the oldest graphs beyond the bound
+                self._trim_graphs()
+            except Exception:                      # not capturable in this configuration: stay eager for this shape
+                torch.cuda.synchronize(xs.device)
+                self._graphs[key] = "eager"
+                return None
+        if ent == "eager":
+            return None
+        graph, sx, sl, oy, om = ent
+        sx.copy_(xs)
+        sl.copy_(xs_lens)
+        graph.replay()
+        self._graphs[key] = self._graphs.pop(key)  # most recently used last
+        return oy.clone(), om.clone()
+
+    def _trim_graphs(self):
+        live = [k for k, v in self._graphs.items() if isinstance(v, tuple)]
+        while len(live) > self.graph_cache_size:
+            self._graphs.pop(live.pop(0))
+        if len(self._graphs) > 4096:               # bookkeeping of shapes seen once stays bounded too
+            for k in [k for k, v in self._graphs.items() if not isinstance(v, tuple)][:2048]:
+                self._graphs.pop(k)
 
     def forward_return_layers(self, xs, xs_lens, decoding_chunk_size: int = 0, num_decoding_left_chunks: int = -1,
                               cat_embs=None, want_layers: bool = False):

@@ -251,6 +251,32 @@ def test_fused_state_carry_step_matches_module_path(hip):
     torch.testing.assert_close(st_f[0]["cnn"].float(), st_m[0]["cnn"].float(), rtol=5e-2, atol=5e-2)
 
 
+def test_graph_cache_replays_recurring_batch_shapes(hip):
+    """Opt-in hipGraph cache (encoder.graph_cache_size): the third batch of a shape is replayed from the graph captured
+    at the second; outputs and masks equal the eager forward (fp32 round-off: the GEMM library may pick differently
+    under capture), new lengths are honoured, other shapes stay eager, the cache stays bounded."""
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_reduced_f32")
+    sd = {k: v for k, v in _sd(g).items() if not k.startswith("global_cmvn")}
+    enc = ConformerEncoder(80, **g["conf"])
+    enc.load_state_dict(sd)
+    enc = enc.cuda().eval()
+    xs = [synth.randn((3, 95, 80), 90 + i, 2.0).cuda() for i in range(4)]
+    lens = [torch.tensor(v, device="cuda") for v in ([95, 60, 33], [95, 95, 95], [95, 41, 17], [70, 95, 8])]
+    with torch.no_grad():
+        want = [enc(x, l) for x, l in zip(xs, lens)]
+        enc.graph_cache_size = 1
+        got = [enc(x, l) for x, l in zip(xs, lens)]
+        assert isinstance(enc._graphs[((3, 95, 80), torch.float32, torch.int64)], tuple)
+        other = enc(xs[0][:, :71], torch.tensor([71, 30, 9], device="cuda"))         # another shape: eager, then captured
+        other2 = enc(xs[0][:, :71], torch.tensor([71, 30, 9], device="cuda"))
+        assert sum(isinstance(v, tuple) for v in enc._graphs.values()) == 1            # bounded: the older graph is gone
+    for (wy, wm), (gy, gm) in zip(want, got):
+        assert torch.equal(wm, gm)
+        torch.testing.assert_close(gy, wy, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(other[0], other2[0], rtol=1e-4, atol=2e-5)
+
+
 def test_minimal_and_ragged_edge_inputs(hip):
     """Shortest input the subsampling accepts (7 frames -> T' = 1), a batch whose shortest member is that short, and
     lengths that are not multiples of anything: fused executor == module path, masks exact, outputs finite."""
