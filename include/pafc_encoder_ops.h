@@ -80,6 +80,17 @@ int pafc_conv3x3s2_nhwc_bf16(int B, int T1, int F1, int Ci, int Co, const void *
 int pafc_conv3x3s2_c1_nhwc_bf16(int B, int T, int F, int C, const void *x, const void *w_c_9, const void *bias, void *out,
                                 int relu, pafc_stream_t stream);
 
+/* The two subsampling convolutions for fp32 activations at bf16 matrix-core speed: every fp32 value travels as
+ * hi + lo, hi = bf16(x), lo = bf16(x - hi) (16 significant bits); a product is three bf16 MFMAs (hi hi + lo hi + hi lo)
+ * accumulated in fp32 -- ~1e-5 relative to the fp32 convolution.  _c1_: x (B, T, F) fp32, w (C, 1, 3, 3) fp32, bias
+ * fp32 -> out_hi / out_lo (B, T1, F1, C) bf16 planes.  second convolution: those planes + the (9, Co, Ci) weight split
+ * the same way by the caller -> out (B, T2, F2, Co) fp32 (+ bias, ReLU).  Shapes and limits as the bf16 entry points. */
+int pafc_conv3x3s2_c1_nhwc_f32split(int B, int T, int F, int C, const float *x, const float *w_c_9, const float *bias,
+                                    void *out_hi, void *out_lo, int relu, pafc_stream_t stream);
+int pafc_conv3x3s2_nhwc_f32split(int B, int T1, int F1, int Ci, int Co, const void *in_hi, const void *in_lo,
+                                 const void *w_hi_tap_co_ci, const void *w_lo_tap_co_ci, const float *bias, float *out,
+                                 int relu, pafc_stream_t stream);
+
 /* out (rows, N) = act(alpha * x (rows, K) . weight (N, K)^T + residual (rows, N) + bias (N)) as one hipBLASLt GEMM
  * with a fused epilogue; act 0 = identity, 1 = SiLU; bias and residual may be NULL; residual may alias out; bias is
  * added as given (not scaled by alpha).  Replaces `activation(w_1(x))` of PositionwiseFeedForward.forward

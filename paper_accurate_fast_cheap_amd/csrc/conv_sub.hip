@@ -236,6 +236,190 @@ __global__ __launch_bounds__(256) void conv3x3s2_c1_kernel(int T, int F, int T1,
     }
 }
 
+// ---- fp32 activations at bf16 matrix-core speed: split operands ---------------------------------------------------------
+// An fp32 model (the YAML default keeps everything but the slot in fp32) would run conv2 on the fp32 MFMA path: 57 ms per
+// 30-minute file through the library against 3.8 ms in bf16.  Every fp32 value is hi + lo with hi = bf16(x) and
+// lo = bf16(x - hi) (16 significant bits); a product needs three bf16 MFMAs (hi hi + lo hi + hi lo; lo lo is below
+// 2^-16 relative) and accumulates in fp32 -- ~1e-5 relative to the fp32 convolution, two orders inside the 1e-3 bar, at
+// 3x the bf16 cost instead of 15x.  conv1 writes its output directly as the two bf16 planes (the same bytes as one fp32
+// plane), the weights are split once when the plan is built.
+
+// conv1 for fp32 inputs: fp32 arithmetic, output as hi / lo bf16 planes
+__global__ __launch_bounds__(256) void conv3x3s2_c1_split_kernel(int T, int F, int T1, int F1, int C, const float *x,
+                                                                 const float *w /* (C, 9) */, const float *bias,
+                                                                 bf16_t *out_hi, bf16_t *out_lo, int relu) {
+    extern __shared__ float s_x[];   // [3][F]
+    const int tid = threadIdx.x;
+    const long bt = blockIdx.x;
+    const int b = (int)(bt / T1), t1 = (int)(bt % T1);
+    const float *xr = x + ((long)b * T + 2 * t1) * F;
+    for (int i = tid; i < 3 * F; i += 256) s_x[i] = xr[i];
+    const int cgs = C / 8, ppi = 256 / cgs;
+    const int cg = tid % cgs, pl = tid / cgs;
+    float wr[9][8], bv[8];
+    {
+        const float *wp = w + (long)cg * 8 * 9;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wr[k][c] = wp[c * 9 + k];
+            bv[c] = bias ? bias[cg * 8 + c] : 0.f;
+        }
+    }
+    __syncthreads();
+    const long obase = bt * (long)F1 * C + cg * 8;
+    for (int f1 = pl; f1 < F1; f1 += ppi) {
+        float xv[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = s_x[kh * F + 2 * f1 + kw];
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = bv[c];
+        // same summation order as the framework's direct convolution is not defined; fp32 FMA chain over the 9 taps
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = fmaf(xv[k], wr[k][c], acc[c]);
+        unsigned hi[8], lo[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float v = relu ? fmaxf(acc[c], 0.f) : acc[c];
+            hi[c] = f32_to_bf16_bits(v);
+            lo[c] = f32_to_bf16_bits(v - bf16_bits_to_f32(hi[c]));
+        }
+        uint4 oh, ol;
+        oh.x = hi[0] | (hi[1] << 16); oh.y = hi[2] | (hi[3] << 16); oh.z = hi[4] | (hi[5] << 16); oh.w = hi[6] | (hi[7] << 16);
+        ol.x = lo[0] | (lo[1] << 16); ol.y = lo[2] | (lo[3] << 16); ol.z = lo[4] | (lo[5] << 16); ol.w = lo[6] | (lo[7] << 16);
+        *reinterpret_cast<uint4 *>(out_hi + obase + (long)f1 * C) = oh;
+        *reinterpret_cast<uint4 *>(out_lo + obase + (long)f1 * C) = ol;
+    }
+}
+
+struct ConvSplitParams {
+    const bf16_t *in_hi, *in_lo;   // (B, T1, F1, Ci) each
+    const bf16_t *wt_hi, *wt_lo;   // (9, Co, Ci) each
+    const float *bias;             // (Co) or null
+    float *out;                    // (B, T2, F2, Co) fp32
+    int B, T1, F1, Ci, Co, T2, F2;
+    long M;
+    int relu;
+    int mtiles, ntiles;
+};
+
+// 128 x 128 x 64 tiles, stage = [A_hi | A_lo | W_hi | W_lo] (64 KiB), two stages, one block per CU
+__global__ __launch_bounds__(256, 1) void conv3x3s2_split_kernel(const ConvSplitParams p) {
+    constexpr int BM = 128, BN = 128, TILE = 128 * BK, STAGE = 4 * TILE;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long nblk = (long)p.mtiles * p.ntiles;
+    long bid = blockIdx.x;
+    const long per = nblk / 8;
+    if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
+    const int mt0 = (int)(bid / p.ntiles), nt0 = (int)(bid % p.ntiles);
+    const long m0 = (long)mt0 * BM;
+    const int n0 = nt0 * BN;
+    const int sub = lane >> 3, pch = lane & 7;
+    long a_off[4], b_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wave * 32 + j * 8 + sub;
+        const int c = pch ^ (row & 7);
+        long m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        const int f2 = (int)(m % p.F2);
+        const long bt = m / p.F2;
+        const int t2 = (int)(bt % p.T2);
+        const int b = (int)(bt / p.T2);
+        a_off[j] = (((long)b * p.T1 + 2 * t2) * p.F1 + 2 * f2) * p.Ci + 8 * c;
+        b_off[j] = (long)(n0 + row) * p.Ci + 8 * c;
+    }
+    const int kblocks = p.Ci / BK;
+    const int iters = 9 * kblocks;
+    const long tap_stride_b = (long)p.Co * p.Ci;
+    auto issue = [&](int it, int buf) {
+        const int tap = it / kblocks, kb = it - tap * kblocks;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const long aoff = ((long)kh * p.F1 + kw) * p.Ci + kb * BK;
+        const long boff = tap * tap_stride_b + kb * BK;
+        bf16_t *S = lds + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rowbase = (wave * 32 + j * 8) * BK;
+            dma16(p.in_hi + a_off[j] + aoff, S + rowbase);
+            dma16(p.in_lo + a_off[j] + aoff, S + TILE + rowbase);
+            dma16(p.wt_hi + b_off[j] + boff, S + 2 * TILE + rowbase);
+            dma16(p.wt_lo + b_off[j] + boff, S + 3 * TILE + rowbase);
+        }
+    };
+    f32x4c acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, kq = lane >> 4;
+    issue(0, 0);
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it + 1 < iters) issue(it + 1, (it + 1) & 1);
+        const bf16_t *S = lds + (it & 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8c ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + i * 16 + fr;
+                const int o = row * BK + (((ks * 4 + kq) ^ (row & 7)) * 8);
+                ah[i] = *reinterpret_cast<const bf16x8c *>(S + o);
+                al[i] = *reinterpret_cast<const bf16x8c *>(S + TILE + o);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wn * 64 + j * 16 + fr;
+                const int o = row * BK + (((ks * 4 + kq) ^ (row & 7)) * 8);
+                bh[j] = *reinterpret_cast<const bf16x8c *>(S + 2 * TILE + o);
+                bl[j] = *reinterpret_cast<const bf16x8c *>(S + 3 * TILE + o);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // small terms first, the dominant hi * hi last
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    __syncthreads();
+    constexpr int LDF = BN + 4;
+    float *O = reinterpret_cast<float *>(lds);   // [128][132] fp32 = 66 KiB of the 128 KiB
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = wn * 64 + j * 16 + fr;
+        const float bv = p.bias ? p.bias[n0 + col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v = acc[i][j][g] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                O[(wm * 64 + i * 16 + 4 * kq + g) * LDF + col] = v;
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = q * 8 + (tid >> 5), c4 = (tid & 31) * 4;
+        const long m = m0 + row;
+        if (m < p.M)
+            *reinterpret_cast<float4 *>(p.out + m * p.Co + n0 + c4) = *reinterpret_cast<const float4 *>(O + row * LDF + c4);
+    }
+}
+
 template <int WM, int WN, int STAGES, int BPC>
 int launch_conv(ConvParams &p, hipStream_t stream) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
@@ -290,5 +474,42 @@ extern "C" int pafc_conv3x3s2_c1_nhwc_bf16(int B, int T, int F, int C, const voi
     hipLaunchKernelGGL(pafc::conv3x3s2_c1_kernel, dim3((unsigned)nblk), dim3(256), 3 * F * sizeof(float), (hipStream_t)stream,
                        T, F, T1, F1, C, (const pafc::bf16_t *)x, (const pafc::bf16_t *)w_c_9, (const pafc::bf16_t *)bias,
                        (pafc::bf16_t *)out, relu);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+extern "C" int pafc_conv3x3s2_c1_nhwc_f32split(int B, int T, int F, int C, const float *x, const float *w_c_9,
+                                               const float *bias, void *out_hi, void *out_lo, int relu,
+                                               pafc_stream_t stream) {
+    if (!x || !w_c_9 || !out_hi || !out_lo) return PAFC_ERR_NULL_POINTER;
+    if (B <= 0 || T < 3 || F < 3 || C <= 0 || C % 8 || (256 % (C / 8)) || C > 2048) return PAFC_ERR_BAD_DIMS;
+    const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
+    const long nblk = (long)B * T1;
+    if (nblk > 0x7fffffffL) return PAFC_ERR_BAD_DIMS;
+    hipLaunchKernelGGL(pafc::conv3x3s2_c1_split_kernel, dim3((unsigned)nblk), dim3(256), 3 * F * sizeof(float),
+                       (hipStream_t)stream, T, F, T1, F1, C, x, w_c_9, bias, (pafc::bf16_t *)out_hi, (pafc::bf16_t *)out_lo, relu);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+extern "C" int pafc_conv3x3s2_nhwc_f32split(int B, int T1, int F1, int Ci, int Co, const void *in_hi, const void *in_lo,
+                                            const void *w_hi_tap_co_ci, const void *w_lo_tap_co_ci, const float *bias,
+                                            float *out, int relu, pafc_stream_t stream) {
+    if (!in_hi || !in_lo || !w_hi_tap_co_ci || !w_lo_tap_co_ci || !out) return PAFC_ERR_NULL_POINTER;
+    if (B <= 0 || T1 < 3 || F1 < 3 || Ci <= 0 || Co <= 0 || Ci % pafc::BK || Co % 128) return PAFC_ERR_BAD_DIMS;
+    pafc::ConvSplitParams p{};
+    p.in_hi = (const pafc::bf16_t *)in_hi; p.in_lo = (const pafc::bf16_t *)in_lo;
+    p.wt_hi = (const pafc::bf16_t *)w_hi_tap_co_ci; p.wt_lo = (const pafc::bf16_t *)w_lo_tap_co_ci;
+    p.bias = bias; p.out = out;
+    p.B = B; p.T1 = T1; p.F1 = F1; p.Ci = Ci; p.Co = Co;
+    p.T2 = (T1 - 3) / 2 + 1; p.F2 = (F1 - 3) / 2 + 1;
+    p.M = (long)B * p.T2 * p.F2;
+    p.relu = relu;
+    p.mtiles = (int)((p.M + 127) / 128);
+    p.ntiles = Co / 128;
+    const size_t lds = 2 * 4 * 128 * pafc::BK * sizeof(pafc::bf16_t);   // 128 KiB
+    if (hipFuncSetAttribute((const void *)pafc::conv3x3s2_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return PAFC_ERR_LAUNCH;
+    hipLaunchKernelGGL(pafc::conv3x3s2_split_kernel, dim3((unsigned)((long)p.mtiles * p.ntiles)), dim3(256), lds,
+                       (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }

@@ -359,3 +359,39 @@ class RnntBeamState:
         _lib.check(self.L.pafc_rnnt_beam_finish(self.B, self.T, self.beam, _lib.ptr(self.ws), self.nws, _lib.ptr(tokens),
                                                 _lib.ptr(lengths), _lib.ptr(scores), self.stream), "pafc_rnnt_beam_finish")
         return tokens, lengths, scores
+
+
+def split_bf16(t: torch.Tensor):
+    """fp32 tensor -> (hi, lo) bf16 planes with t ~= hi + lo (16 significant bits)."""
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    return hi.contiguous(), lo.contiguous()
+
+
+def conv_sub_f32split(x: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor], w2_hi: torch.Tensor,
+                      w2_lo: torch.Tensor, b2: Optional[torch.Tensor]) -> torch.Tensor:
+    """Both subsampling convolutions (+ ReLU) for fp32 activations on the bf16 matrix cores with split operands
+    (include/pafc_encoder_ops.h: pafc_conv3x3s2_*_f32split).  x (B, T, F) fp32; w1 (C, 1, 3, 3) fp32; w2_hi / w2_lo
+    (9, C, C) bf16 = split_bf16 of the second Conv2d weight in (tap, co, ci) order -> (B, T', F', C) fp32."""
+    _lib.require_gpu(x, w1, b1, w2_hi, w2_lo, b2)
+    if x.dtype != torch.float32 or w1.dtype != torch.float32 or w2_hi.dtype != torch.bfloat16 or x.dim() != 3:
+        raise _lib.PafcError("conv_sub_f32split: fp32 x (B, T, F) / w1, bf16 split planes for w2")
+    L = _bind()
+    if not getattr(L, "_pafc_split_bound", False):
+        P, I = c_void_p, c_int
+        _lib._sig(L.pafc_conv3x3s2_c1_nhwc_f32split, I, I, I, I, I, P, P, P, P, P, I, P)
+        _lib._sig(L.pafc_conv3x3s2_nhwc_f32split, I, I, I, I, I, I, P, P, P, P, P, P, I, P)
+        L._pafc_split_bound = True
+    B, T, Fd = x.shape
+    C = w1.shape[0]
+    T1, F1 = (T - 3) // 2 + 1, (Fd - 3) // 2 + 1
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    hi = torch.empty((B, T1, F1, C), dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty_like(hi)
+    st = _lib.stream_of(x)
+    _lib.check(L.pafc_conv3x3s2_c1_nhwc_f32split(B, T, Fd, C, _lib.ptr(x), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(hi),
+                                                 _lib.ptr(lo), 1, st), "pafc_conv3x3s2_c1_nhwc_f32split")
+    out = torch.empty((B, T2, F2, C), dtype=torch.float32, device=x.device)
+    _lib.check(L.pafc_conv3x3s2_nhwc_f32split(B, T1, F1, C, C, _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(w2_hi), _lib.ptr(w2_lo),
+                                              _lib.ptr(b2), _lib.ptr(out), 1, st), "pafc_conv3x3s2_nhwc_f32split")
+    return out

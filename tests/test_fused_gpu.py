@@ -229,3 +229,27 @@ def test_conv3x3s2_c1_nhwc(hip, B, T, Fd, C):
     got = conv3x3s2_c1_nhwc(x.cuda(), w.cuda(), None, relu=False)
     want = F.conv2d(x.float().unsqueeze(1), w.float(), None, stride=2).permute(0, 2, 3, 1)
     torch.testing.assert_close(got.cpu().float(), want, rtol=2 ** -7, atol=1e-2)
+
+
+@pytest.mark.parametrize("B,T,Fd,C", [(1, 35, 80, 128), (2, 131, 80, 256), (1, 403, 40, 512)])
+def test_conv_sub_f32split_matches_fp32_convolutions(hip, B, T, Fd, C):
+    """fp32 activations through the bf16 matrix cores with hi + lo split operands: both subsampling convolutions vs
+    F.conv2d in fp32 (float64 reference), error ~1e-5 relative -- two orders inside the 1e-3 parity bar."""
+    from paper_accurate_fast_cheap_amd.hip_ops import conv_sub_f32split, split_bf16
+    x = synth.randn((B, T, Fd), 1, 2.0)
+    w1 = synth.randn((C, 1, 3, 3), 2, 0.3)
+    b1 = synth.randn((C,), 3, 0.2)
+    w2 = synth.randn((C, C, 3, 3), 4, 0.02)
+    b2 = synth.randn((C,), 5, 0.2)
+    y1 = F.relu(F.conv2d(x.double().unsqueeze(1), w1.double(), b1.double(), stride=2))
+    want = F.relu(F.conv2d(y1, w2.double(), b2.double(), stride=2)).permute(0, 2, 3, 1).float()
+    taps = w2.permute(2, 3, 0, 1).reshape(9, C, C).contiguous().cuda()
+    hi, lo = split_bf16(taps)
+    got = conv_sub_f32split(x.cuda(), w1.cuda(), b1.cuda(), hi, lo, b2.cuda()).cpu()
+    assert got.shape == want.shape and got.dtype == torch.float32
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-4 * scale, float((got - want).abs().max()) / scale
+    # and the fp32 framework convolution itself is not closer to float64 by more than an order of magnitude
+    fw = F.relu(F.conv2d(F.relu(F.conv2d(x.cuda().unsqueeze(1), w1.cuda(), b1.cuda(), stride=2)), w2.cuda(), b2.cuda(),
+                         stride=2)).permute(0, 2, 3, 1).cpu()
+    assert float((got - want).abs().max()) <= 30 * max(float((fw - want).abs().max()), 1e-7 * scale)
