@@ -30,12 +30,17 @@ class LayerPlan:
     def __init__(self, layer: nn.Module):
         self.layer = layer
         slot = layer.self_attn
+        # the slot is either the RWKV time-mix (fused here too) or any other registry slot with the MHA-shaped forward
+        # (Mamba-2): then only the rest of the layer is re-scheduled and the slot module is called as is
+        self.rwkv = type(slot) in (RWKV_TmixWrapper, RWKV_TmixWrapper_bidirectional)
         if isinstance(slot, RWKV_TmixWrapper_bidirectional):
             self.blocks = [slot.rwkv_wrapper_forward.tmix_block, slot.rwkv_wrapper_backward.tmix_block]
-        else:
+        elif self.rwkv:
             self.blocks = [slot.tmix_block]
+        else:
+            self.blocks = []
         self.ndir = len(self.blocks)
-        self.slot_bf16 = bool(slot.do_bfloat16)
+        self.slot_bf16 = bool(getattr(slot, "do_bfloat16", False))
         self._stamp = None
         self.refresh()
 
@@ -52,24 +57,8 @@ class LayerPlan:
             return
         bl = self.blocks
         with torch.no_grad():
-            self.maa_x = [b.time_maa_x.reshape(-1).contiguous() for b in bl]
-            self.W1 = torch.stack([b.time_maa_rkvw_w1 for b in bl]).contiguous()           # (nd, C, 128)
-            self.W1n = torch.stack([b.time_maa_rkvw_w1.t() for b in bl]).contiguous()      # (nd, 128, C): Linear layout
-            self.D1n = torch.stack([b.time_decay_w1.t() for b in bl]).contiguous()         # (nd, 64, C)
-            self.W2 = [b.time_maa_rkvw_w2.contiguous() for b in bl]                        # (4, 32, C) each
-            self.W2t = torch.stack([b.time_maa_rkvw_w2.transpose(1, 2) for b in bl]).contiguous()  # (nd, 4, C, 32)
-            self.maa4 = torch.stack([torch.stack([b.time_maa_r.reshape(-1), b.time_maa_k.reshape(-1),
-                                                  b.time_maa_v.reshape(-1), b.time_maa_w.reshape(-1)])
-                                     for b in bl]).contiguous()                             # (nd, 4, C)
-            # q-major, direction-minor: [r_0, r_1, k_0, k_1, v_0, v_1], each W^T (C_in, C_out)
-            self.Wrkv = torch.stack([getattr(b, n).weight.t() for n in ("receptance", "key", "value") for b in bl]
-                                    ).contiguous()
-            self.D1 = torch.stack([b.time_decay_w1 for b in bl]).contiguous()              # (nd, C, 64)
-            self.D2 = torch.stack([b.time_decay_w2 for b in bl]).contiguous()              # (nd, 64, C)
-            self.time_decay = torch.stack([b.time_decay.reshape(1, -1) for b in bl]).contiguous()  # (nd, 1, C)
-            self.u = [b.time_faaaa.contiguous() for b in bl]
-            wo = torch.cat([b.output.weight for b in bl], dim=1)                           # (C, nd*C)
-            self.Wo = (wo * 0.5 if self.ndir == 2 else wo).contiguous()                    # /2 is exact in bf16
+            if self.rwkv:
+                self._refresh_rwkv(bl)
             # biases of the two FFN output projections, pre-multiplied by ff_scale: the residual-fused GEMM computes
             # x + ff_scale * (h W2^T) + (ff_scale * b2)
             L = self.layer
@@ -84,10 +73,31 @@ class LayerPlan:
                                 hip_ops.glu_interleave(pw1.bias) if pw1.bias is not None else None)
         self._stamp = stamp
 
+    def _refresh_rwkv(self, bl):
+        self.maa_x = [b.time_maa_x.reshape(-1).contiguous() for b in bl]
+        self.W1 = torch.stack([b.time_maa_rkvw_w1 for b in bl]).contiguous()           # (nd, C, 128)
+        self.W1n = torch.stack([b.time_maa_rkvw_w1.t() for b in bl]).contiguous()      # (nd, 128, C): Linear layout
+        self.D1n = torch.stack([b.time_decay_w1.t() for b in bl]).contiguous()         # (nd, 64, C)
+        self.W2 = [b.time_maa_rkvw_w2.contiguous() for b in bl]                        # (4, 32, C) each
+        self.W2t = torch.stack([b.time_maa_rkvw_w2.transpose(1, 2) for b in bl]).contiguous()  # (nd, 4, C, 32)
+        self.maa4 = torch.stack([torch.stack([b.time_maa_r.reshape(-1), b.time_maa_k.reshape(-1),
+                                              b.time_maa_v.reshape(-1), b.time_maa_w.reshape(-1)])
+                                 for b in bl]).contiguous()                             # (nd, 4, C)
+        # q-major, direction-minor: [r_0, r_1, k_0, k_1, v_0, v_1], each W^T (C_in, C_out)
+        self.Wrkv = torch.stack([getattr(b, n).weight.t() for n in ("receptance", "key", "value") for b in bl]
+                                ).contiguous()
+        self.D1 = torch.stack([b.time_decay_w1 for b in bl]).contiguous()              # (nd, C, 64)
+        self.D2 = torch.stack([b.time_decay_w2 for b in bl]).contiguous()              # (nd, 64, C)
+        self.time_decay = torch.stack([b.time_decay.reshape(1, -1) for b in bl]).contiguous()  # (nd, 1, C)
+        self.u = [b.time_faaaa.contiguous() for b in bl]
+        wo = torch.cat([b.output.weight for b in bl], dim=1)                           # (C, nd*C)
+        self.Wo = (wo * 0.5 if self.ndir == 2 else wo).contiguous()                    # /2 is exact in bf16
+
 
 def eligible(layer: nn.Module) -> bool:
+    from .mamba2 import MambaAttWrapper
     slot = layer.self_attn
-    if type(slot) not in (RWKV_TmixWrapper, RWKV_TmixWrapper_bidirectional):
+    if type(slot) not in (RWKV_TmixWrapper, RWKV_TmixWrapper_bidirectional, MambaAttWrapper):
         return False
     cm = layer.conv_module
     return (layer.normalize_before and layer.feed_forward_macaron is not None and cm is not None
@@ -163,7 +173,12 @@ def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optio
     # later ones update the layer-private stream in place.
     x = _ffn_residual(L.feed_forward_macaron, h, x, L.ff_scale, plan.b2_macaron, inplace=False)
     _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_mha.weight, L.norm_mha.bias, out_dtype=slot_dtype, want_x=False)
-    if slot_dtype == x.dtype:
+    if not plan.rwkv:
+        # another slot from the registry (Mamba-2): the module as is; the rest of the layer stays re-scheduled
+        att = L.self_attn(h, h, h)[0]
+        x, h, _ = hip_ops.add_layernorm(x, att.to(x.dtype).contiguous(), 1.0, L.norm_conv.weight, L.norm_conv.bias,
+                                        zero_rows=masked, lens=lens, T=T)
+    elif slot_dtype == x.dtype:
         x = slot_forward(plan, h, residual=x)
         _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_conv.weight, L.norm_conv.bias, zero_rows=masked, lens=lens,
                                         T=T, want_x=False)
