@@ -31,6 +31,13 @@ int pafc_dwconv1d_cl(int dtype, int B, int T_in, int C, int K, int left_pad, int
                      const void *w, const void *bias, void *y, int glu, const int32_t *lens,
                      pafc_stream_t stream);
 
+/* The same kernel with an explicit row stride of x (ldx elements between frames: the input may be a column slice of a
+ * wider activation, as xBC inside Mamba-2's in_proj output) and act: 0 none, 1 GLU on the input (x holds 2C columns),
+ * 2 SiLU on the output (Mamba-2's causal conv1d(k = 4) + SiLU: left_pad = K - 1, T_out = T_in).  K in {3, 4, 7, 15, 31}.
+ * Batch entries are T_in * ldx elements apart. */
+int pafc_dwconv1d_cl_ex(int dtype, int B, int T_in, int C, int K, int left_pad, int T_out, const void *x, long ldx,
+                        const void *w, const void *bias, void *y, int act, const int32_t *lens, pafc_stream_t stream);
+
 /* Residual add + LayerNorm (+ SiLU, + second LayerNorm, + padding masks) in one pass over (rows, C).
  *   x_new = x + alpha * y            (y == NULL: x_new = x; mask_y: rows with t >= lens[b] of y count as zero)
  *   out1  = LN(x_new; gamma1, beta1) (silu1: SiLU on top; zero1: rows with t >= lens[b] are written as zero)
@@ -104,6 +111,20 @@ size_t pafc_linear_act_workspace_bytes(void);
 int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, const void *weight, const void *bias,
                          void *out, int act, float alpha, const void *residual, void *workspace, size_t workspace_bytes,
                          pafc_stream_t stream);
+
+/* Glue of the Mamba-2 block around the chunked scan (restated from the published block -- the reference only wraps the
+ * third-party mamba_ssm Mamba2: mamba_att_wrapper.py:24-35, mamba2_bidirectional.py:12-36; PARITY UNPINNED; headdim 64,
+ * d_state 128, ngroups 1).  xbc: (B, L, d_inner + 256) = [x | B | C] after conv1d + SiLU; dt_raw: the dt columns of
+ * in_proj's output (rows ld_dt apart); z: its gate columns (rows ld_z apart); dt_bias, A_log, D: (d_inner / 64) fp32.
+ * prep -> the fp32 operand planes (B, L, d_inner) of the two scans: r0, r1 = C halves, k0, k1 = a_{t+1} * B halves,
+ * v = dt * x, w = log(-log a_{t+1}) with dt = softplus(dt_raw + dt_bias), a = exp(dt * -exp(A_log)).
+ * finish: out = RMSNorm((y0 + y1 + ((B . C) dt + D) x) * SiLU(z)) * norm_weight, roundings as the module's ops. */
+int pafc_mamba2_prep(int dtype, int B, int L, int d_inner, const void *xbc, const void *dt_raw, long ld_dt,
+                     const float *dt_bias, const float *A_log, float *r0, float *r1, float *k0, float *k1, float *v,
+                     float *w, pafc_stream_t stream);
+int pafc_mamba2_finish(int dtype, int B, int L, int d_inner, const float *y0, const float *y1, const void *xbc,
+                       const void *dt_raw, long ld_dt, const void *z, long ld_z, const float *dt_bias, const float *D,
+                       const void *norm_weight, float eps, void *out, pafc_stream_t stream);
 
 /* Hand-written bf16 GEMM with fused epilogue (csrc/gemm_bf16.hip), batched:
  *   out[z][m][n] = act(alpha * sum_k A[z][m][k] * W[z][n][k] + bias[z][n] + residual[z][m][n]),   z < batch

@@ -34,15 +34,17 @@ template <> struct Pair<bf16_t> {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
-template <typename ET, int K, bool GLU>
+// ACT: 0 plain, 1 GLU on the input (x is (.., 2C)), 2 SiLU on the output (Mamba-2's conv1d + SiLU)
+template <typename ET, int K, int ACT>
 __global__ __launch_bounds__(256) void dwconv_kernel(int T_in, int C, int left_pad, int T_out, const ET *__restrict__ x,
-                                                     const ET *__restrict__ w, const ET *__restrict__ bias,
+                                                     long ldx, const ET *__restrict__ w, const ET *__restrict__ bias,
                                                      ET *__restrict__ y, const int32_t *__restrict__ lens) {
+    constexpr bool GLU = ACT == 1;
     const int c = (blockIdx.y * 256 + threadIdx.x) * 2;
     if (c >= C) return;
     const int b = blockIdx.z;
     const int t0 = blockIdx.x * TO;
-    const int xc = GLU ? 2 * C : C;  // row stride of x in elements
+    const long xc = ldx;             // row stride of x in elements (2C for GLU, C, or a wider row the input is a slice of)
     const ET *xb = x + (size_t)b * T_in * xc;
     const int valid = lens ? min(T_in, lens[b]) : T_in;
 
@@ -91,31 +93,41 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int T_in, int C, int left_p
     }
     ET *yb = y + (size_t)b * T_out * C + c;
 #pragma unroll
-    for (int o = 0; o < TO; ++o)
+    for (int o = 0; o < TO; ++o) {
+        if (ACT == 2) {   // SiLU of the rounded convolution output, as the framework's two ops compute it
+            const float u0 = Pair<ET>::round(a0[o]), u1 = Pair<ET>::round(a1[o]);
+            a0[o] = u0 * sigmoidf_(u0);
+            a1[o] = u1 * sigmoidf_(u1);
+        }
         if (t0 + o < T_out) Pair<ET>::store(yb + (size_t)(t0 + o) * C, make_float2(a0[o], a1[o]));
+    }
 }
 
 template <typename ET, int K>
-int launch(int B, int T_in, int C, int left_pad, int T_out, const void *x, const void *w, const void *bias, void *y,
-           int glu, const int32_t *lens, hipStream_t s) {
+int launch(int B, int T_in, int C, int left_pad, int T_out, const void *x, long ldx, const void *w, const void *bias,
+           void *y, int act, const int32_t *lens, hipStream_t s) {
     dim3 grid((T_out + TO - 1) / TO, (C / 2 + 255) / 256, B), block(256);
-    if (glu)
-        hipLaunchKernelGGL((dwconv_kernel<ET, K, true>), grid, block, 0, s, T_in, C, left_pad, T_out, (const ET *)x,
+    if (act == 1)
+        hipLaunchKernelGGL((dwconv_kernel<ET, K, 1>), grid, block, 0, s, T_in, C, left_pad, T_out, (const ET *)x, ldx,
+                           (const ET *)w, (const ET *)bias, (ET *)y, lens);
+    else if (act == 2)
+        hipLaunchKernelGGL((dwconv_kernel<ET, K, 2>), grid, block, 0, s, T_in, C, left_pad, T_out, (const ET *)x, ldx,
                            (const ET *)w, (const ET *)bias, (ET *)y, lens);
     else
-        hipLaunchKernelGGL((dwconv_kernel<ET, K, false>), grid, block, 0, s, T_in, C, left_pad, T_out, (const ET *)x,
+        hipLaunchKernelGGL((dwconv_kernel<ET, K, 0>), grid, block, 0, s, T_in, C, left_pad, T_out, (const ET *)x, ldx,
                            (const ET *)w, (const ET *)bias, (ET *)y, lens);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 
 template <typename ET>
-int dispatch_k(int K, int B, int T_in, int C, int left_pad, int T_out, const void *x, const void *w, const void *bias,
-               void *y, int glu, const int32_t *lens, hipStream_t s) {
+int dispatch_k(int K, int B, int T_in, int C, int left_pad, int T_out, const void *x, long ldx, const void *w,
+               const void *bias, void *y, int act, const int32_t *lens, hipStream_t s) {
     switch (K) {
-        case 31: return launch<ET, 31>(B, T_in, C, left_pad, T_out, x, w, bias, y, glu, lens, s);
-        case 15: return launch<ET, 15>(B, T_in, C, left_pad, T_out, x, w, bias, y, glu, lens, s);
-        case 7: return launch<ET, 7>(B, T_in, C, left_pad, T_out, x, w, bias, y, glu, lens, s);
-        case 3: return launch<ET, 3>(B, T_in, C, left_pad, T_out, x, w, bias, y, glu, lens, s);
+        case 31: return launch<ET, 31>(B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
+        case 15: return launch<ET, 15>(B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
+        case 7: return launch<ET, 7>(B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
+        case 4: return launch<ET, 4>(B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
+        case 3: return launch<ET, 3>(B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
         default: return PAFC_ERR_UNSUPPORTED;
     }
 }
@@ -130,9 +142,20 @@ extern "C" int pafc_dwconv1d_cl(int dtype, int B, int T_in, int C, int K, int le
     if (B <= 0 || T_in <= 0 || T_out <= 0 || C <= 0 || (C % 2) || K <= 0 || K > pafc::KMAX || left_pad < 0 ||
         B > 65535)
         return PAFC_ERR_BAD_DIMS;
+    return pafc_dwconv1d_cl_ex(dtype, B, T_in, C, K, left_pad, T_out, x, glu ? 2L * C : (long)C, w, bias, y, glu ? 1 : 0, lens,
+                               stream);
+}
+
+extern "C" int pafc_dwconv1d_cl_ex(int dtype, int B, int T_in, int C, int K, int left_pad, int T_out, const void *x, long ldx,
+                                   const void *w, const void *bias, void *y, int act, const int32_t *lens,
+                                   pafc_stream_t stream) {
+    if (!x || !w || !y) return PAFC_ERR_NULL_POINTER;
+    if (B <= 0 || T_in <= 0 || T_out <= 0 || C <= 0 || (C % 2) || K <= 0 || K > pafc::KMAX || left_pad < 0 ||
+        B > 65535 || act < 0 || act > 2 || ldx < (act == 1 ? 2L * C : (long)C) || (ldx % 2))
+        return PAFC_ERR_BAD_DIMS;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PAFC_BF16)
-        return pafc::dispatch_k<pafc::bf16_t>(K, B, T_in, C, left_pad, T_out, x, w, bias, y, glu, lens, s);
-    if (dtype == PAFC_F32) return pafc::dispatch_k<float>(K, B, T_in, C, left_pad, T_out, x, w, bias, y, glu, lens, s);
+        return pafc::dispatch_k<pafc::bf16_t>(K, B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
+    if (dtype == PAFC_F32) return pafc::dispatch_k<float>(K, B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
     return PAFC_ERR_DTYPE;
 }

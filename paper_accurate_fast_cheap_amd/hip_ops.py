@@ -395,3 +395,53 @@ def conv_sub_f32split(x: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tens
     _lib.check(L.pafc_conv3x3s2_nhwc_f32split(B, T1, F1, C, C, _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(w2_hi), _lib.ptr(w2_lo),
                                               _lib.ptr(b2), _lib.ptr(out), 1, st), "pafc_conv3x3s2_nhwc_f32split")
     return out
+
+
+def _bind_mamba():
+    L = _bind()
+    if not getattr(L, "_pafc_mamba_bound", False):
+        from ctypes import c_float, c_long
+        P, I, G = c_void_p, c_int, c_long
+        _lib._sig(L.pafc_dwconv1d_cl_ex, I, I, I, I, I, I, I, I, P, G, P, P, P, I, P, P)
+        _lib._sig(L.pafc_mamba2_prep, I, I, I, I, I, P, P, G, P, P, P, P, P, P, P, P, P)
+        _lib._sig(L.pafc_mamba2_finish, I, I, I, I, I, P, P, P, P, G, P, G, P, P, P, c_float, P, P)
+        L._pafc_mamba_bound = True
+    return L
+
+
+def causal_conv_silu_cl(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """SiLU(causal depthwise conv1d) in channels-last layout: x (B, L, C) -- may be a column slice of a wider tensor --
+    weight (C, 1, K) -> (B, L, C) contiguous (include/pafc_encoder_ops.h: pafc_dwconv1d_cl_ex, act 2)."""
+    _lib.require_gpu(weight, bias)
+    if not x.is_cuda or x.dim() != 3 or x.stride(2) != 1 or x.stride(0) != x.shape[1] * x.stride(1):
+        raise _lib.PafcError("causal_conv_silu_cl: (B, L, C) GPU tensor, unit stride in C, batch stride L * row stride")
+    B, Lq, C = x.shape
+    K = weight.shape[-1]
+    y = torch.empty((B, Lq, C), dtype=x.dtype, device=x.device)
+    rc = _bind_mamba().pafc_dwconv1d_cl_ex(_lib.dtype_code(x.dtype), B, Lq, C, K, K - 1, Lq, _lib.ptr(x), x.stride(1),
+                                           _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), 2, None, _lib.stream_of(x))
+    _lib.check(rc, "pafc_dwconv1d_cl_ex")
+    return y
+
+
+def mamba2_prep(xbc: torch.Tensor, dt_raw: torch.Tensor, dt_bias: torch.Tensor, A_log: torch.Tensor, d_inner: int):
+    """xbc (B, L, d_inner + 256) contiguous, dt_raw (B, L, H) slice -> [r0, r1, k0, k1, v, w] fp32 (B, L, d_inner)."""
+    _lib.require_gpu(xbc, dt_bias, A_log)
+    B, Lq, _ = xbc.shape
+    planes = [torch.empty((B, Lq, d_inner), dtype=torch.float32, device=xbc.device) for _ in range(6)]
+    rc = _bind_mamba().pafc_mamba2_prep(_lib.dtype_code(xbc.dtype), B, Lq, d_inner, _lib.ptr(xbc), _lib.ptr(dt_raw),
+                                        dt_raw.stride(1), _lib.ptr(dt_bias), _lib.ptr(A_log), *[_lib.ptr(t) for t in planes],
+                                        _lib.stream_of(xbc))
+    _lib.check(rc, "pafc_mamba2_prep")
+    return planes
+
+
+def mamba2_finish(y0, y1, xbc, dt_raw, z, dt_bias, D, norm_weight, eps: float, d_inner: int) -> torch.Tensor:
+    _lib.require_gpu(y0, y1, xbc, dt_bias, D, norm_weight)
+    B, Lq, _ = xbc.shape
+    out = torch.empty((B, Lq, d_inner), dtype=xbc.dtype, device=xbc.device)
+    rc = _bind_mamba().pafc_mamba2_finish(_lib.dtype_code(xbc.dtype), B, Lq, d_inner, _lib.ptr(y0), _lib.ptr(y1), _lib.ptr(xbc),
+                                          _lib.ptr(dt_raw), dt_raw.stride(1), _lib.ptr(z), z.stride(1), _lib.ptr(dt_bias),
+                                          _lib.ptr(D), _lib.ptr(norm_weight), float(eps), _lib.ptr(out), _lib.stream_of(xbc))
+    _lib.check(rc, "pafc_mamba2_finish")
+    return out

@@ -61,8 +61,31 @@ class Mamba2(nn.Module):
         self.D = nn.Parameter(torch.ones(self.nheads))
         self.norm = RMSNormGated(self.d_inner, eps=1e-5)
         self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias)
+        self.fused_inference = True    # GPU inference: glue kernels (False: the op-by-op restatement below)
+
+    def _forward_fused(self, u: torch.Tensor) -> torch.Tensor:
+        """Inference on the GPU: the same arithmetic with the glue in three kernels (conv1d + SiLU on the xBC slice of
+        in_proj's output; the six scan operand planes in one pass; residual terms + gate + RMSNorm in one pass) instead
+        of ~40 framework kernels and their (L, 1024) fp32 temporaries."""
+        from .. import hip_ops
+        zxbcdt = self.in_proj(u)                                                       # (B, L, 2 d_inner + 2 N + H)
+        di, N, H = self.d_inner, self.d_state, self.nheads
+        z = zxbcdt[..., :di]
+        dt_raw = zxbcdt[..., 2 * di + 2 * N:]
+        xbc = hip_ops.causal_conv_silu_cl(zxbcdt[..., di:2 * di + 2 * N], self.conv1d.weight, self.conv1d.bias)
+        r0, r1, k0, k1, v, w = hip_ops.mamba2_prep(xbc, dt_raw, self.dt_bias.float(), self.A_log.float(), di)
+        u0 = torch.zeros(H, 64, dtype=torch.float32, device=u.device)
+        y0 = wkv6_forward(r0, k0, v, w, u0)
+        y1 = wkv6_forward(r1, k1, v, w, u0)
+        y = hip_ops.mamba2_finish(y0, y1, xbc, dt_raw, z, self.dt_bias.float(), self.D.float(), self.norm.weight,
+                                  self.norm.eps, di)
+        return self.out_proj(y)
 
     def forward(self, u: torch.Tensor) -> torch.Tensor:
+        if (self.fused_inference and u.is_cuda and not torch.is_grad_enabled() and self.d_state == 128
+                and self.d_inner <= 1024 and u.dtype in (torch.float32, torch.bfloat16)
+                and self.conv1d.weight.dtype == u.dtype):
+            return self._forward_fused(u)
         Bsz, L, _ = u.shape
         H, P, N = self.nheads, self.headdim, self.d_state
         zxbcdt = self.in_proj(u)
