@@ -122,9 +122,21 @@ int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, cons
 int pafc_mamba2_prep(int dtype, int B, int L, int d_inner, const void *xbc, const void *dt_raw, long ld_dt,
                      const float *dt_bias, const float *A_log, float *r0, float *r1, float *k0, float *k1, float *v,
                      float *w, pafc_stream_t stream);
+/* y1 may be NULL; diag != 0 adds the (B . C) dt x term (needed when the scans ran on the WKV kernel, which leaves the
+ * s = t term out; pafc_mamba2_scan includes it). */
 int pafc_mamba2_finish(int dtype, int B, int L, int d_inner, const float *y0, const float *y1, const void *xbc,
                        const void *dt_raw, long ld_dt, const void *z, long ld_z, const float *dt_bias, const float *D,
-                       const void *norm_weight, float eps, void *out, pafc_stream_t stream);
+                       const void *norm_weight, float eps, int diag, void *out, pafc_stream_t stream);
+
+/* Mamba-2 selective scan (SSD), bf16 inputs, chunk-parallel on the matrix cores (csrc/mamba2_scan.hip; PARITY UNPINNED):
+ *   h_t = a_t h_{t-1} + dt_t B_t x_t^T,  y_t = C_t . h_t   per head (head dim 64, state dim 128, B / C shared by the heads)
+ * xbc: (B, L, ldx) bf16 rows [x (H * 64) | B (128) | C (128)] (conv1d + SiLU output); dt, log_a: (B, L, H) fp32 =
+ * softplus(dt_raw + dt_bias) and dt * A (<= 0); y: (B, L, H * 64) fp32 (without the D x skip term).  workspace:
+ * pafc_mamba2_scan_workspace_bytes() bytes (chunk states), chunk_len 0 = library heuristic. */
+int pafc_mamba2_scan_chunk_len(int B, int L, int H);
+size_t pafc_mamba2_scan_workspace_bytes(int B, int L, int H, int chunk_len);
+int pafc_mamba2_scan(int B, int L, int H, const void *xbc, long ldx, const float *dt, const float *log_a, float *y,
+                     int chunk_len, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
 
 /* Hand-written bf16 GEMM with fused epilogue (csrc/gemm_bf16.hip), batched:
  *   out[z][m][n] = act(alpha * sum_k A[z][m][k] * W[z][n][k] + bias[z][n] + residual[z][m][n]),   z < batch

@@ -69,7 +69,7 @@ template <typename ET>
 __global__ __launch_bounds__(256) void mamba2_finish_kernel(int L, int d_inner, const float *y0, const float *y1,
                                                             const ET *xbc, const ET *dt_raw, long ld_dt, const ET *z,
                                                             long ld_z, const float *dt_bias, const float *Dp,
-                                                            const ET *norm_w, float eps, ET *out) {
+                                                            const ET *norm_w, float eps, int diag, ET *out) {
     __shared__ float red[4];
     using E = Elem<ET>;
     const long row = blockIdx.x;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void mamba2_finish_kernel(int L, int d_inner, 
     const ET *xr = xbc + row * ldx;
     const ET *Bp = xr + d_inner, *Cp = Bp + 128;
     float bc = 0.f;
-    if (threadIdx.x < 128) bc = E::load(Bp + threadIdx.x) * E::load(Cp + threadIdx.x);
-    bc = block_sum(bc, red);                      // (B . C) over the 128 state dimensions
+    if (diag && threadIdx.x < 128) bc = E::load(Bp + threadIdx.x) * E::load(Cp + threadIdx.x);
+    bc = block_sum(bc, red);                      // (B . C) over the 128 state dimensions (0 when the scan had the s = t term)
     float g[4];                                   // gated values of this thread (d_inner <= 1024: one pass of 4 each)
     float ss = 0.f;
     const int idx = threadIdx.x * 4;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void mamba2_finish_kernel(int L, int d_inner, 
         const int h = idx >> 6;
         const float dt = softplus_(E::load(dt_raw + row * ld_dt + h) + dt_bias[h]);
         const float4 a = *reinterpret_cast<const float4 *>(y0 + row * d_inner + idx);
-        const float4 b = *reinterpret_cast<const float4 *>(y1 + row * d_inner + idx);
+        const float4 b = y1 ? *reinterpret_cast<const float4 *>(y1 + row * d_inner + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float ya[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -131,8 +131,9 @@ extern "C" int pafc_mamba2_prep(int dtype, int B, int L, int d_inner, const void
 
 extern "C" int pafc_mamba2_finish(int dtype, int B, int L, int d_inner, const float *y0, const float *y1, const void *xbc,
                                   const void *dt_raw, long ld_dt, const void *z, long ld_z, const float *dt_bias,
-                                  const float *D, const void *norm_weight, float eps, void *out, pafc_stream_t stream) {
-    if (!y0 || !y1 || !xbc || !dt_raw || !z || !dt_bias || !D || !norm_weight || !out) return PAFC_ERR_NULL_POINTER;
+                                  const float *D, const void *norm_weight, float eps, int diag, void *out,
+                                  pafc_stream_t stream) {
+    if (!y0 || !xbc || !dt_raw || !z || !dt_bias || !D || !norm_weight || !out) return PAFC_ERR_NULL_POINTER;
     if (B <= 0 || L <= 0 || d_inner <= 0 || d_inner % 64 || d_inner > 1024 || ld_dt < d_inner / 64 || ld_z < d_inner)
         return PAFC_ERR_BAD_DIMS;
     const long rows = (long)B * L;
@@ -141,11 +142,11 @@ extern "C" int pafc_mamba2_finish(int dtype, int B, int L, int d_inner, const fl
     if (dtype == PAFC_BF16)
         hipLaunchKernelGGL(pafc::mamba2_finish_kernel<pafc::bf16_t>, dim3((unsigned)rows), dim3(256), 0, s, L, d_inner, y0, y1,
                            (const pafc::bf16_t *)xbc, (const pafc::bf16_t *)dt_raw, ld_dt, (const pafc::bf16_t *)z, ld_z, dt_bias,
-                           D, (const pafc::bf16_t *)norm_weight, eps, (pafc::bf16_t *)out);
+                           D, (const pafc::bf16_t *)norm_weight, eps, diag, (pafc::bf16_t *)out);
     else if (dtype == PAFC_F32)
         hipLaunchKernelGGL(pafc::mamba2_finish_kernel<float>, dim3((unsigned)rows), dim3(256), 0, s, L, d_inner, y0, y1,
                            (const float *)xbc, (const float *)dt_raw, ld_dt, (const float *)z, ld_z, dt_bias, D,
-                           (const float *)norm_weight, eps, (float *)out);
+                           (const float *)norm_weight, eps, diag, (float *)out);
     else
         return PAFC_ERR_DTYPE;
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;

@@ -404,7 +404,10 @@ def _bind_mamba():
         P, I, G = c_void_p, c_int, c_long
         _lib._sig(L.pafc_dwconv1d_cl_ex, I, I, I, I, I, I, I, I, P, G, P, P, P, I, P, P)
         _lib._sig(L.pafc_mamba2_prep, I, I, I, I, I, P, P, G, P, P, P, P, P, P, P, P, P)
-        _lib._sig(L.pafc_mamba2_finish, I, I, I, I, I, P, P, P, P, G, P, G, P, P, P, c_float, P, P)
+        _lib._sig(L.pafc_mamba2_finish, I, I, I, I, I, P, P, P, P, G, P, G, P, P, P, c_float, I, P, P)
+        from ctypes import c_size_t
+        _lib._sig(L.pafc_mamba2_scan_workspace_bytes, c_size_t, I, I, I, I)
+        _lib._sig(L.pafc_mamba2_scan, I, I, I, I, P, G, P, P, P, I, P, c_size_t, P)
         L._pafc_mamba_bound = True
     return L
 
@@ -436,12 +439,31 @@ def mamba2_prep(xbc: torch.Tensor, dt_raw: torch.Tensor, dt_bias: torch.Tensor, 
     return planes
 
 
-def mamba2_finish(y0, y1, xbc, dt_raw, z, dt_bias, D, norm_weight, eps: float, d_inner: int) -> torch.Tensor:
+def mamba2_scan(xbc: torch.Tensor, dt: torch.Tensor, log_a: torch.Tensor, H: int) -> torch.Tensor:
+    """Mamba-2 selective scan on the dedicated SSD kernel: xbc (B, L, H*64 + 256) bf16 contiguous, dt / log_a (B, L, H)
+    fp32 -> y (B, L, H*64) fp32 (include/pafc_encoder_ops.h: pafc_mamba2_scan)."""
+    _lib.require_gpu(xbc, dt, log_a)
+    if xbc.dtype != torch.bfloat16 or dt.dtype != torch.float32 or log_a.dtype != torch.float32:
+        raise _lib.PafcError("mamba2_scan: bf16 xbc, fp32 dt / log_a")
+    B, Lq, ldx = xbc.shape
+    Lb = _bind_mamba()
+    nws = Lb.pafc_mamba2_scan_workspace_bytes(B, Lq, H, 0)
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=xbc.device)
+    y = torch.empty((B, Lq, H * 64), dtype=torch.float32, device=xbc.device)
+    rc = Lb.pafc_mamba2_scan(B, Lq, H, _lib.ptr(xbc), ldx, _lib.ptr(dt), _lib.ptr(log_a), _lib.ptr(y), 0,
+                             _lib.ptr(ws) if nws else None, nws, _lib.stream_of(xbc))
+    _lib.check(rc, "pafc_mamba2_scan")
+    return y
+
+
+def mamba2_finish(y0, y1, xbc, dt_raw, z, dt_bias, D, norm_weight, eps: float, d_inner: int, diag: bool = True
+                  ) -> torch.Tensor:
     _lib.require_gpu(y0, y1, xbc, dt_bias, D, norm_weight)
     B, Lq, _ = xbc.shape
     out = torch.empty((B, Lq, d_inner), dtype=xbc.dtype, device=xbc.device)
     rc = _bind_mamba().pafc_mamba2_finish(_lib.dtype_code(xbc.dtype), B, Lq, d_inner, _lib.ptr(y0), _lib.ptr(y1), _lib.ptr(xbc),
                                           _lib.ptr(dt_raw), dt_raw.stride(1), _lib.ptr(z), z.stride(1), _lib.ptr(dt_bias),
-                                          _lib.ptr(D), _lib.ptr(norm_weight), float(eps), _lib.ptr(out), _lib.stream_of(xbc))
+                                          _lib.ptr(D), _lib.ptr(norm_weight), float(eps), int(diag), _lib.ptr(out),
+                                          _lib.stream_of(xbc))
     _lib.check(rc, "pafc_mamba2_finish")
     return out

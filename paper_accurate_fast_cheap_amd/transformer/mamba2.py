@@ -62,6 +62,7 @@ class Mamba2(nn.Module):
         self.norm = RMSNormGated(self.d_inner, eps=1e-5)
         self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias)
         self.fused_inference = True    # GPU inference: glue kernels (False: the op-by-op restatement below)
+        self.ssd_kernel = True         # bf16: the dedicated SSD scan kernel (False: operand planes + the WKV-6 scan)
 
     def _forward_fused(self, u: torch.Tensor) -> torch.Tensor:
         """Inference on the GPU: the same arithmetic with the glue in three kernels (conv1d + SiLU on the xBC slice of
@@ -73,6 +74,14 @@ class Mamba2(nn.Module):
         z = zxbcdt[..., :di]
         dt_raw = zxbcdt[..., 2 * di + 2 * N:]
         xbc = hip_ops.causal_conv_silu_cl(zxbcdt[..., di:2 * di + 2 * N], self.conv1d.weight, self.conv1d.bias)
+        if u.dtype == torch.bfloat16 and self.ssd_kernel:
+            # dedicated SSD scan: scalar decay per head and step, B / C shared by the heads -- no operand planes at all
+            dt = F.softplus(dt_raw.float() + self.dt_bias.float()).contiguous()           # (B, L, H), tiny
+            log_a = (dt * (-torch.exp(self.A_log.float()))).contiguous()
+            y = hip_ops.mamba2_scan(xbc, dt, log_a, H)
+            y = hip_ops.mamba2_finish(y, None, xbc, dt_raw, z, self.dt_bias.float(), self.D.float(), self.norm.weight,
+                                      self.norm.eps, di, diag=False)
+            return self.out_proj(y)
         r0, r1, k0, k1, v, w = hip_ops.mamba2_prep(xbc, dt_raw, self.dt_bias.float(), self.A_log.float(), di)
         u0 = torch.zeros(H, 64, dtype=torch.float32, device=u.device)
         y0 = wkv6_forward(r0, k0, v, w, u0)
