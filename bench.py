@@ -240,6 +240,23 @@ def main():
     audio_s = total_frames / 100.0 * args.steps
     value = audio_s / elapsed
 
+    # achievable HBM bandwidth on this box: a 1 GiB device-to-device copy (bytes read + written per second), so that the
+    # scan's rate can be read against the measured ceiling as well as against the 8 TB/s specification
+    copy_gbs = None
+    if rank == 0:
+        a = torch.empty(1 << 30, dtype=torch.uint8, device=device)
+        bq = torch.empty_like(a)
+        for _ in range(3):
+            bq.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            bq.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = round(10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del a, bq
+
     rec = prof.get("wkv6_fwd_bidir") or prof.get("wkv6_fwd")
     roofline = None
     traffic = None   # HBM bytes per launch from rocprofv3 PMC passes of the same op and shape, when recorded
@@ -259,6 +276,8 @@ def main():
                     "frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "launches": rec["n"], "avg_launch_us": round(rec["avg_ms"] * 1e3, 1),
                     "algorithmic_bytes_per_launch": alg_bytes,
+                    "measured_copy_gbs": copy_gbs,
+                    "frac_of_measured_copy": round(alg_bytes / sec / 1e9 / copy_gbs, 4) if copy_gbs else None,
                     "valu_tflops": round(alg_flops / sec / 1e12, 2),
                     "valu_frac": round(alg_flops / sec / 1e12 / VALU_PEAK_TFLOPS, 4)}
 
