@@ -167,6 +167,49 @@ def test_encoder_matches_oracle_on_fresh_inputs(hip):
     _assert_close(out, ref, False, "fresh")
 
 
+def test_config_c1_full_size_fp32_vs_oracle(hip):
+    """BASELINE configs[0] shape on the GPU: 10 utterances (1-5 s here, to keep the CPU oracle to seconds), the FULL
+    12-layer 512-d bidirectional encoder in fp32 + CTC head: HIP path vs the CPU restatement within 1e-3 relative, masks
+    exact, CTC greedy token ids identical wherever the oracle's own top-2 margin exceeds the tolerance."""
+    import bench
+    from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    from paper_accurate_fast_cheap_amd.transformer.search import ctc_greedy_search
+    conf = dict(bench.encoder_conf(), rwkv_do_bfloat16=False)
+    torch.manual_seed(777)
+    enc = ConformerEncoder(80, **conf).eval()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.02)
+    ctc = CTC(200, 512).eval()
+    g = torch.Generator().manual_seed(31)
+    lens = torch.randint(100, 501, (10,), generator=g)
+    lens[0] = 500
+    xs = synth.randn((10, 500, 80), 902, 2.0)
+    sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    ref, ref_masks = EO.encoder_forward(xs, lens, sd, conf, env={})
+    ref_logp = EO.ctc_log_softmax(ref, {"ctc." + k: v for k, v in ctc.state_dict().items()})
+    ref_lens = ref_masks.squeeze(1).sum(1)
+    enc, ctc = enc.cuda(), ctc.cuda()
+    with torch.no_grad():
+        out, masks = enc(xs.cuda(), lens.cuda())
+        logp = ctc.log_softmax(out)
+        toks = [r.tokens for r in ctc_greedy_search(logp, masks.squeeze(1).sum(1), 0)]
+    assert torch.equal(masks.cpu(), ref_masks)
+    scale = float(ref.abs().max())
+    valid = ref_masks.squeeze(1).unsqueeze(-1)
+    err = ((out.cpu() - ref).abs() * valid).max()
+    assert float(err) <= 1e-3 * scale, (float(err), scale)
+    # tokens: frame-wise argmax must agree wherever the oracle's top-2 margin is not within the numerical noise
+    top2 = ref_logp.topk(2, dim=-1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-3
+    same = logp.argmax(-1).cpu() == ref_logp.argmax(-1)
+    assert bool((same | ~safe | ~ref_masks.squeeze(1)).all())
+    if bool((safe | ~ref_masks.squeeze(1)).all()):
+        assert toks == EO.ctc_greedy_search(ref_logp, ref_lens, 0)
+
+
 def test_cpu_tensors_fail_loudly(hip):
     from paper_accurate_fast_cheap_amd import _lib
     from paper_accurate_fast_cheap_amd.utils.class_utils import WENET_ATTENTION_CLASSES
