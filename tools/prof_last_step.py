@@ -15,7 +15,8 @@ def main():
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ends = [r for r in rows if "SoftMaxForward" in r["Kernel_Name"] or "log_softmax_kernel" in r["Kernel_Name"]]
     t0 = int(ends[-2]["End_Timestamp"]) if len(ends) >= 2 else 0
-    last = [r for r in rows if int(r["Start_Timestamp"]) > t0]
+    t1 = int(ends[-1]["End_Timestamp"]) if ends else int(rows[-1]["End_Timestamp"])
+    last = [r for r in rows if t0 < int(r["Start_Timestamp"]) and int(r["End_Timestamp"]) <= t1]
     agg = collections.defaultdict(lambda: [0, 0])
     for r in last:
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
