@@ -61,3 +61,43 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "SO_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.PafcError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_argument_validation_returns_error_codes_without_a_gpu(so_path):
+    """Every entry point validates pointers and dimensions before it touches the device and reports a negative
+    PAFC_ERR_* (the reference's op asserts or faults instead): callable here, on a box without a GPU."""
+    L = ctypes.CDLL(so_path)
+    P, I, G, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+    NULL = P(0)
+    ERR_NULL, ERR_DIMS, ERR_UNSUP = -1, -2, -7
+    one = P(16)      # a non-null, 16-byte aligned address that is never dereferenced (validation fails first)
+    L.pafc_gemm_bf16.argtypes = [G, I, I, I, P, G, G, P, G, G, P, G, P, G, G, P, G, G, F, I, P]
+    assert L.pafc_gemm_bf16(8, 8, 64, 1, NULL, 64, 0, one, 64, 0, NULL, 0, NULL, 0, 0, one, 8, 0, 1.0, 0, NULL) == ERR_NULL
+    assert L.pafc_gemm_bf16(0, 8, 64, 1, one, 64, 0, one, 64, 0, NULL, 0, NULL, 0, 0, one, 8, 0, 1.0, 0, NULL) == ERR_DIMS
+    assert L.pafc_gemm_bf16(8, 8, 48, 1, one, 48, 0, one, 48, 0, NULL, 0, NULL, 0, 0, one, 8, 0, 1.0, 0, NULL) == ERR_UNSUP
+    assert L.pafc_gemm_bf16(8, 8, 64, 1, one, 64, 0, one, 64, 0, NULL, 0, NULL, 0, 0, one, 8, 0, 1.0, 9, NULL) == ERR_UNSUP
+    L.pafc_conv3x3s2_nhwc_bf16.argtypes = [I, I, I, I, I, P, P, P, P, I, P]
+    assert L.pafc_conv3x3s2_nhwc_bf16(1, 9, 9, 64, 128, NULL, one, NULL, one, 1, NULL) == ERR_NULL
+    assert L.pafc_conv3x3s2_nhwc_bf16(1, 2, 9, 64, 128, one, one, NULL, one, 1, NULL) == ERR_DIMS
+    assert L.pafc_conv3x3s2_nhwc_bf16(1, 9, 9, 60, 128, one, one, NULL, one, 1, NULL) == ERR_DIMS
+    L.pafc_ctc_greedy.argtypes = [I, I, I, I, P, P, I, P, P, P, P, P]
+    assert L.pafc_ctc_greedy(1, 2, 4, 5, NULL, NULL, 0, one, one, one, NULL, NULL) == ERR_NULL
+    assert L.pafc_ctc_greedy(1, 2, 4, 5, one, NULL, 7, one, one, one, NULL, NULL) == ERR_DIMS     # blank >= V
+    assert L.pafc_ctc_greedy(5, 2, 4, 5, one, NULL, 0, one, one, one, NULL, NULL) == -6           # dtype
+    L.pafc_ctc_prefix_beam_search.argtypes = [I, I, I, P, P, P, I, I, P, P, P, P, ctypes.c_size_t, P]
+    assert L.pafc_ctc_prefix_beam_search(1, 4, 17, one, one, NULL, 8, 0, one, one, one, one, 1 << 20, NULL) == ERR_UNSUP
+    assert L.pafc_ctc_prefix_beam_search(1, 4, 8, one, one, NULL, 8, 0, one, one, one, one, 8, NULL) == -4  # workspace
+    L.pafc_mamba2_scan.argtypes = [I, I, I, P, G, P, P, P, I, P, ctypes.c_size_t, P]
+    assert L.pafc_mamba2_scan(1, 64, 4, NULL, 512, one, one, one, 0, NULL, 0, NULL) == ERR_NULL
+    assert L.pafc_mamba2_scan(1, 64, 4, one, 100, one, one, one, 0, NULL, 0, NULL) == ERR_DIMS     # row too short
+    L.pafc_mamba2_scan_workspace_bytes.restype = ctypes.c_size_t
+    assert L.pafc_mamba2_scan_workspace_bytes(1, 64, 4, 0) == 0                                     # short: one chunk
+    assert L.pafc_mamba2_scan_workspace_bytes(1, 44998, 16, 0) > 0
+    L.pafc_rnnt_beam_workspace_bytes.restype = ctypes.c_size_t
+    assert L.pafc_rnnt_beam_workspace_bytes(8, 250, 8) > 0 and L.pafc_rnnt_beam_workspace_bytes(0, 250, 8) == 0
+    L.pafc_log_softmax_rows.argtypes = [I, G, I, P, P, P]
+    assert L.pafc_log_softmax_rows(1, 0, 5, one, one, NULL) == ERR_DIMS
+    L.pafc_wkv6_forward_bf16.argtypes = [I, I, I, I, P, P, P, P, P, P, I, P, ctypes.c_size_t, P]
+    assert L.pafc_wkv6_forward_bf16(1, 8, 128, 2, one, one, one, one, one, NULL, 0, NULL, 0, NULL) == ERR_NULL
+    assert L.pafc_wkv6_forward_bf16(1, 8, 100, 2, one, one, one, one, one, one, 0, NULL, 0, NULL) == -3    # head size
+    assert L.pafc_wkv6_forward_bf16(1, 8, 128, 2, P(8), one, one, one, one, one, 0, NULL, 0, NULL) == -8   # alignment
