@@ -155,3 +155,18 @@ def test_gpu_prefix_beam_search_edge_cases(hip):
     assert list(ctc_prefix_beam_search(allblank.cuda(), torch.tensor([5]).cuda(), 2)[0].tokens) == []
     with pytest.raises(PafcError):   # beam beyond the kernel's limit is refused, not truncated
         ctc_prefix_beam(torch.zeros(1, 2, 17, device="cuda"), torch.zeros(1, 2, 17, dtype=torch.int64, device="cuda"), None, 17)
+
+
+def test_end_to_end_decode_example(hip, capsys):
+    """tools/decode_example.py: waveform -> HIP fbank -> encoder -> CTC search on the device -> tokenizer -> WER report,
+    for both CTC decode modes (random weights: the chain and its interfaces are what is checked)."""
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "decode_example.py")
+    spec = importlib.util.spec_from_file_location("decode_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for mode in ("ctc_greedy_search", "ctc_prefix_beam_search"):
+        res = mod.main(["--mode", mode, "--beam_size", "4"])
+        out = capsys.readouterr().out
+        assert len(res) == 3 and all(isinstance(t, int) for r in res for t in r.tokens)
+        assert out.count("utt") == 3 and "Overall ->" in out and "N=" in out
