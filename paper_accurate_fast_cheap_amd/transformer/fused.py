@@ -101,7 +101,7 @@ def eligible(layer: nn.Module) -> bool:
         return False
     cm = layer.conv_module
     return (layer.normalize_before and layer.feed_forward_macaron is not None and cm is not None
-            and cm.use_layer_norm and cm.lorder == 0 and isinstance(cm.activation, nn.SiLU)
+            and cm.use_layer_norm and isinstance(cm.activation, nn.SiLU)
             and isinstance(layer.feed_forward.activation, nn.SiLU)
             and isinstance(layer.feed_forward_macaron.activation, nn.SiLU) and cm.kernel_size in (3, 7, 15, 31)
             and layer.size % 8 == 0 and layer.size <= 1024)
@@ -185,14 +185,19 @@ def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optio
     else:
         att = slot_forward(plan, h).to(x.dtype)
         x, h, _ = hip_ops.add_layernorm(x, att, 1.0, L.norm_conv.weight, L.norm_conv.bias, zero_rows=masked, lens=lens, T=T)
+    left_pad, Tc = (cm.kernel_size - 1) // 2, T
+    if cm.lorder > 0:
+        # causal module: the reference zero-pads lorder frames BEFORE pointwise_conv1 (convolution.py:112-118), so the
+        # left context the depthwise convolution sees is GLU(bias), not zero -- prepend the zero frames here as well
+        h = torch.cat([h.new_zeros(B, cm.lorder, C), h], dim=1)
+        left_pad, Tc = 0, T + cm.lorder
     if plan.pw1_glu is not None and h.dtype == torch.bfloat16:
         # F.glu rides on pointwise_conv1 (half the write, and the depthwise kernel no longer recomputes sigmoids)
-        p = hip_ops.gemm_bf16(h.view(B * T, C), plan.pw1_glu[0], plan.pw1_glu[1], act="glu").view(B, T, C)
-        dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, (cm.kernel_size - 1) // 2, T)
+        p = hip_ops.gemm_bf16(h.view(B * Tc, C), plan.pw1_glu[0], plan.pw1_glu[1], act="glu").view(B, Tc, C)
+        dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, left_pad, T)
     else:
         p = F.linear(h, cm.pointwise_conv1.weight.squeeze(-1), cm.pointwise_conv1.bias)
-        dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, (cm.kernel_size - 1) // 2, T,
-                                         glu=True)
+        dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, left_pad, T, glu=True)
     _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
     if not masked:
         x = hip_ops.linear_bias_act(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none",
