@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void ctc_prefix_beam_kernel(const BeamParams p)
     __shared__ int s_order[NSLOT], s_node[NSLOT], s_tok[NSLOT], s_par[NSLOT];
     __shared__ int tok[MAXB];
     __shared__ double lp[MAXB];
-    __shared__ int n_s[MAXB], n_node[MAXB], n_last[MAXB], n_parent[MAXB];   // next beam staging (n_s unused: keeps layout simple)
+    __shared__ int n_node[MAXB], n_last[MAXB], n_parent[MAXB];              // next beam staging
     __shared__ double n_bs[MAXB], n_bns[MAXB], n_bsc[MAXB];
     __shared__ int s_nb;
 
@@ -175,7 +175,6 @@ __global__ __launch_bounds__(64) void ctc_prefix_beam_kernel(const BeamParams p)
             p.out_score[b * beam + lane] = NEG_INF;
         }
     }
-    (void)n_s;
 }
 
 }  // namespace
