@@ -69,7 +69,8 @@ class Mamba2(nn.Module):
         in_proj's output; the six scan operand planes in one pass; residual terms + gate + RMSNorm in one pass) instead
         of ~40 framework kernels and their (L, 1024) fp32 temporaries."""
         from .. import hip_ops
-        zxbcdt = self.in_proj(u)                                                       # (B, L, 2 d_inner + 2 N + H)
+        lin = lambda t, m: hip_ops.linear_bias_act(t.contiguous(), m.weight, m.bias, "none")   # library GEMM, measured pick
+        zxbcdt = lin(u, self.in_proj)                                                  # (B, L, 2 d_inner + 2 N + H)
         di, N, H = self.d_inner, self.d_state, self.nheads
         z = zxbcdt[..., :di]
         dt_raw = zxbcdt[..., 2 * di + 2 * N:]
@@ -81,7 +82,7 @@ class Mamba2(nn.Module):
             y = hip_ops.mamba2_scan(xbc, dt, log_a, H)
             y = hip_ops.mamba2_finish(y, None, xbc, dt_raw, z, self.dt_bias.float(), self.D.float(), self.norm.weight,
                                       self.norm.eps, di, diag=False)
-            return self.out_proj(y)
+            return lin(y, self.out_proj)
         r0, r1, k0, k1, v, w = hip_ops.mamba2_prep(xbc, dt_raw, self.dt_bias.float(), self.A_log.float(), di)
         u0 = torch.zeros(H, 64, dtype=torch.float32, device=u.device)
         y0 = wkv6_forward(r0, k0, v, w, u0)
