@@ -1,0 +1,75 @@
+"""Long-form decoding by fixed-size windows (reference: wenet/bin/recognize_wav2.py:323-351 `feats_batcher`, the decode
+loop :431-470, and the window time shift of `hyps_to_ctm` :523-548): a long file is cut into windows of `chunk_size`
+input frames, `batch_size` windows form one batch, the last window is zero-padded and its length shortened; the
+hypotheses of the windows are concatenated in order and every window starts `chunk_size * frame_shift` later than the
+previous one.  This is how the bidirectional encoder runs on audio of arbitrary length without any state carry (the
+uni-directional one can stream instead: encoder.forward_chunk_carry / stream_chunks).
+
+The word-level CTM of the reference additionally needs `wenet/bin/ctc_align.py` (`ctc_align`,
+`adjust_model_time_offset`, recognize_wav2.py:41), which is not part of the released tree; what can be restated is the
+token-level stitching below: token ids with the start time of their first frame."""
+import math
+from typing import Dict, Iterator, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+def feats_batcher(infeats: torch.Tensor, chunk_size: int, batch_size: int, device=None
+                  ) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+    """(1, T, F) features -> batches ((n_windows, chunk_size, F), int32 lengths (n_windows,)); n_windows == batch_size
+    except possibly in the last batch; only the very last window can be shorter than chunk_size (zero-padded)."""
+    assert infeats.dim() == 3 and infeats.shape[0] == 1 and chunk_size > 0 and batch_size > 0
+    T, nf = infeats.shape[1], infeats.shape[2]
+    per = chunk_size * batch_size
+    for b in range(math.ceil(T / per)):
+        fb = infeats[:, b * per:(b + 1) * per, :]
+        nw = math.ceil(fb.shape[1] / chunk_size)
+        lens = torch.full((nw,), chunk_size, dtype=torch.int32)
+        pad = nw * chunk_size - fb.shape[1]
+        if pad > 0:
+            lens[-1] -= pad
+            fb = F.pad(fb, (0, 0, 0, pad, 0, 0), mode="constant", value=0)
+        yield fb.reshape(nw, chunk_size, nf), (lens.to(device) if device is not None else lens.to(infeats.device))
+
+
+def window_offsets_ms(n_windows: int, chunk_size: int, input_frame_ms: float = 10.0) -> List[float]:
+    """Start time of every window (hyps_to_ctm: `time_shift_ms += chunk_size * input_frame_length` per window)."""
+    return [i * chunk_size * input_frame_ms for i in range(n_windows)]
+
+
+@torch.no_grad()
+def decode_windows(model, feats: torch.Tensor, chunk_size: int, batch_size: int, mode: str = "ctc_greedy_search",
+                   beam_size: int = 10, input_frame_ms: float = 10.0, output_frame_ms: float = 40.0,
+                   **decode_kw) -> Dict[str, object]:
+    """Decode a long file window by window with `model.decode` and stitch the token sequences.
+
+    Returns {"tokens": all token ids in order, "windows": per-window token lists, "window_start_ms": start time of each
+    window, "token_start_ms": start time of every token when the search reports frame indices (GPU greedy search),
+    else None}.  Shards naturally: give each rank a contiguous range of batches (utils/sharding.py)."""
+    windows: List[List[int]] = []
+    frames: List[Optional[List[int]]] = []
+    for fb, lens in feats_batcher(feats, chunk_size, batch_size, feats.device):
+        if mode == "ctc_greedy_search" and fb.is_cuda:
+            # same search, plus the first-frame index of every token (the kernel reports it for free)
+            from ..hip_ops import ctc_greedy
+            enc, mask = model._forward_encoder(fb, lens)
+            logp = model.ctc_logprobs(enc)
+            tk, nt, fr = ctc_greedy(logp.contiguous(), mask.squeeze(1).sum(1), decode_kw.get("blank_id", 0),
+                                    want_frames=True)
+            tk, nt, fr = tk.cpu(), nt.cpu(), fr.cpu()
+            for i in range(tk.shape[0]):
+                n = int(nt[i])
+                windows.append(tk[i, :n].tolist())
+                frames.append(fr[i, :n].tolist())
+        else:
+            res = model.decode([mode], fb, lens, beam_size=beam_size, **decode_kw)[mode]
+            for r in res:
+                windows.append(list(r.tokens))
+                frames.append(None)
+    starts = window_offsets_ms(len(windows), chunk_size, input_frame_ms)
+    tokens = [t for w in windows for t in w]
+    tstart = None
+    if all(f is not None for f in frames):
+        tstart = [s + f * output_frame_ms for s, fr in zip(starts, frames) for f in fr]
+    return {"tokens": tokens, "windows": windows, "window_start_ms": starts, "token_start_ms": tstart}

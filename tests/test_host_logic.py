@@ -164,3 +164,21 @@ def test_two_rank_gloo_sharding_and_gather(tmp_path):
                          env=env, capture_output=True, text=True, timeout=180)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "GLOO_OK" in out.stdout
+
+
+def test_feats_batcher_windows_like_the_reference():
+    """recognize_wav2.py:323-351: windows of chunk_size frames in batches of batch_size; only the last window is padded
+    (with zeros) and only its length is shortened; concatenating the valid frames gives the input back."""
+    from paper_accurate_fast_cheap_amd.utils.longform import feats_batcher, window_offsets_ms
+    x = torch.arange(1 * 1037 * 3, dtype=torch.float32).view(1, 1037, 3) + 1.0
+    batches = list(feats_batcher(x, 100, 4))
+    assert [tuple(b.shape) for b, _ in batches] == [(4, 100, 3), (4, 100, 3), (3, 100, 3)]
+    assert [l.tolist() for _, l in batches] == [[100] * 4, [100] * 4, [100, 100, 37]]
+    assert all(l.dtype == torch.int32 for _, l in batches)
+    back = torch.cat([b[i, :int(l[i])] for b, l in batches for i in range(b.shape[0])])
+    assert torch.equal(back, x[0])
+    assert float(batches[-1][0][2, 37:].abs().max()) == 0.0
+    # exact multiples: no padding, full lengths; a file shorter than one window: one short window
+    assert [l.tolist() for _, l in feats_batcher(x[:, :800], 100, 4)] == [[100] * 4, [100] * 4]
+    assert [l.tolist() for _, l in feats_batcher(x[:, :42], 100, 4)] == [[42]]
+    assert window_offsets_ms(3, 2000) == [0.0, 20000.0, 40000.0]

@@ -170,3 +170,24 @@ def test_end_to_end_decode_example(hip, capsys):
         out = capsys.readouterr().out
         assert len(res) == 3 and all(isinstance(t, int) for r in res for t in r.tokens)
         assert out.count("utt") == 3 and "Overall ->" in out and "N=" in out
+
+
+def test_decode_windows_stitches_long_form(hip):
+    """utils/longform.decode_windows: window batches through the encoder + CTC greedy search on the GPU, token lists
+    stitched in order with window / token start times; equal to decoding every window by itself."""
+    import bench
+    from paper_accurate_fast_cheap_amd.utils.longform import decode_windows, feats_batcher
+    model, _ = bench.build_model("bf16", torch.device("cuda"))
+    g = torch.Generator(device="cuda").manual_seed(1)
+    feats = (torch.randn(1, 2450, 80, device="cuda", generator=g) * 2 + 8).to(torch.bfloat16)
+    out = decode_windows(model, feats, 600, 2)
+    assert len(out["windows"]) == 5 and out["window_start_ms"] == [0.0, 6000.0, 12000.0, 18000.0, 24000.0]
+    assert out["tokens"] == [t for w in out["windows"] for t in w]
+    assert len(out["token_start_ms"]) == len(out["tokens"]) and out["token_start_ms"] == sorted(out["token_start_ms"])
+    singles = []
+    with torch.no_grad():
+        for fb, lens in feats_batcher(feats, 600, 2):
+            singles += [list(r.tokens) for r in model.decode(["ctc_greedy_search"], fb, lens)["ctc_greedy_search"]]
+    assert singles == out["windows"]
+    beam = decode_windows(model, feats, 600, 2, mode="ctc_prefix_beam_search", beam_size=4)
+    assert len(beam["windows"]) == 5 and beam["token_start_ms"] is None
