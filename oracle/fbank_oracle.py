@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY (same rule as oracle/wkv6_oracle.c).
 
-*** parity unpinned ***  The arithmetic lives in a third-party dependency that is absent from /root/reference and
+*** parity unpinned ***  (cross-checked, not pinned: tests/test_oracle_goldens.py compares this restatement with the
+independent Kaldi-compatible extractor shipped in `transformers`, max |delta log-mel| 1.6e-4.)  The arithmetic lives in a third-party dependency that is absent from /root/reference and
 from this image: torchaudio.compliance.kaldi.fbank (requirements.txt:17 `torchaudio>=2.2.2`; the README installs
 PyTorch 2.5.1 / torchaudio 2.5.1, README_RevPaper_Choose3.md:41).  The reference's call sites are
 wenet/dataset/processor.py:363-369, wenet/bin/encoder-rtf.py:575-583, wenet/bin/recognize_wav2.py:510-518:

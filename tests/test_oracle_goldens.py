@@ -165,3 +165,24 @@ def test_padding_dependence_is_reproduced():
     out_1, _ = EO.encoder_forward(g["xs"][2:3, :n].contiguous(), g["lens"][2:3], sd, g["conf"], env={})
     t1 = out_1.shape[1]
     assert not torch.allclose(out_b[2:3, :t1], out_1, atol=1e-3)
+
+
+def test_fbank_oracle_agrees_with_an_independent_kaldi_compatible_extractor():
+    """torchaudio (the reference's fbank, dataset/processor.py:363-369) is absent from the image, so the fbank oracle is
+    restated from the Kaldi definition.  Cross-check against an INDEPENDENT implementation of the same definition that
+    is installed here: transformers' SeamlessM4TFeatureExtractor (its `_extract_fbank_features` is documented and
+    tested upstream as torchaudio.compliance.kaldi.fbank-compatible: povey window, pre-emphasis 0.97, DC removal, 512-
+    point power spectrum, 80 Kaldi mel bins from 20 Hz, log with the float-epsilon floor, 2^15 input scaling)."""
+    np = pytest.importorskip("numpy")
+    tr = pytest.importorskip("transformers")
+    from oracle import fbank_oracle as FO
+    fe = tr.SeamlessM4TFeatureExtractor(feature_size=80, sampling_rate=16000, num_mel_bins=80)
+    rng = np.random.default_rng(0)
+    for seconds, amp in ((3.0, 0.1), (0.5, 0.5), (1.234, 0.01)):
+        w = (rng.standard_normal(int(16000 * seconds)) * amp).astype(np.float32)
+        want = torch.from_numpy(fe._extract_fbank_features(w))
+        got = FO.fbank(torch.from_numpy(w * 2 ** 15).unsqueeze(0), num_mel_bins=80, frame_length=25.0, frame_shift=10.0,
+                       dither=0.0, energy_floor=0.0, sample_frequency=16000.0)
+        assert got.shape == want.shape == (1 + (len(w) - 400) // 160, 80)
+        assert float((got - want).abs().max()) < 2e-3, float((got - want).abs().max())   # log-mel values are 5..26
+        assert float((got - want).abs().mean()) < 5e-5
