@@ -186,3 +186,44 @@ def test_fbank_oracle_agrees_with_an_independent_kaldi_compatible_extractor():
         assert got.shape == want.shape == (1 + (len(w) - 400) // 160, 80)
         assert float((got - want).abs().max()) < 2e-3, float((got - want).abs().max())   # log-mel values are 5..26
         assert float((got - want).abs().mean()) < 5e-5
+
+
+def test_mamba2_oracle_agrees_with_an_independent_port_of_the_published_block():
+    """`mamba_ssm` (the reference's Mamba-2, mamba_att_wrapper.py:24-35, mamba2_bidirectional.py:40-62) is absent from
+    the image, so the Mamba-2 oracle restates the published block.  Cross-check against an INDEPENDENT implementation
+    that is installed here: transformers' Mamba2Mixer (the upstream port of mamba_ssm's Mamba2 with the same parameter
+    names and layout -- in_proj / conv1d / dt_bias / A_log / D / norm / out_proj -- whose CPU path is a chunked SSD,
+    not a sequential recurrence), on the paper's configuration (headdim 64, d_state 128, d_conv 4, expand 2, 1 group,
+    gate before the RMSNorm, eps 1e-5) with the same weights, at lengths below, at and across its chunk size."""
+    tr = pytest.importorskip("transformers")
+    try:
+        from transformers.models.mamba2.modeling_mamba2 import Mamba2Mixer
+    except ImportError:
+        pytest.skip("this transformers has no Mamba2Mixer")
+    from oracle import mamba2_oracle as MO
+    torch.manual_seed(0)
+    d_model, H = 128, 4
+    cfg = tr.Mamba2Config(hidden_size=d_model, state_size=128, conv_kernel=4, expand=2, head_dim=64, num_heads=H,
+                          n_groups=1, use_bias=False, use_conv_bias=True, rms_norm=True, chunk_size=64,
+                          num_hidden_layers=1, layer_norm_epsilon=1e-5, time_step_limit=(0.0, float("inf")))
+    mixer = Mamba2Mixer(cfg, 0).eval()
+    with torch.no_grad():
+        for n, p in mixer.named_parameters():
+            if n in ("in_proj.weight", "out_proj.weight"):
+                p.copy_(torch.randn_like(p) * 0.08)
+            elif n.startswith("conv1d."):
+                p.copy_(torch.randn_like(p) * 0.3)
+            elif n == "norm.weight":
+                p.copy_(1 + 0.2 * torch.randn_like(p))
+        mixer.D.copy_(torch.randn(H))
+        mixer.A_log.copy_(torch.log(torch.empty(H).uniform_(1, 16)))
+    sd = {"m." + k: v.detach() for k, v in mixer.state_dict().items()}
+    assert {k[2:] for k in sd} == {"in_proj.weight", "conv1d.weight", "conv1d.bias", "dt_bias", "A_log", "D",
+                                   "norm.weight", "out_proj.weight"}
+    for L in (1, 7, 64, 150):
+        u = torch.randn(2, L, d_model)
+        with torch.no_grad():
+            want = mixer(u)
+        got = MO.mamba2_forward(u, sd, "m.")
+        assert got.shape == want.shape
+        assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max())), (L, float((got - want).abs().max()))
