@@ -38,6 +38,17 @@ int pafc_dwconv1d_cl(int dtype, int B, int T_in, int C, int K, int left_pad, int
 int pafc_dwconv1d_cl_ex(int dtype, int B, int T_in, int C, int K, int left_pad, int T_out, const void *x, long ldx,
                         const void *w, const void *bias, void *y, int act, const int32_t *lens, pafc_stream_t stream);
 
+/* Gradients of the same convolution for the training step (config c4; the reference differentiates nn.Conv1d through
+ * autograd: convolution.py:131 under train_utils.py:646-660).  The input gradient is the forward kernel itself on dy with
+ * the taps reversed and left_pad' = K - 1 - left_pad; this entry point is the other half:
+ *   dw[c][k] = sum_{b,t} dy[b][t][c] * x[b][t + k - left_pad][c],   dbias[c] = sum_{b,t} dy[b][t][c]
+ *   x: (B, T_in, ldx >= C), dy: (B, T_out, C) in `dtype`; dw: (C, K) and dbias: (C) or NULL in float32 (summed in a
+ *   fixed order: deterministic).  workspace: pafc_dwconv1d_cl_wgrad_workspace_bytes(B, T_out, C, K) bytes. */
+size_t pafc_dwconv1d_cl_wgrad_workspace_bytes(int B, int T_out, int C, int K);
+int pafc_dwconv1d_cl_wgrad(int dtype, int B, int T_in, int C, int K, int left_pad, int T_out, const void *x, long ldx,
+                           const void *dy, float *dw, float *dbias, void *workspace, size_t workspace_bytes,
+                           pafc_stream_t stream);
+
 /* Residual add + LayerNorm (+ SiLU, + second LayerNorm, + padding masks) in one pass over (rows, C).
  *   x_new = x + alpha * y            (y == NULL: x_new = x; mask_y: rows with t >= lens[b] of y count as zero)
  *   out1  = LN(x_new; gamma1, beta1) (silu1: SiLU on top; zero1: rows with t >= lens[b] are written as zero)

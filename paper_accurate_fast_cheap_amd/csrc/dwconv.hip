@@ -132,6 +132,100 @@ int dispatch_k(int K, int B, int T_in, int C, int left_pad, int T_out, const voi
     }
 }
 
+
+// Weight / bias gradient of the same convolution (the training step, config c4):
+//   dw[c][k] = sum_{b,t} dy[b][t][c] * x[b][t + k - left_pad][c],   db[c] = sum_{b,t} dy[b][t][c]
+// A lane owns 2 channels and keeps their 2 (K + 1) sums in registers while its block walks WG_SPAN output frames in
+// tiles of TO (same register tiling as the forward: every x row of a tile is loaded once and meets the <= K dy rows
+// it was multiplied into); a block leaves one fp32 partial per (k, c), a second kernel adds the partials in a fixed
+// order (deterministic: no atomics).
+constexpr int WG_SPAN = 8 * TO;
+
+template <typename ET, int K>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(int T_in, int C, int left_pad, int T_out,
+                                                           const ET *__restrict__ x, long ldx,
+                                                           const ET *__restrict__ dy, float *__restrict__ part) {
+    const int c = (blockIdx.y * 256 + threadIdx.x) * 2;
+    if (c >= C) return;
+    const int b = blockIdx.z;
+    const ET *xb = x + (size_t)b * T_in * ldx;
+    const ET *db = dy + (size_t)b * T_out * C;
+    float a0[K], a1[K], s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) a0[k] = a1[k] = 0.f;
+    constexpr int NR = TO + K - 1;
+    for (int t0 = blockIdx.x * WG_SPAN; t0 < min(T_out, (int)(blockIdx.x + 1) * WG_SPAN); t0 += TO) {
+        float2 g[TO], in[NR];
+#pragma unroll
+        for (int o = 0; o < TO; ++o) {
+            const int t = min(t0 + o, T_out - 1);
+            g[o] = Pair<ET>::load(db + (size_t)t * C + c);
+            if (t0 + o >= T_out) g[o] = make_float2(0.f, 0.f);
+            s0 += g[o].x;
+            s1 += g[o].y;
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int s = t0 - left_pad + q;
+            in[q] = Pair<ET>::load(xb + (size_t)min(max(s, 0), T_in - 1) * ldx + c);
+            if (!(s >= 0 && s < T_in)) in[q] = make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q)
+#pragma unroll
+            for (int o = 0; o < TO; ++o) {
+                const int k = q - o;
+                if (k >= 0 && k < K) {
+                    a0[k] = fmaf(g[o].x, in[q].x, a0[k]);
+                    a1[k] = fmaf(g[o].y, in[q].y, a1[k]);
+                }
+            }
+    }
+    float *pp = part + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * (K + 1) * C + c;
+#pragma unroll
+    for (int k = 0; k < K; ++k) *reinterpret_cast<float2 *>(pp + (size_t)k * C) = make_float2(a0[k], a1[k]);
+    *reinterpret_cast<float2 *>(pp + (size_t)K * C) = make_float2(s0, s1);
+}
+
+// dw (C, K) and db (C) in fp32 from nblk partials of (K + 1, C)
+__global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(int C, int K, int nblk, const float *__restrict__ part,
+                                                                  float *__restrict__ dw, float *__restrict__ dbias) {
+    const int i = blockIdx.x * 256 + threadIdx.x;      // over (K + 1) * C, c fastest: coalesced reads
+    if (i >= (K + 1) * C) return;
+    const int k = i / C, c = i - k * C;
+    float s = 0.f;
+    for (int p = 0; p < nblk; ++p) s += part[(size_t)p * (K + 1) * C + i];
+    if (k < K)
+        dw[(size_t)c * K + k] = s;
+    else if (dbias)
+        dbias[c] = s;
+}
+
+template <typename ET, int K>
+int launch_wgrad(int B, int T_in, int C, int left_pad, int T_out, const void *x, long ldx, const void *dy, float *part,
+                 float *dw, float *dbias, hipStream_t s) {
+    const int nx = (T_out + WG_SPAN - 1) / WG_SPAN;
+    dim3 grid(nx, (C / 2 + 255) / 256, B), block(256);
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<ET, K>), grid, block, 0, s, T_in, C, left_pad, T_out, (const ET *)x, ldx,
+                       (const ET *)dy, part);
+    hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3(((K + 1) * C + 255) / 256), block, 0, s, C, K, nx * B, part, dw,
+                       dbias);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+template <typename ET>
+int dispatch_wgrad(int K, int B, int T_in, int C, int left_pad, int T_out, const void *x, long ldx, const void *dy,
+                   float *part, float *dw, float *dbias, hipStream_t s) {
+    switch (K) {
+        case 31: return launch_wgrad<ET, 31>(B, T_in, C, left_pad, T_out, x, ldx, dy, part, dw, dbias, s);
+        case 15: return launch_wgrad<ET, 15>(B, T_in, C, left_pad, T_out, x, ldx, dy, part, dw, dbias, s);
+        case 7: return launch_wgrad<ET, 7>(B, T_in, C, left_pad, T_out, x, ldx, dy, part, dw, dbias, s);
+        case 4: return launch_wgrad<ET, 4>(B, T_in, C, left_pad, T_out, x, ldx, dy, part, dw, dbias, s);
+        case 3: return launch_wgrad<ET, 3>(B, T_in, C, left_pad, T_out, x, ldx, dy, part, dw, dbias, s);
+        default: return PAFC_ERR_UNSUPPORTED;
+    }
+}
+
 }  // namespace
 }  // namespace pafc
 
@@ -157,5 +251,26 @@ extern "C" int pafc_dwconv1d_cl_ex(int dtype, int B, int T_in, int C, int K, int
     if (dtype == PAFC_BF16)
         return pafc::dispatch_k<pafc::bf16_t>(K, B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
     if (dtype == PAFC_F32) return pafc::dispatch_k<float>(K, B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
+    return PAFC_ERR_DTYPE;
+}
+
+extern "C" size_t pafc_dwconv1d_cl_wgrad_workspace_bytes(int B, int T_out, int C, int K) {
+    if (B <= 0 || T_out <= 0 || C <= 0 || K <= 0) return 0;
+    return (size_t)B * ((T_out + pafc::WG_SPAN - 1) / pafc::WG_SPAN) * (K + 1) * C * sizeof(float);
+}
+
+extern "C" int pafc_dwconv1d_cl_wgrad(int dtype, int B, int T_in, int C, int K, int left_pad, int T_out, const void *x,
+                                      long ldx, const void *dy, float *dw, float *dbias, void *workspace,
+                                      size_t workspace_bytes, pafc_stream_t stream) {
+    if (!x || !dy || !dw || !workspace) return PAFC_ERR_NULL_POINTER;
+    if (B <= 0 || T_in <= 0 || T_out <= 0 || C <= 0 || (C % 2) || K <= 0 || K > pafc::KMAX || left_pad < 0 ||
+        B > 65535 || ldx < C || (ldx % 2))
+        return PAFC_ERR_BAD_DIMS;
+    if (workspace_bytes < pafc_dwconv1d_cl_wgrad_workspace_bytes(B, T_out, C, K)) return PAFC_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    if (dtype == PAFC_BF16)
+        return pafc::dispatch_wgrad<pafc::bf16_t>(K, B, T_in, C, left_pad, T_out, x, ldx, dy, part, dw, dbias, s);
+    if (dtype == PAFC_F32) return pafc::dispatch_wgrad<float>(K, B, T_in, C, left_pad, T_out, x, ldx, dy, part, dw, dbias, s);
     return PAFC_ERR_DTYPE;
 }

@@ -13,6 +13,10 @@ def _bind():
         return L
     P, I = c_void_p, c_int
     _lib._sig(L.pafc_dwconv1d_cl, I, I, I, I, I, I, I, I, P, P, P, P, I, P, P)
+    from ctypes import c_long, c_size_t
+    L.pafc_dwconv1d_cl_wgrad_workspace_bytes.restype = c_size_t
+    L.pafc_dwconv1d_cl_wgrad_workspace_bytes.argtypes = [I, I, I, I]
+    _lib._sig(L.pafc_dwconv1d_cl_wgrad, I, I, I, I, I, I, I, I, P, c_long, P, P, P, P, c_size_t, P)
     L._pafc_ops_bound = True
     return L
 
@@ -34,6 +38,59 @@ def depthwise_conv1d_cl(x: torch.Tensor, weight: torch.Tensor, bias: Optional[to
                                   _lib.stream_of(x))
     _lib.check(rc, "pafc_dwconv1d_cl")
     return y
+
+
+def depthwise_conv1d_cl_wgrad(x: torch.Tensor, dy: torch.Tensor, K: int, left_pad: int, want_bias: bool = True):
+    """(dw (C, 1, K), dbias (C) or None) in float32 for y = depthwise_conv1d_cl(x, w, bias, left_pad, dy.shape[1])."""
+    _lib.require_gpu(x, dy)
+    B, T, C = x.shape
+    if dy.shape[0] != B or dy.shape[2] != C or dy.dtype != x.dtype or not dy.is_contiguous() or x.stride(2) != 1 \
+            or x.stride(0) != T * x.stride(1):
+        raise _lib.PafcError("dy must be contiguous (B, T_out, C) in x's dtype; x (B, T, C) with unit channel stride")
+    L = _bind()
+    nbytes = L.pafc_dwconv1d_cl_wgrad_workspace_bytes(B, dy.shape[1], C, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    dw = torch.empty(C, 1, K, dtype=torch.float32, device=x.device)
+    db = torch.empty(C, dtype=torch.float32, device=x.device) if want_bias else None
+    rc = L.pafc_dwconv1d_cl_wgrad(_lib.dtype_code(x.dtype), B, T, C, K, left_pad, dy.shape[1], _lib.ptr(x), x.stride(1),
+                                  _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), nbytes, _lib.stream_of(x))
+    _lib.check(rc, "pafc_dwconv1d_cl_wgrad")
+    return dw, db
+
+
+class _DepthwiseConvCL(torch.autograd.Function):
+    """Autograd over the channels-last depthwise convolution: dx is the forward kernel on dy with the taps reversed and
+    left_pad' = K - 1 - left_pad, dw / dbias the reduction kernel (what autograd derives for nn.Conv1d,
+    convolution.py:131)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, left_pad, out_len):
+        ctx.save_for_backward(x, weight)
+        ctx.left_pad, ctx.has_bias = left_pad, bias is not None
+        return depthwise_conv1d_cl(x, weight, bias, left_pad, out_len)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        K = weight.shape[-1]
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = depthwise_conv1d_cl(dy, weight.flip(-1).contiguous(), None, K - 1 - ctx.left_pad, x.shape[1])
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = depthwise_conv1d_cl_wgrad(x, dy, K, ctx.left_pad, want_bias=ctx.has_bias)
+            dw = dw.to(weight.dtype)
+            db = db.to(weight.dtype) if db is not None else None
+        return dx, dw, db, None, None
+
+
+def depthwise_conv1d_cl_autograd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], left_pad: int,
+                                 out_len: int) -> torch.Tensor:
+    """Training-side entry: parameters are cast to the activation dtype (what autocast does for nn.Conv1d), gradients
+    come back in the parameters' dtype."""
+    w = weight.to(x.dtype)
+    b = bias.to(x.dtype) if bias is not None else None
+    return _DepthwiseConvCL.apply(x.contiguous(), w, b, left_pad, out_len)
 
 
 def _bind2():

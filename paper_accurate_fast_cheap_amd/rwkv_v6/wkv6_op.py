@@ -126,6 +126,11 @@ class _WKV6(torch.autograd.Function):
 def wkv6(r, k, v, w, u, reverse: bool = False):
     """y = WKV6(...) with autograd when any operand needs a gradient."""
     u = u.contiguous()
+    if torch.is_autocast_enabled() and len({t.dtype for t in (r, k, v, w, u)}) > 1:
+        # under autocast the projections come out in the autocast dtype while the decay / bonus keep the parameter
+        # dtype: the kernel wants one dtype (model.py:116-120) -- bf16 when that is the autocast dtype, else fp32
+        dt = torch.bfloat16 if torch.get_autocast_dtype("cuda") == torch.bfloat16 else torch.float32
+        r, k, v, w, u = (t.to(dt).contiguous() for t in (r, k, v, w, u))
     if torch.is_grad_enabled() and any(t.requires_grad for t in (r, k, v, w, u)):
         return _WKV6.apply(r, k, v, w, u, reverse)
     return wkv6_forward(r, k, v, w, u, reverse=reverse)

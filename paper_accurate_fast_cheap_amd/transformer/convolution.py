@@ -40,7 +40,7 @@ class ConvolutionModule(nn.Module):
     def forward(self, x: torch.Tensor, mask_pad: torch.Tensor = torch.ones((0, 0, 0), dtype=torch.bool),
                 cache: torch.Tensor = torch.zeros((0, 0, 0))) -> Tuple[torch.Tensor, torch.Tensor]:
         """x (B, T, C), mask_pad (B, 1, T) or (0,0,0), cache (B, C, lorder) for causal -> (B, T, C), new_cache."""
-        from ..hip_ops import depthwise_conv1d_cl
+        from ..hip_ops import depthwise_conv1d_cl, depthwise_conv1d_cl_autograd
         keep = mask_pad.transpose(1, 2) if mask_pad.size(2) > 0 else None  # (B, T, 1)
         if keep is not None:
             x = x.masked_fill(~keep, 0.0)
@@ -54,14 +54,12 @@ class ConvolutionModule(nn.Module):
             new_cache = torch.zeros((0, 0, 0), dtype=x.dtype, device=x.device)
         x = F.linear(x, self.pointwise_conv1.weight.squeeze(-1), self.pointwise_conv1.bias)
         x = F.glu(x, dim=-1)
+        lp = 0 if self.lorder > 0 else (self.kernel_size - 1) // 2
+        out_len = x.size(1) - self.lorder if self.lorder > 0 else x.size(1)
         if torch.is_grad_enabled() and (x.requires_grad or self.depthwise_conv.weight.requires_grad):
-            # training: the channels-last kernel is forward-only, autograd goes through the library convolution
-            x = self.depthwise_conv._conv_forward(x.transpose(1, 2), self.depthwise_conv.weight,
-                                                  self.depthwise_conv.bias).transpose(1, 2)
+            x = depthwise_conv1d_cl_autograd(x, self.depthwise_conv.weight, self.depthwise_conv.bias, lp, out_len)
         else:
-            x = depthwise_conv1d_cl(x, self.depthwise_conv.weight, self.depthwise_conv.bias,
-                                    left_pad=0 if self.lorder > 0 else (self.kernel_size - 1) // 2,
-                                    out_len=x.size(1) - self.lorder if self.lorder > 0 else x.size(1))
+            x = depthwise_conv1d_cl(x, self.depthwise_conv.weight, self.depthwise_conv.bias, left_pad=lp, out_len=out_len)
         if self.use_layer_norm:
             x = self.activation(self.norm(x))
         else:

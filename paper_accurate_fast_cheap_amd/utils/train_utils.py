@@ -21,21 +21,45 @@ def wrap_model_ddp(model: torch.nn.Module, device: Optional[torch.device] = None
 
 
 def train_step(model: torch.nn.Module, batch: dict, optimizer: torch.optim.Optimizer, device: torch.device,
-               grad_clip: float = 0.1, accum_grad: int = 1, scheduler=None, step_index: int = 0) -> dict:
+               grad_clip: float = 0.1, accum_grad: int = 1, scheduler=None, step_index: int = 0,
+               amp_dtype: Optional[torch.dtype] = None, scaler=None, clip_hard_maxvalue: float = float("inf"),
+               clip_hard_warmup: float = float("inf")) -> dict:
     """One batch: returns {'loss', 'grad_norm', 'updated'}.  grad_clip 0.1 and Adam lr 1e-4 are the YAML's
-    (conf/rwkv/*.yaml: grad_clip, optim_conf)."""
+    (conf/rwkv/*.yaml: grad_clip, optim_conf).
+
+    Mixed precision as in batch_forward / batch_backward / update_parameter_and_lr (train_utils.py:609-729): with a
+    `scaler` (the reference's `--use_amp`: fp16 autocast + GradScaler) the loss is scaled for backward, the gradients
+    un-scaled before clipping and `scaler.step` does the skip-on-overflow; `amp_dtype=torch.bfloat16` without a scaler
+    is the `dtype: bf16` autocast of the reference's other engine -- the natural one on MI355X (bf16 MFMA, no loss
+    scaling) and the only one the bf16 time-mix slot accepts.  `clip_hard_maxvalue` / `clip_hard_warmup`
+    (train_utils.py:683-684,712-716): after the warm-up batches an update whose gradient norm exceeds the hard
+    maximum is dropped."""
     model.train()
-    out = model(batch, device)
+    if scaler is not None and amp_dtype is None:
+        amp_dtype = torch.float16
+    with torch.autocast(device_type=device.type, dtype=amp_dtype, enabled=amp_dtype is not None):
+        out = model(batch, device)
     loss = out["loss"]
-    (loss / accum_grad).backward()
+    scaled = loss / accum_grad
+    (scaler.scale(scaled) if scaler is not None else scaled).backward()
     info = {"loss": loss.detach(), "grad_norm": None, "updated": False}
     if (step_index + 1) % accum_grad == 0:
         params = [p for p in model.parameters() if p.requires_grad]
-        grad_norm = torch.nn.utils.clip_grad_norm_(params, grad_clip)
+        if scaler is not None:
+            scaler.unscale_(optimizer)
+            grad_norm = torch.nn.utils.clip_grad_norm_(params, grad_clip)
+            scale_before = scaler.get_scale()
+            scaler.step(optimizer)              # skips the update itself when the un-scaled gradients overflowed
+            scaler.update()
+            info["updated"] = bool(torch.isfinite(grad_norm)) and scaler.get_scale() >= scale_before
+        else:
+            grad_norm = torch.nn.utils.clip_grad_norm_(params, grad_clip)
+            if torch.isfinite(grad_norm):       # train_utils.py:702-711: skip the update on inf / nan
+                if (clip_hard_maxvalue == float("inf") or step_index < clip_hard_warmup
+                        or float(grad_norm) <= clip_hard_maxvalue):
+                    optimizer.step()
+                    info["updated"] = True
         info["grad_norm"] = grad_norm.detach()
-        if torch.isfinite(grad_norm):       # train_utils.py:702-711: skip the update on inf / nan
-            optimizer.step()
-            info["updated"] = True
         optimizer.zero_grad(set_to_none=True)
         if scheduler is not None:
             scheduler.step()

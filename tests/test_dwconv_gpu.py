@@ -34,3 +34,68 @@ def test_dwconv_causal_form(hip):
     ref = F.conv1d(x.transpose(1, 2), w, None, padding=0, groups=C).transpose(1, 2)
     got = depthwise_conv1d_cl(x.cuda(), w.cuda(), None, 0, T).cpu()
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,C,K,causal", [(1, 1, 128, 31, False), (2, 50, 128, 31, False), (3, 300, 512, 31, False),
+                                            (2, 133, 256, 15, True), (2, 40, 128, 7, False), (32, 129, 128, 15, False)])
+def test_dwconv_gradients_match_conv1d_autograd(hip, dtype, B, T, C, K, causal):
+    """The training-side op: dx / dw / dbias against float64 autograd through F.conv1d on the same (rounded) operands."""
+    from paper_accurate_fast_cheap_amd.hip_ops import depthwise_conv1d_cl_autograd
+    T_in = T + K - 1 if causal else T
+    x = synth.randn((B, T_in, C), 1).to(dtype)
+    w = synth.randn((C, 1, K), 2, 0.2)                 # fp32 master parameters, cast inside (as autocast would)
+    b = synth.randn((C,), 3, 0.1)
+    gy = synth.randn((B, T, C), 4).to(dtype)
+    xr = x.double().requires_grad_()
+    wr = w.to(dtype).double().requires_grad_()
+    br = b.to(dtype).double().requires_grad_()
+    ref = F.conv1d(xr.transpose(1, 2), wr, br, padding=0 if causal else (K - 1) // 2, groups=C).transpose(1, 2)
+    ref.backward(gy.double())
+    xg = x.cuda().requires_grad_()
+    wg = w.cuda().requires_grad_()
+    bg = b.cuda().requires_grad_()
+    got = depthwise_conv1d_cl_autograd(xg, wg, bg, 0 if causal else (K - 1) // 2, T)
+    got.backward(gy.cuda())
+    assert wg.grad.dtype == torch.float32 and wg.grad.shape == w.shape and xg.grad.dtype == dtype
+    lo = dtype == torch.bfloat16
+    torch.testing.assert_close(got.detach().cpu().double(), ref.detach(), rtol=2 ** -7 if lo else 1e-4, atol=2e-2 if lo else 1e-5)
+    torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, rtol=2 ** -7 if lo else 1e-4, atol=2e-2 if lo else 1e-5)
+    # the sums over B*T are accumulated in fp32 from exact products; bf16 only rounds the result once
+    scale = float(wr.grad.abs().max())
+    assert float((wg.grad.cpu().double() - wr.grad).abs().max()) <= (1e-2 if lo else 1e-5) * scale
+    assert float((bg.grad.cpu().double() - br.grad).abs().max()) <= (1e-2 if lo else 1e-5) * float(br.grad.abs().max())
+
+
+def test_dwconv_gradients_without_bias_and_frozen_weight(hip):
+    from paper_accurate_fast_cheap_amd.hip_ops import depthwise_conv1d_cl_autograd
+    x = synth.randn((2, 37, 128), 1).cuda().requires_grad_()
+    w = synth.randn((128, 1, 15), 2, 0.2).cuda()                      # frozen (the FT-LFXL recipe trains the slot only)
+    y = depthwise_conv1d_cl_autograd(x, w, None, 7, 37)
+    y.sum().backward()
+    ref = F.conv_transpose1d(torch.ones(2, 128, 37), w.cpu(), padding=7, groups=128).transpose(1, 2)
+    torch.testing.assert_close(x.grad.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_conv_module_training_path_uses_the_kernels(hip):
+    """ConvolutionModule under autograd == the library path it replaced (nn.Conv1d between two transposes)."""
+    from paper_accurate_fast_cheap_amd.transformer.convolution import ConvolutionModule
+    torch.manual_seed(0)
+    m = ConvolutionModule(128, 15, torch.nn.SiLU(), "layer_norm", causal=False, bias=True).cuda()
+    x = synth.randn((3, 61, 128), 7).cuda().requires_grad_()
+    mask = (torch.arange(61)[None, :] < torch.tensor([61, 40, 13])[:, None]).unsqueeze(1).cuda()
+    y, _ = m(x, mask)
+    y.square().sum().backward()
+    got = {n: p.grad.clone() for n, p in m.named_parameters()}
+    gx = x.grad.clone()
+    m.zero_grad(); x.grad = None
+    xm = x.masked_fill(~mask.transpose(1, 2), 0.0)
+    h = F.glu(F.linear(xm, m.pointwise_conv1.weight.squeeze(-1), m.pointwise_conv1.bias), dim=-1)
+    h = m.depthwise_conv(h.transpose(1, 2)).transpose(1, 2)
+    h = F.linear(m.activation(m.norm(h)), m.pointwise_conv2.weight.squeeze(-1), m.pointwise_conv2.bias)
+    h = h.masked_fill(~mask.transpose(1, 2), 0.0)
+    torch.testing.assert_close(y, h, rtol=1e-4, atol=1e-5)
+    h.square().sum().backward()
+    torch.testing.assert_close(gx, x.grad, rtol=1e-3, atol=1e-4)
+    for n, p in m.named_parameters():
+        torch.testing.assert_close(got[n], p.grad, rtol=1e-3, atol=1e-3 * float(p.grad.abs().max()))

@@ -168,3 +168,149 @@ def test_two_rank_gloo_ddp_step(tmp_path):
                          env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "DDP_OK" in out.stdout
+
+
+class _TinyCtc(torch.nn.Module):
+    """The CPU-runnable tail of the path (FFN + CTC head) -- enough to exercise the step's control flow."""
+
+    def __init__(self):
+        super().__init__()
+        from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+        from paper_accurate_fast_cheap_amd.transformer.positionwise_feed_forward import PositionwiseFeedForward
+        self.ff = PositionwiseFeedForward(16, 32, 0.0, torch.nn.SiLU())
+        self.ctc = CTC(11, 16)
+        self.seen_dtype = None
+
+    def forward(self, batch, device):
+        h = self.ff(batch["feats"])
+        self.seen_dtype = h.dtype
+        loss, _ = self.ctc(h.float(), batch["feats_lengths"], batch["target"], batch["target_lengths"])
+        return {"loss": loss}
+
+
+def _tiny_batch():
+    g = torch.Generator().manual_seed(1)
+    return {"feats": torch.randn(4, 12, 16, generator=g), "feats_lengths": torch.tensor([12, 10, 9, 7]),
+            "target": torch.randint(1, 11, (4, 3), generator=g), "target_lengths": torch.tensor([3, 2, 3, 1])}
+
+
+def test_train_step_hard_clip_drops_the_update_after_warmup():
+    """train_utils.py:683-684,712-716: grad_norm above grad_clip_hard_maxvalue => no update once past the warm-up."""
+    from paper_accurate_fast_cheap_amd.utils.train_utils import train_step
+    torch.manual_seed(0)
+    model, batch, cpu = _TinyCtc(), _tiny_batch(), torch.device("cpu")
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    before = [p.detach().clone() for p in model.parameters()]
+    info = train_step(model, batch, opt, cpu, step_index=5, clip_hard_maxvalue=1e-6, clip_hard_warmup=3)
+    assert not info["updated"] and float(info["grad_norm"]) > 1e-6
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
+    assert all(p.grad is None for p in model.parameters())                      # gradients are dropped all the same
+    info = train_step(model, batch, opt, cpu, step_index=2, clip_hard_maxvalue=1e-6, clip_hard_warmup=3)
+    assert info["updated"]                                                      # still inside the warm-up
+    info = train_step(model, batch, opt, cpu, step_index=9, clip_hard_maxvalue=1e6, clip_hard_warmup=3)
+    assert info["updated"]
+
+
+def test_train_step_accumulates_over_accum_grad_batches():
+    from paper_accurate_fast_cheap_amd.utils.train_utils import train_step
+    torch.manual_seed(0)
+    model, batch, cpu = _TinyCtc(), _tiny_batch(), torch.device("cpu")
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    before = [p.detach().clone() for p in model.parameters()]
+    info = train_step(model, batch, opt, cpu, accum_grad=2, step_index=0)
+    assert not info["updated"] and info["grad_norm"] is None
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
+    g1 = [p.grad.clone() for p in model.parameters()]
+    info = train_step(model, batch, opt, cpu, accum_grad=2, step_index=1, grad_clip=1e9)
+    assert info["updated"]
+    # two identical half-weighted batches accumulate to the gradient of one: the first call left exactly half of it
+    model2 = _TinyCtc()
+    model2.load_state_dict({k: v for k, v in zip(model.state_dict().keys(), before)})
+    model2(batch, cpu)["loss"].backward()
+    for h, p in zip(g1, model2.parameters()):
+        assert torch.allclose(2 * h, p.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_train_step_bf16_autocast_on_cpu():
+    """`dtype: bf16` (train_utils.py:614-626): the forward runs under autocast, master weights and grads stay fp32."""
+    from paper_accurate_fast_cheap_amd.utils.train_utils import train_step
+    torch.manual_seed(0)
+    model, batch, cpu = _TinyCtc(), _tiny_batch(), torch.device("cpu")
+    ref = _TinyCtc()
+    ref.load_state_dict(model.state_dict())
+    ref(batch, cpu)["loss"].backward()
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    grads = {}
+    hooks = [p.register_hook(lambda g, n=n: grads.__setitem__(n, g.clone())) for n, p in model.named_parameters()]
+    info = train_step(model, batch, opt, cpu, grad_clip=1e9, amp_dtype=torch.bfloat16)
+    for h in hooks:
+        h.remove()
+    assert model.seen_dtype == torch.bfloat16 and info["updated"]
+    for n, p in ref.named_parameters():
+        assert grads[n].dtype == torch.float32
+        assert float((grads[n] - p.grad).abs().max()) <= 0.05 * float(p.grad.abs().max()) + 1e-4, n
+
+
+@pytest.mark.gpu
+def test_train_step_amp_scaler_semantics(hip):
+    """`--use_amp` (train_utils.py:635,655-657,698-709): fp16 autocast, scaled backward, unscale -> clip -> scaler.step;
+    an overflowing batch is skipped by the scaler and halves the scale."""
+    from paper_accurate_fast_cheap_amd.utils.train_utils import train_step
+    torch.manual_seed(0)
+    dev = torch.device("cuda")
+    model = _TinyCtc().to(dev)
+    batch = {k: v.to(dev) for k, v in _tiny_batch().items()}
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    before = [p.detach().clone() for p in model.parameters()]
+    info = train_step(model, batch, opt, dev, scaler=scaler, grad_clip=0.1)
+    assert model.seen_dtype == torch.float16 and info["updated"] and torch.isfinite(info["grad_norm"])
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
+    before = [p.detach().clone() for p in model.parameters()]
+    bad = dict(batch, feats=batch["feats"] * float("inf"))
+    info = train_step(model, bad, opt, dev, scaler=scaler, grad_clip=0.1)
+    assert not info["updated"] and scaler.get_scale() == 512.0
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
+
+
+@pytest.mark.gpu
+def test_train_step_bf16_autocast_through_the_encoder(hip):
+    """The whole model under bf16 autocast (fp32 master weights, bf16 time-mix slot): loss close to the fp32 step's,
+    fp32 gradients for the fp32 parameters, every parameter reached, an update made."""
+    from paper_accurate_fast_cheap_amd.utils.init_model import init_model
+    from paper_accurate_fast_cheap_amd.utils.train_utils import train_step
+    for golden in ("encoder_reduced_bf16slot", "encoder_reduced_f32"):
+        g = load_golden(golden)
+        cfg = dict(encoder="conformer", encoder_conf=dict(g["conf"], dropout_rate=0.0, positional_dropout_rate=0.0),
+                   input_dim=80, output_dim=50, ctc="ctc", ctc_conf={"ctc_blank_id": 0}, model_conf={}, dataset_conf={})
+
+        class A:
+            checkpoint = None
+        torch.manual_seed(3)
+        model, _ = init_model(A(), cfg)
+        model = model.cuda()
+        batch = {"feats": synth.randn((4, 120, 80), 1, 2.0), "feats_lengths": torch.tensor([120, 100, 90, 64]),
+                 "target": torch.randint(1, 50, (4, 6), generator=torch.Generator().manual_seed(2)),
+                 "target_lengths": torch.tensor([6, 5, 4, 3])}
+        dev = torch.device("cuda")
+        model.train()
+        ref = model(batch, dev)["loss"]
+        ref.backward()
+        ref_loss = float(ref.detach())
+        ref_grads = {n: p.grad.float().clone() for n, p in model.named_parameters()}
+        model.zero_grad(set_to_none=True)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        grads = {}
+        hooks = [p.register_hook(lambda gr, n=n: grads.__setitem__(n, gr)) for n, p in model.named_parameters()]
+        info = train_step(model, batch, opt, dev, grad_clip=0.1, amp_dtype=torch.bfloat16)
+        for h in hooks:
+            h.remove()
+        assert info["updated"] and torch.isfinite(info["grad_norm"])
+        assert float(info["loss"]) == pytest.approx(ref_loss, rel=3e-2), golden
+        for n, p in model.named_parameters():
+            assert n in grads, n
+            assert grads[n].dtype == p.dtype and torch.isfinite(grads[n]).all(), n
+            a, b = ref_grads[n].flatten().double(), grads[n].flatten().double()
+            if float(a.norm()) > 1e-6 * max(1.0, a.numel() ** 0.5):      # LoRA outputs start with exactly zero gradient
+                assert float(a @ b / (a.norm() * b.norm())) > 0.97, (golden, n)
+                assert 0.8 < float(b.norm() / a.norm()) < 1.25, (golden, n)

@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--amp", default="none", choices=["none", "bf16"],
+                    help="bf16: forward under torch.autocast(bfloat16) (the reference's `dtype: bf16`), fp32 master weights")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     if world > 1:
@@ -49,11 +51,12 @@ def main():
         if world > 1:
             dist.barrier(); torch.cuda.synchronize()
     info = None
+    amp = torch.bfloat16 if args.amp == "bf16" else None
     for i in range(args.warmup):
-        info = train_step(model, batch, opt, device, step_index=i)
+        info = train_step(model, batch, opt, device, step_index=i, amp_dtype=amp)
     sync(); t0 = time.perf_counter()
     for i in range(args.steps):
-        info = train_step(model, batch, opt, device, step_index=i)
+        info = train_step(model, batch, opt, device, step_index=i, amp_dtype=amp)
     sync(); dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t)
@@ -63,7 +66,7 @@ def main():
                           "value": round(frames / 100.0 / dt, 1), "unit": "audio-sec/sec", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
                           "utts_per_gpu": args.batch, "frames_per_gpu_step": int(lens.sum()),
-                          "loss": float(info["loss"]), "grad_norm": float(info["grad_norm"]), "dtype": "fp32 + bf16 slot",
+                          "loss": float(info["loss"]), "grad_norm": float(info["grad_norm"]), "dtype": "fp32 + bf16 slot" + (", bf16 autocast" if amp else ""),
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
 
 
