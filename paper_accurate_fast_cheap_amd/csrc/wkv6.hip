@@ -490,54 +490,116 @@ __global__ __launch_bounds__(64, 3) void wkv6_row_kernel(const RowParams p) {
 
 struct EpiParams {
     const void *r, *k, *v, *w, *u, *gy;
-    const float *P, *Q;
+    float *P;            // in: P_t; out (in place): the chunk-local running sum of the gw recursion's terms
+    const float *Q;
     void *gr, *gk, *gw, *gu;
-    int B, T, C, H, reverse;
+    float *tot, *gup;    // (B*H, NE, 64): per-chunk totals of the recursion terms / of the gu sums
+    int B, T, C, H, reverse, TCH, NE;
 };
 
-// one wave per (b, h), lane = channel; serial over time but only O(N) work per step
+constexpr int EPI_MAX_CHUNKS = 64;
+__host__ __device__ inline int epi_chunk_steps(int T) {
+    const int t = (T + EPI_MAX_CHUNKS - 1) / EPI_MAX_CHUNKS;
+    return t < 16 ? 16 : (t + 7) / 8 * 8;
+}
+
+// Epilogue, pass 1: one wave per (time chunk, b, h), lane = channel.  Everything here is independent across steps
+// except Z, a plain running sum over time of per-step terms -- so the time axis is cut into <= 64 chunks, a wave
+// leaves its chunk-LOCAL running sums in P's slots and its total in `tot`; pass 2 adds the totals of the earlier
+// chunks.  (The serial form -- one wave per (b, h) walking all T steps one load-latency at a time -- took 290 us for
+// 32 x 500 steps; the loads of a group of steps are now in flight together.)
 template <typename ET>
 __global__ __launch_bounds__(64) void wkv6_bwd_epilogue_kernel(const EpiParams p) {
     using E = Elem<ET>;
-    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int lane = threadIdx.x;
     const int T = p.T, C = p.C;
     const size_t base = (size_t)b * T * C + (size_t)h * N + lane;
     const ET *r = (const ET *)p.r + base, *k = (const ET *)p.k + base, *v = (const ET *)p.v + base;
-    const ET *w = (const ET *)p.w + base, *gy = (const ET *)p.gy + base;
-    const float *P = p.P + base, *Q = p.Q + base;
-    ET *gr = (ET *)p.gr + base, *gk = (ET *)p.gk + base, *gw = (ET *)p.gw + base;
+    const ET *gy = (const ET *)p.gy + base;
+    float *P = p.P + base;
+    const float *Q = p.Q + base;
+    ET *gr = (ET *)p.gr + base, *gk = (ET *)p.gk + base;
     const float u = E::load((const ET *)p.u + h * N + lane);
-
-    float gu = 0.f, Z = 0.f;
-    float k_prev = 0.f, v_prev = 0.f, q_prev = 0.f;
     auto at = [&](int s) { return (size_t)(p.reverse ? (T - 1 - s) : s) * C; };
-    // software pipeline: values of step s+1 are loaded while step s is reduced
-    float nr = E::load(r + at(0)), nk = E::load(k + at(0)), nv = E::load(v + at(0)), nw = E::load(w + at(0));
-    float ng = E::load(gy + at(0)), nP = P[at(0)], nQ = Q[at(0)];
-    for (int s = 0; s < T; ++s) {
-        const float rr = nr, kk = nk, vv = nv, ww = nw, gg = ng, Ps = nP, Qs = nQ;
-        const size_t o = at(s);
-        if (s + 1 < T) {
-            const size_t n = at(s + 1);
-            nr = E::load(r + n); nk = E::load(k + n); nv = E::load(v + n); nw = E::load(w + n);
-            ng = E::load(gy + n); nP = P[n]; nQ = Q[n];
-        }
-        const float c = wave_sum(vv * gg);
-        const float e = wave_sum(v_prev * gg);
-        E::store(gr + o, fmaf(u * kk, c, Ps));
-        E::store(gk + o, fmaf(u * rr, c, Qs));
-        gu = fmaf(rr * kk, c, gu);
-        if (s > 0) Z += k_prev * (q_prev - rr * e) - rr * (Ps - k_prev * e);
-        const float gwv = (s == 0 || s == T - 1) ? 0.f : Z * -__expf(ww);
-        E::store(gw + o, gwv);
-        k_prev = kk; v_prev = vv; q_prev = Qs;
+    const int s0 = blockIdx.x * p.TCH, s1 = min(T, s0 + p.TCH);
+
+    float gu = 0.f, Z = 0.f, k_prev = 0.f, v_prev = 0.f, q_prev = 0.f;
+    if (s0 > 0 && s0 < T) {
+        const size_t o = at(s0 - 1);
+        k_prev = E::load(k + o); v_prev = E::load(v + o); q_prev = Q[o];
     }
-    E::store((ET *)p.gu + (size_t)b * C + h * N + lane, gu);
+    constexpr int U = 4;
+    for (int sb = s0; sb < s1; sb += U) {
+        float rr[U], kk[U], vv[U], gg[U], Ps[U], Qs[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const size_t o = at(min(sb + i, s1 - 1));
+            rr[i] = E::load(r + o); kk[i] = E::load(k + o); vv[i] = E::load(v + o); gg[i] = E::load(gy + o);
+            Ps[i] = P[o]; Qs[i] = Q[o];
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int s = sb + i;
+            if (s < s1) {       // wave-uniform
+                const size_t o = at(s);
+                const float c = wave_sum(vv[i] * gg[i]);
+                const float e = wave_sum(v_prev * gg[i]);
+                E::store(gr + o, fmaf(u * kk[i], c, Ps[i]));
+                E::store(gk + o, fmaf(u * rr[i], c, Qs[i]));
+                gu = fmaf(rr[i] * kk[i], c, gu);
+                if (s > 0) Z += k_prev * (q_prev - rr[i] * e) - rr[i] * (Ps[i] - k_prev * e);
+                P[o] = Z;
+                k_prev = kk[i]; v_prev = vv[i]; q_prev = Qs[i];
+            }
+        }
+    }
+    const size_t slot = ((size_t)blockIdx.y * p.NE + blockIdx.x) * N + lane;
+    p.tot[slot] = Z;
+    p.gup[slot] = gu;
+}
+
+// Epilogue, pass 2: gw_t = (sum of the earlier chunks' totals + local running sum) * (-exp(w_t)); gu summed over chunks.
+template <typename ET>
+__global__ __launch_bounds__(64) void wkv6_bwd_gw_kernel(const EpiParams p) {
+    using E = Elem<ET>;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int lane = threadIdx.x;
+    const int T = p.T, C = p.C;
+    const size_t base = (size_t)b * T * C + (size_t)h * N + lane;
+    const ET *w = (const ET *)p.w + base;
+    const float *Zl = p.P + base;
+    ET *gw = (ET *)p.gw + base;
+    auto at = [&](int s) { return (size_t)(p.reverse ? (T - 1 - s) : s) * C; };
+    const int s0 = blockIdx.x * p.TCH, s1 = min(T, s0 + p.TCH);
+    const float *tot = p.tot + (size_t)blockIdx.y * p.NE * N + lane;
+    float off = 0.f;
+    for (int c = 0; c < (int)blockIdx.x; ++c) off += tot[(size_t)c * N];
+    if (blockIdx.x == 0) {
+        const float *gp = p.gup + (size_t)blockIdx.y * p.NE * N + lane;
+        float g = 0.f;
+        for (int c = 0; c < p.NE; ++c) g += gp[(size_t)c * N];
+        E::store((ET *)p.gu + (size_t)b * C + h * N + lane, g);
+    }
+    constexpr int U = 8;
+    for (int sb = s0; sb < s1; sb += U) {
+        float ww[U], zz[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const size_t o = at(min(sb + i, s1 - 1));
+            ww[i] = E::load(w + o); zz[i] = Zl[o];
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int s = sb + i;
+            if (s < s1) E::store(gw + at(s), (s == 0 || s == T - 1) ? 0.f : (off + zz[i]) * -__expf(ww[i]));
+        }
+    }
 }
 
 size_t bwd_ws_bytes(int B, int T, int C, int H, int L) {
     size_t n = 2 * (size_t)B * T * C;                      // P, Q
+    n += 2 * (size_t)B * H * EPI_MAX_CHUNKS * N;           // epilogue: per-chunk totals (gw recursion, gu)
     if (L < T) {
         const size_t NC = (T + L - 1) / L;
         n += 2 * (size_t)B * H * NC * (N * N + N);          // chunk states + decays of S and G
@@ -558,8 +620,12 @@ int launch_bwd(int B, int T, int C, int H, const void *r, const void *k, const v
     const int rev = reverse ? 1 : 0;
     const int NC = (T + L - 1) / L;
     float *P = ws, *Q = P + (size_t)B * T * C;
-    float *ws_state = Q + (size_t)B * T * C;
+    float *tot = Q + (size_t)B * T * C, *gup = tot + (size_t)B * H * EPI_MAX_CHUNKS * N;
+    float *ws_state = gup + (size_t)B * H * EPI_MAX_CHUNKS * N;
     float *ws_decay = ws_state + 2 * (size_t)B * H * NC * (N * N);
+    // the matrix-core forward kernels want 16-byte aligned operands (forward_impl checks the same)
+    const bool mfma = use_mfma() &&
+                      ((((uintptr_t)r | (uintptr_t)k | (uintptr_t)v | (uintptr_t)w | (uintptr_t)gy | (uintptr_t)gv) & 15) == 0);
     // dir 0: S from (k, v, w) in forward time; dir 1: G from (r, gy, w) in reverse time, whose pass C is gv
     FwdParams fp{};
     fp.d[0] = DirArgs{k, k, v, w, u, gv, nullptr, nullptr, rev, nullptr};            // r, y unused by pass A
@@ -568,14 +634,16 @@ int launch_bwd(int B, int T, int C, int H, const void *r, const void *k, const v
     fp.nc_local = NC - 1;
     fp.ws_state = ws_state; fp.ws_decay = ws_decay;
     if (NC > 1) {
-        hipLaunchKernelGGL((wkv6_chunk_kernel<ET, false>), dim3(NC - 1, B * H, 2), dim3(64), 0, stream, fp);
+        if (mfma) hipLaunchKernelGGL((wkv6_mfma_kernel<ET, false>), dim3(NC - 1, B * H, 2), dim3(64), 0, stream, fp);
+        else hipLaunchKernelGGL((wkv6_chunk_kernel<ET, false>), dim3(NC - 1, B * H, 2), dim3(64), 0, stream, fp);
         hipLaunchKernelGGL(wkv6_scan_kernel, dim3(16, B * H, 2), dim3(256), 0, stream, fp);
     }
     FwdParams fg = fp;  // pass C for direction 1 only: present it as direction 0 of a one-direction launch
     fg.d[0] = fp.d[1];
     fg.ws_state = ws_state + (size_t)B * H * NC * (N * N);
     fg.ws_decay = ws_decay + (size_t)B * H * NC * N;
-    hipLaunchKernelGGL((wkv6_chunk_kernel<ET, true>), dim3(NC, B * H, 1), dim3(64), 0, stream, fg);
+    if (mfma) hipLaunchKernelGGL((wkv6_mfma_kernel<ET, true>), dim3(NC, B * H, 1), dim3(64), 0, stream, fg);
+    else hipLaunchKernelGGL((wkv6_chunk_kernel<ET, true>), dim3(NC, B * H, 1), dim3(64), 0, stream, fg);
 
     RowParams rp{};
     rp.d[0] = RowArgs{k, v, gy, w, P, rev};
@@ -584,8 +652,11 @@ int launch_bwd(int B, int T, int C, int H, const void *r, const void *k, const v
     rp.ws_state = ws_state;
     hipLaunchKernelGGL(wkv6_row_kernel<ET>, dim3(NC, B * H, 2), dim3(64), 0, stream, rp);
 
-    EpiParams ep{r, k, v, w, u, gy, P, Q, gr, gk, gw, gu, B, T, C, H, rev};
-    hipLaunchKernelGGL(wkv6_bwd_epilogue_kernel<ET>, dim3(B * H), dim3(64), 0, stream, ep);
+    EpiParams ep{r, k, v, w, u, gy, P, Q, gr, gk, gw, gu, tot, gup, B, T, C, H, rev, 0, 0};
+    ep.TCH = epi_chunk_steps(T);
+    ep.NE = (T + ep.TCH - 1) / ep.TCH;
+    hipLaunchKernelGGL(wkv6_bwd_epilogue_kernel<ET>, dim3(ep.NE, B * H), dim3(64), 0, stream, ep);
+    hipLaunchKernelGGL(wkv6_bwd_gw_kernel<ET>, dim3(ep.NE, B * H), dim3(64), 0, stream, ep);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 

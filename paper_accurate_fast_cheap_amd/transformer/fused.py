@@ -214,9 +214,10 @@ def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optio
 
 
 def carry_eligible(layer: nn.Module, x: torch.Tensor) -> bool:
-    """State-carrying chunk step through the fused kernels: uni-directional bf16 slot, one stream (B = 1), causal conv."""
+    """State-carrying chunk step through the fused kernels: uni-directional bf16 slot, causal conv; B concurrent streams
+    of equal chunk length (B = 1 is the reference's forward_chunk contract, B > 1 is B independent streams per step)."""
     cm = layer.conv_module
-    return (cm is not None and type(layer.self_attn) is RWKV_TmixWrapper and x.shape[0] == 1 and layer.normalize_before
+    return (cm is not None and type(layer.self_attn) is RWKV_TmixWrapper and layer.normalize_before
             and layer.feed_forward_macaron is not None and cm.use_layer_norm and cm.lorder > 0
             and isinstance(cm.activation, nn.SiLU) and isinstance(layer.feed_forward.activation, nn.SiLU)
             and isinstance(layer.feed_forward_macaron.activation, nn.SiLU) and cm.kernel_size <= 31
@@ -225,41 +226,46 @@ def carry_eligible(layer: nn.Module, x: torch.Tensor) -> bool:
 
 
 def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict]) -> Tuple[torch.Tensor, dict]:
-    """ConformerEncoderLayer.forward_carry (one chunk with recurrent-state carry) on the fused kernels, B = 1, bf16:
-    the same carries -- "shift" (1, 1, C) last normalised frame, "wkv" float32 (1, H, N, N), "cnn" (1, C, lorder) --
+    """ConformerEncoderLayer.forward_carry (one chunk with recurrent-state carry) on the fused kernels, bf16, B streams:
+    the same carries -- "shift" (B, 1, C) last normalised frame, "wkv" float32 (B, H, N, N), "cnn" (B, C, lorder) --
     and the same arithmetic as the module path; ~25 launches instead of ~50.  The previous frame is prepended to the
     slot input so that the token shift of the chunk's first frame sees it; that extra frame's own outputs are dropped
     before the scan, which starts from the carried state."""
     L = plan.layer
     carry = carry or {}
     B, T, C = x.shape
-    M = T
+    M = B * T
+    x = x.contiguous()
     _, h0, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff_macaron.weight, L.norm_ff_macaron.bias, want_x=False)
     x = _ffn_residual(L.feed_forward_macaron, h0, x, L.ff_scale, plan.b2_macaron, inplace=False)
     _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_mha.weight, L.norm_mha.bias, want_x=False)
     shift = carry.get("shift")
     if shift is None:
-        shift = h.new_zeros(1, 1, C)
-    hx = torch.cat([shift.to(h.dtype), h], dim=1)                                            # (1, T + 1, C)
+        shift = h.new_zeros(B, 1, C)
+    hx = torch.cat([shift.to(h.dtype), h], dim=1)                                            # (B, T + 1, C)
+    M1 = B * (T + 1)
     xxx = hip_ops.tmix_shift_mix(hx, plan.maa_x[0], None)
-    t = hip_ops.gemm_bf16(xxx.view(1, M + 1, C), plan.W1n, act="tanh")
-    z = hip_ops.tmix_lora_mix4(hx, t, plan.W2t, plan.maa4)                                    # (4, 1, M + 1, C)
-    rkv = torch.bmm(z[:3].view(3, M + 1, C), plan.Wrkv)
-    w = torch.bmm(hip_ops.gemm_bf16(z[3], plan.D1n, act="tanh"), plan.D2) + plan.time_decay
-    y, s_out = wkv6_forward(rkv[0, 1:].view(1, T, C), rkv[1, 1:].view(1, T, C), rkv[2, 1:].view(1, T, C),
-                            w[0, 1:].view(1, T, C), plan.u[0], s_in=carry.get("wkv"), want_state=True)
+    t = hip_ops.gemm_bf16(xxx.view(1, M1, C), plan.W1n, act="tanh")
+    z = hip_ops.tmix_lora_mix4(hx, t, plan.W2t, plan.maa4)                                    # (4, 1, B, T + 1, C)
+    rkv = torch.bmm(z[:3].view(3, M1, C), plan.Wrkv).view(3, B, T + 1, C)
+    w = (torch.bmm(hip_ops.gemm_bf16(z[3].view(1, M1, C), plan.D1n, act="tanh"), plan.D2) + plan.time_decay).view(B, T + 1, C)
+    if B == 1:
+        r_, k_, v_, w_ = rkv[0, :, 1:], rkv[1, :, 1:], rkv[2, :, 1:], w[:, 1:]                # contiguous views
+    else:
+        r_, k_, v_, w_ = (a[:, 1:].contiguous() for a in (rkv[0], rkv[1], rkv[2], w))
+    y, s_out = wkv6_forward(r_, k_, v_, w_, plan.u[0], s_in=carry.get("wkv"), want_state=True)
     ln = plan.blocks[0].ln_x
     _, yn, _ = hip_ops.add_layernorm(y.view(M, C), None, 1.0, ln.weight, ln.bias, eps=ln.eps, want_x=False)
-    x = hip_ops.linear_bias_act(yn, plan.Wo, None, "none", residual=x.view(M, C), inplace=True).view(1, T, C)
+    x = hip_ops.linear_bias_act(yn, plan.Wo, None, "none", residual=x.view(M, C), inplace=True).view(B, T, C)
     new = {"shift": h[:, -1:].clone(), "wkv": s_out}
     cm = L.conv_module
     _, hc, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_conv.weight, L.norm_conv.bias, want_x=False)
     cnn = carry.get("cnn")
-    left = cnn.transpose(1, 2).to(hc.dtype) if cnn is not None and cnn.numel() > 0 else hc.new_zeros(1, cm.lorder, C)
-    cx = torch.cat([left, hc], dim=1)                                                         # (1, lorder + T, C)
+    left = cnn.transpose(1, 2).to(hc.dtype) if cnn is not None and cnn.numel() > 0 else hc.new_zeros(B, cm.lorder, C)
+    cx = torch.cat([left, hc], dim=1)                                                         # (B, lorder + T, C)
     new["cnn"] = cx[:, -cm.lorder:, :].transpose(1, 2)
     if plan.pw1_glu is not None:
-        p = hip_ops.gemm_bf16(cx.view(-1, C), plan.pw1_glu[0], plan.pw1_glu[1], act="glu").view(1, -1, C)
+        p = hip_ops.gemm_bf16(cx.view(-1, C), plan.pw1_glu[0], plan.pw1_glu[1], act="glu").view(B, -1, C)
         dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, 0, T)
     else:
         p = F.linear(cx, cm.pointwise_conv1.weight.squeeze(-1), cm.pointwise_conv1.bias)

@@ -294,6 +294,40 @@ def test_fused_state_carry_step_matches_module_path(hip):
     torch.testing.assert_close(st_f[0]["cnn"].float(), st_m[0]["cnn"].float(), rtol=5e-2, atol=5e-2)
 
 
+def test_fused_state_carry_step_serves_concurrent_streams(hip):
+    """B independent streams per chunk step (the serving shape): stream b of a batched run equals the same stream run
+    alone -- the carries are per stream, nothing leaks across the batch -- eagerly and from the replayed hipGraph."""
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_reduced_uni_bf16model")
+    conf = dict(g["conf"], causal=True, cnn_module_kernel=15)
+    torch.manual_seed(6)
+    enc = ConformerEncoder(80, **conf)
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.05)
+    enc = enc.to(torch.bfloat16).cuda().eval()
+    xs = synth.randn((3, 4 * 8 * 9 + 3, 80), 80, 2.0).to(torch.bfloat16).cuda()
+    with torch.no_grad():
+        both = enc.stream_chunks(xs, 8, use_graph=False)
+        assert getattr(enc, "_carry_plans", None) is not None
+        _, st = enc.forward_chunk_carry(xs[:, :35], 0, None)
+        assert st[0]["wkv"].shape[0] == 3 and st[0]["shift"].shape == (3, 1, enc.output_size())
+        assert st[0]["cnn"].shape[0] == 3
+        graphed = enc.stream_chunks(xs, 8, use_graph=True)
+        for b in range(3):
+            alone = enc.stream_chunks(xs[b:b + 1].contiguous(), 8, use_graph=False)
+            # same kernels on the same rows; only the GEMM tile a row lands in differs with the batch
+            d = (both[b:b + 1].float() - alone.float()).abs()
+            assert float(d.mean()) < 5e-3 and float(d.max()) < 0.15, (b, float(d.mean()), float(d.max()))
+        d = (both.float() - graphed.float()).abs()
+        assert float(d.mean()) < 5e-3 and float(d.max()) < 0.15
+        enc.fused_inference = False
+        module = enc.stream_chunks(xs, 8, use_graph=False)
+    d = (both.float() - module.float()).abs()
+    assert float(d.mean()) < 2e-2 and float(d.max()) < 0.4
+
+
 def test_graph_cache_replays_recurring_batch_shapes(hip):
     """Opt-in hipGraph cache (encoder.graph_cache_size): the third batch of a shape is replayed from the graph captured
     at the second; outputs and masks equal the eager forward (fp32 round-off: the GEMM library may pick differently

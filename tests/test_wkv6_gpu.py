@@ -102,7 +102,7 @@ def test_errors_are_reported_not_asserted(hip):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,T,C,H,chunk", [(1, 1, 64, 1, 0), (2, 2, 64, 1, 0), (2, 3, 128, 2, 0), (2, 37, 128, 2, 8),
                                             (3, 100, 192, 3, 16), (2, 257, 512, 8, 64), (1, 499, 512, 8, 0),
-                                            (1, 499, 512, 8, 10 ** 6)])
+                                            (1, 499, 512, 8, 10 ** 6), (1, 1500, 128, 2, 0)])
 def test_backward_matches_oracle(hip, dtype, B, T, C, H, chunk):
     """gr, gk, gv, gw, gu vs the C restatement of kernel_backward_101/102/103/201."""
     from paper_accurate_fast_cheap_amd.rwkv_v6.wkv6_op import wkv6_backward
@@ -118,10 +118,11 @@ def test_backward_matches_oracle(hip, dtype, B, T, C, H, chunk):
         assert err <= tol, f"{name}: err {err:.3e} scale {scale:.3e}"
 
 
-def test_backward_reverse_direction_and_autograd(hip):
+@pytest.mark.parametrize("T", [61, 1100])      # 1100: the epilogue's time chunks are longer than its minimum
+def test_backward_reverse_direction_and_autograd(hip, T):
     """reverse=True gradients == gradients of the flipped problem; and autograd through the op equals the oracle."""
     from paper_accurate_fast_cheap_amd.rwkv_v6.wkv6_op import wkv6, wkv6_backward
-    B, T, C, H = 2, 61, 128, 2
+    B, C, H = 2, 128, 2
     a = _inputs(B, T, C, H, 3000, torch.float32)
     gy = synth.randn((B, T, C), 3001)
     flip = lambda t: t.flip(1).contiguous()
