@@ -93,6 +93,97 @@ def depthwise_conv1d_cl_autograd(x: torch.Tensor, weight: torch.Tensor, bias: Op
     return _DepthwiseConvCL.apply(x.contiguous(), w, b, left_pad, out_len)
 
 
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """dw (M, N) = dy^T @ x for dy (R, M), x (R, N) bf16 with unit column stride: nn.Linear's weight gradient."""
+    if not (dy.is_cuda and x.is_cuda):
+        raise _lib.PafcError("gemm_tn runs on the MI355X only; there is no CPU fallback")
+    R, M = dy.shape
+    N = x.shape[1]
+    if (dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or x.shape[0] != R or dy.stride(1) != 1
+            or x.stride(1) != 1 or out_dtype not in (torch.float32, torch.bfloat16)):
+        raise _lib.PafcError("gemm_tn: dy (R, M) and x (R, N) bf16 with unit column stride; fp32 or bf16 output")
+    L = _lib.lib()
+    if not getattr(L, "_pafc_tn_bound", False):
+        from ctypes import c_long, c_size_t
+        L.pafc_gemm_tn_workspace_bytes.restype = c_size_t
+        L.pafc_gemm_tn_workspace_bytes.argtypes = [c_long, c_int, c_int]
+        _lib._sig(L.pafc_gemm_tn_bf16, c_int, c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int,
+                  c_void_p, c_size_t, c_void_p)
+        L._pafc_tn_bound = True
+    nbytes = L.pafc_gemm_tn_workspace_bytes(R, M, N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    dw = torch.empty(M, N, dtype=out_dtype, device=dy.device)
+    rc = L.pafc_gemm_tn_bf16(R, M, N, _lib.ptr(dy), dy.stride(0), _lib.ptr(x), x.stride(0), _lib.ptr(dw),
+                             _lib.dtype_code(out_dtype), _lib.ptr(ws), nbytes, _lib.stream_of(dy))
+    _lib.check(rc, "pafc_gemm_tn_bf16")
+    return dw
+
+
+class _LinearTrainBf16(torch.autograd.Function):
+    """nn.Linear for the bf16 training step: forward and input gradient through the library GEMM, the weight gradient
+    through gemm_tn (the library's pick for that layout runs at 5 % of the matrix peak), straight into the weight's
+    dtype -- fp32 master weights receive the fp32 sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        wb = weight if weight.dtype == torch.bfloat16 else weight.to(torch.bfloat16)
+        bb = None if bias is None else (bias if bias.dtype == torch.bfloat16 else bias.to(torch.bfloat16))
+        ctx.save_for_backward(x, wb)
+        ctx.w_dtype = weight.dtype
+        ctx.b_dtype = None if bias is None else bias.dtype
+        return torch.nn.functional.linear(x, wb, bb)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wb = ctx.saved_tensors
+        N, K = wb.shape
+        dy2 = dy.reshape(-1, N)
+        if dy2.stride(1) != 1 or dy2.stride(0) % 8 or dy2.data_ptr() % 16:
+            dy2 = dy2.contiguous()
+        x2 = x.reshape(-1, K)
+        if x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ wb).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = gemm_tn(dy2, x2, ctx.w_dtype if ctx.w_dtype in (torch.float32, torch.bfloat16) else torch.float32)
+            dw = dw.to(ctx.w_dtype)
+        if ctx.b_dtype is not None and ctx.needs_input_grad[2]:
+            db = dy2.sum(0, dtype=torch.float32).to(ctx.b_dtype)
+        return dx, dw, db
+
+
+def linear_train_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """bf16 activations on the GPU under autograd (autocast(bfloat16) over fp32 master weights, or a bf16 module such
+    as the time-mix slot), dims the kernel takes."""
+    if not (x.is_cuda and torch.is_grad_enabled() and weight.requires_grad and weight.dim() == 2):
+        return False
+    if weight.shape[0] % 8 or weight.shape[1] % 8 or x.numel() // max(1, x.shape[-1]) < 256:
+        return False
+    if weight.numel() > 2048 * 1024:      # many output tiles already fill the chip: the library's kernel is as good
+        return False
+    if x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16:
+        return True
+    return (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            and x.dtype in (torch.bfloat16, torch.float32) and weight.dtype in (torch.float32, torch.bfloat16))
+
+
+def linear_train(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """F.linear whose weight gradient goes through the hand-written kernel (see linear_train_eligible)."""
+    if x.dtype != torch.bfloat16:
+        x = x.to(torch.bfloat16)          # what autocast does to F.linear's input
+    return _LinearTrainBf16.apply(x, weight, bias)
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """The projections of the encoder layer as the modules call them: F.linear, except in the bf16 training step, where
+    the weight gradient takes the hand-written kernel (linear_train)."""
+    if linear_train_eligible(x, weight):
+        return linear_train(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 def _bind2():
     L = _bind()
     if getattr(L, "_pafc_glue_bound", False):

@@ -74,16 +74,25 @@ class RWKV_Tmix_x060c(nn.Module):
         xxx = torch.tanh(xxx @ self.time_maa_rkvw_w1).view(B * T, 4, -1).transpose(0, 1)
         xxx = torch.bmm(xxx, self.time_maa_rkvw_w2).view(4, B, T, C)
         mr, mk, mv, mw = xxx.unbind(dim=0)
-        r = self.receptance(x + xx * (self.time_maa_r + mr))
-        k = self.key(x + xx * (self.time_maa_k + mk))
-        v = self.value(x + xx * (self.time_maa_v + mv))
+        lin = self._linear(x)
+        r = lin(x + xx * (self.time_maa_r + mr), self.receptance.weight, None)
+        k = lin(x + xx * (self.time_maa_k + mk), self.key.weight, None)
+        v = lin(x + xx * (self.time_maa_v + mv), self.value.weight, None)
         w = x + xx * (self.time_maa_w + mw)
         w = self.time_decay + torch.tanh(w @ self.time_decay_w1) @ self.time_decay_w2
         return r.contiguous(), k.contiguous(), v.contiguous(), w.contiguous()
 
     def finish(self, y: torch.Tensor) -> torch.Tensor:
         """model.py:323-324: LayerNorm over all C channels (not per head), output projection."""
-        return self.output(self.ln_x(y))
+        return self._linear(y)(self.ln_x(y), self.output.weight, None)
+
+    @staticmethod
+    def _linear(x: torch.Tensor):
+        """F.linear; in the GPU training step the variant whose weight gradient runs on the hand-written kernel."""
+        if x.is_cuda and torch.is_grad_enabled():
+            from ..hip_ops import linear
+            return linear
+        return F.linear
 
     def forward(self, x: torch.Tensor, reverse: bool = False) -> torch.Tensor:
         r, k, v, w = self.mix_project(x, reverse)

@@ -40,7 +40,7 @@ class ConvolutionModule(nn.Module):
     def forward(self, x: torch.Tensor, mask_pad: torch.Tensor = torch.ones((0, 0, 0), dtype=torch.bool),
                 cache: torch.Tensor = torch.zeros((0, 0, 0))) -> Tuple[torch.Tensor, torch.Tensor]:
         """x (B, T, C), mask_pad (B, 1, T) or (0,0,0), cache (B, C, lorder) for causal -> (B, T, C), new_cache."""
-        from ..hip_ops import depthwise_conv1d_cl, depthwise_conv1d_cl_autograd
+        from ..hip_ops import depthwise_conv1d_cl, depthwise_conv1d_cl_autograd, linear
         keep = mask_pad.transpose(1, 2) if mask_pad.size(2) > 0 else None  # (B, T, 1)
         if keep is not None:
             x = x.masked_fill(~keep, 0.0)
@@ -52,7 +52,7 @@ class ConvolutionModule(nn.Module):
             new_cache = x[:, -self.lorder:, :].transpose(1, 2)
         else:
             new_cache = torch.zeros((0, 0, 0), dtype=x.dtype, device=x.device)
-        x = F.linear(x, self.pointwise_conv1.weight.squeeze(-1), self.pointwise_conv1.bias)
+        x = linear(x, self.pointwise_conv1.weight.squeeze(-1), self.pointwise_conv1.bias)
         x = F.glu(x, dim=-1)
         lp = 0 if self.lorder > 0 else (self.kernel_size - 1) // 2
         out_len = x.size(1) - self.lorder if self.lorder > 0 else x.size(1)
@@ -64,7 +64,7 @@ class ConvolutionModule(nn.Module):
             x = self.activation(self.norm(x))
         else:
             x = self.activation(self.norm(x.transpose(1, 2)).transpose(1, 2))
-        x = F.linear(x, self.pointwise_conv2.weight.squeeze(-1), self.pointwise_conv2.bias)
+        x = linear(x, self.pointwise_conv2.weight.squeeze(-1), self.pointwise_conv2.bias)
         if keep is not None:
             x = x.masked_fill(~keep, 0.0)
         return x, new_cache

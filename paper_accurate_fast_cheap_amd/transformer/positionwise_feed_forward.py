@@ -13,4 +13,8 @@ class PositionwiseFeedForward(torch.nn.Module):
         self.w_2 = torch.nn.Linear(hidden_units, idim, bias=bias)
 
     def forward(self, xs: torch.Tensor) -> torch.Tensor:
+        if xs.is_cuda and torch.is_grad_enabled():      # training on the GPU: weight gradients through gemm_tn
+            from ..hip_ops import linear
+            h = self.dropout(self.activation(linear(xs, self.w_1.weight, self.w_1.bias)))
+            return linear(h, self.w_2.weight, self.w_2.bias)
         return self.w_2(self.dropout(self.activation(self.w_1(xs))))

@@ -253,3 +253,64 @@ def test_conv_sub_f32split_matches_fp32_convolutions(hip, B, T, Fd, C):
     fw = F.relu(F.conv2d(F.relu(F.conv2d(x.cuda().unsqueeze(1), w1.cuda(), b1.cuda(), stride=2)), w2.cuda(), b2.cuda(),
                          stride=2)).permute(0, 2, 3, 1).cpu()
     assert float((got - want).abs().max()) <= 30 * max(float((fw - want).abs().max()), 1e-7 * scale)
+
+
+@pytest.mark.parametrize("R,M,N", [(64, 128, 128), (1, 8, 8), (63, 136, 72), (1000, 512, 512), (4097, 2048, 512),
+                                   (16000, 512, 2048), (300, 5000, 512)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_gemm_tn_weight_gradient(hip, R, M, N, out_dtype):
+    """dw = dy^T x (nn.Linear's weight gradient): every tile / split / ragged-R / ragged-column path against a float64
+    product of the same bf16 operands; the fp32 result carries no bf16 rounding."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_tn
+    dy = synth.randn((R, M), 11, 1.0).to(torch.bfloat16)
+    x = synth.randn((R, N), 12, 1.0).to(torch.bfloat16)
+    ref = dy.double().t() @ x.double()
+    got = gemm_tn(dy.cuda(), x.cuda(), out_dtype).cpu()
+    assert got.dtype == out_dtype and got.shape == (M, N)
+    scale = float(ref.abs().max())
+    tol = 2e-5 * scale * max(1.0, (R / 1000) ** 0.5) if out_dtype == torch.float32 else 2 ** -7 * scale
+    assert float((got.double() - ref).abs().max()) <= tol
+
+
+def test_gemm_tn_strided_operands_and_determinism(hip):
+    """Column slices of wider activations (row stride > width) and bit-identical repeats (fixed summation order)."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_tn
+    wide_a = synth.randn((777, 1024), 13, 1.0).to(torch.bfloat16).cuda()
+    wide_b = synth.randn((777, 640), 14, 1.0).to(torch.bfloat16).cuda()
+    dy, x = wide_a[:, 256:768], wide_b[:, 64:576]
+    a = gemm_tn(dy, x)
+    b = gemm_tn(dy, x)
+    assert torch.equal(a, b)
+    ref = dy.double().t() @ x.double()
+    assert float((a.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_linear_train_matches_autograd(hip):
+    """The training Linear (library forward / dgrad, hand-written wgrad): fp32 master weights under bf16 autocast and a
+    bf16 module, against float64 autograd on the same rounded operands."""
+    from paper_accurate_fast_cheap_amd.hip_ops import linear_train, linear_train_eligible
+    x = synth.randn((4, 300, 512), 15, 1.0).cuda().requires_grad_()
+    w = synth.randn((2048, 512), 16, 0.05).cuda().requires_grad_()
+    b = synth.randn((2048,), 17, 0.1).cuda().requires_grad_()
+    gy = synth.randn((4, 300, 2048), 18, 1.0).cuda()
+    assert not linear_train_eligible(x, w)                      # fp32 outside autocast: not this path
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert linear_train_eligible(x, w)
+        y = linear_train(x, w, b)
+    y.backward(gy.to(y.dtype))
+    assert y.dtype == torch.bfloat16 and w.grad.dtype == torch.float32 and x.grad.dtype == torch.float32
+    xr = x.detach().to(torch.bfloat16).double().cpu().requires_grad_()
+    wr = w.detach().to(torch.bfloat16).double().cpu().requires_grad_()
+    br = b.detach().to(torch.bfloat16).double().cpu().requires_grad_()
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(gy.to(torch.bfloat16).double().cpu())
+    assert float((y.double().cpu() - yr).abs().max()) <= 2 ** -7 * float(yr.abs().max())
+    assert float((w.grad.double().cpu() - wr.grad).abs().max()) <= 1e-4 * float(wr.grad.abs().max())
+    assert float((b.grad.double().cpu() - br.grad).abs().max()) <= 1e-4 * float(br.grad.abs().max())
+    assert float((x.grad.double().cpu() - xr.grad).abs().max()) <= 2 ** -6 * float(xr.grad.abs().max())
+    xb = x.detach().to(torch.bfloat16).requires_grad_()
+    wb = w.detach().to(torch.bfloat16).requires_grad_()
+    assert linear_train_eligible(xb, wb)
+    linear_train(xb, wb, None).backward(gy.to(torch.bfloat16))
+    assert wb.grad.dtype == torch.bfloat16
+    assert float((wb.grad.double().cpu() - wr.grad).abs().max()) <= 2 ** -7 * float(wr.grad.abs().max())
