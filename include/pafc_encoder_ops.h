@@ -113,12 +113,13 @@ int pafc_conv3x3s2_nhwc_f32split(int B, int T1, int F1, int Ci, int Co, const vo
  * computes as grad_output^T @ input for every projection of the encoder layer (positionwise_feed_forward.py:47-55,
  * convolution.py:118-141, rwkv_v6/src/model.py:286-324 under train_utils.py:646-660).  dy: (R, M) and x: (R, N) bf16,
  * row strides lda / ldb elements (multiples of 8), R = batch x time; M, N multiples of 8.  dw: (M, N) contiguous in
- * dw_dtype (PAFC_F32: fp32 master weights get the fp32 sum, no intermediate bf16 rounding; PAFC_BF16).  The R axis is
- * split over several blocks per output tile and the partial tiles are added in a fixed order (deterministic).
+ * dw_dtype (PAFC_F32: fp32 master weights get the fp32 sum, no intermediate bf16 rounding; PAFC_BF16).  dbias: (M) in
+ * dw_dtype or NULL -- the bias gradient sum_r dy[r][m], from the same pass over dy.  The R axis is split over several
+ * blocks per output tile and the partial tiles are added in a fixed order (deterministic).
  * workspace: pafc_gemm_tn_workspace_bytes(R, M, N) bytes, 16-byte aligned like dy, x and dw. */
 size_t pafc_gemm_tn_workspace_bytes(long R, int M, int N);
-int pafc_gemm_tn_bf16(long R, int M, int N, const void *dy, long lda, const void *x, long ldb, void *dw, int dw_dtype,
-                      void *workspace, size_t workspace_bytes, pafc_stream_t stream);
+int pafc_gemm_tn_bf16(long R, int M, int N, const void *dy, long lda, const void *x, long ldb, void *dw, void *dbias,
+                      int dw_dtype, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
 
 /* out (rows, N) = act(alpha * x (rows, K) . weight (N, K)^T + residual (rows, N) + bias (N)) as one hipBLASLt GEMM
  * with a fused epilogue; act 0 = identity, 1 = SiLU; bias and residual may be NULL; residual may alias out; bias is

@@ -32,6 +32,7 @@ typedef short s16x8t __attribute__((ext_vector_type(8)));
 struct TnParams {
     const bf16_t *A, *B;     // dY (R, M) with row stride lda; X (R, N) with row stride ldb
     float *part;             // (S, M, N) fp32
+    float *bias_part;        // (S, M) fp32 column sums of dY (the bias gradient), or null
     long R, lda, ldb, rows_per_split;
     int M, N, mtiles, ntiles, S;
 };
@@ -84,6 +85,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4t{0.f, 0.f, 0.f, 0.f};
+    // bias gradient = column sums of dY: one more MFMA per dY operand against a block of ones, in the blocks of the
+    // first N-tile only (wave column 0), instead of a separate reduction pass over dY
+    const bool want_bias = p.bias_part != nullptr && nt == 0 && wn == 0;   // wave-uniform
+    f32x4t accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = f32x4t{0.f, 0.f, 0.f, 0.f};
+    const s16x8t ones_bits = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+    const bf16x8t ones = __builtin_bit_cast(bf16x8t, ones_bits);
 
     // transposing reads: lane 4 q + pp of 16-lane group g supplies the address of row (8 g + 4 h + q), columns
     // 16 blk + 4 pp .. + 3 and receives column (lane & 15) of the four rows
@@ -128,7 +137,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (want_bias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+            }
         }
+    }
+    if (want_bias && (lane & 15) == 0) {   // all 16 columns of accb hold the same sums
+        float *bo = p.bias_part + (size_t)blockIdx.y * p.M;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + 4 * g + r;
+                if (m < p.M) bo[m] = accb[i][r];
+            }
     }
 
     // C/D layout: column = lane & 15 (n), row = 4 (lane >> 4) + reg (m); 16 lanes write 64 contiguous bytes
@@ -182,20 +206,23 @@ extern "C" size_t pafc_gemm_tn_workspace_bytes(long R, int M, int N) {
     if (R <= 0 || M <= 0 || N <= 0) return 0;
     int S; long rps;
     pafc::plan(R, M, N, &S, &rps);
-    return (size_t)S * M * N * sizeof(float);
+    return (size_t)S * M * (N + 1) * sizeof(float);      // partial tiles + partial column sums
 }
 
 extern "C" int pafc_gemm_tn_bf16(long R, int M, int N, const void *dy, long lda, const void *x, long ldb, void *dw,
-                                 int dw_dtype, void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
+                                 void *dbias, int dw_dtype, void *workspace, size_t workspace_bytes,
+                                 pafc_stream_t stream) {
     if (!dy || !x || !dw || !workspace) return PAFC_ERR_NULL_POINTER;
     if (R <= 0 || M < 8 || N < 8 || (M % 8) || (N % 8) || lda < M || ldb < N || (lda % 8) || (ldb % 8))
         return PAFC_ERR_BAD_DIMS;
     if (dw_dtype != PAFC_F32 && dw_dtype != PAFC_BF16) return PAFC_ERR_DTYPE;
-    if ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dw | (uintptr_t)workspace) & 15) != 0) return PAFC_ERR_ALIGNMENT;
+    if ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dw | (uintptr_t)dbias | (uintptr_t)workspace) & 15) != 0)
+        return PAFC_ERR_ALIGNMENT;
     pafc::TnParams p{};
     pafc::plan(R, M, N, &p.S, &p.rows_per_split);
-    if (workspace_bytes < (size_t)p.S * M * N * sizeof(float)) return PAFC_ERR_WORKSPACE;
+    if (workspace_bytes < (size_t)p.S * M * (N + 1) * sizeof(float)) return PAFC_ERR_WORKSPACE;
     p.A = (const pafc::bf16_t *)dy; p.B = (const pafc::bf16_t *)x; p.part = (float *)workspace;
+    p.bias_part = dbias ? p.part + (size_t)p.S * M * N : nullptr;
     p.R = R; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N;
     p.mtiles = (M + pafc::TBM - 1) / pafc::TBM; p.ntiles = (N + pafc::TBN - 1) / pafc::TBN;
     if ((long)p.mtiles * p.ntiles > 2147483647L || p.S > 65535) return PAFC_ERR_BAD_DIMS;
@@ -209,5 +236,9 @@ extern "C" int pafc_gemm_tn_bf16(long R, int M, int N, const void *dy, long lda,
     hipLaunchKernelGGL(pafc::gemm_tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, n4, p.S, n4,
                        (const float4 *)workspace, dw_dtype == PAFC_F32 ? (float4 *)dw : nullptr,
                        dw_dtype == PAFC_BF16 ? (uint2 *)dw : nullptr);
+    if (dbias)
+        hipLaunchKernelGGL(pafc::gemm_tn_reduce_kernel, dim3((unsigned)((M / 4 + 255) / 256)), dim3(256), 0, s, (long)(M / 4),
+                           p.S, (long)(M / 4), (const float4 *)p.bias_part, dw_dtype == PAFC_F32 ? (float4 *)dbias : nullptr,
+                           dw_dtype == PAFC_BF16 ? (uint2 *)dbias : nullptr);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }

@@ -93,8 +93,9 @@ def depthwise_conv1d_cl_autograd(x: torch.Tensor, weight: torch.Tensor, bias: Op
     return _DepthwiseConvCL.apply(x.contiguous(), w, b, left_pad, out_len)
 
 
-def gemm_tn(dy: torch.Tensor, x: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
-    """dw (M, N) = dy^T @ x for dy (R, M), x (R, N) bf16 with unit column stride: nn.Linear's weight gradient."""
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, out_dtype: torch.dtype = torch.float32, want_bias: bool = False):
+    """dw (M, N) = dy^T @ x for dy (R, M), x (R, N) bf16 with unit column stride: nn.Linear's weight gradient;
+    with want_bias also db (M) = dy.sum(0) from the same pass -> (dw, db)."""
     if not (dy.is_cuda and x.is_cuda):
         raise _lib.PafcError("gemm_tn runs on the MI355X only; there is no CPU fallback")
     R, M = dy.shape
@@ -107,16 +108,17 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, out_dtype: torch.dtype = torch.fl
         from ctypes import c_long, c_size_t
         L.pafc_gemm_tn_workspace_bytes.restype = c_size_t
         L.pafc_gemm_tn_workspace_bytes.argtypes = [c_long, c_int, c_int]
-        _lib._sig(L.pafc_gemm_tn_bf16, c_int, c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int,
-                  c_void_p, c_size_t, c_void_p)
+        _lib._sig(L.pafc_gemm_tn_bf16, c_int, c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
+                  c_int, c_void_p, c_size_t, c_void_p)
         L._pafc_tn_bound = True
     nbytes = L.pafc_gemm_tn_workspace_bytes(R, M, N)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
     dw = torch.empty(M, N, dtype=out_dtype, device=dy.device)
-    rc = L.pafc_gemm_tn_bf16(R, M, N, _lib.ptr(dy), dy.stride(0), _lib.ptr(x), x.stride(0), _lib.ptr(dw),
+    db = torch.empty(M, dtype=out_dtype, device=dy.device) if want_bias else None
+    rc = L.pafc_gemm_tn_bf16(R, M, N, _lib.ptr(dy), dy.stride(0), _lib.ptr(x), x.stride(0), _lib.ptr(dw), _lib.ptr(db),
                              _lib.dtype_code(out_dtype), _lib.ptr(ws), nbytes, _lib.stream_of(dy))
     _lib.check(rc, "pafc_gemm_tn_bf16")
-    return dw
+    return (dw, db) if want_bias else dw
 
 
 class _LinearTrainBf16(torch.autograd.Function):
@@ -146,10 +148,16 @@ class _LinearTrainBf16(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = (dy2 @ wb).view(x.shape)
+        want_b = ctx.b_dtype is not None and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = gemm_tn(dy2, x2, ctx.w_dtype if ctx.w_dtype in (torch.float32, torch.bfloat16) else torch.float32)
+            od = ctx.w_dtype if ctx.w_dtype in (torch.float32, torch.bfloat16) else torch.float32
+            if want_b:
+                dw, db = gemm_tn(dy2, x2, od, want_bias=True)
+                db = db.to(ctx.b_dtype)
+            else:
+                dw = gemm_tn(dy2, x2, od)
             dw = dw.to(ctx.w_dtype)
-        if ctx.b_dtype is not None and ctx.needs_input_grad[2]:
+        elif want_b:
             db = dy2.sum(0, dtype=torch.float32).to(ctx.b_dtype)
         return dx, dw, db
 

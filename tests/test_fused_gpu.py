@@ -270,6 +270,11 @@ def test_gemm_tn_weight_gradient(hip, R, M, N, out_dtype):
     scale = float(ref.abs().max())
     tol = 2e-5 * scale * max(1.0, (R / 1000) ** 0.5) if out_dtype == torch.float32 else 2 ** -7 * scale
     assert float((got.double() - ref).abs().max()) <= tol
+    got2, db = gemm_tn(dy.cuda(), x.cuda(), out_dtype, want_bias=True)     # + the bias gradient from the same pass
+    assert torch.equal(got2.cpu(), got) and db.shape == (M,) and db.dtype == out_dtype
+    rb = dy.double().sum(0)
+    btol = (2e-5 if out_dtype == torch.float32 else 2 ** -7) * max(1.0, float(rb.abs().max()))
+    assert float((db.cpu().double() - rb).abs().max()) <= btol
 
 
 def test_gemm_tn_strided_operands_and_determinism(hip):
