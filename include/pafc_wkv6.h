@@ -115,6 +115,17 @@ int pafc_wkv6_backward(int dtype, int B, int T, int C, int H, const void *r, con
                        void *gw, void *gu, int reverse, int chunk_len, void *workspace,
                        size_t workspace_bytes, pafc_stream_t stream);
 
+/* The same with an initial state and its gradient: replaces torch.ops.wkv6state.backward (kernel_backward_111/222,
+ * wkv6state_cuda.cu:66-296; WKV_6STATE src/model.py:54-103, which the reference builds but never runs).
+ *   s_in: float32 (B, H, N, N) [value i][key j] -- the layout of pafc_wkv6_forward_state -- or NULL (zero state);
+ *   gs:   float32 (B, H, N, N), same layout, dL/ds_in per batch entry, or NULL when not wanted (the reference sums it
+ *         over the batch on the host, model.py:100).
+ * With a state gw at the first step is no longer zero (the state it decays is not); gw at the last step stays zero. */
+int pafc_wkv6_backward_state(int dtype, int B, int T, int C, int H, const void *r, const void *k, const void *v,
+                             const void *w, const void *u, const float *s_in, const void *gy, void *gr, void *gk, void *gv,
+                             void *gw, void *gu, float *gs, int reverse, int chunk_len, void *workspace,
+                             size_t workspace_bytes, pafc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

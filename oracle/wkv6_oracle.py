@@ -95,3 +95,22 @@ def forward_closed_form_f64(r, k, v, w, u):
     y = torch.empty(B, T, C, dtype=torch.float64)
     lib().wkv6_oracle_forward_closed_form_f64(B, T, C, H, *[_p(t) for t in args], _p(y))
     return y
+
+
+def state_recurrence_f64(r, k, v, w, u, s):
+    """The recurrence from an initial state as a differentiable float64 torch loop -- wkv6state_cuda.cu:6-65
+    (kernel_forward: y_t[i] = sum_j r_t[j] (u[j] k_t[j] v_t[i] + S[i][j]);  S[i][j] <- S[i][j] exp(-exp(w_t[j])) +
+    k_t[j] v_t[i]) -- so that autograd yields what kernel_backward_111/222 (:66-296) compute analytically: gr, gk, gv,
+    gw, gu and gs.  r, k, v, w: (B, T, C); u: (H, N); s: (B, H, N, N) indexed [value i][key j].  Small T only."""
+    import torch
+    B, T, C = r.shape
+    H, N = u.shape
+    r, k, v, w = (t.double().view(B, T, H, N) for t in (r, k, v, w))
+    u = u.double()
+    S = s.double()
+    ys = []
+    for t in range(T):
+        kv = v[:, t, :, :, None] * k[:, t, :, None, :]                      # (B, H, i, j)
+        ys.append(((u[None, :, None, :] * kv + S) * r[:, t, :, None, :]).sum(-1))
+        S = S * torch.exp(-torch.exp(w[:, t]))[:, :, None, :] + kv
+    return torch.stack(ys, 1).reshape(B, T, C), S

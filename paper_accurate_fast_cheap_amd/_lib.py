@@ -54,6 +54,7 @@ def lib():
     _sig(L.pafc_wkv6_forward_bidir_wbias, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, P, Z, P)
     _sig(L.pafc_wkv6_bwd_workspace_bytes, Z, I, I, I, I, I)
     _sig(L.pafc_wkv6_backward, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, I, I, P, Z, P)
+    _sig(L.pafc_wkv6_backward_state, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P, Z, P)
     _sig(L.pafc_ctc_greedy, I, I, I, I, I, P, P, I, P, P, P, P, P)
     _lib = L
     return _lib

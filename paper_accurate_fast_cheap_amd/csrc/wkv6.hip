@@ -360,6 +360,8 @@ struct RowArgs {
     const void *a, *p, *q, *w;
     float *out;      // (B, T, C) fp32
     int reverse;
+    const float *s_in;   // (B, H, N, N) [value i][key j] initial state or null; only read when NC == 1 (else the scan
+                         // has already put it into ws_state[0])
 };
 
 struct RowParams {
@@ -403,6 +405,10 @@ __global__ __launch_bounds__(64, 3) void wkv6_row_kernel(const RowParams p) {
             const float4 v4 = ws[i / 4];
             st[i] = v4.x; st[i + 1] = v4.y; st[i + 2] = v4.z; st[i + 3] = v4.w;
         }
+    } else if (D.s_in != nullptr) {
+        const float *si = D.s_in + ((size_t)b * p.H + h) * (size_t)(N * N) + lane;   // lane j: column j of [i][j]
+#pragma unroll
+        for (int i = 0; i < N; ++i) st[i] = si[(size_t)i * N];
     } else {
 #pragma unroll
         for (int i = 0; i < N; ++i) st[i] = 0.f;
@@ -495,6 +501,7 @@ struct EpiParams {
     void *gr, *gk, *gw, *gu;
     float *tot, *gup;    // (B*H, NE, 64): per-chunk totals of the recursion terms / of the gu sums
     int B, T, C, H, reverse, TCH, NE;
+    const float *s_in, *gs;   // initial state and its adjoint, (B, H, N, N) [value i][key j], or null (zero state)
 };
 
 constexpr int EPI_MAX_CHUNKS = 64;
@@ -525,6 +532,11 @@ __global__ __launch_bounds__(64) void wkv6_bwd_epilogue_kernel(const EpiParams p
     const int s0 = blockIdx.x * p.TCH, s1 = min(T, s0 + p.TCH);
 
     float gu = 0.f, Z = 0.f, k_prev = 0.f, v_prev = 0.f, q_prev = 0.f;
+    float z0 = 0.f;   // with an initial state: Z_0 = <G_0, S_0>[j] - r_0 P_0  (G_0 = gs; zero state: 0 - 0)
+    if (s0 == 0 && p.s_in != nullptr) {
+        const size_t so = ((size_t)b * p.H + h) * (size_t)(N * N) + lane;
+        for (int i = 0; i < N; ++i) z0 = fmaf(p.gs[so + (size_t)i * N], p.s_in[so + (size_t)i * N], z0);
+    }
     if (s0 > 0 && s0 < T) {
         const size_t o = at(s0 - 1);
         k_prev = E::load(k + o); v_prev = E::load(v + o); q_prev = Q[o];
@@ -549,6 +561,7 @@ __global__ __launch_bounds__(64) void wkv6_bwd_epilogue_kernel(const EpiParams p
                 E::store(gk + o, fmaf(u * rr[i], c, Qs[i]));
                 gu = fmaf(rr[i] * kk[i], c, gu);
                 if (s > 0) Z += k_prev * (q_prev - rr[i] * e) - rr[i] * (Ps[i] - k_prev * e);
+                else if (p.s_in != nullptr) Z = z0 - rr[i] * Ps[i];
                 P[o] = Z;
                 k_prev = kk[i]; v_prev = vv[i]; q_prev = Qs[i];
             }
@@ -592,7 +605,9 @@ __global__ __launch_bounds__(64) void wkv6_bwd_gw_kernel(const EpiParams p) {
 #pragma unroll
         for (int i = 0; i < U; ++i) {
             const int s = sb + i;
-            if (s < s1) E::store(gw + at(s), (s == 0 || s == T - 1) ? 0.f : (off + zz[i]) * -__expf(ww[i]));
+            // zero state: gw_0 = 0 (nothing to decay); always gw_{T-1} = 0 (nothing after it), as the reference stores them
+            if (s < s1)
+                E::store(gw + at(s), ((s == 0 && p.s_in == nullptr) || s == T - 1) ? 0.f : (off + zz[i]) * -__expf(ww[i]));
         }
     }
 }
@@ -600,6 +615,7 @@ __global__ __launch_bounds__(64) void wkv6_bwd_gw_kernel(const EpiParams p) {
 size_t bwd_ws_bytes(int B, int T, int C, int H, int L) {
     size_t n = 2 * (size_t)B * T * C;                      // P, Q
     n += 2 * (size_t)B * H * EPI_MAX_CHUNKS * N;           // epilogue: per-chunk totals (gw recursion, gu)
+    n += (size_t)B * H * N * N;                            // adjoint of the initial state when the caller passes no gs
     if (L < T) {
         const size_t NC = (T + L - 1) / L;
         n += 2 * (size_t)B * H * NC * (N * N + N);          // chunk states + decays of S and G
@@ -615,27 +631,29 @@ int bwd_chunk_len(int B, int T, int H, int chunk_len) {
 
 template <typename ET>
 int launch_bwd(int B, int T, int C, int H, const void *r, const void *k, const void *v, const void *w, const void *u,
-               const void *gy, void *gr, void *gk, void *gv, void *gw, void *gu, int reverse, int L, float *ws,
-               hipStream_t stream) {
+               const void *gy, void *gr, void *gk, void *gv, void *gw, void *gu, const float *s_in, float *gs,
+               int reverse, int L, float *ws, hipStream_t stream) {
     const int rev = reverse ? 1 : 0;
     const int NC = (T + L - 1) / L;
     float *P = ws, *Q = P + (size_t)B * T * C;
     float *tot = Q + (size_t)B * T * C, *gup = tot + (size_t)B * H * EPI_MAX_CHUNKS * N;
-    float *ws_state = gup + (size_t)B * H * EPI_MAX_CHUNKS * N;
+    float *gs_scratch = gup + (size_t)B * H * EPI_MAX_CHUNKS * N;
+    float *ws_state = gs_scratch + (size_t)B * H * N * N;
+    if (s_in != nullptr && gs == nullptr) gs = gs_scratch;      // the gw recursion starts from <gs, s_in>
     float *ws_decay = ws_state + 2 * (size_t)B * H * NC * (N * N);
     // the matrix-core forward kernels want 16-byte aligned operands (forward_impl checks the same)
     const bool mfma = use_mfma() &&
                       ((((uintptr_t)r | (uintptr_t)k | (uintptr_t)v | (uintptr_t)w | (uintptr_t)gy | (uintptr_t)gv) & 15) == 0);
     // dir 0: S from (k, v, w) in forward time; dir 1: G from (r, gy, w) in reverse time, whose pass C is gv
     FwdParams fp{};
-    fp.d[0] = DirArgs{k, k, v, w, u, gv, nullptr, nullptr, rev, nullptr};            // r, y unused by pass A
-    fp.d[1] = DirArgs{k, r, gy, w, u, gv, nullptr, nullptr, 1 - rev, nullptr};       // forward kernel with r<->k, v := gy
+    fp.d[0] = DirArgs{k, k, v, w, u, gv, s_in, nullptr, rev, nullptr};               // r, y unused by pass A
+    fp.d[1] = DirArgs{k, r, gy, w, u, gv, nullptr, gs, 1 - rev, nullptr};            // forward kernel with r<->k, v := gy
     fp.B = B; fp.T = T; fp.C = C; fp.H = H; fp.L = L; fp.NC = NC;
-    fp.nc_local = NC - 1;
+    fp.nc_local = gs ? NC : NC - 1;     // the adjoint of the initial state is the FINAL state of the reverse-time sweep
     fp.ws_state = ws_state; fp.ws_decay = ws_decay;
     if (NC > 1) {
-        if (mfma) hipLaunchKernelGGL((wkv6_mfma_kernel<ET, false>), dim3(NC - 1, B * H, 2), dim3(64), 0, stream, fp);
-        else hipLaunchKernelGGL((wkv6_chunk_kernel<ET, false>), dim3(NC - 1, B * H, 2), dim3(64), 0, stream, fp);
+        if (mfma) hipLaunchKernelGGL((wkv6_mfma_kernel<ET, false>), dim3(fp.nc_local, B * H, 2), dim3(64), 0, stream, fp);
+        else hipLaunchKernelGGL((wkv6_chunk_kernel<ET, false>), dim3(fp.nc_local, B * H, 2), dim3(64), 0, stream, fp);
         hipLaunchKernelGGL(wkv6_scan_kernel, dim3(16, B * H, 2), dim3(256), 0, stream, fp);
     }
     FwdParams fg = fp;  // pass C for direction 1 only: present it as direction 0 of a one-direction launch
@@ -646,13 +664,13 @@ int launch_bwd(int B, int T, int C, int H, const void *r, const void *k, const v
     else hipLaunchKernelGGL((wkv6_chunk_kernel<ET, true>), dim3(NC, B * H, 1), dim3(64), 0, stream, fg);
 
     RowParams rp{};
-    rp.d[0] = RowArgs{k, v, gy, w, P, rev};
-    rp.d[1] = RowArgs{r, gy, v, w, Q, 1 - rev};
+    rp.d[0] = RowArgs{k, v, gy, w, P, rev, s_in};
+    rp.d[1] = RowArgs{r, gy, v, w, Q, 1 - rev, nullptr};
     rp.B = B; rp.T = T; rp.C = C; rp.H = H; rp.L = L; rp.NC = NC;
     rp.ws_state = ws_state;
     hipLaunchKernelGGL(wkv6_row_kernel<ET>, dim3(NC, B * H, 2), dim3(64), 0, stream, rp);
 
-    EpiParams ep{r, k, v, w, u, gy, P, Q, gr, gk, gw, gu, tot, gup, B, T, C, H, rev, 0, 0};
+    EpiParams ep{r, k, v, w, u, gy, P, Q, gr, gk, gw, gu, tot, gup, B, T, C, H, rev, 0, 0, s_in, gs};
     ep.TCH = epi_chunk_steps(T);
     ep.NE = (T + ep.TCH - 1) / ep.TCH;
     hipLaunchKernelGGL(wkv6_bwd_epilogue_kernel<ET>, dim3(ep.NE, B * H), dim3(64), 0, stream, ep);
@@ -742,9 +760,10 @@ size_t pafc_wkv6_bwd_workspace_bytes(int B, int T, int C, int H, int chunk_len) 
     return pafc::bwd_ws_bytes(B, T, C, H, pafc::bwd_chunk_len(B, T, H, chunk_len));
 }
 
-int pafc_wkv6_backward(int dtype, int B, int T, int C, int H, const void *r, const void *k, const void *v,
-                       const void *w, const void *u, const void *gy, void *gr, void *gk, void *gv, void *gw, void *gu,
-                       int reverse, int chunk_len, void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
+int pafc_wkv6_backward_state(int dtype, int B, int T, int C, int H, const void *r, const void *k, const void *v,
+                             const void *w, const void *u, const float *s_in, const void *gy, void *gr, void *gk, void *gv,
+                             void *gw, void *gu, float *gs, int reverse, int chunk_len, void *workspace,
+                             size_t workspace_bytes, pafc_stream_t stream) {
     if (B <= 0 || T <= 0 || C <= 0 || H <= 0 || C % H != 0 || (long)B * H > 65535) return PAFC_ERR_BAD_DIMS;
     if (C / H != pafc::N) return PAFC_ERR_HEAD_SIZE;
     if (!r || !k || !v || !w || !u || !gy || !gr || !gk || !gv || !gw || !gu || !workspace) return PAFC_ERR_NULL_POINTER;
@@ -752,11 +771,19 @@ int pafc_wkv6_backward(int dtype, int B, int T, int C, int H, const void *r, con
     if (workspace_bytes < pafc::bwd_ws_bytes(B, T, C, H, L)) return PAFC_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PAFC_BF16)
-        return pafc::launch_bwd<pafc::bf16_t>(B, T, C, H, r, k, v, w, u, gy, gr, gk, gv, gw, gu, reverse, L,
+        return pafc::launch_bwd<pafc::bf16_t>(B, T, C, H, r, k, v, w, u, gy, gr, gk, gv, gw, gu, s_in, gs, reverse, L,
                                               (float *)workspace, s);
     if (dtype == PAFC_F32)
-        return pafc::launch_bwd<float>(B, T, C, H, r, k, v, w, u, gy, gr, gk, gv, gw, gu, reverse, L, (float *)workspace, s);
+        return pafc::launch_bwd<float>(B, T, C, H, r, k, v, w, u, gy, gr, gk, gv, gw, gu, s_in, gs, reverse, L,
+                                       (float *)workspace, s);
     return PAFC_ERR_DTYPE;
+}
+
+int pafc_wkv6_backward(int dtype, int B, int T, int C, int H, const void *r, const void *k, const void *v,
+                       const void *w, const void *u, const void *gy, void *gr, void *gk, void *gv, void *gw, void *gu,
+                       int reverse, int chunk_len, void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
+    return pafc_wkv6_backward_state(dtype, B, T, C, H, r, k, v, w, u, nullptr, gy, gr, gk, gv, gw, gu, nullptr, reverse,
+                                    chunk_len, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

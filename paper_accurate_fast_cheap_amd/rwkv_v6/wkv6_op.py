@@ -89,22 +89,54 @@ def wkv6_forward_bidir(fwd: Tuple[torch.Tensor, ...], bwd: Tuple[torch.Tensor, .
     return yf, yb
 
 
-def wkv6_backward(r, k, v, w, u, gy, *, reverse: bool = False, chunk_len: int = 0):
+def wkv6_backward(r, k, v, w, u, gy, *, reverse: bool = False, chunk_len: int = 0, s_in=None, want_gs: bool = False):
     """(gr, gk, gv, gw, gu): what WKV_6.backward returns (model.py:135-152); gu already summed over the
-    batch and shaped (H, N)."""
-    _lib.require_gpu(r, k, v, w, u, gy)
+    batch and shaped (H, N).  With s_in (float32 (B, H, N, N), the layout of wkv6_forward's state) the recurrence
+    starts from it, and with want_gs the tuple ends with gs = dL/ds_in per batch entry (WKV_6STATE.backward,
+    model.py:84-101, without its sum over the batch)."""
+    _lib.require_gpu(r, k, v, w, u, gy, s_in)
     B, T, C, H = _shape(r, u)
     code = _same(r, k, v, w, u, gy)
+    if s_in is not None and (s_in.dtype != torch.float32 or s_in.shape != (B, H, HEAD_SIZE, HEAD_SIZE)):
+        raise _lib.PafcError("s_in must be float32 (B, H, 64, 64)")
     gr, gk, gv, gw = (torch.empty_like(r) for _ in range(4))
     gu = torch.empty(B, C, dtype=r.dtype, device=r.device)
+    gs = torch.empty(B, H, HEAD_SIZE, HEAD_SIZE, dtype=torch.float32, device=r.device) if want_gs else None
     L = _lib.lib()
     nbytes = L.pafc_wkv6_bwd_workspace_bytes(B, T, C, H, chunk_len)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=r.device) if nbytes else None
     P = _lib.ptr
-    rc = L.pafc_wkv6_backward(code, B, T, C, H, P(r), P(k), P(v), P(w), P(u), P(gy), P(gr), P(gk), P(gv), P(gw), P(gu),
-                              int(reverse), chunk_len, P(ws), nbytes, _lib.stream_of(r))
-    _lib.check(rc, "pafc_wkv6_backward")
-    return gr, gk, gv, gw, torch.sum(gu.float(), 0).to(r.dtype).view(H, C // H)
+    rc = L.pafc_wkv6_backward_state(code, B, T, C, H, P(r), P(k), P(v), P(w), P(u), P(s_in), P(gy), P(gr), P(gk), P(gv),
+                                    P(gw), P(gu), P(gs), int(reverse), chunk_len, P(ws), nbytes, _lib.stream_of(r))
+    _lib.check(rc, "pafc_wkv6_backward_state")
+    out = (gr, gk, gv, gw, torch.sum(gu.float(), 0).to(r.dtype).view(H, C // H))
+    return out + (gs,) if want_gs else out
+
+
+class _WKV6State(torch.autograd.Function):
+    """Autograd wrapper = the reference's WKV_6STATE (model.py:54-103): the recurrence from an initial state, with the
+    gradient of that state (per batch entry; a state parameter broadcast over the batch gets their sum from autograd)."""
+
+    @staticmethod
+    def forward(ctx, r, k, v, w, u, s, reverse):
+        ctx.save_for_backward(r, k, v, w, u, s)
+        ctx.reverse = reverse
+        return wkv6_forward(r, k, v, w, u, s_in=s, reverse=reverse)
+
+    @staticmethod
+    def backward(ctx, gy):
+        r, k, v, w, u, s = ctx.saved_tensors
+        gr, gk, gv, gw, gu, gs = wkv6_backward(r, k, v, w, u, gy.contiguous(), reverse=ctx.reverse, s_in=s, want_gs=True)
+        return gr, gk, gv, gw, gu, gs, None
+
+
+def wkv6_state(r, k, v, w, u, s, reverse: bool = False):
+    """y = WKV6(...) started from state s (float32 (B, H, N, N)), differentiable in r, k, v, w, u and s."""
+    u = u.contiguous()
+    s = s.contiguous()
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (r, k, v, w, u, s)):
+        return _WKV6State.apply(r, k, v, w, u, s, reverse)
+    return wkv6_forward(r, k, v, w, u, s_in=s, reverse=reverse)
 
 
 class _WKV6(torch.autograd.Function):

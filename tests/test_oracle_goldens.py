@@ -227,3 +227,19 @@ def test_mamba2_oracle_agrees_with_an_independent_port_of_the_published_block():
         got = MO.mamba2_forward(u, sd, "m.")
         assert got.shape == want.shape
         assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max())), (L, float((got - want).abs().max()))
+
+
+def test_state_recurrence_f64_agrees_with_the_pinned_c_restatement():
+    """The differentiable float64 recurrence used to check the state-carrying backward (oracle/wkv6_oracle.py) computes
+    what the golden-pinned C restatement of wkv6state_cuda.cu:6-65 computes: outputs and final state, with a state."""
+    from oracle import wkv6_oracle as WO
+    from tests import synth
+    B, T, C, H = 2, 23, 128, 2
+    r, k, v = (synth.randn((B, T, C), 70 + i, 0.5) for i in range(3))
+    w = synth.randn((B, T, C), 73, 0.5) - 1.0
+    u = synth.randn((H, 64), 74, 0.3)
+    s = synth.randn((B, H, 64, 64), 75, 0.5)
+    y_c, s_c = WO.forward(r, k, v, w, u, s_in=s, want_state=True)
+    y_p, s_p = WO.state_recurrence_f64(r, k, v, w, u, s)
+    torch.testing.assert_close(y_p.float(), y_c, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(s_p.float(), s_c, rtol=1e-4, atol=1e-4)

@@ -169,3 +169,54 @@ def test_lane_ops_selftest(hip):
         x = lambda l: float(l + 1)
         exp = [x(lane ^ 1), x(lane ^ 2), x(row + (t & 8) + 7 - (t & 7)), x(row + 15 - t)]
         assert o[lane].tolist() == exp, (lane, o[lane].tolist(), exp)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,C,H,chunk", [(2, 1, 64, 1, 0), (2, 2, 128, 2, 0), (2, 45, 128, 2, 16), (1, 150, 128, 2, 0),
+                                            (1, 150, 128, 2, 10 ** 6), (2, 70, 64, 1, 32)])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_backward_with_initial_state(hip, dtype, B, T, C, H, chunk, reverse):
+    """WKV_6STATE (wkv6state_cuda.cu:66-296, built but never run by the reference): gradients of the recurrence started
+    from a state, including the state's own, against float64 autograd through the recurrence (one chunk, several chunks,
+    ragged chunks, both time directions)."""
+    from paper_accurate_fast_cheap_amd.rwkv_v6.wkv6_op import wkv6_backward, wkv6_forward
+    a = _inputs(B, T, C, H, 5000 + T, dtype)
+    s = synth.randn((B, H, 64, 64), 5100 + T, 0.5)
+    gy = synth.randn((B, T, C), 5200 + T).to(dtype)
+    flip = (lambda t: t.flip(1)) if reverse else (lambda t: t)
+    leaves = [flip(t).double().requires_grad_() for t in a[:4]] + [a[4].double().requires_grad_(), s.double().requires_grad_()]
+    y_ref, _ = WO.state_recurrence_f64(*leaves)
+    y_ref.backward(flip(gy).double())
+    y = wkv6_forward(*[t.cuda() for t in a], s_in=s.cuda(), reverse=reverse)
+    torch.testing.assert_close(y.cpu().float(), flip(y_ref.detach()).float(), **_tol(dtype))
+    got = wkv6_backward(*[t.cuda() for t in a], gy.cuda(), reverse=reverse, chunk_len=chunk, s_in=s.cuda(), want_gs=True)
+    grad = lambda l: l.grad if l.grad is not None else torch.zeros_like(l)     # T == 1: nothing depends on w
+    want = [flip(grad(l)) for l in leaves[:4]] + [grad(leaves[4]), grad(leaves[5])]
+    for name, g, rf in zip(("gr", "gk", "gv", "gw", "gu", "gs"), got, want):
+        scale = max(1.0, float(rf.abs().max()))
+        tol = 3e-4 * scale if dtype == torch.float32 else 2 ** -6 * scale
+        if T > 1 and name == "gw":           # the last step's gw is stored as zero, as the reference does (:294)
+            last = 0 if reverse else T - 1
+            assert float(g[:, last].abs().max()) == 0.0
+            keep = [t for t in range(T) if t != last]
+            g, rf = g[:, keep], rf[:, keep]
+        err = float((g.cpu().double() - rf).abs().max())
+        assert err <= tol, f"{name}: err {err:.3e} scale {scale:.3e}"
+
+
+def test_state_autograd_function(hip):
+    """wkv6_state under autograd: a state parameter broadcast over the batch receives the batch sum (model.py:100)."""
+    from paper_accurate_fast_cheap_amd.rwkv_v6.wkv6_op import wkv6_state
+    B, T, C, H = 3, 33, 128, 2
+    a = _inputs(B, T, C, H, 6000, torch.float32)
+    s_param = synth.randn((H, 64, 64), 6001, 0.5).cuda().requires_grad_()
+    leaves = [t.cuda().requires_grad_() for t in a]
+    gy = synth.randn((B, T, C), 6002).cuda()
+    wkv6_state(*leaves, s_param.unsqueeze(0).expand(B, -1, -1, -1), False).backward(gy)
+    ref = [t.double().requires_grad_() for t in a] + [s_param.detach().cpu().double().requires_grad_()]
+    y_ref, _ = WO.state_recurrence_f64(*ref[:5], ref[5].unsqueeze(0).expand(B, -1, -1, -1))
+    y_ref.backward(gy.cpu().double())
+    assert s_param.grad.shape == (H, 64, 64)
+    torch.testing.assert_close(s_param.grad.cpu().double(), ref[5].grad, rtol=1e-3, atol=3e-4 * float(ref[5].grad.abs().max()))
+    torch.testing.assert_close(leaves[3].grad[:, :-1].cpu().double(), ref[3].grad[:, :-1], rtol=1e-3,
+                               atol=3e-4 * float(ref[3].grad.abs().max()))
