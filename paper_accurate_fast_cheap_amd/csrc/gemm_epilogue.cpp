@@ -110,7 +110,9 @@ static int linear_impl(int dtype, int batch, long rows, int N, int K, const void
         // workspace (no split-K / stream-K bookkeeping) are ever timed
         // and only long-form problems (rows >= 32768) are measured at all: that is where the first pick was seen to lose
         // (FFN w_1 at 44 998 rows: 176 -> 140 us), and it keeps the set of library kernels ever launched small
-        const bool tune = !(te && te[0] == '0') && batch == 1 && rows >= 32768 && workspace &&
+        const char *me = getenv("PAFC_GEMM_TUNE_MIN_ROWS");      // A/B measurements only
+        const long min_rows = me ? atol(me) : 32768;
+        const bool tune = !(te && te[0] == '0') && batch == 1 && rows >= min_rows && workspace &&
                           workspace_bytes >= kMaxWorkspace;
         const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.a, p.b, p.d, p.d, pref, tune ? kMaxAlgos : 1,
                                                                    res, &found);
