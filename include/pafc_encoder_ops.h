@@ -65,6 +65,18 @@ int pafc_add_layernorm(int dtype, int dtype_out, int rows, int C, const void *x,
                        void *out1, long ld1, int silu1, int zero1, const void *gamma2, const void *beta2, void *out2,
                        long ld2, float eps, pafc_stream_t stream);
 
+/* LayerNorm backward for the training step (config c4): the seven nn.LayerNorm of the layer under autograd
+ * (encoder_layer.py:201-259, convolution.py:136, src/model.py:323; train_utils.py:646-660).  mean / rstd are recomputed
+ * from x (one wave per row, as pafc_add_layernorm):
+ *   xhat = (x - mean) rstd;  dx = rstd (dy gamma - mean_c(dy gamma) - xhat mean_c(dy gamma xhat))
+ *   dgamma_dbeta: float32 (2, C) = [sum_rows dy xhat ; sum_rows dy], summed in a fixed order (deterministic).
+ * x, gamma, dx in dtype_x; dy in dtype_dy (a bf16 output of an fp32 norm has a bf16 gradient); C % 8 == 0, C <= 1024.
+ * workspace: pafc_layernorm_bwd_workspace_bytes(rows, C) bytes. */
+size_t pafc_layernorm_bwd_workspace_bytes(long rows, int C);
+int pafc_layernorm_bwd(int dtype_x, int dtype_dy, long rows, int C, const void *x, const void *dy, const void *gamma,
+                       float eps, void *dx, float *dgamma_dbeta, void *workspace, size_t workspace_bytes,
+                       pafc_stream_t stream);
+
 /* Token shift + first lerp of the time-mix for ndir directions from one read of x (src/model.py:274-276):
  *   xx_d = shift_d(x) - x,  out[d] = x + xx_d * maa_x_d;   shift_0 = x_{t-1} (or x_{t+1} when reverse0), shift_1 = x_{t+1}
  * x: (B, T, C); maa_x0/1: (C); out: (ndir, B, T, C).  Zero beyond the sequence ends, like ZeroPad2d((0,0,1,-1)). */

@@ -7,6 +7,12 @@ from . import _lib
 from ._lib import c_int, c_void_p
 
 
+def train_kernels_enabled() -> bool:
+    """PAFC_TRAIN_KERNELS=0: the training step differentiates through the framework's own operators (A/B measurements)."""
+    import os
+    return os.environ.get("PAFC_TRAIN_KERNELS", "1") != "0"
+
+
 def _bind():
     L = _lib.lib()
     if getattr(L, "_pafc_ops_bound", False):
@@ -93,6 +99,72 @@ def depthwise_conv1d_cl_autograd(x: torch.Tensor, weight: torch.Tensor, bias: Op
     return _DepthwiseConvCL.apply(x.contiguous(), w, b, left_pad, out_len)
 
 
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float):
+    """(dx in x's dtype, dgamma, dbeta in float32) of y = LayerNorm(x) over the last axis."""
+    _lib.require_gpu(x, dy, gamma)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if dy.shape != x.shape or gamma.dtype != x.dtype or gamma.shape != (C,):
+        raise _lib.PafcError("layernorm_bwd: dy shaped like x, gamma (C) in x's dtype")
+    L = _lib.lib()
+    if not getattr(L, "_pafc_lnb_bound", False):
+        from ctypes import c_float, c_long, c_size_t
+        L.pafc_layernorm_bwd_workspace_bytes.restype = c_size_t
+        L.pafc_layernorm_bwd_workspace_bytes.argtypes = [c_long, c_int]
+        _lib._sig(L.pafc_layernorm_bwd, c_int, c_int, c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                  c_void_p, c_void_p, c_size_t, c_void_p)
+        L._pafc_lnb_bound = True
+    nbytes = L.pafc_layernorm_bwd_workspace_bytes(rows, C)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    dx = torch.empty_like(x)
+    dgb = torch.empty(2, C, dtype=torch.float32, device=x.device)
+    rc = L.pafc_layernorm_bwd(_lib.dtype_code(x.dtype), _lib.dtype_code(dy.dtype), rows, C, _lib.ptr(x), _lib.ptr(dy),
+                              _lib.ptr(gamma), float(eps), _lib.ptr(dx), _lib.ptr(dgb), _lib.ptr(ws), nbytes,
+                              _lib.stream_of(x))
+    _lib.check(rc, "pafc_layernorm_bwd")
+    return dx, dgb[0], dgb[1]
+
+
+class _LayerNormTrain(torch.autograd.Function):
+    """nn.LayerNorm for the GPU training step: forward = the inference kernel (one pass, optionally straight to bf16 for
+    a consumer that would cast anyway), backward = one pass over (x, dy) + a small reduction, instead of the framework's
+    fp32 forward, cast and three backward kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        g = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+        b = bias if bias.dtype == x.dtype else bias.to(x.dtype)
+        _, y, _ = add_layernorm(x, None, 1.0, g, b, out_dtype=out_dtype, want_x=False, eps=eps)
+        ctx.save_for_backward(x, g)
+        ctx.eps, ctx.w_dtype, ctx.b_dtype = eps, weight.dtype, bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dx, dg, db = layernorm_bwd(x, dy.contiguous(), g, ctx.eps)
+        return dx, dg.to(ctx.w_dtype), db.to(ctx.b_dtype), None, None
+
+
+def layer_norm_train_eligible(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor]) -> bool:
+    return (x.is_cuda and torch.is_grad_enabled() and weight is not None and bias is not None and train_kernels_enabled()
+            and x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] % 8 == 0 and x.shape[-1] <= 1024
+            and (x.requires_grad or weight.requires_grad))
+
+
+def layer_norm(x: torch.Tensor, weight, bias, eps: float, bf16_out: bool = False) -> torch.Tensor:
+    """F.layer_norm over the last axis as the modules call it; in the GPU training step the kernels above.  bf16_out:
+    the consumer is a projection that autocast would feed bf16 anyway -- under bf16 autocast the fp32 norm then writes
+    bf16 directly (same values as the framework's fp32 result cast by the consumer)."""
+    if layer_norm_train_eligible(x, weight, bias):
+        amp = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+        if amp and x.dtype == torch.bfloat16 and weight.dtype == torch.float32:
+            x = x.float()                 # autocast runs layer_norm in fp32
+        out_dtype = torch.bfloat16 if (bf16_out and amp) else x.dtype
+        return _LayerNormTrain.apply(x.contiguous(), weight, bias, eps, out_dtype)
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+
+
 def gemm_tn(dy: torch.Tensor, x: torch.Tensor, out_dtype: torch.dtype = torch.float32, want_bias: bool = False):
     """dw (M, N) = dy^T @ x for dy (R, M), x (R, N) bf16 with unit column stride: nn.Linear's weight gradient;
     with want_bias also db (M) = dy.sum(0) from the same pass -> (dw, db)."""
@@ -162,10 +234,44 @@ class _LinearTrainBf16(torch.autograd.Function):
         return dx, dw, db
 
 
+class _MatmulTrainBf16(torch.autograd.Function):
+    """y = x @ W for a parameter stored (K, N) -- the LoRA matrices of the time-mix (src/model.py:277,289) -- with the
+    weight gradient x^T dy through gemm_tn."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return x @ weight
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        K, N = weight.shape
+        dy2 = dy.reshape(-1, N)
+        if dy2.stride(1) != 1 or dy2.stride(0) % 8 or dy2.data_ptr() % 16:
+            dy2 = dy2.contiguous()
+        x2 = x.reshape(-1, K)
+        if x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        dx = (dy2 @ weight.t()).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = gemm_tn(x2, dy2, torch.bfloat16) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def matmul_param(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """x @ weight for a 2-D bf16 parameter; in the GPU training step the weight gradient takes the hand-written kernel."""
+    if (x.is_cuda and torch.is_grad_enabled() and weight.requires_grad and weight.dim() == 2 and train_kernels_enabled()
+            and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.shape[0] % 8 == 0
+            and weight.shape[1] % 8 == 0 and x.numel() // x.shape[-1] >= 256):
+        return _MatmulTrainBf16.apply(x, weight)
+    return x @ weight
+
+
 def linear_train_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
     """bf16 activations on the GPU under autograd (autocast(bfloat16) over fp32 master weights, or a bf16 module such
     as the time-mix slot), dims the kernel takes."""
-    if not (x.is_cuda and torch.is_grad_enabled() and weight.requires_grad and weight.dim() == 2):
+    if not (x.is_cuda and torch.is_grad_enabled() and weight.requires_grad and weight.dim() == 2
+            and train_kernels_enabled()):
         return False
     if weight.shape[0] % 8 or weight.shape[1] % 8 or x.numel() // max(1, x.shape[-1]) < 256:
         return False

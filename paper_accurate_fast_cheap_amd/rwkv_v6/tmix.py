@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..transformer.layer_norm import LayerNorm
 from .wkv6_op import wkv6, wkv6_forward
 
 D_MIX_LORA = 32
@@ -60,7 +61,7 @@ class RWKV_Tmix_x060c(nn.Module):
         self.key = nn.Linear(n_embd, dim_att, bias=False)
         self.value = nn.Linear(n_embd, dim_att, bias=False)
         self.output = nn.Linear(dim_att, n_embd, bias=False)
-        self.ln_x = nn.LayerNorm(dim_att)
+        self.ln_x = LayerNorm(dim_att)
 
     # ------------------------------------------------------------------------------------------
     def mix_project(self, x: torch.Tensor, reverse: bool = False):
@@ -71,7 +72,8 @@ class RWKV_Tmix_x060c(nn.Module):
         prev = F.pad(x, (0, 0, -1, 1)) if reverse else F.pad(x, (0, 0, 1, -1))
         xx = prev - x
         xxx = x + xx * self.time_maa_x
-        xxx = torch.tanh(xxx @ self.time_maa_rkvw_w1).view(B * T, 4, -1).transpose(0, 1)
+        mm = self._matmul(x)
+        xxx = torch.tanh(mm(xxx, self.time_maa_rkvw_w1)).view(B * T, 4, -1).transpose(0, 1)
         xxx = torch.bmm(xxx, self.time_maa_rkvw_w2).view(4, B, T, C)
         mr, mk, mv, mw = xxx.unbind(dim=0)
         lin = self._linear(x)
@@ -79,12 +81,20 @@ class RWKV_Tmix_x060c(nn.Module):
         k = lin(x + xx * (self.time_maa_k + mk), self.key.weight, None)
         v = lin(x + xx * (self.time_maa_v + mv), self.value.weight, None)
         w = x + xx * (self.time_maa_w + mw)
-        w = self.time_decay + torch.tanh(w @ self.time_decay_w1) @ self.time_decay_w2
+        w = self.time_decay + mm(torch.tanh(mm(w, self.time_decay_w1)), self.time_decay_w2)
         return r.contiguous(), k.contiguous(), v.contiguous(), w.contiguous()
 
     def finish(self, y: torch.Tensor) -> torch.Tensor:
         """model.py:323-324: LayerNorm over all C channels (not per head), output projection."""
         return self._linear(y)(self.ln_x(y), self.output.weight, None)
+
+    @staticmethod
+    def _matmul(x: torch.Tensor):
+        """x @ W for the LoRA parameters; in the GPU training step the variant with the hand-written weight gradient."""
+        if x.is_cuda and torch.is_grad_enabled():
+            from ..hip_ops import matmul_param
+            return matmul_param
+        return torch.matmul
 
     @staticmethod
     def _linear(x: torch.Tensor):

@@ -11,6 +11,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .layer_norm import LayerNorm
+
 
 class ConvolutionModule(nn.Module):
     def __init__(self, channels: int, kernel_size: int = 15, activation: nn.Module = nn.ReLU(),
@@ -32,7 +34,7 @@ class ConvolutionModule(nn.Module):
             self.norm = nn.BatchNorm1d(channels)
         else:
             self.use_layer_norm = True
-            self.norm = nn.LayerNorm(channels)
+            self.norm = LayerNorm(channels)
         self.pointwise_conv2 = nn.Conv1d(channels, channels, kernel_size=1, stride=1, padding=0, bias=bias)
         self.activation = activation
         self.kernel_size = kernel_size

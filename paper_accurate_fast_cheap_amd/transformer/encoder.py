@@ -7,6 +7,7 @@ same return shapes.  Scope: num_langs == 0 and the recurrent slot keys; the MHA 
 the plain TransformerEncoder are not part of the accelerated path.
 """
 import os
+from .layer_norm import LayerNorm
 from typing import List, Optional, Tuple
 
 import torch
@@ -33,7 +34,7 @@ class BaseEncoder(torch.nn.Module):
             input_size, output_size, dropout_rate,
             WENET_EMB_CLASSES[pos_enc_layer_type](output_size, positional_dropout_rate))
         self.normalize_before = normalize_before
-        self.after_norm = torch.nn.LayerNorm(output_size, eps=1e-5)
+        self.after_norm = LayerNorm(output_size, eps=1e-5)
         self.static_chunk_size = static_chunk_size
         self.use_dynamic_chunk = use_dynamic_chunk
         self.use_dynamic_left_chunk = use_dynamic_left_chunk

@@ -8,6 +8,8 @@ from typing import Optional, Tuple
 import torch
 from torch import nn
 
+from .layer_norm import LayerNorm
+
 
 class ConformerEncoderLayer(nn.Module):
     def __init__(self, size: int, self_attn: nn.Module, feed_forward: Optional[nn.Module] = None,
@@ -18,16 +20,25 @@ class ConformerEncoderLayer(nn.Module):
         self.feed_forward = feed_forward
         self.feed_forward_macaron = feed_forward_macaron
         self.conv_module = conv_module
-        self.norm_ff = nn.LayerNorm(size, eps=1e-5)
-        self.norm_mha = nn.LayerNorm(size, eps=1e-5)
+        self.norm_ff = LayerNorm(size, eps=1e-5)
+        self.norm_mha = LayerNorm(size, eps=1e-5)
         if feed_forward_macaron is not None:
-            self.norm_ff_macaron = nn.LayerNorm(size, eps=1e-5)
+            self.norm_ff_macaron = LayerNorm(size, eps=1e-5)
             self.ff_scale = 0.5
         else:
             self.ff_scale = 1.0
         if self.conv_module is not None:
-            self.norm_conv = nn.LayerNorm(size, eps=1e-5)
-            self.norm_final = nn.LayerNorm(size, eps=1e-5)
+            self.norm_conv = LayerNorm(size, eps=1e-5)
+            self.norm_final = LayerNorm(size, eps=1e-5)
+        if normalize_before:
+            # pre-norm branches whose first operation is a projection (FFN w_1, pointwise_conv1) or the slot's own cast
+            # to bf16: the consumer takes bf16 under autocast (layer_norm.py)
+            self.norm_ff.consumer_casts = True
+            if feed_forward_macaron is not None:
+                self.norm_ff_macaron.consumer_casts = True
+            if self.conv_module is not None:
+                self.norm_conv.consumer_casts = True
+            self.norm_mha.consumer_casts = bool(getattr(self_attn, "do_bfloat16", False))
         self.dropout = nn.Dropout(dropout_rate)
         self.size = size
         self.normalize_before = normalize_before

@@ -319,3 +319,57 @@ def test_linear_train_matches_autograd(hip):
     linear_train(xb, wb, None).backward(gy.to(torch.bfloat16))
     assert wb.grad.dtype == torch.bfloat16
     assert float((wb.grad.double().cpu() - wr.grad).abs().max()) <= 2 ** -7 * float(wr.grad.abs().max())
+
+
+@pytest.mark.parametrize("xd,yd", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                   (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("rows,C", [(1, 8), (5, 512), (64, 512), (1000, 512), (257, 1024), (130, 136)])
+def test_layernorm_backward_kernel(hip, xd, yd, rows, C):
+    """dx, dgamma, dbeta of LayerNorm against float64 autograd on the same operands (every dtype pairing the training
+    step produces: fp32 norm with fp32 or bf16 output, bf16 norm)."""
+    from paper_accurate_fast_cheap_amd.hip_ops import layernorm_bwd
+    x = synth.randn((rows, C), 31, 1.5).to(xd)
+    g = (1 + 0.3 * synth.randn((C,), 32, 1.0)).to(xd)
+    dy = synth.randn((rows, C), 33, 1.0).to(yd)
+    xr = x.double().requires_grad_()
+    gr = g.double().requires_grad_()
+    br = torch.zeros(C, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-5).backward(dy.double())
+    dx, dg, db = layernorm_bwd(x.cuda(), dy.cuda(), g.cuda(), 1e-5)
+    assert dx.dtype == xd and dg.dtype == db.dtype == torch.float32
+    lo = xd == torch.bfloat16
+    assert float((dx.cpu().double() - xr.grad).abs().max()) <= (2 ** -7 if lo else 2e-5) * max(1.0, float(xr.grad.abs().max()))
+    assert float((dg.cpu().double() - gr.grad).abs().max()) <= 2e-5 * max(1.0, float(gr.grad.abs().max())) * max(1.0, rows ** 0.5 / 8)
+    assert float((db.cpu().double() - br.grad).abs().max()) <= 2e-5 * max(1.0, float(br.grad.abs().max())) * max(1.0, rows ** 0.5 / 8)
+
+
+def test_layernorm_module_training_path(hip):
+    """The LayerNorm module under autograd on the GPU: kernels' result == nn.LayerNorm's, with and without bf16
+    autocast; under autocast a norm whose consumer casts writes bf16 and still hands fp32 gradients to fp32 leaves."""
+    from paper_accurate_fast_cheap_amd.transformer.layer_norm import LayerNorm
+    torch.manual_seed(0)
+    m = LayerNorm(512, eps=1e-5).cuda()
+    with torch.no_grad():
+        m.weight.normal_(1.0, 0.2); m.bias.normal_(0.0, 0.2)
+    ref = torch.nn.LayerNorm(512, eps=1e-5).cuda()
+    ref.load_state_dict(m.state_dict())
+    x = synth.randn((3, 50, 512), 41, 1.5).cuda().requires_grad_()
+    xr = x.detach().clone().requires_grad_()
+    gy = synth.randn((3, 50, 512), 42, 1.0).cuda()
+    m(x).backward(gy)
+    ref(xr).backward(gy)
+    torch.testing.assert_close(x.grad, xr.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(m.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(m.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-4)
+    m.zero_grad(); x.grad = None
+    m.consumer_casts = True
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(x)
+        yr = ref(xr)
+    assert y.dtype == torch.bfloat16 and yr.dtype == torch.float32
+    # the same values up to the last bf16 bit (the two kernels sum a row in different orders)
+    torch.testing.assert_close(y.float(), yr.to(torch.bfloat16).float(), rtol=2 ** -7, atol=2 ** -8)
+    y.backward(gy.to(torch.bfloat16))
+    assert x.grad.dtype == torch.float32 and m.weight.grad.dtype == torch.float32
+    with torch.no_grad():
+        assert m(x).dtype == torch.float32        # no autograd: nn.LayerNorm itself

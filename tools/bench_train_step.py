@@ -57,6 +57,8 @@ def main():
     sync(); t0 = time.perf_counter()
     for i in range(args.steps):
         info = train_step(model, batch, opt, device, step_index=i, amp_dtype=amp)
+        if os.environ.get("PAFC_BENCH_TRACE_LOSS") == "1" and rank == 0:
+            print(f"step {i}: loss {float(info['loss']):.3f} grad_norm {float(info['grad_norm']):.2f}", file=sys.stderr)
     sync(); dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t)
