@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long 
     // the MFMA leaves a lane with 8 columns of ITS row; through LDS the tile goes back to whole 128-byte row
     // segments per 8 lanes, so z is stored in full lines
     constexpr int LDZ = 64 + 8;
-    __shared__ __attribute__((aligned(16))) bf16_t s_z[4][4][16][LDZ];   // [wave][q][row][col]
+    __shared__ __attribute__((aligned(16))) bf16_t s_z[4][16][LDZ];   // [wave][row][col]: one map's tile at a time
     for (int d = 0; d < ndir; ++d) {
         const bool rev = (d == 0) ? (rev0 != 0) : true;
         const bool has_nb = rev ? (tt < T - 1) : (tt > 0);
@@ -249,20 +249,25 @@ __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long 
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             tb[q] = *reinterpret_cast<const uint4 *>(t + ((size_t)d * rows + rowc) * 128 + 32 * q + 8 * qq);
-        // a wave covers CBW = 2 column blocks of 32 (blockIdx.y picks which): 8x more waves than one wave per
-        // 16 rows, short fully unrolled bodies -> the loads of a body are all in flight together
+        // a wave covers 2 column blocks of 32 (blockIdx.y picks which 64 columns): x and the shifted difference of
+        // both stay in registers across the four maps
+        float xc[2][VEC], xx[2][VEC];
 #pragma unroll
         for (int cbi = 0; cbi < 2; ++cbi) {
-            const int cb = blockIdx.y * 2 + cbi;
-            const int col = cb * 32 + 8 * qq;                       // this lane's 8 output columns
-            const int colA = cb * 32 + 8 * (r16 >> 2) + (r16 & 3);  // column whose W2 row this lane feeds (slot r16)
-            float xc[VEC], xn[VEC], xx[VEC];
-            load8<bf16_t>(x + rowc * C + col, xc);
-            load8<bf16_t>(x + (has_nb ? nb : rowc) * C + col, xn);   // branch-free: select after the load
+            const int col = (blockIdx.y * 2 + cbi) * 32 + 8 * qq;            // this lane's 8 output columns
+            float xn[VEC];
+            load8<bf16_t>(x + rowc * C + col, xc[cbi]);
+            load8<bf16_t>(x + (has_nb ? nb : rowc) * C + col, xn);          // branch-free: select after the load
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) xx[e] = round_bf16((has_nb ? xn[e] : 0.f) - xc[e]);
+            for (int e = 0; e < VEC; ++e) xx[cbi][e] = round_bf16((has_nb ? xn[e] : 0.f) - xc[cbi][e]);
+        }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int cbi = 0; cbi < 2; ++cbi) {
+                const int cb = blockIdx.y * 2 + cbi;
+                const int col = cb * 32 + 8 * qq;
+                const int colA = cb * 32 + 8 * (r16 >> 2) + (r16 & 3);  // column whose W2 row this lane feeds (slot r16)
                 const bf16_t *wq = w2t + ((size_t)(d * 4 + q) * C) * 32 + 8 * qq;
                 const uint4 a1 = *reinterpret_cast<const uint4 *>(wq + (size_t)colA * 32);
                 const uint4 a2 = *reinterpret_cast<const uint4 *>(wq + (size_t)(colA + 4) * 32);
@@ -275,27 +280,25 @@ __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long 
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     const float mv = round_bf16(e < 4 ? m1[e] : m2[e - 4]);
-                    o[e] = round_bf16(xc[e] + round_bf16(xx[e] * round_bf16(av[e] + mv)));
+                    o[e] = round_bf16(xc[cbi][e] + round_bf16(xx[cbi][e] * round_bf16(av[e] + mv)));
                 }
-                store8<bf16_t>(&s_z[wave][q][r16][cbi * 32 + 8 * qq], o);
+                store8<bf16_t>(&s_z[wave][r16][cbi * 32 + 8 * qq], o);
             }
-        }
-        // s_z[wave] is private to this wave and LDS operations of one wave complete in order: a compiler fence is all
-        // the synchronisation the re-layout needs (no block barrier: the four waves run independently)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
+            // s_z[wave] is private to this wave and LDS operations of one wave complete in order: a compiler fence is
+            // all the synchronisation the re-layout needs (no block barrier: the four waves run independently)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int rr = half * 8 + (lane >> 3), cc = (lane & 7) * 8;
                 const long orow = ((long)blockIdx.x * 4 + wave) * 16 + rr;
                 if (orow < rows)
                     *reinterpret_cast<uint4 *>(z + (((size_t)q * ndir + d) * rows + orow) * C + blockIdx.y * 64 + cc) =
-                        *reinterpret_cast<const uint4 *>(&s_z[wave][q][rr][cc]);
+                        *reinterpret_cast<const uint4 *>(&s_z[wave][rr][cc]);
             }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
