@@ -172,6 +172,11 @@ int pafc_mamba2_scan_chunk_len(int B, int L, int H);
 size_t pafc_mamba2_scan_workspace_bytes(int B, int L, int H, int chunk_len);
 int pafc_mamba2_scan(int B, int L, int H, const void *xbc, long ldx, const float *dt, const float *log_a, float *y,
                      int chunk_len, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
+/* The same scan run right-to-left on un-flipped tensors (reverse != 0: step s of the recurrence is time index L - 1 - s,
+ * inputs read and y written at their own time index): the second Mamba2 of Mamba2Bidirectional without its two
+ * torch.flip copies (mamba2_bidirectional.py:130-145). */
+int pafc_mamba2_scan_dir(int B, int L, int H, const void *xbc, long ldx, const float *dt, const float *log_a, float *y,
+                         int reverse, int chunk_len, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
 
 /* Hand-written bf16 GEMM with fused epilogue (csrc/gemm_bf16.hip), batched:
  *   out[z][m][n] = act(alpha * sum_k A[z][m][k] * W[z][n][k] + bias[z][n] + residual[z][m][n]),   z < batch

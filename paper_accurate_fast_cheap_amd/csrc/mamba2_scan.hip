@@ -57,6 +57,7 @@ struct SsdParams {
     const float *dt, *la;  // (B, L, H): softplus(dt_raw + dt_bias), log a = dt * A
     float *y;              // (B, L, d_inner) fp32
     int B, L, H, d_inner, Lc, NC, nc_local;
+    int reverse;           // 1: step s of the recurrence is time index L - 1 - s (the right-to-left direction, un-flipped I/O)
     float *ws_state;       // [B][H][NC][128][64]
     float *ws_decay;       // [B][H][NC]
 };
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(64, 2) void mamba2_ssd_kernel(const SsdParams p) {
     const bf16_t *xb = p.xbc + (size_t)b * p.L * p.ldx;
     for (int s0 = s_begin; s0 < s_end; s0 += SBL) {
         const bool live = s0 + t16 < s_end;
-        const int srow = min(s0 + t16, s_end - 1);
+        const int sstep = min(s0 + t16, s_end - 1);
+        const int srow = p.reverse ? p.L - 1 - sstep : sstep;    // time index of this lane's step
         const bf16_t *row = xb + (size_t)srow * p.ldx;
         // ---- loads (Lt layout): x of this head, B and C of the step --------------------------------------------
         uint2 xr[4], Br[8], Cr[WRITE_Y ? 8 : 1];
@@ -219,8 +221,9 @@ __global__ __launch_bounds__(64, 2) void mamba2_ssd_kernel(const SsdParams p) {
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int tt = pass * 4 + (lane >> 4), col = (lane & 15) * 4;
+                const int trow = p.reverse ? p.L - 1 - (s0 + tt) : s0 + tt;
                 if (tt < nvalid)
-                    *reinterpret_cast<float4 *>(p.y + ((size_t)b * p.L + s0 + tt) * p.d_inner + h * SP + col) =
+                    *reinterpret_cast<float4 *>(p.y + ((size_t)b * p.L + trow) * p.d_inner + h * SP + col) =
                         *reinterpret_cast<const float4 *>(&s_y[tt][col]);
             }
         }
@@ -276,6 +279,12 @@ extern "C" size_t pafc_mamba2_scan_workspace_bytes(int B, int L, int H, int chun
 
 extern "C" int pafc_mamba2_scan(int B, int L, int H, const void *xbc, long ldx, const float *dt, const float *log_a, float *y,
                                 int chunk_len, void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
+    return pafc_mamba2_scan_dir(B, L, H, xbc, ldx, dt, log_a, y, 0, chunk_len, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pafc_mamba2_scan_dir(int B, int L, int H, const void *xbc, long ldx, const float *dt, const float *log_a,
+                                    float *y, int reverse, int chunk_len, void *workspace, size_t workspace_bytes,
+                                    pafc_stream_t stream) {
     if (!xbc || !dt || !log_a || !y) return PAFC_ERR_NULL_POINTER;
     if (B <= 0 || L <= 0 || H <= 0 || (long)B * H > 65535 || ldx < (long)H * 64 + 256 || (ldx % 4)) return PAFC_ERR_BAD_DIMS;
     if (((uintptr_t)xbc & 7) || ((uintptr_t)y & 15)) return PAFC_ERR_ALIGNMENT;
@@ -285,7 +294,7 @@ extern "C" int pafc_mamba2_scan(int B, int L, int H, const void *xbc, long ldx, 
     if (Lc >= L) Lc = L;
     pafc::SsdParams p{};
     p.xbc = (const pafc::bf16_t *)xbc; p.ldx = ldx; p.dt = dt; p.la = log_a; p.y = y;
-    p.B = B; p.L = L; p.H = H; p.d_inner = H * 64; p.Lc = Lc;
+    p.B = B; p.L = L; p.H = H; p.d_inner = H * 64; p.Lc = Lc; p.reverse = reverse ? 1 : 0;
     p.NC = (L + Lc - 1) / Lc;
     p.nc_local = p.NC - 1;
     hipStream_t s = (hipStream_t)stream;

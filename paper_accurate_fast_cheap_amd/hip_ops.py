@@ -670,21 +670,28 @@ def _bind_mamba():
         from ctypes import c_size_t
         _lib._sig(L.pafc_mamba2_scan_workspace_bytes, c_size_t, I, I, I, I)
         _lib._sig(L.pafc_mamba2_scan, I, I, I, I, P, G, P, P, P, I, P, c_size_t, P)
+        _lib._sig(L.pafc_mamba2_scan_dir, I, I, I, I, P, G, P, P, P, I, I, P, c_size_t, P)
         L._pafc_mamba_bound = True
     return L
 
 
-def causal_conv_silu_cl(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+def causal_conv_silu_cl(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], reverse: bool = False
+                        ) -> torch.Tensor:
     """SiLU(causal depthwise conv1d) in channels-last layout: x (B, L, C) -- may be a column slice of a wider tensor --
-    weight (C, 1, K) -> (B, L, C) contiguous (include/pafc_encoder_ops.h: pafc_dwconv1d_cl_ex, act 2)."""
+    weight (C, 1, K) -> (B, L, C) contiguous (include/pafc_encoder_ops.h: pafc_dwconv1d_cl_ex, act 2).  reverse: the
+    convolution that is causal in reversed time (what flip -> conv -> flip computes), i.e. the taps reversed and looking
+    right: same kernel, left_pad 0."""
     _lib.require_gpu(weight, bias)
     if not x.is_cuda or x.dim() != 3 or x.stride(2) != 1 or x.stride(0) != x.shape[1] * x.stride(1):
         raise _lib.PafcError("causal_conv_silu_cl: (B, L, C) GPU tensor, unit stride in C, batch stride L * row stride")
     B, Lq, C = x.shape
     K = weight.shape[-1]
     y = torch.empty((B, Lq, C), dtype=x.dtype, device=x.device)
-    rc = _bind_mamba().pafc_dwconv1d_cl_ex(_lib.dtype_code(x.dtype), B, Lq, C, K, K - 1, Lq, _lib.ptr(x), x.stride(1),
-                                           _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), 2, None, _lib.stream_of(x))
+    if reverse:
+        weight = weight.flip(-1).contiguous()
+    rc = _bind_mamba().pafc_dwconv1d_cl_ex(_lib.dtype_code(x.dtype), B, Lq, C, K, 0 if reverse else K - 1, Lq, _lib.ptr(x),
+                                           x.stride(1), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), 2, None,
+                                           _lib.stream_of(x))
     _lib.check(rc, "pafc_dwconv1d_cl_ex")
     return y
 
@@ -701,7 +708,7 @@ def mamba2_prep(xbc: torch.Tensor, dt_raw: torch.Tensor, dt_bias: torch.Tensor, 
     return planes
 
 
-def mamba2_scan(xbc: torch.Tensor, dt: torch.Tensor, log_a: torch.Tensor, H: int) -> torch.Tensor:
+def mamba2_scan(xbc: torch.Tensor, dt: torch.Tensor, log_a: torch.Tensor, H: int, reverse: bool = False) -> torch.Tensor:
     """Mamba-2 selective scan on the dedicated SSD kernel: xbc (B, L, H*64 + 256) bf16 contiguous, dt / log_a (B, L, H)
     fp32 -> y (B, L, H*64) fp32 (include/pafc_encoder_ops.h: pafc_mamba2_scan)."""
     _lib.require_gpu(xbc, dt, log_a)
@@ -712,9 +719,9 @@ def mamba2_scan(xbc: torch.Tensor, dt: torch.Tensor, log_a: torch.Tensor, H: int
     nws = Lb.pafc_mamba2_scan_workspace_bytes(B, Lq, H, 0)
     ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=xbc.device)
     y = torch.empty((B, Lq, H * 64), dtype=torch.float32, device=xbc.device)
-    rc = Lb.pafc_mamba2_scan(B, Lq, H, _lib.ptr(xbc), ldx, _lib.ptr(dt), _lib.ptr(log_a), _lib.ptr(y), 0,
-                             _lib.ptr(ws) if nws else None, nws, _lib.stream_of(xbc))
-    _lib.check(rc, "pafc_mamba2_scan")
+    rc = Lb.pafc_mamba2_scan_dir(B, Lq, H, _lib.ptr(xbc), ldx, _lib.ptr(dt), _lib.ptr(log_a), _lib.ptr(y), int(reverse), 0,
+                                 _lib.ptr(ws) if nws else None, nws, _lib.stream_of(xbc))
+    _lib.check(rc, "pafc_mamba2_scan_dir")
     return y
 
 

@@ -64,7 +64,7 @@ class Mamba2(nn.Module):
         self.fused_inference = True    # GPU inference: glue kernels (False: the op-by-op restatement below)
         self.ssd_kernel = True         # bf16: the dedicated SSD scan kernel (False: operand planes + the WKV-6 scan)
 
-    def _forward_fused(self, u: torch.Tensor) -> torch.Tensor:
+    def _forward_fused(self, u: torch.Tensor, reverse: bool = False) -> torch.Tensor:
         """Inference on the GPU: the same arithmetic with the glue in three kernels (conv1d + SiLU on the xBC slice of
         in_proj's output; the six scan operand planes in one pass; residual terms + gate + RMSNorm in one pass) instead
         of ~40 framework kernels and their (L, 1024) fp32 temporaries."""
@@ -74,28 +74,35 @@ class Mamba2(nn.Module):
         di, N, H = self.d_inner, self.d_state, self.nheads
         z = zxbcdt[..., :di]
         dt_raw = zxbcdt[..., 2 * di + 2 * N:]
-        xbc = hip_ops.causal_conv_silu_cl(zxbcdt[..., di:2 * di + 2 * N], self.conv1d.weight, self.conv1d.bias)
+        xbc = hip_ops.causal_conv_silu_cl(zxbcdt[..., di:2 * di + 2 * N], self.conv1d.weight, self.conv1d.bias, reverse)
         if u.dtype == torch.bfloat16 and self.ssd_kernel:
             # dedicated SSD scan: scalar decay per head and step, B / C shared by the heads -- no operand planes at all
             dt = F.softplus(dt_raw.float() + self.dt_bias.float()).contiguous()           # (B, L, H), tiny
             log_a = (dt * (-torch.exp(self.A_log.float()))).contiguous()
-            y = hip_ops.mamba2_scan(xbc, dt, log_a, H)
+            y = hip_ops.mamba2_scan(xbc, dt, log_a, H, reverse)
             y = hip_ops.mamba2_finish(y, None, xbc, dt_raw, z, self.dt_bias.float(), self.D.float(), self.norm.weight,
                                       self.norm.eps, di, diag=False)
             return lin(y, self.out_proj)
         r0, r1, k0, k1, v, w = hip_ops.mamba2_prep(xbc, dt_raw, self.dt_bias.float(), self.A_log.float(), di)
         u0 = torch.zeros(H, 64, dtype=torch.float32, device=u.device)
-        y0 = wkv6_forward(r0, k0, v, w, u0)
-        y1 = wkv6_forward(r1, k1, v, w, u0)
+        y0 = wkv6_forward(r0, k0, v, w, u0, reverse=reverse)
+        y1 = wkv6_forward(r1, k1, v, w, u0, reverse=reverse)
         y = hip_ops.mamba2_finish(y0, y1, xbc, dt_raw, z, self.dt_bias.float(), self.D.float(), self.norm.weight,
                                   self.norm.eps, di)
         return self.out_proj(y)
 
-    def forward(self, u: torch.Tensor) -> torch.Tensor:
-        if (self.fused_inference and u.is_cuda and not torch.is_grad_enabled() and self.d_state == 128
+    def fused_eligible(self, u: torch.Tensor) -> bool:
+        return (self.fused_inference and u.is_cuda and not torch.is_grad_enabled() and self.d_state == 128
                 and self.d_inner <= 1024 and u.dtype in (torch.float32, torch.bfloat16)
-                and self.conv1d.weight.dtype == u.dtype):
-            return self._forward_fused(u)
+                and self.conv1d.weight.dtype == u.dtype)
+
+    def forward(self, u: torch.Tensor, reverse: bool = False) -> torch.Tensor:
+        """reverse: the block run right-to-left on the un-flipped sequence = flip(forward(flip(u))) without the copies
+        (only the bf16 kernels take the flag; elsewhere the two flips are made)."""
+        if self.fused_eligible(u) and (not reverse or (u.dtype == torch.bfloat16 and self.ssd_kernel)):
+            return self._forward_fused(u, reverse)
+        if reverse:
+            return torch.flip(self.forward(torch.flip(u, [1])), [1])
         Bsz, L, _ = u.shape
         H, P, N = self.nheads, self.headdim, self.d_state
         zxbcdt = self.in_proj(u)
@@ -135,8 +142,7 @@ class Mamba2Bidirectional(nn.Module):
         self.mamba_backward = Mamba2(d_model, headdim=headdim, **kw)
 
     def forward(self, u: torch.Tensor) -> torch.Tensor:
-        out_b = torch.flip(self.mamba_backward(torch.flip(u, [1])), [1])
-        return (self.mamba_forward(u) + out_b) / 2
+        return (self.mamba_forward(u) + self.mamba_backward(u, reverse=True)) / 2
 
 
 class MambaAttWrapper(nn.Module):

@@ -113,3 +113,26 @@ def test_mamba_ssd_scan_raw_vs_sequential(hip):
     got = mamba2_scan(xbc.cuda(), dt.cuda(), la.cuda(), H).cpu().double().view(B, L, H, 64)
     err = (got - y).abs().max() / y.abs().max()
     assert float(err) < 2e-4, float(err)
+
+
+@pytest.mark.parametrize("L,B", [(1, 1), (37, 2), (300, 1), (1030, 1)])
+def test_mamba_reverse_direction_without_flips(hip, L, B):
+    """The right-to-left Mamba2 of Mamba2Bidirectional (mamba2_bidirectional.py:130-145) run on the un-flipped sequence
+    (reverse taps / reverse scan inside the kernels) == flip(block(flip(u))), for one and several scan chunks."""
+    from paper_accurate_fast_cheap_amd.transformer.mamba2 import Mamba2, Mamba2Bidirectional
+    torch.manual_seed(5)
+    m = Mamba2(128, headdim=64).to(torch.bfloat16).cuda().eval()
+    with torch.no_grad():
+        m.conv1d.weight.normal_(0, 0.3)
+        u = synth.randn((B, L, 128), 91, 1.0).to(torch.bfloat16).cuda()
+        want = torch.flip(m(torch.flip(u, [1])), [1])
+        got = m(u, reverse=True)
+        # the same kernels on the same values; only the order in which a scan chunk's blocks see them differs
+        d = (got.float() - want.float()).abs()
+        assert float(d.max()) <= 2e-2 * max(1.0, float(want.float().abs().max())), float(d.max())
+        m32 = Mamba2(128, headdim=64).cuda().eval()          # fp32 path: the flag falls back to the two flips
+        u32 = u.float()
+        torch.testing.assert_close(m32(u32, reverse=True), torch.flip(m32(torch.flip(u32, [1])), [1]), rtol=1e-4, atol=1e-5)
+        bi = Mamba2Bidirectional(128, headdim=64).to(torch.bfloat16).cuda().eval()
+        ref = (bi.mamba_forward(u) + torch.flip(bi.mamba_backward(torch.flip(u, [1])), [1])) / 2
+        torch.testing.assert_close(bi(u).float(), ref.float(), rtol=2e-2, atol=2e-2)
