@@ -178,6 +178,15 @@ int pafc_mamba2_scan(int B, int L, int H, const void *xbc, long ldx, const float
 int pafc_mamba2_scan_dir(int B, int L, int H, const void *xbc, long ldx, const float *dt, const float *log_a, float *y,
                          int reverse, int chunk_len, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
 
+/* The scan as mamba_ssm's returns it: y in bf16 with the skip term inside, y = bf16(scan + D[h] x), one rounding
+ * (D: float32 (H); y_bf16: (B, L, H * 64)).  Halves the scan's output bytes and leaves the block's tail to
+ * pafc_mamba2_gate_norm: out = RMSNorm(y * silu(z)) * norm_weight (rows = B * L, z with row stride ld_z, all in `dtype`). */
+int pafc_mamba2_scan_skip_bf16(int B, int L, int H, const void *xbc, long ldx, const float *dt, const float *log_a,
+                               const float *D, void *y_bf16, int reverse, int chunk_len, void *workspace,
+                               size_t workspace_bytes, pafc_stream_t stream);
+int pafc_mamba2_gate_norm(int dtype, long rows, int d_inner, const void *y, const void *z, long ld_z,
+                          const void *norm_weight, float eps, void *out, pafc_stream_t stream);
+
 /* Hand-written bf16 GEMM with fused epilogue (csrc/gemm_bf16.hip), batched:
  *   out[z][m][n] = act(alpha * sum_k A[z][m][k] * W[z][n][k] + bias[z][n] + residual[z][m][n]),   z < batch
  * A: (M, K) rows lda apart; W: (N, K) = nn.Linear.weight layout, rows ldw apart; out / residual: (M, N), rows ldo / ldr

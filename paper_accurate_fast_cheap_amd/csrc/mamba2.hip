@@ -107,6 +107,45 @@ __global__ __launch_bounds__(256) void mamba2_finish_kernel(int L, int d_inner, 
     }
 }
 
+
+// out = RMSNorm(y * silu(z)) * w for a scan output that already carries the skip term (pafc_mamba2_scan_skip_bf16): one
+// wave per row, the row (d_inner <= 1024 = 16 values per lane) stays in registers between the two passes.
+template <typename ET>
+__global__ __launch_bounds__(256) void mamba2_gate_norm_kernel(long rows, int d_inner, const ET *__restrict__ y,
+                                                               const ET *__restrict__ z, long ld_z,
+                                                               const ET *__restrict__ norm_w, float eps, ET *__restrict__ out) {
+    using E = Elem<ET>;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float g[2][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = (it * 64 + lane) * 8;
+        if (c < d_inner) {
+            float yv[8], zv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { yv[e] = E::load(y + row * d_inner + c + e); zv[e] = E::load(z + row * ld_z + c + e); }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float s = E::round(zv[e] * __builtin_amdgcn_rcpf(1.f + __expf(-zv[e])));   // F.silu(z) in the model dtype
+                g[it][e] = E::round(yv[e] * s);
+                ss = fmaf(g[it][e], g[it][e], ss);
+            }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(ss) / (float)d_inner + eps);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = (it * 64 + lane) * 8;
+        if (c < d_inner) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) E::store(out + row * d_inner + c + e, g[it][e] * rs * E::load(norm_w + c + e));
+        }
+    }
+}
+
 }  // namespace
 }  // namespace pafc
 
@@ -147,6 +186,24 @@ extern "C" int pafc_mamba2_finish(int dtype, int B, int L, int d_inner, const fl
         hipLaunchKernelGGL(pafc::mamba2_finish_kernel<float>, dim3((unsigned)rows), dim3(256), 0, s, L, d_inner, y0, y1,
                            (const float *)xbc, (const float *)dt_raw, ld_dt, (const float *)z, ld_z, dt_bias, D,
                            (const float *)norm_weight, eps, diag, (float *)out);
+    else
+        return PAFC_ERR_DTYPE;
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+extern "C" int pafc_mamba2_gate_norm(int dtype, long rows, int d_inner, const void *y, const void *z, long ld_z,
+                                     const void *norm_weight, float eps, void *out, pafc_stream_t stream) {
+    if (!y || !z || !norm_weight || !out) return PAFC_ERR_NULL_POINTER;
+    if (rows <= 0 || d_inner <= 0 || d_inner % 8 || d_inner > 1024 || ld_z < d_inner || rows > 4L * 0x7fffffffL)
+        return PAFC_ERR_BAD_DIMS;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == PAFC_BF16)
+        hipLaunchKernelGGL(pafc::mamba2_gate_norm_kernel<pafc::bf16_t>, grid, block, 0, s, rows, d_inner, (const pafc::bf16_t *)y,
+                           (const pafc::bf16_t *)z, ld_z, (const pafc::bf16_t *)norm_weight, eps, (pafc::bf16_t *)out);
+    else if (dtype == PAFC_F32)
+        hipLaunchKernelGGL(pafc::mamba2_gate_norm_kernel<float>, grid, block, 0, s, rows, d_inner, (const float *)y,
+                           (const float *)z, ld_z, (const float *)norm_weight, eps, (float *)out);
     else
         return PAFC_ERR_DTYPE;
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;

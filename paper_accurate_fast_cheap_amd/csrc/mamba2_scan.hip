@@ -55,20 +55,23 @@ struct SsdParams {
     const bf16_t *xbc;     // (B, L, ldx): [x (d_inner) | B (128) | C (128)]
     long ldx;
     const float *dt, *la;  // (B, L, H): softplus(dt_raw + dt_bias), log a = dt * A
-    float *y;              // (B, L, d_inner) fp32
+    float *y;              // (B, L, d_inner) fp32, or null when y16 is set
+    bf16_t *y16;           // (B, L, d_inner) bf16 = round(scan + D[h] * x): what mamba_ssm's scan returns (skip term inside)
+    const float *Dskip;    // (H), with y16
     int B, L, H, d_inner, Lc, NC, nc_local;
     int reverse;           // 1: step s of the recurrence is time index L - 1 - s (the right-to-left direction, un-flipped I/O)
     float *ws_state;       // [B][H][NC][128][64]
     float *ws_decay;       // [B][H][NC]
 };
 
-template <bool WRITE_Y>
+template <bool WRITE_Y, bool Y16 = false>
 __global__ __launch_bounds__(64, 2) void mamba2_ssd_kernel(const SsdParams p) {
     const int c = blockIdx.x;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int lane = threadIdx.x, t16 = lane & 15, q = lane >> 4;
     __shared__ float s_cum[SBL], s_dt[SBL];
     __shared__ __attribute__((aligned(16))) float s_y[WRITE_Y ? SBL : 1][SP + 4];
+    __shared__ __attribute__((aligned(16))) bf16_t s_x[(WRITE_Y && Y16) ? SBL : 1][SP + 8];   // x of the block, [step][channel], for the skip term
 
     // 0/1 selection operands of the layout-changing MFMAs (as in wkv6_mfma.inc)
     su32x4 selA = {0u, 0u, 0u, 0u}, selB = {0u, 0u, 0u, 0u};
@@ -95,6 +98,8 @@ __global__ __launch_bounds__(64, 2) void mamba2_ssd_kernel(const SsdParams p) {
                     S[jm][in][g] = src ? src[(16 * jm + 4 * q + g) * SP + 16 * in + t16] : 0.f;
     }
     float lsum = 0.f;   // log of the chunk's decay product (pass A output)
+    float dk = 0.f;     // D[h] of the skip term, read once (a load inside the store loop would be re-issued every pass)
+    if constexpr (WRITE_Y && Y16) dk = p.Dskip[h];
 
     const int s_begin = c * p.Lc, s_end = min(p.L, s_begin + p.Lc);
     const bf16_t *xb = p.xbc + (size_t)b * p.L * p.ldx;
@@ -126,6 +131,10 @@ __global__ __launch_bounds__(64, 2) void mamba2_ssd_kernel(const SsdParams p) {
         cum += row_shr_zero<0x118>(cum);
         __syncthreads();                                          // previous block's readers of the tables are done
         if (q == 0) { s_cum[t16] = cum; s_dt[t16] = dt_own; }
+        if constexpr (WRITE_Y && Y16) {
+#pragma unroll
+            for (int in = 0; in < 4; ++in) *reinterpret_cast<uint2 *>(&s_x[t16][16 * in + 4 * q]) = xr[in];
+        }
         __syncthreads();
         const float c15 = s_cum[15];
         const float4 cs4 = *reinterpret_cast<const float4 *>(&s_cum[4 * q]);
@@ -222,9 +231,20 @@ __global__ __launch_bounds__(64, 2) void mamba2_ssd_kernel(const SsdParams p) {
             for (int pass = 0; pass < 4; ++pass) {
                 const int tt = pass * 4 + (lane >> 4), col = (lane & 15) * 4;
                 const int trow = p.reverse ? p.L - 1 - (s0 + tt) : s0 + tt;
-                if (tt < nvalid)
-                    *reinterpret_cast<float4 *>(p.y + ((size_t)b * p.L + trow) * p.d_inner + h * SP + col) =
-                        *reinterpret_cast<const float4 *>(&s_y[tt][col]);
+                if (tt < nvalid) {
+                    const float4 v = *reinterpret_cast<const float4 *>(&s_y[tt][col]);
+                    if constexpr (Y16) {     // + D x, one rounding to bf16 (x staged in LDS by the lanes that loaded it)
+                        const uint2 xq = *reinterpret_cast<const uint2 *>(&s_x[tt][col]);
+                        const float o0 = fmaf(dk, bf16_bits_to_f32(xq.x & 0xffffu), v.x);
+                        const float o1 = fmaf(dk, __uint_as_float(xq.x & 0xffff0000u), v.y);
+                        const float o2 = fmaf(dk, bf16_bits_to_f32(xq.y & 0xffffu), v.z);
+                        const float o3 = fmaf(dk, __uint_as_float(xq.y & 0xffff0000u), v.w);
+                        *reinterpret_cast<uint2 *>(p.y16 + ((size_t)b * p.L + trow) * p.d_inner + h * SP + col) =
+                            make_uint2(scvt_pk(o0, o1), scvt_pk(o2, o3));
+                    } else {
+                        *reinterpret_cast<float4 *>(p.y + ((size_t)b * p.L + trow) * p.d_inner + h * SP + col) = v;
+                    }
+                }
             }
         }
     }
@@ -282,29 +302,46 @@ extern "C" int pafc_mamba2_scan(int B, int L, int H, const void *xbc, long ldx, 
     return pafc_mamba2_scan_dir(B, L, H, xbc, ldx, dt, log_a, y, 0, chunk_len, workspace, workspace_bytes, stream);
 }
 
-extern "C" int pafc_mamba2_scan_dir(int B, int L, int H, const void *xbc, long ldx, const float *dt, const float *log_a,
-                                    float *y, int reverse, int chunk_len, void *workspace, size_t workspace_bytes,
-                                    pafc_stream_t stream) {
-    if (!xbc || !dt || !log_a || !y) return PAFC_ERR_NULL_POINTER;
+namespace pafc {
+namespace {
+int ssd_launch(int B, int L, int H, const void *xbc, long ldx, const float *dt, const float *log_a, float *y, bf16_t *y16,
+               const float *Dskip, int reverse, int chunk_len, void *workspace, size_t workspace_bytes, hipStream_t s) {
+    if (!xbc || !dt || !log_a || (!y && !y16) || (y16 && !Dskip)) return PAFC_ERR_NULL_POINTER;
     if (B <= 0 || L <= 0 || H <= 0 || (long)B * H > 65535 || ldx < (long)H * 64 + 256 || (ldx % 4)) return PAFC_ERR_BAD_DIMS;
-    if (((uintptr_t)xbc & 7) || ((uintptr_t)y & 15)) return PAFC_ERR_ALIGNMENT;
+    if (((uintptr_t)xbc & 7) || ((uintptr_t)y & 15) || ((uintptr_t)y16 & 7)) return PAFC_ERR_ALIGNMENT;
     int Lc = chunk_len > 0 ? chunk_len : pafc_mamba2_scan_chunk_len(B, L, H);
     if (!workspace) Lc = L;
     if (Lc < L) Lc = (Lc + 15) / 16 * 16;
     if (Lc >= L) Lc = L;
-    pafc::SsdParams p{};
-    p.xbc = (const pafc::bf16_t *)xbc; p.ldx = ldx; p.dt = dt; p.la = log_a; p.y = y;
+    SsdParams p{};
+    p.xbc = (const bf16_t *)xbc; p.ldx = ldx; p.dt = dt; p.la = log_a; p.y = y; p.y16 = y16; p.Dskip = Dskip;
     p.B = B; p.L = L; p.H = H; p.d_inner = H * 64; p.Lc = Lc; p.reverse = reverse ? 1 : 0;
     p.NC = (L + Lc - 1) / Lc;
     p.nc_local = p.NC - 1;
-    hipStream_t s = (hipStream_t)stream;
     if (p.NC > 1) {
         if (workspace_bytes < pafc_mamba2_scan_workspace_bytes(B, L, H, Lc)) return PAFC_ERR_WORKSPACE;
         p.ws_state = (float *)workspace;
-        p.ws_decay = p.ws_state + (size_t)B * H * p.NC * (pafc::SN * pafc::SP);
-        hipLaunchKernelGGL(pafc::mamba2_ssd_kernel<false>, dim3(p.nc_local, B * H), dim3(64), 0, s, p);
-        hipLaunchKernelGGL(pafc::mamba2_ssd_scan_kernel, dim3(pafc::SN * pafc::SP / 256, B * H), dim3(256), 0, s, p);
+        p.ws_decay = p.ws_state + (size_t)B * H * p.NC * (SN * SP);
+        hipLaunchKernelGGL((mamba2_ssd_kernel<false, false>), dim3(p.nc_local, B * H), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(mamba2_ssd_scan_kernel, dim3(SN * SP / 256, B * H), dim3(256), 0, s, p);
     }
-    hipLaunchKernelGGL(pafc::mamba2_ssd_kernel<true>, dim3(p.NC, B * H), dim3(64), 0, s, p);
+    if (y16) hipLaunchKernelGGL((mamba2_ssd_kernel<true, true>), dim3(p.NC, B * H), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((mamba2_ssd_kernel<true, false>), dim3(p.NC, B * H), dim3(64), 0, s, p);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+}  // namespace
+}  // namespace pafc
+
+extern "C" int pafc_mamba2_scan_dir(int B, int L, int H, const void *xbc, long ldx, const float *dt, const float *log_a,
+                                    float *y, int reverse, int chunk_len, void *workspace, size_t workspace_bytes,
+                                    pafc_stream_t stream) {
+    return pafc::ssd_launch(B, L, H, xbc, ldx, dt, log_a, y, nullptr, nullptr, reverse, chunk_len, workspace, workspace_bytes,
+                            (hipStream_t)stream);
+}
+
+extern "C" int pafc_mamba2_scan_skip_bf16(int B, int L, int H, const void *xbc, long ldx, const float *dt, const float *log_a,
+                                          const float *D, void *y_bf16, int reverse, int chunk_len, void *workspace,
+                                          size_t workspace_bytes, pafc_stream_t stream) {
+    return pafc::ssd_launch(B, L, H, xbc, ldx, dt, log_a, nullptr, (pafc::bf16_t *)y_bf16, D, reverse, chunk_len, workspace,
+                            workspace_bytes, (hipStream_t)stream);
 }

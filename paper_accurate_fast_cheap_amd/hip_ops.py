@@ -671,6 +671,8 @@ def _bind_mamba():
         _lib._sig(L.pafc_mamba2_scan_workspace_bytes, c_size_t, I, I, I, I)
         _lib._sig(L.pafc_mamba2_scan, I, I, I, I, P, G, P, P, P, I, P, c_size_t, P)
         _lib._sig(L.pafc_mamba2_scan_dir, I, I, I, I, P, G, P, P, P, I, I, P, c_size_t, P)
+        _lib._sig(L.pafc_mamba2_scan_skip_bf16, I, I, I, I, P, G, P, P, P, P, I, I, P, c_size_t, P)
+        _lib._sig(L.pafc_mamba2_gate_norm, I, I, G, I, P, P, G, P, c_float, P, P)
         L._pafc_mamba_bound = True
     return L
 
@@ -708,21 +710,46 @@ def mamba2_prep(xbc: torch.Tensor, dt_raw: torch.Tensor, dt_bias: torch.Tensor, 
     return planes
 
 
-def mamba2_scan(xbc: torch.Tensor, dt: torch.Tensor, log_a: torch.Tensor, H: int, reverse: bool = False) -> torch.Tensor:
+def mamba2_scan(xbc: torch.Tensor, dt: torch.Tensor, log_a: torch.Tensor, H: int, reverse: bool = False,
+                D: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Mamba-2 selective scan on the dedicated SSD kernel: xbc (B, L, H*64 + 256) bf16 contiguous, dt / log_a (B, L, H)
-    fp32 -> y (B, L, H*64) fp32 (include/pafc_encoder_ops.h: pafc_mamba2_scan)."""
-    _lib.require_gpu(xbc, dt, log_a)
+    fp32 -> y (B, L, H*64) fp32 (include/pafc_encoder_ops.h: pafc_mamba2_scan_dir); with D (H) fp32 the scan returns
+    bf16(y + D x) as mamba_ssm's does (pafc_mamba2_scan_skip_bf16)."""
+    _lib.require_gpu(xbc, dt, log_a, D)
     if xbc.dtype != torch.bfloat16 or dt.dtype != torch.float32 or log_a.dtype != torch.float32:
         raise _lib.PafcError("mamba2_scan: bf16 xbc, fp32 dt / log_a")
     B, Lq, ldx = xbc.shape
     Lb = _bind_mamba()
     nws = Lb.pafc_mamba2_scan_workspace_bytes(B, Lq, H, 0)
     ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=xbc.device)
+    if D is not None:
+        if D.dtype != torch.float32 or D.shape != (H,):
+            raise _lib.PafcError("mamba2_scan: D must be float32 (H)")
+        y = torch.empty((B, Lq, H * 64), dtype=torch.bfloat16, device=xbc.device)
+        rc = Lb.pafc_mamba2_scan_skip_bf16(B, Lq, H, _lib.ptr(xbc), ldx, _lib.ptr(dt), _lib.ptr(log_a), _lib.ptr(D),
+                                           _lib.ptr(y), int(reverse), 0, _lib.ptr(ws) if nws else None, nws,
+                                           _lib.stream_of(xbc))
+        _lib.check(rc, "pafc_mamba2_scan_skip_bf16")
+        return y
     y = torch.empty((B, Lq, H * 64), dtype=torch.float32, device=xbc.device)
     rc = Lb.pafc_mamba2_scan_dir(B, Lq, H, _lib.ptr(xbc), ldx, _lib.ptr(dt), _lib.ptr(log_a), _lib.ptr(y), int(reverse), 0,
                                  _lib.ptr(ws) if nws else None, nws, _lib.stream_of(xbc))
     _lib.check(rc, "pafc_mamba2_scan_dir")
     return y
+
+
+def mamba2_gate_norm(y: torch.Tensor, z: torch.Tensor, norm_weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """RMSNorm(y * silu(z)) * norm_weight over the last axis; z may be a column slice of a wider tensor."""
+    _lib.require_gpu(y, norm_weight)
+    d = y.shape[-1]
+    rows = y.numel() // d
+    if z.dtype != y.dtype or norm_weight.dtype != y.dtype or z.stride(-1) != 1 or z.shape != y.shape or not z.is_cuda:
+        raise _lib.PafcError("mamba2_gate_norm: y, z, norm_weight in one dtype; z shaped like y with unit channel stride")
+    out = torch.empty_like(y)
+    rc = _bind_mamba().pafc_mamba2_gate_norm(_lib.dtype_code(y.dtype), rows, d, _lib.ptr(y), _lib.ptr(z), z.stride(-2),
+                                             _lib.ptr(norm_weight), float(eps), _lib.ptr(out), _lib.stream_of(y))
+    _lib.check(rc, "pafc_mamba2_gate_norm")
+    return out
 
 
 def mamba2_finish(y0, y1, xbc, dt_raw, z, dt_bias, D, norm_weight, eps: float, d_inner: int, diag: bool = True

@@ -63,6 +63,8 @@ class Mamba2(nn.Module):
         self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias)
         self.fused_inference = True    # GPU inference: glue kernels (False: the op-by-op restatement below)
         self.ssd_kernel = True         # bf16: the dedicated SSD scan kernel (False: operand planes + the WKV-6 scan)
+        import os
+        self.scan_bf16_out = os.environ.get("PAFC_MAMBA_SCAN_F32") != "1"   # scan writes bf16(y + D x); else fp32 y + finish kernel
 
     def _forward_fused(self, u: torch.Tensor, reverse: bool = False) -> torch.Tensor:
         """Inference on the GPU: the same arithmetic with the glue in three kernels (conv1d + SiLU on the xBC slice of
@@ -79,9 +81,13 @@ class Mamba2(nn.Module):
             # dedicated SSD scan: scalar decay per head and step, B / C shared by the heads -- no operand planes at all
             dt = F.softplus(dt_raw.float() + self.dt_bias.float()).contiguous()           # (B, L, H), tiny
             log_a = (dt * (-torch.exp(self.A_log.float()))).contiguous()
-            y = hip_ops.mamba2_scan(xbc, dt, log_a, H, reverse)
-            y = hip_ops.mamba2_finish(y, None, xbc, dt_raw, z, self.dt_bias.float(), self.D.float(), self.norm.weight,
-                                      self.norm.eps, di, diag=False)
+            if self.scan_bf16_out:
+                y = hip_ops.mamba2_scan(xbc, dt, log_a, H, reverse, D=self.D.float())       # bf16, skip term inside
+                y = hip_ops.mamba2_gate_norm(y, z, self.norm.weight, self.norm.eps)
+            else:
+                y = hip_ops.mamba2_scan(xbc, dt, log_a, H, reverse)
+                y = hip_ops.mamba2_finish(y, None, xbc, dt_raw, z, self.dt_bias.float(), self.D.float(), self.norm.weight,
+                                          self.norm.eps, di, diag=False)
             return lin(y, self.out_proj)
         r0, r1, k0, k1, v, w = hip_ops.mamba2_prep(xbc, dt_raw, self.dt_bias.float(), self.A_log.float(), di)
         u0 = torch.zeros(H, 64, dtype=torch.float32, device=u.device)

@@ -136,3 +136,27 @@ def test_mamba_reverse_direction_without_flips(hip, L, B):
         bi = Mamba2Bidirectional(128, headdim=64).to(torch.bfloat16).cuda().eval()
         ref = (bi.mamba_forward(u) + torch.flip(bi.mamba_backward(torch.flip(u, [1])), [1])) / 2
         torch.testing.assert_close(bi(u).float(), ref.float(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("reverse", [False, True])
+def test_mamba_scan_bf16_output_carries_the_skip_term(hip, reverse):
+    """pafc_mamba2_scan_skip_bf16 == bf16(fp32 scan + D x) (one rounding), both directions; and pafc_mamba2_gate_norm ==
+    RMSNorm(y * silu(z)) * w as the module computes it."""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    torch.manual_seed(11)
+    B, L, H = 2, 333, 4
+    xbc = (0.5 * torch.randn(B, L, H * 64 + 256)).to(torch.bfloat16).cuda()
+    dt = (0.02 + 0.1 * torch.rand(B, L, H)).cuda()
+    log_a = (-dt * (1 + 3 * torch.rand(H)).cuda()).contiguous()
+    D = torch.randn(H).cuda()
+    y32 = hip_ops.mamba2_scan(xbc, dt, log_a, H, reverse)
+    y16 = hip_ops.mamba2_scan(xbc, dt, log_a, H, reverse, D=D)
+    want = (y32 + xbc[..., :H * 64].float().view(B, L, H, 64).mul(D.view(1, 1, H, 1)).view(B, L, H * 64)).to(torch.bfloat16)
+    assert y16.dtype == torch.bfloat16
+    torch.testing.assert_close(y16.float(), want.float(), rtol=2 ** -7, atol=1e-3)     # fma vs mul + add before the rounding
+    z = torch.randn(B, L, H * 64 + 40).to(torch.bfloat16).cuda()[..., 8:8 + H * 64]
+    w = (1 + 0.2 * torch.randn(H * 64)).to(torch.bfloat16).cuda()
+    got = hip_ops.mamba2_gate_norm(y16, z, w, 1e-5)
+    g = (y16 * torch.nn.functional.silu(z)).float()
+    ref = (g * torch.rsqrt(g.pow(2).mean(-1, keepdim=True) + 1e-5) * w.float()).to(torch.bfloat16)
+    torch.testing.assert_close(got.float(), ref.float(), rtol=2 ** -6, atol=2e-2)
