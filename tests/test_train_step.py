@@ -314,3 +314,19 @@ def test_train_step_bf16_autocast_through_the_encoder(hip):
             if float(a.norm()) > 1e-6 * max(1.0, a.numel() ** 0.5):      # LoRA outputs start with exactly zero gradient
                 assert float(a @ b / (a.norm() * b.norm())) > 0.97, (golden, n)
                 assert 0.8 < float(b.norm() / a.norm()) < 1.25, (golden, n)
+
+
+@pytest.mark.gpu
+def test_conv_module_under_fp16_autocast(hip):
+    """`--use_amp` is fp16 autocast (train_utils.py:635): the conv module must run (library depthwise convolution, the
+    kernels being fp32 / bf16) and hand fp32 gradients to its fp32 parameters."""
+    from paper_accurate_fast_cheap_amd.transformer.convolution import ConvolutionModule
+    torch.manual_seed(0)
+    m = ConvolutionModule(128, 15, torch.nn.SiLU(), "layer_norm", causal=False, bias=True).cuda()
+    x = synth.randn((2, 40, 128), 3).cuda().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.float16):
+        y, _ = m(x)
+    y.float().square().sum().backward()
+    ref, _ = m(x.detach())
+    assert torch.isfinite(y).all() and float((y.float() - ref.float()).abs().max()) < 0.05 * float(ref.abs().max()) + 1e-2
+    assert all(p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all() for p in m.parameters())
