@@ -31,7 +31,7 @@ def train_step(model: torch.nn.Module, batch: dict, optimizer: torch.optim.Optim
     `scaler` (the reference's `--use_amp`: fp16 autocast + GradScaler) the loss is scaled for backward, the gradients
     un-scaled before clipping and `scaler.step` does the skip-on-overflow; `amp_dtype=torch.bfloat16` without a scaler
     is the `dtype: bf16` autocast of the reference's other engine -- the natural one on MI355X (bf16 MFMA, no loss
-    scaling) and the only one the bf16 time-mix slot accepts.  `clip_hard_maxvalue` / `clip_hard_warmup`
+    scaling) and the only one the bf16 time-mix slot accepts (GradScaler cannot un-scale bf16 gradients).  `clip_hard_maxvalue` / `clip_hard_warmup`
     (train_utils.py:683-684,712-716): after the warm-up batches an update whose gradient norm exceeds the hard
     maximum is dropped."""
     model.train()

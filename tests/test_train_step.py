@@ -330,3 +330,38 @@ def test_conv_module_under_fp16_autocast(hip):
     ref, _ = m(x.detach())
     assert torch.isfinite(y).all() and float((y.float() - ref.float()).abs().max()) < 0.05 * float(ref.abs().max()) + 1e-2
     assert all(p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("golden", ["encoder_reduced_f32"])
+def test_train_step_fp16_amp_through_the_encoder(hip, golden):
+    """The reference's `--use_amp` (fp16 autocast + GradScaler, train_utils.py:635-709) end to end: the step runs, the
+    loss is close to the fp32 loss, the update is made (or skipped by the scaler on overflow, never half-applied).
+    fp32 slot only: GradScaler cannot un-scale the bf16 gradients of a bf16 slot (a framework limit the reference shares);
+    the mixed-precision mode of the bf16 slot is bf16 autocast."""
+    from paper_accurate_fast_cheap_amd.utils.init_model import init_model
+    from paper_accurate_fast_cheap_amd.utils.train_utils import train_step
+    g = load_golden(golden)
+    cfg = dict(encoder="conformer", encoder_conf=dict(g["conf"], dropout_rate=0.0, positional_dropout_rate=0.0),
+               input_dim=80, output_dim=50, ctc="ctc", ctc_conf={"ctc_blank_id": 0}, model_conf={}, dataset_conf={})
+
+    class A:
+        checkpoint = None
+    torch.manual_seed(3)
+    model, _ = init_model(A(), cfg)
+    model = model.cuda()
+    batch = {"feats": synth.randn((4, 120, 80), 1, 2.0), "feats_lengths": torch.tensor([120, 100, 90, 64]),
+             "target": torch.randint(1, 50, (4, 6), generator=torch.Generator().manual_seed(2)),
+             "target_lengths": torch.tensor([6, 5, 4, 3])}
+    dev = torch.device("cuda")
+    model.train()
+    ref_loss = float(model(batch, dev)["loss"].detach())
+    model.zero_grad(set_to_none=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    scaler = torch.amp.GradScaler("cuda", init_scale=256.0)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    info = train_step(model, batch, opt, dev, grad_clip=0.1, scaler=scaler)
+    assert float(info["loss"]) == pytest.approx(ref_loss, rel=3e-2)
+    changed = any(not torch.equal(before[n], p.detach()) for n, p in model.named_parameters())
+    assert changed == bool(info["updated"])
+    assert all(torch.isfinite(p).all() for p in model.parameters())
