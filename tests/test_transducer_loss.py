@@ -111,3 +111,38 @@ def test_transducer_training_forward_backward_cpu():
     out["loss"].backward()
     for name, prm in model.named_parameters():
         assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("amp", [False, True])
+def test_transducer_training_step_on_gpu(hip, amp):
+    """The hybrid objective (transducer_weight RNN-T + ctc_weight CTC, transducer.py:70-148) over the accelerated
+    encoder, one DDP-style step on the GPU, in fp32 and under bf16 autocast: finite loss, every parameter reached, the
+    update made."""
+    from tests.conftest import load_golden
+    from paper_accurate_fast_cheap_amd.transducer.predictor import RNNPredictor
+    from paper_accurate_fast_cheap_amd.transducer.transducer import Transducer
+    from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    from paper_accurate_fast_cheap_amd.utils.train_utils import train_step
+    g = load_golden("encoder_reduced_bf16slot")
+    conf = dict(g["conf"], dropout_rate=0.0, positional_dropout_rate=0.0)
+    torch.manual_seed(1)
+    enc = ConformerEncoder(80, **conf)
+    V, D = 30, enc.output_size()
+    model = Transducer(V, 0, enc, RNNPredictor(V, 32, 48, 0.0, 48, 1, dropout=0.0), TransducerJoint(V, D, 48, 64),
+                       ctc=CTC(V, D), ctc_weight=0.3, transducer_weight=0.7).cuda()
+    gen = torch.Generator().manual_seed(5)
+    batch = {"feats": torch.randn(3, 90, 80, generator=gen), "feats_lengths": torch.tensor([90, 71, 50]),
+             "target": torch.randint(1, V, (3, 5), generator=gen), "target_lengths": torch.tensor([5, 4, 2])}
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    grads = {}
+    hooks = [p.register_hook(lambda gr, n=n: grads.__setitem__(n, gr)) for n, p in model.named_parameters()]
+    info = train_step(model, batch, opt, torch.device("cuda"), grad_clip=5.0,
+                      amp_dtype=torch.bfloat16 if amp else None)
+    for h in hooks:
+        h.remove()
+    assert torch.isfinite(info["loss"]) and info["updated"] and torch.isfinite(info["grad_norm"])
+    missing = [n for n, _ in model.named_parameters() if n not in grads]
+    assert not missing, missing
+    assert all(torch.isfinite(v).all() for v in grads.values())
