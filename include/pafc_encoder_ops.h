@@ -94,6 +94,20 @@ int pafc_tmix_mix4(int dtype, int B, int T, int C, int ndir, int reverse0, const
 int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const void *x, const void *t, const void *w2t,
                              const void *maa, void *z, pafc_stream_t stream);
 
+/* Backward of the two element-wise groups of the time-mix block for the training step (config c4; the reference
+ * differentiates src/model.py:274-284 op by op through autograd).  One direction per call (reverse: the shift is
+ * x_{t+1}); sums in fp32, maa gradients in float32 summed in a fixed order (deterministic).
+ *   shift_mix:  xxx = x + (shift(x) - x) maa_x.  dxxx (B, T, C) -> dx (B, T, C), dmaa_x float32 (C).
+ *   mix4:       z_q = x + (shift(x) - x) (maa_q + m_q), q = r, k, v, w.  m, dm: (4, B*T, C); maa: (4, C); dz_q (B*T, C)
+ *               -> dx (B, T, C), dm, dmaa float32 (4, C).
+ * C % 8 == 0, C <= 1024; workspace: pafc_tmix_bwd_workspace_bytes(B*T, C) bytes. */
+size_t pafc_tmix_bwd_workspace_bytes(long rows, int C);
+int pafc_tmix_shift_mix_bwd(int dtype, int B, int T, int C, int reverse, const void *x, const void *maa_x, const void *dxxx,
+                            void *dx, float *dmaa_x, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
+int pafc_tmix_mix4_bwd(int dtype, int B, int T, int C, int reverse, const void *x, const void *m, const void *maa,
+                       const void *dz_r, const void *dz_k, const void *dz_v, const void *dz_w, void *dx, void *dm,
+                       float *dmaa, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
+
 /* 3x3 stride-2 convolution + bias (+ ReLU), NHWC, bf16, as an implicit GEMM on the matrix cores:
  *   out[b][t2][f2][co] = act(bias[co] + sum_{kh,kw,ci} w[co][ci][kh][kw] in[b][2 t2 + kh][2 f2 + kw][ci]),
  *   T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1.

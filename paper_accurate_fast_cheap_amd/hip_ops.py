@@ -361,11 +361,100 @@ def tmix_mix4(x: torch.Tensor, m: torch.Tensor, maa: torch.Tensor, reverse0: boo
     _lib.require_gpu(x, m, maa)
     B, T, C = x.shape
     ndir = m.shape[0]
+    if m.dtype != x.dtype or maa.dtype != x.dtype:
+        raise _lib.PafcError("tmix_mix4: x, m and maa must share one dtype")
     z = torch.empty((4, ndir, B * T, C), dtype=x.dtype, device=x.device)
     rc = _bind2().pafc_tmix_mix4(_lib.dtype_code(x.dtype), B, T, C, ndir, int(reverse0), _lib.ptr(x), _lib.ptr(m),
                                  _lib.ptr(maa), _lib.ptr(z), _lib.stream_of(x))
     _lib.check(rc, "pafc_tmix_mix4")
     return z
+
+
+def _bind_tmix_bwd():
+    L = _bind2()
+    if not getattr(L, "_pafc_tmixbwd_bound", False):
+        from ctypes import c_long, c_size_t
+        P, I = c_void_p, c_int
+        L.pafc_tmix_bwd_workspace_bytes.restype = c_size_t
+        L.pafc_tmix_bwd_workspace_bytes.argtypes = [c_long, c_int]
+        _lib._sig(L.pafc_tmix_shift_mix_bwd, I, I, I, I, I, I, P, P, P, P, P, P, c_size_t, P)
+        _lib._sig(L.pafc_tmix_mix4_bwd, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P)
+        L._pafc_tmixbwd_bound = True
+    return L
+
+
+class _ShiftMixTrain(torch.autograd.Function):
+    """xxx = x + (shift(x) - x) * maa_x (src/model.py:274-276) for one direction: forward tmix_shift_mix, backward one
+    pass (pafc_tmix_shift_mix_bwd) instead of the framework's pad / sub / mul / add chain and its reduction."""
+
+    @staticmethod
+    def forward(ctx, x, maa_x, reverse):
+        mx = maa_x.reshape(-1).to(x.dtype).contiguous()
+        ctx.save_for_backward(x, mx)
+        ctx.reverse, ctx.maa_shape, ctx.maa_dtype = reverse, maa_x.shape, maa_x.dtype
+        return tmix_shift_mix(x, mx, None, reverse)[0]
+
+    @staticmethod
+    def backward(ctx, dxxx):
+        x, mx = ctx.saved_tensors
+        B, T, C = x.shape
+        L = _bind_tmix_bwd()
+        nbytes = L.pafc_tmix_bwd_workspace_bytes(B * T, C)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        dx = torch.empty_like(x)
+        dmaa = torch.empty(C, dtype=torch.float32, device=x.device)
+        dxxx = dxxx.contiguous()
+        rc = L.pafc_tmix_shift_mix_bwd(_lib.dtype_code(x.dtype), B, T, C, int(ctx.reverse), _lib.ptr(x), _lib.ptr(mx),
+                                       _lib.ptr(dxxx), _lib.ptr(dx), _lib.ptr(dmaa), _lib.ptr(ws), nbytes, _lib.stream_of(x))
+        _lib.check(rc, "pafc_tmix_shift_mix_bwd")
+        return dx, dmaa.to(ctx.maa_dtype).view(ctx.maa_shape), None
+
+
+class _Mix4Train(torch.autograd.Function):
+    """z_q = x + (shift(x) - x) * (maa_q + m_q), q = r, k, v, w (src/model.py:280-284) for one direction: forward
+    tmix_mix4, backward one pass (pafc_tmix_mix4_bwd).  Returns the four maps as separate outputs so that autograd hands
+    back four gradients instead of assembling one stacked tensor."""
+
+    @staticmethod
+    def forward(ctx, x, m, maa4, reverse):
+        B, T, C = x.shape
+        mm = m.reshape(1, 4, B * T, C).to(x.dtype).contiguous()     # under autocast the LoRA product is bf16, x may be fp32
+        a4 = maa4.reshape(1, 4, C).to(x.dtype).contiguous()
+        z = tmix_mix4(x, mm, a4, reverse)                           # (4, 1, B*T, C)
+        ctx.save_for_backward(x, mm, a4)
+        ctx.reverse, ctx.maa_shape, ctx.maa_dtype, ctx.m_shape, ctx.m_dtype = reverse, maa4.shape, maa4.dtype, m.shape, m.dtype
+        return tuple(z[q, 0].view(B, T, C) for q in range(4))
+
+    @staticmethod
+    def backward(ctx, *dz):
+        x, mm, a4 = ctx.saved_tensors
+        B, T, C = x.shape
+        dz = [(torch.zeros_like(x) if g is None else g.contiguous()) for g in dz]
+        L = _bind_tmix_bwd()
+        nbytes = L.pafc_tmix_bwd_workspace_bytes(B * T, C)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        dx = torch.empty_like(x)
+        dm = torch.empty_like(mm)
+        dmaa = torch.empty(4, C, dtype=torch.float32, device=x.device)
+        P = _lib.ptr
+        rc = L.pafc_tmix_mix4_bwd(_lib.dtype_code(x.dtype), B, T, C, int(ctx.reverse), P(x), P(mm), P(a4), P(dz[0]), P(dz[1]),
+                                  P(dz[2]), P(dz[3]), P(dx), P(dm), P(dmaa), P(ws), nbytes, _lib.stream_of(x))
+        _lib.check(rc, "pafc_tmix_mix4_bwd")
+        return dx, dm.view(ctx.m_shape).to(ctx.m_dtype), dmaa.to(ctx.maa_dtype).view(ctx.maa_shape), None
+
+
+def tmix_train_eligible(x: torch.Tensor) -> bool:
+    return (x.is_cuda and torch.is_grad_enabled() and train_kernels_enabled() and x.dim() == 3
+            and x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] % 8 == 0 and x.shape[-1] <= 1024)
+
+
+def shift_mix_train(x: torch.Tensor, maa_x: torch.Tensor, reverse: bool) -> torch.Tensor:
+    return _ShiftMixTrain.apply(x.contiguous(), maa_x, reverse)
+
+
+def mix4_train(x: torch.Tensor, m: torch.Tensor, maa4: torch.Tensor, reverse: bool):
+    """m: (4, B, T, C) LoRA outputs in the order r, k, v, w; maa4: (4, C) (or anything that reshapes to it)."""
+    return _Mix4Train.apply(x.contiguous(), m, maa4, reverse)
 
 
 _gemm_ws = {}

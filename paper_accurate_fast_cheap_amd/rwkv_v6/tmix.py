@@ -68,15 +68,30 @@ class RWKV_Tmix_x060c(nn.Module):
         """model.py:274-289: token shift, data-dependent mixes, r/k/v projections and the decay LoRA.
         Returns contiguous (r, k, v, w) in the block's dtype."""
         B, T, C = x.shape
+        mm = self._matmul(x)
+        lin = self._linear(x)
+        if x.is_cuda and torch.is_grad_enabled():
+            from .. import hip_ops
+            if hip_ops.tmix_train_eligible(x) and self.time_maa_x.dtype == x.dtype:
+                # GPU training step: the two element-wise groups as one kernel each, forward and backward
+                xxx = hip_ops.shift_mix_train(x, self.time_maa_x, reverse)
+                xxx = torch.tanh(mm(xxx, self.time_maa_rkvw_w1)).view(B * T, 4, -1).transpose(0, 1)
+                m = torch.bmm(xxx, self.time_maa_rkvw_w2).view(4, B, T, C)
+                maa4 = torch.stack([self.time_maa_r.reshape(C), self.time_maa_k.reshape(C), self.time_maa_v.reshape(C),
+                                    self.time_maa_w.reshape(C)])
+                zr, zk, zv, zw = hip_ops.mix4_train(x, m, maa4, reverse)
+                r = lin(zr, self.receptance.weight, None)
+                k = lin(zk, self.key.weight, None)
+                v = lin(zv, self.value.weight, None)
+                w = self.time_decay + mm(torch.tanh(mm(zw, self.time_decay_w1)), self.time_decay_w2)
+                return r.contiguous(), k.contiguous(), v.contiguous(), w.contiguous()
         # model.py:262,274: ZeroPad2d((0,0,1,-1)) = x_{t-1}, zero at t=0; reversed time: x_{t+1}, zero at T-1
         prev = F.pad(x, (0, 0, -1, 1)) if reverse else F.pad(x, (0, 0, 1, -1))
         xx = prev - x
         xxx = x + xx * self.time_maa_x
-        mm = self._matmul(x)
         xxx = torch.tanh(mm(xxx, self.time_maa_rkvw_w1)).view(B * T, 4, -1).transpose(0, 1)
         xxx = torch.bmm(xxx, self.time_maa_rkvw_w2).view(4, B, T, C)
         mr, mk, mv, mw = xxx.unbind(dim=0)
-        lin = self._linear(x)
         r = lin(x + xx * (self.time_maa_r + mr), self.receptance.weight, None)
         k = lin(x + xx * (self.time_maa_k + mk), self.key.weight, None)
         v = lin(x + xx * (self.time_maa_v + mv), self.value.weight, None)

@@ -373,3 +373,87 @@ def test_layernorm_module_training_path(hip):
     assert x.grad.dtype == torch.float32 and m.weight.grad.dtype == torch.float32
     with torch.no_grad():
         assert m(x).dtype == torch.float32        # no autograd: nn.LayerNorm itself
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("B,T,C", [(1, 1, 64), (2, 37, 128), (3, 50, 512), (1, 21, 1024)])
+def test_tmix_elementwise_backward_kernels(hip, dtype, reverse, B, T, C):
+    """shift_mix_train / mix4_train (forward kernels + pafc_tmix_*_bwd) against float64 autograd through the op-by-op
+    chain of src/model.py:274-284 on the same operands."""
+    import torch.nn.functional as F
+    from paper_accurate_fast_cheap_amd.hip_ops import mix4_train, shift_mix_train
+    x = synth.randn((B, T, C), 51, 1.0).to(dtype)
+    maa_x = torch.rand(1, 1, C).to(dtype)
+    maa4 = torch.rand(4, C).to(dtype)
+    m = (0.3 * synth.randn((4, B, T, C), 52, 1.0)).to(dtype)
+    g1 = synth.randn((B, T, C), 53, 1.0).to(dtype)
+    g4 = [synth.randn((B, T, C), 54 + q, 1.0).to(dtype) for q in range(4)]
+
+    def shift(t):
+        return F.pad(t, (0, 0, -1, 1)) if reverse else F.pad(t, (0, 0, 1, -1))
+    xr, ar, a4r, mr = (t.double().requires_grad_() for t in (x, maa_x, maa4, m))
+    xx = shift(xr) - xr
+    xxx_ref = xr + xx * ar
+    z_ref = [xr + xx * (a4r[q].view(1, 1, C) + mr[q]) for q in range(4)]
+    (xxx_ref * g1.double()).sum().backward(retain_graph=True)
+    gx1, ga1 = xr.grad.clone(), ar.grad.clone()
+    xr.grad = None
+    sum((z_ref[q] * g4[q].double()).sum() for q in range(4)).backward()
+
+    xg, ag, a4g, mg = (t.cuda().requires_grad_() for t in (x, maa_x, maa4, m))
+    xxx = shift_mix_train(xg, ag, reverse)
+    lo = dtype == torch.bfloat16
+    # bf16: the forward kernels round where the op-by-op chain rounds (three times); values reach |x| + |xx| ~ 8
+    tol = dict(rtol=2 ** -6, atol=6e-2) if lo else dict(rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xxx.detach().cpu().double(), xxx_ref.detach(), **tol)
+    xxx.backward(g1.cuda())
+    torch.testing.assert_close(xg.grad.cpu().double(), gx1, **tol)
+    assert ag.grad.shape == maa_x.shape
+    assert float((ag.grad.cpu().double() - ga1).abs().max()) <= (2 ** -6 if lo else 1e-4) * max(1.0, float(ga1.abs().max()))
+    xg.grad = None
+    z = mix4_train(xg, mg, a4g, reverse)
+    for q in range(4):
+        torch.testing.assert_close(z[q].detach().cpu().double(), z_ref[q].detach(), **tol)
+    sum((z[q] * g4[q].cuda()).sum() for q in range(4)).backward()
+    tol4 = dict(rtol=2 ** -5, atol=1e-1) if lo else dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, **tol4)
+    torch.testing.assert_close(mg.grad.cpu().double(), mr.grad, **tol)
+    assert float((a4g.grad.cpu().double() - a4r.grad).abs().max()) <= (2 ** -6 if lo else 1e-4) * max(1.0, float(a4r.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_tmix_block_training_path_equals_framework_autograd(hip, dtype, reverse, monkeypatch):
+    """RWKV_Tmix_x060c.mix_project under autograd: the kernel path (shift_mix / mix4 / linear / matmul functions) gives
+    the outputs and parameter gradients of the op-by-op framework path (PAFC_TRAIN_KERNELS=0)."""
+    from paper_accurate_fast_cheap_amd.rwkv_v6.tmix import RWKV_Tmix_x060c
+    torch.manual_seed(4)
+    blk = RWKV_Tmix_x060c(64, 12, 128, 128, 3)
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            if n.endswith("_w1") or n.endswith("_w2"):
+                p.normal_(0, 0.1)
+    blk = blk.to(dtype).cuda()
+    x = synth.randn((2, 300, 128), 61, 1.0).to(dtype).cuda()
+    gs = [synth.randn((2, 300, 128), 62 + i, 1.0).to(dtype).cuda() for i in range(4)]
+
+    def run():
+        blk.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_()
+        outs = blk.mix_project(xi, reverse)
+        sum((o * g).sum() for o, g in zip(outs, gs)).backward()
+        return [o.detach().float() for o in outs], xi.grad.float(), {n: p.grad.float().clone() for n, p in blk.named_parameters()
+                                                                      if p.grad is not None}
+    o_k, gx_k, gp_k = run()
+    monkeypatch.setenv("PAFC_TRAIN_KERNELS", "0")
+    o_f, gx_f, gp_f = run()
+    lo = dtype == torch.bfloat16
+    for a, b in zip(o_k, o_f):
+        torch.testing.assert_close(a, b, rtol=2 ** -6 if lo else 1e-4, atol=5e-2 if lo else 1e-4)
+    scale = float(gx_f.abs().max())
+    assert float((gx_k - gx_f).abs().max()) <= (0.05 if lo else 1e-3) * scale
+    assert set(gp_k) == set(gp_f)
+    for n in gp_f:
+        s = max(float(gp_f[n].abs().max()), 1e-6)
+        assert float((gp_k[n] - gp_f[n]).abs().max()) <= (0.08 if lo else 2e-3) * s, n
