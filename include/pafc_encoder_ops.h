@@ -124,6 +124,14 @@ int pafc_conv3x3s2_nhwc_bf16(int B, int T1, int F1, int Ci, int Co, const void *
 int pafc_conv3x3s2_c1_nhwc_bf16(int B, int T, int F, int C, const void *x, const void *w_c_9, const void *bias, void *out,
                                 int relu, pafc_stream_t stream);
 
+/* Weight / bias gradient of that first convolution for the training step (config c4; autograd through
+ * Conv2dSubsampling4.conv[0:2], subsampling.py:201-226).  act: the forward's ReLU output (B, T1, F1, C), dact: its incoming
+ * gradient; the ReLU mask is applied here.  dw_db: float32 (10, C) = [9 taps (kh, kw) ; bias], summed in a fixed order.
+ * workspace: pafc_conv3x3s2_c1_wgrad_workspace_bytes(B, T, C) bytes.  (The input has no gradient: it is the features.) */
+size_t pafc_conv3x3s2_c1_wgrad_workspace_bytes(int B, int T, int C);
+int pafc_conv3x3s2_c1_wgrad_bf16(int B, int T, int F, int C, const void *x, const void *act, const void *dact, float *dw_db,
+                                 void *workspace, size_t workspace_bytes, pafc_stream_t stream);
+
 /* The two subsampling convolutions for fp32 activations at bf16 matrix-core speed: every fp32 value travels as
  * hi + lo, hi = bf16(x), lo = bf16(x - hi) (16 significant bits); a product is three bf16 MFMAs (hi hi + lo hi + hi lo)
  * accumulated in fp32 -- ~1e-5 relative to the fp32 convolution.  _c1_: x (B, T, F) fp32, w (C, 1, 3, 3) fp32, bias

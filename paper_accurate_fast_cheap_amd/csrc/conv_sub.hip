@@ -236,6 +236,86 @@ __global__ __launch_bounds__(256) void conv3x3s2_c1_kernel(int T, int F, int T1,
     }
 }
 
+// ---- first convolution, weight / bias gradient for the training step (config c4) ---------------------------------------
+//   dW[c][k] = sum_{b,t1,f1} dY[b][t1][f1][c] x[b][2 t1 + kh][2 f1 + kw],  db[c] = sum dY,   dY = dA * (A > 0)
+// (A = the forward's ReLU output, dA its incoming gradient: the ReLU mask is applied here, so the 1.3 GB gradient map of
+// the c4 step is read once and never rewritten).  Same ownership as the forward: a thread owns 8 channels and a quarter
+// of a row's positions, the three input rows of an output row sit in LDS; a block walks C1_ROWS output rows keeping its
+// 10 x 8 sums in registers and leaves one fp32 partial per (k, c); a second kernel adds the partials in a fixed order.
+constexpr int C1_ROWS = 32;
+
+__global__ __launch_bounds__(256) void conv3x3s2_c1_wgrad_kernel(int T, int F, int T1, int F1, int C, long nrows,
+                                                                 const bf16_t *__restrict__ x, const bf16_t *__restrict__ act,
+                                                                 const bf16_t *__restrict__ dact, float *__restrict__ part) {
+    extern __shared__ float s_x[];   // [3][F], then reused for the cross-wave sums
+    const int tid = threadIdx.x;
+    const int cgs = C / 8, ppi = 256 / cgs;
+    const int cg = tid % cgs, pl = tid / cgs;
+    float acc[10][8];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
+    const long r_end = min(nrows, ((long)blockIdx.x + 1) * C1_ROWS);
+    for (long bt = (long)blockIdx.x * C1_ROWS; bt < r_end; ++bt) {
+        const int b = (int)(bt / T1), t1 = (int)(bt % T1);
+        const bf16_t *xr = x + ((long)b * T + 2 * t1) * F;
+        __syncthreads();
+        for (int i = tid; i < 3 * F; i += 256) s_x[i] = bf16_bits_to_f32(xr[i]);
+        __syncthreads();
+        const bf16_t *arow = act + bt * (long)F1 * C + cg * 8, *grow = dact + bt * (long)F1 * C + cg * 8;
+        for (int f1 = pl; f1 < F1; f1 += ppi) {
+            float a[8], g[8];
+            Elem<bf16_t>::unpack(*reinterpret_cast<const uint4 *>(arow + (long)f1 * C), a);
+            Elem<bf16_t>::unpack(*reinterpret_cast<const uint4 *>(grow + (long)f1 * C), g);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) g[c] = a[c] > 0.f ? g[c] : 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float xv = s_x[kh * F + 2 * f1 + kw];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[kh * 3 + kw][c] = fmaf(g[c], xv, acc[kh * 3 + kw][c]);
+                }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[9][c] += g[c];
+        }
+    }
+    // sums of the ppi position lanes of a channel group -> [k][C] partial of this block
+    float *po = part + (size_t)blockIdx.x * 10 * C;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 8; ++c) s_x[pl * C + cg * 8 + c] = acc[k][c];
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            float s = 0.f;
+            for (int q = 0; q < ppi; ++q) s += s_x[q * C + c];
+            po[(size_t)k * C + c] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void conv_c1_wgrad_reduce_kernel(int n, int nblk, const float *__restrict__ part,
+                                                                    float *__restrict__ out) {
+    __shared__ float s_sum[64][16];
+    const int ch = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + ch;
+    float s = 0.f;
+    if (i < n)
+        for (int b = slice; b < nblk; b += 64) s += part[(size_t)b * n + i];
+    s_sum[slice][ch] = s;
+    __syncthreads();
+    if (slice == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) t += s_sum[k][ch];
+        out[i] = t;
+    }
+}
+
 // ---- fp32 activations at bf16 matrix-core speed: split operands ---------------------------------------------------------
 // An fp32 model (the YAML default keeps everything but the slot in fp32) would run conv2 on the fp32 MFMA path: 57 ms per
 // 30-minute file through the library against 3.8 ms in bf16.  Every fp32 value is hi + lo with hi = bf16(x) and
@@ -511,5 +591,28 @@ extern "C" int pafc_conv3x3s2_nhwc_f32split(int B, int T1, int F1, int Ci, int C
         return PAFC_ERR_LAUNCH;
     hipLaunchKernelGGL(pafc::conv3x3s2_split_kernel, dim3((unsigned)((long)p.mtiles * p.ntiles)), dim3(256), lds,
                        (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+extern "C" size_t pafc_conv3x3s2_c1_wgrad_workspace_bytes(int B, int T, int C) {
+    if (B <= 0 || T < 3 || C <= 0) return 0;
+    const long nrows = (long)B * ((T - 3) / 2 + 1);
+    return (size_t)((nrows + pafc::C1_ROWS - 1) / pafc::C1_ROWS) * 10 * C * sizeof(float);
+}
+
+extern "C" int pafc_conv3x3s2_c1_wgrad_bf16(int B, int T, int F, int C, const void *x, const void *act, const void *dact,
+                                            float *dw_db, void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
+    if (!x || !act || !dact || !dw_db || !workspace) return PAFC_ERR_NULL_POINTER;
+    if (B <= 0 || T < 3 || F < 3 || C <= 0 || C % 8 || (256 % (C / 8)) || C > 2048) return PAFC_ERR_BAD_DIMS;
+    if (workspace_bytes < pafc_conv3x3s2_c1_wgrad_workspace_bytes(B, T, C)) return PAFC_ERR_WORKSPACE;
+    const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
+    const long nrows = (long)B * T1;
+    const int nblk = (int)((nrows + pafc::C1_ROWS - 1) / pafc::C1_ROWS);
+    const size_t lds = sizeof(float) * (size_t)((3 * F > (256 / (C / 8)) * C) ? 3 * F : (256 / (C / 8)) * C);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pafc::conv3x3s2_c1_wgrad_kernel, dim3(nblk), dim3(256), lds, s, T, F, T1, F1, C, nrows,
+                       (const pafc::bf16_t *)x, (const pafc::bf16_t *)act, (const pafc::bf16_t *)dact, (float *)workspace);
+    hipLaunchKernelGGL(pafc::conv_c1_wgrad_reduce_kernel, dim3((10 * C + 15) / 16), dim3(1024), 0, s, 10 * C, nblk,
+                       (const float *)workspace, dw_db);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }

@@ -636,6 +636,76 @@ def conv3x3s2_c1_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
     return out
 
 
+class _Conv1Train(torch.autograd.Function):
+    """relu(Conv2d(1, C, 3, 2)(x)) in NHWC for the GPU training step (subsampling.py:201-226, conv[0:2]): forward = the
+    inference kernel, backward = pafc_conv3x3s2_c1_wgrad_bf16 (the library runs this layer as im2col + one small GEMM per
+    batch entry: 6 ms forward + backward at the c4 shape).  x: (B, T, F) bf16 features (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        wb = weight.to(torch.bfloat16)
+        a = conv3x3s2_c1_nhwc(x, wb, None if bias is None else bias.to(torch.bfloat16), relu=True)
+        ctx.save_for_backward(x, a)
+        ctx.w_dtype, ctx.b_dtype, ctx.w_shape = weight.dtype, (None if bias is None else bias.dtype), weight.shape
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, a = ctx.saved_tensors
+        B, T, Fd = x.shape
+        C = a.shape[-1]
+        L = _bind()
+        if not getattr(L, "_pafc_c1w_bound", False):
+            from ctypes import c_size_t
+            L.pafc_conv3x3s2_c1_wgrad_workspace_bytes.restype = c_size_t
+            L.pafc_conv3x3s2_c1_wgrad_workspace_bytes.argtypes = [c_int, c_int, c_int]
+            _lib._sig(L.pafc_conv3x3s2_c1_wgrad_bf16, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                      c_void_p, c_void_p, c_size_t, c_void_p)
+            L._pafc_c1w_bound = True
+        nbytes = L.pafc_conv3x3s2_c1_wgrad_workspace_bytes(B, T, C)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        out = torch.empty(10, C, dtype=torch.float32, device=x.device)
+        da = da.contiguous()
+        rc = L.pafc_conv3x3s2_c1_wgrad_bf16(B, T, Fd, C, _lib.ptr(x), _lib.ptr(a), _lib.ptr(da), _lib.ptr(out), _lib.ptr(ws),
+                                            nbytes, _lib.stream_of(x))
+        _lib.check(rc, "pafc_conv3x3s2_c1_wgrad_bf16")
+        dw = out[:9].t().reshape(ctx.w_shape).to(ctx.w_dtype)
+        db = out[9].to(ctx.b_dtype) if ctx.b_dtype is not None else None
+        return None, dw, db
+
+
+class _Conv2Train(torch.autograd.Function):
+    """relu(Conv2d(C, C, 3, 2)(a)) NHWC -> NHWC for the GPU training step (subsampling.py conv[2:4]): forward = the
+    hand-written implicit GEMM (1.0 PFLOP/s; the library's forward runs at a third of that), backward = the library's
+    convolution backward on channels_last views of the same memory."""
+
+    @staticmethod
+    def forward(ctx, a, weight, bias):
+        Co, Ci = weight.shape[0], weight.shape[1]
+        wb = weight.to(torch.bfloat16)
+        taps = wb.permute(2, 3, 0, 1).reshape(9, Co, Ci).contiguous()
+        y = conv3x3s2_nhwc(a, taps, None if bias is None else bias.to(torch.bfloat16), relu=True)
+        ctx.save_for_backward(a, y, wb)
+        ctx.w_dtype, ctx.b_dtype = weight.dtype, (None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, y, wb = ctx.saved_tensors
+        g = (dy * (y > 0)).permute(0, 3, 1, 2)                       # NCHW view of NHWC memory (channels_last)
+        gi, gw, gb = torch.ops.aten.convolution_backward(g, a.permute(0, 3, 1, 2), wb, [wb.shape[0]], [2, 2], [0, 0], [1, 1],
+                                                         False, [0, 0], 1, [ctx.needs_input_grad[0], True,
+                                                                            ctx.b_dtype is not None])
+        da = gi.permute(0, 2, 3, 1).contiguous() if gi is not None else None
+        return da, gw.to(ctx.w_dtype), (gb.to(ctx.b_dtype) if gb is not None else None)
+
+
+def conv_sub_train(x: torch.Tensor, c1_weight, c1_bias, c2_weight, c2_bias) -> torch.Tensor:
+    """The two subsampling convolutions + ReLUs of the bf16 training step, NHWC: x (B, T, F) -> (B, T', F', C) bf16."""
+    a = _Conv1Train.apply(x.to(torch.bfloat16).contiguous(), c1_weight, c1_bias)
+    return _Conv2Train.apply(a, c2_weight, c2_bias)
+
+
 def ctc_prefix_beam(top_logp: torch.Tensor, top_idx: torch.Tensor, lens: Optional[torch.Tensor], beam: int,
                     blank_id: int = 0):
     """GPU-resident CTC prefix beam search (include/pafc_search.h).  top_logp (B, T, K) float32 / top_idx (B, T, K) =

@@ -82,12 +82,31 @@ class Conv2dSubsampling4(BaseSubsampling):
         if x.is_cuda and not torch.is_grad_enabled() and x.size(1) >= 7:
             x, pos_emb = self.pos_enc(self._forward_nhwc(x), offset)
             return x, pos_emb, x_mask[:, :, 2::2][:, :, 2::2]
+        if self._train_kernels_eligible(x):
+            # GPU training step under bf16 autocast: both convolutions on the hand-written kernels, NHWC end to end; the
+            # (c, f) -> (f, c) column permutation of `out`'s weight is part of the graph, so its gradient lands in place
+            from .. import hip_ops
+            c1, c2, lin = self.conv[0], self.conv[2], self.out[0]
+            y = hip_ops.conv_sub_train(x, c1.weight, c1.bias, c2.weight, c2.bias)
+            b, t, f, c = y.shape
+            w_lin = lin.weight.view(-1, c, f).permute(0, 2, 1).reshape(-1, f * c)
+            x = torch.nn.functional.linear(y.view(b, t, f * c), w_lin, lin.bias)
+            x, pos_emb = self.pos_enc(x, offset)
+            return x, pos_emb, x_mask[:, :, 2::2][:, :, 2::2]
         x = x.unsqueeze(1)  # (B, 1, T, F)
         x = self.conv(x)
         b, c, t, f = x.size()
         x = self.out(x.transpose(1, 2).contiguous().view(b, t, c * f))
         x, pos_emb = self.pos_enc(x, offset)
         return x, pos_emb, x_mask[:, :, 2::2][:, :, 2::2]
+
+    def _train_kernels_eligible(self, x: torch.Tensor) -> bool:
+        if not (x.is_cuda and torch.is_grad_enabled() and x.size(1) >= 7 and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+            return False
+        from ..hip_ops import train_kernels_enabled
+        C = self.conv[0].out_channels
+        return train_kernels_enabled() and C % 128 == 0 and 256 % (C // 8) == 0 and self.conv[2].in_channels % 64 == 0
 
 
 class LinearNoSubsampling(BaseSubsampling):

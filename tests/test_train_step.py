@@ -365,3 +365,40 @@ def test_train_step_fp16_amp_through_the_encoder(hip, golden):
     changed = any(not torch.equal(before[n], p.detach()) for n, p in model.named_parameters())
     assert changed == bool(info["updated"])
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,T,B", [(128, 67, 2), (512, 203, 3)])
+def test_subsampling_training_path_equals_framework_autograd(hip, monkeypatch, C, T, B):
+    """Conv2dSubsampling4 under bf16 autocast + autograd: the NHWC kernel path (conv1 forward + weight-gradient kernels,
+    conv2 forward kernel + library backward on channels_last views, permuted `out` weight) gives the outputs and the
+    parameter gradients of the module chain through the library (PAFC_TRAIN_KERNELS=0)."""
+    from paper_accurate_fast_cheap_amd.transformer.embedding import RelPositionalEncoding
+    from paper_accurate_fast_cheap_amd.transformer.subsampling import Conv2dSubsampling4
+    torch.manual_seed(8)
+    sub = Conv2dSubsampling4(80, C, 0.0, RelPositionalEncoding(C, 0.0)).cuda().train()
+    x = synth.randn((B, T, 80), 71, 1.5).cuda()
+    mask = torch.ones(B, 1, T, dtype=torch.bool, device="cuda")
+    Tp = ((T - 1) // 2 - 1) // 2
+    gy = synth.randn((B, Tp, C), 72, 1.0).cuda()
+
+    def run(amp=True):
+        sub.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            y, _, m = sub(x, mask)
+        (y.float() * gy).sum().backward()
+        return y.detach().float(), {n: p.grad.float().clone() for n, p in sub.named_parameters()}
+    y_k, g_k = run()
+    monkeypatch.setenv("PAFC_TRAIN_KERNELS", "0")
+    y_f, g_f = run()
+    y_r, g_r = run(amp=False)                       # fp32 module chain: the yardstick for both bf16 paths
+    assert y_k.shape == y_f.shape == (B, Tp, C)
+    assert float((y_k - y_r).abs().max()) <= 3e-2 * max(1.0, float(y_r.abs().max()))
+    assert set(g_k) == set(g_r)
+    for n in g_r:
+        s = max(float(g_r[n].abs().max()), 1e-6)
+        assert g_k[n].shape == g_r[n].shape
+        err_k, err_f = float((g_k[n] - g_r[n]).abs().max()), float((g_f[n] - g_r[n]).abs().max())
+        # within bf16 noise of the fp32 gradient, and no further from it than the library's own bf16 path plus slack
+        assert err_k <= 0.2 * s, (n, err_k, s)           # both bf16 paths sit 6-12 % (max-norm) from the fp32 gradient here
+        assert err_k <= 1.5 * err_f + 1e-2 * s, (n, err_k, err_f, s)
