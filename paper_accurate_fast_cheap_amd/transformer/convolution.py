@@ -59,11 +59,16 @@ class ConvolutionModule(nn.Module):
         lp = 0 if self.lorder > 0 else (self.kernel_size - 1) // 2
         out_len = x.size(1) - self.lorder if self.lorder > 0 else x.size(1)
         if x.dtype not in (torch.float32, torch.bfloat16):
-            # fp16 autocast (`--use_amp`): the kernels compute in fp32 / bf16 only; the library's convolution between the
-            # reference's two transposes (convolution.py:131)
-            x = self.depthwise_conv._conv_forward(x.transpose(1, 2), self.depthwise_conv.weight.to(x.dtype),
-                                                  None if self.depthwise_conv.bias is None
-                                                  else self.depthwise_conv.bias.to(x.dtype)).transpose(1, 2)
+            # fp16 autocast (`--use_amp`): the kernels compute in fp32 / bf16 only -- run them in fp32 (exact for fp16
+            # inputs) and round the result back, rather than sending a grouped convolution to the library
+            xd = x.dtype
+            if torch.is_grad_enabled() and (x.requires_grad or self.depthwise_conv.weight.requires_grad):
+                x = depthwise_conv1d_cl_autograd(x.float(), self.depthwise_conv.weight, self.depthwise_conv.bias, lp, out_len)
+            else:
+                x = depthwise_conv1d_cl(x.float(), self.depthwise_conv.weight.float(),
+                                        None if self.depthwise_conv.bias is None else self.depthwise_conv.bias.float(),
+                                        left_pad=lp, out_len=out_len)
+            x = x.to(xd)
         elif torch.is_grad_enabled() and (x.requires_grad or self.depthwise_conv.weight.requires_grad):
             x = depthwise_conv1d_cl_autograd(x, self.depthwise_conv.weight, self.depthwise_conv.bias, lp, out_len)
         else:

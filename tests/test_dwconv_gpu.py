@@ -91,7 +91,11 @@ def test_conv_module_training_path_uses_the_kernels(hip):
     m.zero_grad(); x.grad = None
     xm = x.masked_fill(~mask.transpose(1, 2), 0.0)
     h = F.glu(F.linear(xm, m.pointwise_conv1.weight.squeeze(-1), m.pointwise_conv1.bias), dim=-1)
-    h = m.depthwise_conv(h.transpose(1, 2)).transpose(1, 2)
+    # the depthwise convolution spelled out with element-wise ops (unfold * taps, summed): the library's grouped
+    # convolution would JIT-compile a kernel here, which takes seconds to minutes on a fresh box
+    K = m.kernel_size
+    hp = F.pad(h, (0, 0, (K - 1) // 2, (K - 1) // 2)).unfold(1, K, 1)                  # (B, T, C, K)
+    h = (hp * m.depthwise_conv.weight.squeeze(1)).sum(-1) + m.depthwise_conv.bias
     h = F.linear(m.activation(m.norm(h)), m.pointwise_conv2.weight.squeeze(-1), m.pointwise_conv2.bias)
     h = h.masked_fill(~mask.transpose(1, 2), 0.0)
     torch.testing.assert_close(y, h, rtol=1e-4, atol=1e-5)

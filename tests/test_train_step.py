@@ -318,8 +318,8 @@ def test_train_step_bf16_autocast_through_the_encoder(hip):
 
 @pytest.mark.gpu
 def test_conv_module_under_fp16_autocast(hip):
-    """`--use_amp` is fp16 autocast (train_utils.py:635): the conv module must run (library depthwise convolution, the
-    kernels being fp32 / bf16) and hand fp32 gradients to its fp32 parameters."""
+    """`--use_amp` is fp16 autocast (train_utils.py:635): the conv module must run (the depthwise kernels in fp32, the
+    result rounded back to fp16) and hand fp32 gradients to its fp32 parameters."""
     from paper_accurate_fast_cheap_amd.transformer.convolution import ConvolutionModule
     torch.manual_seed(0)
     m = ConvolutionModule(128, 15, torch.nn.SiLU(), "layer_norm", causal=False, bias=True).cuda()
