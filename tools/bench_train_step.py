@@ -17,13 +17,17 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of N > 1 on one GPU with "
+                                                           "PAFC_BENCH_ONE_GPU=1)")
     ap.add_argument("--amp", default="none", choices=["none", "bf16"],
                     help="bf16: forward under torch.autocast(bfloat16) (the reference's `dtype: bf16`), fp32 master weights")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
+        dist.init_process_group(args.dist_backend)
+    if os.environ.get("PAFC_BENCH_ONE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     from paper_accurate_fast_cheap_amd import _lib
@@ -61,7 +65,8 @@ def main():
             print(f"step {i}: loss {float(info['loss']):.3f} grad_norm {float(info['grad_norm']):.2f}", file=sys.stderr)
     sync(); dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t)
+        t = torch.tensor([dt], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t)
     frames = int(lens.sum()) * world * args.steps
     if rank == 0:
         print(json.dumps({"metric": "training audio-sec/sec (c4: fwd + bwd + all-reduce + clip + Adam, CTC objective)",
