@@ -183,18 +183,18 @@ __global__ __launch_bounds__(256, BLOCKS_PER_CU) void conv3x3s2_kernel(const Con
 }
 
 // ---- first convolution: Conv2d(1, C, 3, 2) + ReLU, one input channel, NHWC out ----------------------------------------
-// 9 MACs per output against 2 bytes written: a pure write-bound pass (3.6 GB for a 30-minute file).  One block per output
-// row (b, t1): the three input rows sit in LDS as fp32, a thread owns 8 consecutive channels (its 9 x 8 weights stay in
-// registers) and walks the row's positions, storing 16 bytes per position -- every wave writes whole 1 KiB rows.
-__global__ __launch_bounds__(256) void conv3x3s2_c1_kernel(int T, int F, int T1, int F1, int C, const bf16_t *x,
+// 9 MACs per output against 2 bytes written: a pure write-bound pass (3.6 GB for a 30-minute file).  A block takes
+// C1F_ROWS output rows (b, t1) in turn: the three input rows of the current one sit in LDS as fp32, a thread owns 8
+// consecutive channels -- its 9 x 8 weights stay in registers for the whole block (fetching them per output row was a
+// third of the kernel: 1000 -> 700 us = 5.1 TB/s of stores) -- and walks the row's positions, storing 16 bytes per
+// position: every wave writes whole 1 KiB rows.
+constexpr int C1F_ROWS = 4;   // output rows per block: the 9 x 8 weights of a thread are fetched once per block
+
+__global__ __launch_bounds__(256) void conv3x3s2_c1_kernel(int T, int F, int T1, int F1, int C, long nrows, const bf16_t *x,
                                                            const bf16_t *w /* (C, 9) */, const bf16_t *bias, bf16_t *out,
                                                            int relu) {
     extern __shared__ float s_x[];   // [3][F]
     const int tid = threadIdx.x;
-    const long bt = blockIdx.x;                         // b * T1 + t1
-    const int b = (int)(bt / T1), t1 = (int)(bt % T1);
-    const bf16_t *xr = x + ((long)b * T + 2 * t1) * F;
-    for (int i = tid; i < 3 * F; i += 256) s_x[i] = bf16_bits_to_f32(xr[i]);
     const int cgs = C / 8;                              // channel groups per position
     const int ppi = 256 / cgs;                          // positions per block iteration (C = 512: 4)
     const int cg = tid % cgs, pl = tid / cgs;
@@ -208,31 +208,38 @@ __global__ __launch_bounds__(256) void conv3x3s2_c1_kernel(int T, int F, int T1,
             bv[c] = bias ? bf16_bits_to_f32(bias[cg * 8 + c]) : 0.f;
         }
     }
-    __syncthreads();
-    bf16_t *orow = out + bt * (long)F1 * C + cg * 8;
-    for (int f1 = pl; f1 < F1; f1 += ppi) {
-        float xv[9];
+    const long r_end = min(nrows, ((long)blockIdx.x + 1) * C1F_ROWS);
+    for (long bt = (long)blockIdx.x * C1F_ROWS; bt < r_end; ++bt) {   // bt = b * T1 + t1
+        const int b = (int)(bt / T1), t1 = (int)(bt % T1);
+        const bf16_t *xr = x + ((long)b * T + 2 * t1) * F;
+        __syncthreads();
+        for (int i = tid; i < 3 * F; i += 256) s_x[i] = bf16_bits_to_f32(xr[i]);
+        __syncthreads();
+        bf16_t *orow = out + bt * (long)F1 * C + cg * 8;
+        for (int f1 = pl; f1 < F1; f1 += ppi) {
+            float xv[9];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+            for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = s_x[kh * F + 2 * f1 + kw];
-        float acc[8];
+                for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = s_x[kh * F + 2 * f1 + kw];
+            float acc[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = bv[c];
+            for (int c = 0; c < 8; ++c) acc[c] = bv[c];
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
+            for (int k = 0; k < 9; ++k)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] = fmaf(xv[k], wr[k][c], acc[c]);
-        if (relu) {
+                for (int c = 0; c < 8; ++c) acc[c] = fmaf(xv[k], wr[k][c], acc[c]);
+            if (relu) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] = fmaxf(acc[c], 0.f);
+                for (int c = 0; c < 8; ++c) acc[c] = fmaxf(acc[c], 0.f);
+            }
+            uint4 o;
+            o.x = f32_to_bf16_bits(acc[0]) | (f32_to_bf16_bits(acc[1]) << 16);
+            o.y = f32_to_bf16_bits(acc[2]) | (f32_to_bf16_bits(acc[3]) << 16);
+            o.z = f32_to_bf16_bits(acc[4]) | (f32_to_bf16_bits(acc[5]) << 16);
+            o.w = f32_to_bf16_bits(acc[6]) | (f32_to_bf16_bits(acc[7]) << 16);
+            *reinterpret_cast<uint4 *>(orow + (long)f1 * C) = o;
         }
-        uint4 o;
-        o.x = f32_to_bf16_bits(acc[0]) | (f32_to_bf16_bits(acc[1]) << 16);
-        o.y = f32_to_bf16_bits(acc[2]) | (f32_to_bf16_bits(acc[3]) << 16);
-        o.z = f32_to_bf16_bits(acc[4]) | (f32_to_bf16_bits(acc[5]) << 16);
-        o.w = f32_to_bf16_bits(acc[6]) | (f32_to_bf16_bits(acc[7]) << 16);
-        *reinterpret_cast<uint4 *>(orow + (long)f1 * C) = o;
     }
 }
 
@@ -551,9 +558,9 @@ extern "C" int pafc_conv3x3s2_c1_nhwc_bf16(int B, int T, int F, int C, const voi
     const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
     const long nblk = (long)B * T1;
     if (nblk > 0x7fffffffL) return PAFC_ERR_BAD_DIMS;
-    hipLaunchKernelGGL(pafc::conv3x3s2_c1_kernel, dim3((unsigned)nblk), dim3(256), 3 * F * sizeof(float), (hipStream_t)stream,
-                       T, F, T1, F1, C, (const pafc::bf16_t *)x, (const pafc::bf16_t *)w_c_9, (const pafc::bf16_t *)bias,
-                       (pafc::bf16_t *)out, relu);
+    hipLaunchKernelGGL(pafc::conv3x3s2_c1_kernel, dim3((unsigned)((nblk + pafc::C1F_ROWS - 1) / pafc::C1F_ROWS)), dim3(256),
+                       3 * F * sizeof(float), (hipStream_t)stream, T, F, T1, F1, C, nblk, (const pafc::bf16_t *)x,
+                       (const pafc::bf16_t *)w_c_9, (const pafc::bf16_t *)bias, (pafc::bf16_t *)out, relu);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 
