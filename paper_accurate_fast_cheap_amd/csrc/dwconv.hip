@@ -49,10 +49,23 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int T_in, int C, int left_p
     const int valid = lens ? min(T_in, lens[b]) : T_in;
 
     float w0[K], w1[K];
+    if constexpr (sizeof(ET) == 2) {
+        // the 2 K taps of channels c, c + 1 are K consecutive dwords (c is even): K loads instead of 2 K two-byte ones --
+        // the tap fetch was the larger half of this kernel's load instructions
+        const uint32_t *wd = reinterpret_cast<const uint32_t *>(w + (size_t)c * K);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        w0[k] = Elem<ET>::load(w + (size_t)c * K + k);
-        w1[k] = Elem<ET>::load(w + (size_t)(c + 1) * K + k);
+        for (int j = 0; j < K; ++j) {
+            const uint32_t d = wd[j];
+            const float lo = bf16_bits_to_f32(d & 0xffffu), hi = __uint_as_float(d & 0xffff0000u);
+            if (2 * j < K) w0[2 * j] = lo; else w1[2 * j - K] = lo;
+            if (2 * j + 1 < K) w0[2 * j + 1] = hi; else w1[2 * j + 1 - K] = hi;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            w0[k] = Elem<ET>::load(w + (size_t)c * K + k);
+            w1[k] = Elem<ET>::load(w + (size_t)(c + 1) * K + k);
+        }
     }
     float2 bv = make_float2(0.f, 0.f);
     if (bias) bv = Pair<ET>::load(bias + c);
