@@ -309,6 +309,7 @@ def test_fused_state_carry_step_serves_concurrent_streams(hip):
     enc = enc.to(torch.bfloat16).cuda().eval()
     xs = synth.randn((3, 4 * 8 * 9 + 3, 80), 80, 2.0).to(torch.bfloat16).cuda()
     with torch.no_grad():
+        enc.fused_inference = True                              # whatever PAFC_DISABLE_FUSED says
         both = enc.stream_chunks(xs, 8, use_graph=False)
         assert getattr(enc, "_carry_plans", None) is not None
         _, st = enc.forward_chunk_carry(xs[:, :35], 0, None)
