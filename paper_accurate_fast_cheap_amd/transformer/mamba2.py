@@ -113,7 +113,14 @@ class Mamba2(nn.Module):
         H, P, N = self.nheads, self.headdim, self.d_state
         zxbcdt = self.in_proj(u)
         z, xBC, dt = torch.split(zxbcdt, [self.d_inner, self.d_inner + 2 * N, H], dim=-1)
-        xBC = F.silu(self.conv1d(xBC.transpose(1, 2))[..., :L].transpose(1, 2))        # causal: keep the first L
+        if xBC.is_cuda and xBC.dtype in (torch.float32, torch.bfloat16) and xBC.shape[-1] % 2 == 0 and self.d_conv in (3, 4, 7, 15, 31):
+            # channels-last depthwise kernels (forward and gradients) instead of the library's grouped convolution, which
+            # JIT-compiles a kernel per shape
+            from ..hip_ops import depthwise_conv1d_cl_autograd
+            xBC = F.silu(depthwise_conv1d_cl_autograd(xBC.contiguous(), self.conv1d.weight, self.conv1d.bias,
+                                                      self.d_conv - 1, L))
+        else:
+            xBC = F.silu(self.conv1d(xBC.transpose(1, 2))[..., :L].transpose(1, 2))    # causal: keep the first L
         x, Bm, Cm = torch.split(xBC, [self.d_inner, N, N], dim=-1)
         dt = F.softplus(dt.float() + self.dt_bias.float())                            # (B, L, H)
         A = -torch.exp(self.A_log.float())                                             # (H,)
