@@ -260,7 +260,7 @@ def main():
     rec = prof.get("wkv6_fwd_bidir") or prof.get("wkv6_fwd")
     roofline = None
     traffic = None   # HBM bytes per launch from rocprofv3 PMC passes of the same op and shape, when recorded
-    tpath = os.path.join(ROOT, "profiles", "r01g_wkv6_bidir_T44998_bf16_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01i_wkv6_bidir_T44998_bf16_hbm_traffic.json")
     if rec and os.path.exists(tpath):
         tj = json.load(open(tpath))
         m = rec["meta"]
