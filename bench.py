@@ -128,6 +128,47 @@ def cpu_baseline(model, feats_cpu_f32, conf, sample_frames: int):
                       f"bf16 time-mix slot, {threads} torch/OpenMP threads, {dt:.1f} s wall"}
 
 
+def scan_source_sha() -> str:
+    """sha256 prefix of the scan kernels' sources: a PMC traffic file is only quoted for the kernels it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("wkv6.hip", "wkv6_mfma.inc"):
+        with open(os.path.join(ROOT, "paper_accurate_fast_cheap_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def scan_traffic(meta):
+    """HBM bytes per launch of the scan from the rocprofv3 PMC passes committed under profiles/ (tools/summarize_wkv_pmc.py),
+    or None when no file was collected on the present kernel sources and shape."""
+    import glob
+    sha = scan_source_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_wkv6_bidir_*_hbm_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if tj.get("scan_source_sha") == sha and all(tj["shape"].get(k) == meta[k] for k in ("B", "T", "C", "ndir", "elem_bytes")):
+            return tj["hbm_bytes_per_launch_corrected"], os.path.basename(path)
+    return None, None
+
+
+def spawn_ranks(n: int, argv, script: str = None) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as a child torchrun -- the parent has made
+    no GPU call -- relay their output and return the child's exit code (wenet's recipe launches the same way,
+    examples/gigaspeech/s0/run-pipeline-v3.sh:135-137)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,13 +191,22 @@ def main():
         # ~90 distinct (B, T) shapes: MIOpen's default exhaustive per-shape search costs seconds each; the
         # immediate-mode heuristic is the production setting for ragged batches
         os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+    one_gpu = os.environ.get("PAFC_BENCH_ONE_GPU") == "1"   # rehearsal of the N > 1 code path on a single-GPU box
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        have = torch.cuda.device_count()           # counts devices without initialising the GPU
+        if have < args.gpus and not one_gpu:
+            sys.exit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s) (PAFC_BENCH_ONE_GPU=1 "
+                     f"--dist-backend gloo rehearses the multi-rank path on one)")
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(args.dist_backend)  # RCCL; only used for the timing barrier and the max-reduce
-    if os.environ.get("PAFC_BENCH_ONE_GPU") == "1":   # rehearsal of the N > 1 code path on a single-GPU box
+    if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -200,10 +250,20 @@ def main():
                 fb[j, :n] = src[off:off + n]
             batches.append((fb, torch.tensor(L, dtype=torch.int32, device=device)))
     frames_per_step = int(sum(int(l.sum()) for _, l in batches))
+    progress = None
+    if args.workload == "c2" and rank == 0:   # a long ragged run is never silent: one line per pass over the shard
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        progress = open(os.path.join(ROOT, "gpurun_out", "bench_c2_progress.log"), "a")
+
     def step():
         for fb, lens in batches:
             enc, mask = model._forward_encoder(fb, lens)
             logp = model.ctc_logprobs(enc)
+            if greedy is not None:            # c2 = encoder + CTC log-softmax + greedy tokens (search.py:106-121)
+                toks = greedy(logp, mask.squeeze(1).sum(1), 0)
+        if progress is not None:
+            progress.write(f"{time.strftime('%H:%M:%S')} pass over {len(batches)} batches queued\n")
+            progress.flush()
         return logp
 
     def barrier():
@@ -259,13 +319,8 @@ def main():
 
     rec = prof.get("wkv6_fwd_bidir") or prof.get("wkv6_fwd")
     roofline = None
-    traffic = None   # HBM bytes per launch from rocprofv3 PMC passes of the same op and shape, when recorded
-    tpath = os.path.join(ROOT, "profiles", "r01i_wkv6_bidir_T44998_bf16_hbm_traffic.json")
-    if rec and os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        m = rec["meta"]
-        if all(tj["shape"][k] == m[k] for k in ("B", "T", "C", "ndir", "elem_bytes")):
-            traffic = tj["hbm_bytes_per_launch_corrected"]
+    # HBM bytes per launch from the rocprofv3 PMC passes of the same op and shape ON THE PRESENT KERNEL SOURCES, else null
+    traffic, traffic_file = scan_traffic(rec["meta"]) if rec else (None, None)
     if rec:
         m = rec["meta"]
         alg_bytes = m["B"] * m["T"] * m["C"] * 5 * m["elem_bytes"] * m["ndir"]
@@ -274,6 +329,7 @@ def main():
         roofline = {"kernel": "wkv6 forward scan, both directions (chunk_state + state_scan + chunk_output kernels)",
                     "bound": "hbm", "achieved": round(alg_bytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": traffic_file,
                     "launches": rec["n"], "avg_launch_us": round(rec["avg_ms"] * 1e3, 1),
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "measured_copy_gbs": copy_gbs,

@@ -78,10 +78,17 @@ def rwkv_wrapper(query: torch.Tensor, sd: SD, p: str, head_size: int, do_bfloat1
     return y, cache
 
 
-def rwkv_wrapper_bidirectional(query, sd: SD, p: str, head_size: int, do_bfloat16: bool, cache=None):
+def rwkv_wrapper_bidirectional(query, sd: SD, p: str, head_size: int, do_bfloat16: bool, cache=None,
+                               out_as_query: bool = False):
     """RWKV_TmixWrapper_bidirectional.forward, rwkv_wrapper_bidirectional.py:30-64 (same arithmetic as
     rwkv_wrapper_bidirectional2.py:95-150).  The inner wrappers have do_bfloat16 forced False (:27-28);
-    the flip is over the whole padded length (:44); the sum and /2 happen in bf16 (:49), then .float() (:55-56)."""
+    the flip is over the whole padded length (:44); the sum and /2 happen in bf16 (:49), then .float() (:55-56).
+
+    out_as_query: the ONE deliberate departure, for the whole-model-bf16 mode of `encoder-rtf.py --bf16`
+    (encoder-rtf.py:424-426): there the reference's `.float()` hands fp32 to a LayerNorm with bf16 parameters and
+    raises, so the mode is defined as "the slot returns the query dtype" -- identical to the reference for an fp32
+    query, and the only change that lets its own graph run for a bf16 one."""
+    qd = query.dtype
     if do_bfloat16:
         query = query.to(torch.bfloat16)
     x = query
@@ -90,7 +97,42 @@ def rwkv_wrapper_bidirectional(query, sd: SD, p: str, head_size: int, do_bfloat1
     b, _ = rwkv_wrapper(xf, sd, p + "rwkv_wrapper_backward.", head_size, False, cache)
     out = (a + torch.flip(b, [1])) / 2
     if do_bfloat16:
-        out = out.float()
+        out = out.to(qd) if out_as_query else out.float()
+    if cache is None:
+        cache = torch.zeros((0, 0, 0, 0))
+    return out, cache
+
+
+def draw_direction_dropout(both: bool, p: float = 0.2) -> Tuple[bool, Optional[bool]]:
+    """The host RNG draws of the train-time branch, in the reference's order and from the same (default CPU)
+    generator: `Bernoulli(1 - p).sample((1,))` for keep (rwkv_wrapper_bidirectional_direction_dropout.py:60-62) and,
+    only when the right-to-left branch is not kept and only in the `_both` class, a second draw from the same
+    distribution for which single direction runs (..._direction_dropout_both.py:63-64).
+    Returns (keep, left_only): left_only is None when no second draw was made."""
+    bern = torch.distributions.bernoulli.Bernoulli(1 - p)
+    keep = bool(bern.sample((1,)) == 1)
+    if keep or not both:
+        return keep, None
+    return keep, bool(bern.sample((1,)) <= 0.5)
+
+
+def rwkv_wrapper_dir_dropout_train(query, sd: SD, p: str, head_size: int, do_bfloat16: bool, both: bool, keep: bool,
+                                   left_only: Optional[bool], cache=None):
+    """Train-time branch of RWKV_TmixWrapper_bidirectional_direction_dropout{,_both}.forward
+    (rwkv_wrapper_bidirectional_direction_dropout.py:59-69, ..._both.py:55-71) for given draws (draw_direction_dropout):
+    keep -> (left + flipped right) / 2; else left only, or in `_both` the direction the second draw chose."""
+    x = query
+    fwd = lambda: rwkv_wrapper(x, sd, p + "rwkv_wrapper_forward.", head_size, do_bfloat16, cache)[0]
+
+    def bwd():
+        xf = torch.flip(x, [1])
+        return torch.flip(rwkv_wrapper(xf, sd, p + "rwkv_wrapper_backward.", head_size, do_bfloat16, cache)[0], [1])
+    if keep:
+        out = (fwd() + bwd()) / 2
+    elif not both or left_only:
+        out = fwd()
+    else:
+        out = bwd()
     if cache is None:
         cache = torch.zeros((0, 0, 0, 0))
     return out, cache
@@ -137,12 +179,13 @@ ATTENTION = {
 }
 
 
-def self_attn(x, sd: SD, p: str, kind: str, head_size: int, do_bfloat16: bool, layer_id: int, cache=None, env=None):
+def self_attn(x, sd: SD, p: str, kind: str, head_size: int, do_bfloat16: bool, layer_id: int, cache=None, env=None,
+              out_as_query: bool = False):
     k = ATTENTION[kind]
     if k == "uni":
         return rwkv_wrapper(x, sd, p, head_size, do_bfloat16, cache)
     if k == "bi":
-        return rwkv_wrapper_bidirectional(x, sd, p, head_size, do_bfloat16, cache)
+        return rwkv_wrapper_bidirectional(x, sd, p, head_size, do_bfloat16, cache, out_as_query=out_as_query)
     return rwkv_wrapper_dir_dropout_eval(x, sd, p, head_size, do_bfloat16, layer_id, cache, env)
 
 
@@ -186,7 +229,8 @@ def conformer_layer(x, mask_pad, sd: SD, p: str, conf: dict, layer_id: int, env=
     x = r + 0.5 * positionwise_ff(layer_norm(x, sd, p + "norm_ff_macaron."), sd, p + "feed_forward_macaron.")
     r = x
     a, _ = self_attn(layer_norm(x, sd, p + "norm_mha."), sd, p + "self_attn.", conf["selfattention_layer_type"],
-                     head_size, conf.get("rwkv_do_bfloat16", True), layer_id, env=env)
+                     head_size, conf.get("rwkv_do_bfloat16", True), layer_id, env=env,
+                     out_as_query=bool(conf.get("oracle_slot_out_as_query", False)))
     x = r + a
     r = x
     x = r + conv_module(layer_norm(x, sd, p + "norm_conv."), mask_pad, sd, p + "conv_module.", conf["cnn_module_kernel"])
@@ -253,6 +297,24 @@ def encoder_forward_chunk(xs, sd: SD, conf: dict, env=None):
         xs = conformer_layer(xs, empty_mask, sd, f"encoders.{i}.", conf, i, env)
     xs = layer_norm(xs, sd, "after_norm.")
     return xs, torch.zeros((0, 0, 0, 0)), torch.zeros((conf["num_blocks"], 0, 0, 0))
+
+
+def encoder_forward_chunk_by_chunk(xs, decoding_chunk_size: int, sd: SD, conf: dict, env=None):
+    """BaseEncoder.forward_chunk_by_chunk, encoder.py:341-402: overlapping input windows of
+    (chunk - 1) * subsampling + right_context + 1 frames every subsampling * chunk frames (subsampling_rate 4,
+    right_context 6: subsampling.py:197-199), each through forward_chunk, outputs concatenated, all-ones mask.
+    With the recurrent slot and the non-causal conv module the caches stay empty, so every window is an independent
+    full-context pass."""
+    assert decoding_chunk_size > 0 and xs.size(0) == 1
+    subsampling, context = 4, 6 + 1
+    stride = subsampling * decoding_chunk_size
+    window = (decoding_chunk_size - 1) * subsampling + context
+    outs = []
+    for cur in range(0, xs.size(1) - context + 1, stride):
+        y, _, _ = encoder_forward_chunk(xs[:, cur:min(cur + window, xs.size(1))], sd, conf, env)
+        outs.append(y)
+    ys = torch.cat(outs, 1)
+    return ys, torch.ones((1, 1, ys.size(1)), dtype=torch.bool)
 
 
 # ----------------------------------------------------------------------------

@@ -16,6 +16,8 @@ class ConformerEncoderLayer(nn.Module):
                  feed_forward_macaron: Optional[nn.Module] = None, conv_module: Optional[nn.Module] = None,
                  dropout_rate: float = 0.1, normalize_before: bool = True):
         super().__init__()
+        if not normalize_before:
+            raise NotImplementedError("post-norm layers (normalize_before: false) are outside the accelerated path")
         self.self_attn = self_attn
         self.feed_forward = feed_forward
         self.feed_forward_macaron = feed_forward_macaron
@@ -30,15 +32,14 @@ class ConformerEncoderLayer(nn.Module):
         if self.conv_module is not None:
             self.norm_conv = LayerNorm(size, eps=1e-5)
             self.norm_final = LayerNorm(size, eps=1e-5)
-        if normalize_before:
-            # pre-norm branches whose first operation is a projection (FFN w_1, pointwise_conv1) or the slot's own cast
-            # to bf16: the consumer takes bf16 under autocast (layer_norm.py)
-            self.norm_ff.consumer_casts = True
-            if feed_forward_macaron is not None:
-                self.norm_ff_macaron.consumer_casts = True
-            if self.conv_module is not None:
-                self.norm_conv.consumer_casts = True
-            self.norm_mha.consumer_casts = bool(getattr(self_attn, "do_bfloat16", False))
+        # pre-norm branches whose first operation is a projection (FFN w_1, pointwise_conv1) or the slot's own cast
+        # to bf16: the consumer takes bf16 under autocast (layer_norm.py)
+        self.norm_ff.consumer_casts = True
+        if feed_forward_macaron is not None:
+            self.norm_ff_macaron.consumer_casts = True
+        if self.conv_module is not None:
+            self.norm_conv.consumer_casts = True
+        self.norm_mha.consumer_casts = bool(getattr(self_attn, "do_bfloat16", False))
         self.dropout = nn.Dropout(dropout_rate)
         self.size = size
         self.normalize_before = normalize_before
@@ -49,42 +50,22 @@ class ConformerEncoderLayer(nn.Module):
                 cnn_cache: torch.Tensor = torch.zeros((0, 0, 0, 0)),
                 cat_embs: Optional[torch.Tensor] = None
                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """-> (x, mask, new_att_cache, new_cnn_cache), the tuple of the reference's layer (encoder_layer.py:165-261).
+        A chain of pre-norm residual branches -- half-step macaron FFN, slot, conv module, half-step FFN -- closed by
+        norm_final when there is a conv module.  The recurrent slot hands `att_cache` back untouched."""
+        drop = self.dropout
         if self.feed_forward_macaron is not None:
-            residual = x
-            if self.normalize_before:
-                x = self.norm_ff_macaron(x)
-            x = residual + self.ff_scale * self.dropout(self.feed_forward_macaron(x))
-            if not self.normalize_before:
-                x = self.norm_ff_macaron(x)
-
-        residual = x
-        if self.normalize_before:
-            x = self.norm_mha(x)
-        x_att, new_att_cache = self.self_attn(x, x, x, mask, pos_emb, att_cache)
-        x = residual + self.dropout(x_att)
-        if not self.normalize_before:
-            x = self.norm_mha(x)
-
-        new_cnn_cache = torch.zeros((0, 0, 0), dtype=x.dtype, device=x.device)
-        if self.conv_module is not None:
-            residual = x
-            if self.normalize_before:
-                x = self.norm_conv(x)
-            x, new_cnn_cache = self.conv_module(x, mask_pad, cnn_cache)
-            x = residual + self.dropout(x)
-            if not self.normalize_before:
-                x = self.norm_conv(x)
-
-        residual = x
-        if self.normalize_before:
-            x = self.norm_ff(x)
-        x = residual + self.ff_scale * self.dropout(self.feed_forward(x))
-        if not self.normalize_before:
-            x = self.norm_ff(x)
-
-        if self.conv_module is not None:
-            x = self.norm_final(x)
-        return x, mask, new_att_cache, new_cnn_cache
+            x = x + self.ff_scale * drop(self.feed_forward_macaron(self.norm_ff_macaron(x)))
+        h = self.norm_mha(x)
+        att, new_att_cache = self.self_attn(h, h, h, mask, pos_emb, att_cache)
+        x = x + drop(att)
+        if self.conv_module is None:
+            x = x + self.ff_scale * drop(self.feed_forward(self.norm_ff(x)))
+            return x, mask, new_att_cache, x.new_zeros((0, 0, 0))
+        c, new_cnn_cache = self.conv_module(self.norm_conv(x), mask_pad, cnn_cache)
+        x = x + drop(c)
+        x = x + self.ff_scale * drop(self.feed_forward(self.norm_ff(x)))
+        return self.norm_final(x), mask, new_att_cache, new_cnn_cache
 
     def forward_carry(self, x: torch.Tensor, carry: Optional[dict]) -> Tuple[torch.Tensor, dict]:
         """One chunk WITH recurrent-state carry (uni-directional slot only): what the reference's forward_chunk

@@ -49,7 +49,7 @@ class LayerPlan:
         ps = [p for b in self.blocks for p in b.parameters()] + [L.feed_forward_macaron.w_2.bias, L.feed_forward.w_2.bias,
                                                                     L.conv_module.pointwise_conv1.weight,
                                                                     L.conv_module.pointwise_conv1.bias]
-        return tuple((p.data_ptr(), p._version, p.dtype) for p in ps)
+        return tuple((p.data_ptr(), p._version, p.dtype) for p in ps if p is not None)
 
     def refresh(self):
         stamp = self._current_stamp()
@@ -172,19 +172,19 @@ def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optio
     # first add of a layer writes a fresh tensor (the incoming stream may be a caller-visible layer output), the
     # later ones update the layer-private stream in place.
     x = _ffn_residual(L.feed_forward_macaron, h, x, L.ff_scale, plan.b2_macaron, inplace=False)
-    _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_mha.weight, L.norm_mha.bias, out_dtype=slot_dtype, want_x=False)
+    _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_mha.weight, L.norm_mha.bias, out_dtype=slot_dtype, want_x=False, eps=L.norm_mha.eps)
     if not plan.rwkv:
         # another slot from the registry (Mamba-2): the module as is; the rest of the layer stays re-scheduled
         att = L.self_attn(h, h, h)[0]
         x, h, _ = hip_ops.add_layernorm(x, att.to(x.dtype).contiguous(), 1.0, L.norm_conv.weight, L.norm_conv.bias,
-                                        zero_rows=masked, lens=lens, T=T)
+                                        zero_rows=masked, lens=lens, T=T, eps=L.norm_conv.eps)
     elif slot_dtype == x.dtype:
         x = slot_forward(plan, h, residual=x)
         _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_conv.weight, L.norm_conv.bias, zero_rows=masked, lens=lens,
-                                        T=T, want_x=False)
+                                        T=T, want_x=False, eps=L.norm_conv.eps)
     else:
         att = slot_forward(plan, h).to(x.dtype)
-        x, h, _ = hip_ops.add_layernorm(x, att, 1.0, L.norm_conv.weight, L.norm_conv.bias, zero_rows=masked, lens=lens, T=T)
+        x, h, _ = hip_ops.add_layernorm(x, att, 1.0, L.norm_conv.weight, L.norm_conv.bias, zero_rows=masked, lens=lens, T=T, eps=L.norm_conv.eps)
     left_pad, Tc = (cm.kernel_size - 1) // 2, T
     if cm.lorder > 0:
         # causal module: the reference zero-pads lorder frames BEFORE pointwise_conv1 (convolution.py:112-118), so the
@@ -202,14 +202,19 @@ def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optio
     if not masked:
         x = hip_ops.linear_bias_act(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none",
                                     residual=x, inplace=True)
-        _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff.weight, L.norm_ff.bias, want_x=False)
+        _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff.weight, L.norm_ff.bias, want_x=False, eps=L.norm_ff.eps)
     else:   # padded frames of the conv branch count as zero (convolution.py:140-141): the add stays in the norm pass
         c = F.linear(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias)
-        x, h, _ = hip_ops.add_layernorm(x, c, 1.0, L.norm_ff.weight, L.norm_ff.bias, lens=lens, T=T, mask_y=True)
+        x, h, _ = hip_ops.add_layernorm(x, c, 1.0, L.norm_ff.weight, L.norm_ff.bias, lens=lens, T=T, mask_y=True, eps=L.norm_ff.eps)
     x = _ffn_residual(L.feed_forward, h, x, L.ff_scale, plan.b2, inplace=True)
+    if next_norm is not None and next_norm.eps != L.norm_final.eps:      # the one-pass pair shares one epsilon
+        _, out, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False,
+                                          eps=L.norm_final.eps)
+        _, hn, _ = hip_ops.add_layernorm(out, None, 1.0, next_norm.weight, next_norm.bias, want_x=False, eps=next_norm.eps)
+        return out, hn
     _, out, hn = hip_ops.add_layernorm(x, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False,
                                        gamma2=next_norm.weight if next_norm is not None else None,
-                                       beta2=next_norm.bias if next_norm is not None else None)
+                                       beta2=next_norm.bias if next_norm is not None else None, eps=L.norm_final.eps)
     return out, hn
 
 
@@ -236,9 +241,9 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict])
     B, T, C = x.shape
     M = B * T
     x = x.contiguous()
-    _, h0, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff_macaron.weight, L.norm_ff_macaron.bias, want_x=False)
+    _, h0, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff_macaron.weight, L.norm_ff_macaron.bias, want_x=False, eps=L.norm_ff_macaron.eps)
     x = _ffn_residual(L.feed_forward_macaron, h0, x, L.ff_scale, plan.b2_macaron, inplace=False)
-    _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_mha.weight, L.norm_mha.bias, want_x=False)
+    _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_mha.weight, L.norm_mha.bias, want_x=False, eps=L.norm_mha.eps)
     shift = carry.get("shift")
     if shift is None:
         shift = h.new_zeros(B, 1, C)
@@ -259,7 +264,7 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict])
     x = hip_ops.linear_bias_act(yn, plan.Wo, None, "none", residual=x.view(M, C), inplace=True).view(B, T, C)
     new = {"shift": h[:, -1:].clone(), "wkv": s_out}
     cm = L.conv_module
-    _, hc, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_conv.weight, L.norm_conv.bias, want_x=False)
+    _, hc, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_conv.weight, L.norm_conv.bias, want_x=False, eps=L.norm_conv.eps)
     cnn = carry.get("cnn")
     left = cnn.transpose(1, 2).to(hc.dtype) if cnn is not None and cnn.numel() > 0 else hc.new_zeros(B, cm.lorder, C)
     cx = torch.cat([left, hc], dim=1)                                                         # (B, lorder + T, C)
@@ -273,9 +278,9 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict])
     _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
     x = hip_ops.linear_bias_act(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none",
                                 residual=x, inplace=True)
-    _, h2, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff.weight, L.norm_ff.bias, want_x=False)
+    _, h2, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff.weight, L.norm_ff.bias, want_x=False, eps=L.norm_ff.eps)
     x = _ffn_residual(L.feed_forward, h2, x, L.ff_scale, plan.b2, inplace=True)
-    _, out, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False)
+    _, out, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False, eps=L.norm_final.eps)
     return out, new
 
 
@@ -296,7 +301,7 @@ def encoder_layers_forward(plan: EncoderPlan, xs: torch.Tensor, masks: torch.Ten
     lens = masks.squeeze(1).sum(1).to(torch.int32) if masks.numel() > 0 else None
     xs = xs.contiguous()
     first = plan.layers[0].layer.norm_ff_macaron
-    _, h, _ = hip_ops.add_layernorm(xs, None, 1.0, first.weight, first.bias)
+    _, h, _ = hip_ops.add_layernorm(xs, None, 1.0, first.weight, first.bias, eps=first.eps)
     outs: List[torch.Tensor] = []
     n = len(plan.layers)
     for i, lp in enumerate(plan.layers):

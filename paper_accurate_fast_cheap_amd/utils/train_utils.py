@@ -9,15 +9,59 @@ import torch
 import torch.distributed as dist
 
 
-def wrap_model_ddp(model: torch.nn.Module, device: Optional[torch.device] = None, find_unused_parameters: bool = False):
+def _rs_ag_hook(group, bucket):
+    """Gradient averaging of one DDP bucket as reduce-scatter + all-gather.  On the 8-GPU xGMI mesh every GPU has a direct
+    link to each of the other seven, so each phase moves bucket/8 per link on all seven links at once, where a ring
+    all-reduce passes 2*(7/8) of the bucket over one link per hop ("Comm backend")."""
+    pg = group if group is not None else dist.group.WORLD
+    world = dist.get_world_size(pg)
+    flat = bucket.buffer()
+    n = flat.numel()
+    per = (n + world - 1) // world
+    padded = flat if per * world == n else torch.cat([flat, flat.new_zeros(per * world - n)])
+    shard = torch.empty(per, dtype=flat.dtype, device=flat.device)
+
+    def gather(_=None):
+        shard.div_(world)
+        out = torch.empty_like(padded)
+        dist.all_gather_into_tensor(out, shard, group=pg)
+        flat.copy_(out[:n])
+        return flat
+    work = dist.reduce_scatter_tensor(shard, padded, op=dist.ReduceOp.SUM, group=pg, async_op=True)
+    try:
+        return work.get_future().then(gather)      # RCCL: chained on the collective's stream, overlaps with backward
+    except RuntimeError:                            # a backend without futures for this collective (gloo): finish it here
+        work.wait()
+        done = torch.futures.Future()
+        done.set_result(gather())
+        return done
+
+
+def wrap_model_ddp(model: torch.nn.Module, device: Optional[torch.device] = None, find_unused_parameters: bool = False,
+                   grad_sync: str = "allreduce", bucket_cap_mb: int = 25):
     """train_utils.py:354-372 (torch_ddp engine).  On MI355X the default bucket (25 MB) keeps each all-reduce far
-    above the ~MB where the 7-link xGMI mesh saturates; gradient_as_bucket_view avoids one copy of the fp32 grads."""
+    above the ~MB where the 7-link xGMI mesh saturates; gradient_as_bucket_view avoids one copy of the fp32 grads.
+
+    grad_sync: "allreduce" (DDP's own bucketed all-reduce, RCCL picks the algorithm), "fp16" (the reference's
+    `--fp16_grad_sync`: fp16_compress_hook, train_utils.py:368-372), "bf16" (same with bf16: no overflow at gradient
+    scale), "rs_ag" (explicit reduce-scatter + all-gather per bucket, see _rs_ag_hook)."""
     if device is not None and device.type == "cuda":
         model = model.to(device)
-        return torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index],
-                                                         find_unused_parameters=find_unused_parameters,
-                                                         gradient_as_bucket_view=True)
-    return torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=find_unused_parameters)
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index],
+                                                        find_unused_parameters=find_unused_parameters,
+                                                        gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb)
+    else:
+        ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=find_unused_parameters,
+                                                        bucket_cap_mb=bucket_cap_mb)
+    if grad_sync in ("fp16", "bf16"):
+        from torch.distributed.algorithms.ddp_comm_hooks import default as comm_hooks
+        ddp.register_comm_hook(state=None, hook=comm_hooks.fp16_compress_hook if grad_sync == "fp16"
+                               else comm_hooks.bf16_compress_hook)
+    elif grad_sync == "rs_ag":
+        ddp.register_comm_hook(state=None, hook=_rs_ag_hook)
+    elif grad_sync != "allreduce":
+        raise ValueError(f"grad_sync must be allreduce, fp16, bf16 or rs_ag, not {grad_sync!r}")
+    return ddp
 
 
 def train_step(model: torch.nn.Module, batch: dict, optimizer: torch.optim.Optimizer, device: torch.device,

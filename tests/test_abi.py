@@ -101,3 +101,23 @@ def test_argument_validation_returns_error_codes_without_a_gpu(so_path):
     assert L.pafc_wkv6_forward_bf16(1, 8, 128, 2, one, one, one, one, one, NULL, 0, NULL, 0, NULL) == ERR_NULL
     assert L.pafc_wkv6_forward_bf16(1, 8, 100, 2, one, one, one, one, one, one, 0, NULL, 0, NULL) == -3    # head size
     assert L.pafc_wkv6_forward_bf16(1, 8, 128, 2, P(8), one, one, one, one, one, 0, NULL, 0, NULL) == -8   # alignment
+
+
+def test_torch_ops_wkv6_schema_matches_the_reference_binding(so_path):
+    """torch.ops.wkv6.{forward,backward,forward_fp32,backward_fp32} exist with the reference's argument lists
+    (wenet/rwkv_v6/cuda/wkv6_op.cpp:9-41) and have no CPU implementation: a host tensor fails loudly."""
+    import torch
+    from paper_accurate_fast_cheap_amd.rwkv_v6 import torch_ops
+    torch_ops.register()
+    torch_ops.register()          # idempotent
+    fwd_args = ["B", "T", "C", "H", "r", "k", "v", "w", "u", "y"]
+    bwd_args = ["B", "T", "C", "H", "r", "k", "v", "w", "u", "gy", "gr", "gk", "gv", "gw", "gu"]
+    for name, args in (("forward", fwd_args), ("forward_fp32", fwd_args), ("backward", bwd_args), ("backward_fp32", bwd_args)):
+        schema = getattr(torch.ops.wkv6, name).default._schema
+        assert [a.name for a in schema.arguments] == args, name
+        assert len(schema.returns) == 0
+        written = [a.name for a in schema.arguments if a.alias_info is not None and a.alias_info.is_write]
+        assert written == (["y"] if "forward" in name else ["gr", "gk", "gv", "gw", "gu"])
+    t = torch.zeros(1, 4, 64)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.wkv6.forward_fp32(1, 4, 64, 1, t, t, t, t, torch.zeros(1, 64), torch.empty(1, 4, 64))

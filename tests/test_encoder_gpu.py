@@ -138,14 +138,32 @@ def test_encoder_reduced(hip, variant):
         if not bf:
             assert ours == g["greedy"]
         else:
-            # a bf16 rounding flip upstream may legitimately flip an argmax between two near-tied tokens: every
-            # frame where our argmax differs from the reference's must be such a near-tie IN THE REFERENCE's own
-            # log-probs, and such frames must be rare
-            ref_top, our_top = glogp.float().argmax(-1), logp.float().argmax(-1)
-            diff = ref_top != our_top
-            margin = glogp.float().gather(-1, ref_top[..., None]) - glogp.float().gather(-1, our_top[..., None])
-            assert float(diff.float().mean()) <= (0.15 if wm else 0.05)
-            assert float(margin[diff[..., None]].max() if diff.any() else 0.0) <= (0.5 if wm else 0.15)
+            flips = _token_parity(logp, glogp, masks.squeeze(1), 0.1 if not wm else 0.4, f"encoder_reduced_{variant}")
+            if flips == 0:
+                assert ours == g["greedy"]
+
+
+def _token_parity(logp, ref_logp, valid, logp_tol, what):
+    """Token ids are the bit-exact bar.  A path that rounds to bf16 inside cannot promise the reference's argmax on a
+    frame whose two best tokens the REFERENCE itself separates by less than the bf16 noise: with e = the measured
+    max |log-prob difference| of this comparison (itself held to `logp_tol`, the spread the reference shows against
+    itself across summation orders), an argmax can only move where the reference's top-2 margin is <= 2e.  So: every
+    frame whose reference margin exceeds 2e must carry the reference's token, and the flipped frames are counted and
+    reported.  Returns the number of flipped valid frames."""
+    logp, ref_logp = logp.float().cpu(), ref_logp.float().cpu()
+    valid = valid.cpu()
+    e = float(((logp - ref_logp).abs() * valid[..., None]).max())
+    assert e <= logp_tol, f"{what}: max |dlogp| {e:.4g} > {logp_tol}"
+    top2 = ref_logp.topk(2, dim=-1).values
+    margin = top2[..., 0] - top2[..., 1]
+    same = logp.argmax(-1) == ref_logp.argmax(-1)
+    decided = (margin > 2 * e) & valid
+    assert bool((same | ~decided).all()), f"{what}: token differs on a frame the reference decides by more than 2e = {2 * e:.4g}"
+    flips = int((~same & valid).sum())
+    print(f"[token parity] {what}: {flips} of {int(valid.sum())} valid frames flipped, all with reference top-2 margin "
+          f"<= {2 * e:.4g} (max |dlogp| {e:.4g}); largest margin among flipped frames "
+          f"{float(margin[~same & valid].max()) if flips else 0.0:.4g}")
+    return flips
 
 
 def test_encoder_matches_oracle_on_fresh_inputs(hip):
@@ -168,9 +186,10 @@ def test_encoder_matches_oracle_on_fresh_inputs(hip):
 
 
 def test_config_c1_full_size_fp32_vs_oracle(hip):
-    """BASELINE configs[0] shape on the GPU: 10 utterances (1-5 s here, to keep the CPU oracle to seconds), the FULL
-    12-layer 512-d bidirectional encoder in fp32 + CTC head: HIP path vs the CPU restatement within 1e-3 relative, masks
-    exact, CTC greedy token ids identical wherever the oracle's own top-2 margin exceeds the tolerance."""
+    """BASELINE configs[0] on the GPU: 10 utterances with the config's own length filter (100..2000 frames, conf yaml
+    :113; the longest is exactly 2000), the FULL 12-layer 512-d bidirectional encoder in fp32 + CTC head: HIP path vs
+    the CPU restatement ELEMENT-wise within 1e-3 relative (absolute floor 5e-2 * 1e-3 for values near zero), masks
+    exact, CTC greedy token ids identical on every frame the oracle decides by more than the numerical noise."""
     import bench
     from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
     from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
@@ -184,9 +203,9 @@ def test_config_c1_full_size_fp32_vs_oracle(hip):
                 p.normal_(0, 0.02)
     ctc = CTC(200, 512).eval()
     g = torch.Generator().manual_seed(31)
-    lens = torch.randint(100, 501, (10,), generator=g)
-    lens[0] = 500
-    xs = synth.randn((10, 500, 80), 902, 2.0)
+    lens = torch.randint(100, 2001, (10,), generator=g)
+    lens[0] = 2000
+    xs = synth.randn((10, 2000, 80), 902, 2.0)
     sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
     ref, ref_masks = EO.encoder_forward(xs, lens, sd, conf, env={})
     ref_logp = EO.ctc_log_softmax(ref, {"ctc." + k: v for k, v in ctc.state_dict().items()})
@@ -196,18 +215,180 @@ def test_config_c1_full_size_fp32_vs_oracle(hip):
         out, masks = enc(xs.cuda(), lens.cuda())
         logp = ctc.log_softmax(out)
         toks = [r.tokens for r in ctc_greedy_search(logp, masks.squeeze(1).sum(1), 0)]
-    assert torch.equal(masks.cpu(), ref_masks)
-    scale = float(ref.abs().max())
-    valid = ref_masks.squeeze(1).unsqueeze(-1)
-    err = ((out.cpu() - ref).abs() * valid).max()
-    assert float(err) <= 1e-3 * scale, (float(err), scale)
-    # tokens: frame-wise argmax must agree wherever the oracle's top-2 margin is not within the numerical noise
-    top2 = ref_logp.topk(2, dim=-1).values
-    safe = (top2[..., 0] - top2[..., 1]) > 1e-3
-    same = logp.argmax(-1).cpu() == ref_logp.argmax(-1)
-    assert bool((same | ~safe | ~ref_masks.squeeze(1)).all())
-    if bool((safe | ~ref_masks.squeeze(1)).all()):
+    assert out.shape == (10, 499, 512) and torch.equal(masks.cpu(), ref_masks)
+    valid = ref_masks.squeeze(1)
+    got = out.cpu()[valid]
+    want = ref[valid]
+    _assert_close(got, want, False, "c1 encoder output, valid frames")
+    flips = _token_parity(logp, ref_logp, valid, 1e-3 * float(ref_logp.abs().max()), "c1 fp32")
+    if flips == 0:
         assert toks == EO.ctc_greedy_search(ref_logp, ref_lens, 0)
+
+
+def _bf16_headline(xs, lens, enc, ctc, conf, what):
+    """HIP fused path in the bench's precision (whole-model bf16, bidirectional slot) vs (1) the oracle in MATCHED precision
+    (every op rounds to bf16, the slot returns the query dtype: oracle_slot_out_as_query) and (2) the exact model: the
+    same bf16-valued parameters and inputs in fp32 arithmetic with an fp32 slot.  The HIP path keeps fp32 accumulators
+    across fused steps, so it must sit at least as close to the exact model as the reference's own rounding does."""
+    from paper_accurate_fast_cheap_amd.transformer.search import ctc_greedy_search
+    sd_b = {k: v.detach().cpu().to(torch.bfloat16) for k, v in enc.state_dict().items()}
+    csd_b = {"ctc." + k: v.detach().cpu().to(torch.bfloat16) for k, v in ctc.state_dict().items()}
+    xb = xs.to(torch.bfloat16)
+    ref, ref_masks = EO.encoder_forward(xb, lens, sd_b, dict(conf, oracle_slot_out_as_query=True), env={})
+    assert ref.dtype == torch.bfloat16
+    ref_logp = EO.ctc_log_softmax(ref, csd_b)
+    sd_f = {k: v.float() for k, v in sd_b.items()}
+    exact, _ = EO.encoder_forward(xb.float(), lens, sd_f, dict(conf, rwkv_do_bfloat16=False), env={})
+    exact_logp = EO.ctc_log_softmax(exact, {k: v.float() for k, v in csd_b.items()})
+    encb, ctcb = enc.to(torch.bfloat16).cuda().eval(), ctc.to(torch.bfloat16).cuda().eval()
+    with torch.no_grad():
+        encb.fused_inference = True
+        out, masks = encb(xb.cuda(), lens.cuda())
+        assert encb._fused(out) is not None                       # the fused executor (what bench.py times) really ran
+        logp = ctcb.log_softmax(out)
+        toks = [r.tokens for r in ctc_greedy_search(logp, masks.squeeze(1).sum(1), 0)]
+    assert out.dtype == torch.bfloat16 and torch.equal(masks.cpu(), ref_masks)
+    valid = ref_masks.squeeze(1)
+    o, r, x = out.float().cpu()[valid], ref.float()[valid], exact[valid]
+    d_ref = (o - r).abs()
+    e_hip, e_ref = (o - x).abs(), (r - x).abs()
+    print(f"[headline bf16] {what}: vs matched-precision oracle max {float(d_ref.max()):.4g} mean {float(d_ref.mean()):.4g}; "
+          f"vs exact model: HIP max {float(e_hip.max()):.4g} mean {float(e_hip.mean()):.4g}, oracle-bf16 max "
+          f"{float(e_ref.max()):.4g} mean {float(e_ref.mean()):.4g}")
+    # matched precision: two bf16 roundings of the same O(1) graph (ulp 0.03 at |x| = 4), 12 layers deep
+    deep = conf["num_blocks"] > 2
+    assert float(d_ref.mean()) <= (4e-2 if deep else 2e-2) and float(d_ref.max()) <= (1.0 if deep else 0.4)
+    # against the exact model the HIP path is no further away than the reference's own bf16 arithmetic
+    assert float(e_hip.mean()) <= 1.1 * float(e_ref.mean()) + 1e-3
+    assert float(e_hip.max()) <= 1.5 * float(e_ref.max()) + 1e-2
+    # tokens: flips only where the oracle itself is undecided at the measured noise
+    flips = _token_parity(logp, ref_logp, valid, 1.5 if deep else 0.6, f"{what} vs matched-precision oracle")
+    if flips == 0:
+        assert toks == EO.ctc_greedy_search(ref_logp.float(), ref_masks.squeeze(1).sum(1), 0)
+    # and the frame error rate against the exact model's tokens is not worse than the oracle's own
+    ex_top = exact_logp.argmax(-1)
+    fer_hip = float(((logp.float().cpu().argmax(-1) != ex_top) & valid).sum()) / float(valid.sum())
+    fer_ref = float(((ref_logp.float().argmax(-1) != ex_top) & valid).sum()) / float(valid.sum())
+    print(f"[headline bf16] {what}: frames whose token differs from the exact model's: HIP {fer_hip:.4f}, oracle-bf16 {fer_ref:.4f}")
+    assert fer_hip <= fer_ref + 0.02
+
+
+def test_headline_bf16_bidirectional_reduced_vs_oracle(hip):
+    from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_reduced_bf16slot")
+    sd = {k: v for k, v in _sd(g).items() if not k.startswith("global_cmvn")}
+    enc = ConformerEncoder(80, **g["conf"])
+    enc.load_state_dict(sd)
+    ctc = CTC(50, 128)
+    ctc.load_state_dict(synth.synth_state_dict(g["ctc_spec"], g["ctc_seed"]))
+    _bf16_headline(g["xs"], g["lens"], enc, ctc, g["conf"], "reduced 2-layer, ragged B=3")
+
+
+def test_headline_bf16_bidirectional_full_size_c2_batch_vs_oracle(hip):
+    """The bench's model (12 x 512, bidirectional, whole-model bf16) on a c2-shaped ragged batch -- decode batch trimmed
+    from 64 to 8 utterances of 1-6 s so that the three CPU passes take seconds."""
+    import bench
+    from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    conf = bench.encoder_conf()
+    torch.manual_seed(777)
+    enc = ConformerEncoder(80, **conf).eval()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.02)
+    ctc = CTC(200, 512).eval()
+    lens = torch.tensor([600, 577, 431, 402, 300, 222, 133, 100])
+    xs = synth.randn((8, 600, 80), 903, 2.0)
+    _bf16_headline(xs, lens, enc, ctc, conf, "full-size 12-layer, c2-shaped ragged B=8")
+
+
+def test_bf16slot_full_size_vs_oracle(hip):
+    """The YAML-default precision (fp32 model, bf16 slot returning fp32 -- what the reference CAN run) at full size on
+    the same ragged batch: HIP fused path vs the oracle, bf16-inside tolerance, token rule as above."""
+    import bench
+    from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    conf = bench.encoder_conf()
+    torch.manual_seed(777)
+    enc = ConformerEncoder(80, **conf).eval()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.02)
+    ctc = CTC(200, 512).eval()
+    lens = torch.tensor([600, 577, 431, 402, 300, 222, 133, 100])
+    xs = synth.randn((8, 600, 80), 903, 2.0)
+    sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    ref, ref_masks = EO.encoder_forward(xs, lens, sd, conf, env={})
+    ref_logp = EO.ctc_log_softmax(ref, {"ctc." + k: v for k, v in ctc.state_dict().items()})
+    enc, ctc = enc.cuda(), ctc.cuda()
+    with torch.no_grad():
+        out, masks = enc(xs.cuda(), lens.cuda())
+        logp = ctc.log_softmax(out)
+    assert out.dtype == torch.float32 and torch.equal(masks.cpu(), ref_masks)
+    valid = ref_masks.squeeze(1)
+    d = (out.cpu()[valid] - ref[valid]).abs()
+    print(f"[bf16slot full size] max {float(d.max()):.4g} mean {float(d.mean()):.4g}")
+    assert float(d.mean()) <= 1.5e-2 and float(d.max()) <= 0.4      # 24 bf16 slots deep (2-layer goldens: 6e-3 / 0.1)
+    _token_parity(logp, ref_logp, valid, 0.5, "bf16slot full size")
+
+
+@pytest.mark.parametrize("variant", ["bf16slot", "f32", "uni_bf16slot"])
+def test_forward_chunk_by_chunk_golden(hip, variant):
+    """BaseEncoder.forward_chunk_by_chunk vs the reference's own output (tests/golden/make_goldens_r2.py): the batched
+    window path of the fused executor and the window-by-window module path both reproduce it."""
+    from paper_accurate_fast_cheap_amd.transformer.cmvn import GlobalCMVN
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_chunk_by_chunk")
+    c = g["cases"][variant]
+    enc = ConformerEncoder(80, global_cmvn=GlobalCMVN(torch.zeros(80), torch.ones(80)), **c["conf"])
+    enc.load_state_dict(_sd(c))
+    enc = enc.cuda().eval()
+    xs = g["xs"].cuda()
+    bf = variant != "f32"
+    with torch.no_grad():
+        for chunk, want in c["outs"].items():
+            for fused_on in (True, False):
+                enc.fused_inference = fused_on
+                ys, masks = enc.forward_chunk_by_chunk(xs, chunk, -1)
+                assert torch.equal(masks.cpu(), want["masks"]) and ys.dtype == want["ys"].dtype
+                _assert_close(ys, want["ys"], bf, f"{variant} chunk {chunk} fused={fused_on}")
+        enc.fused_inference = True
+        assert enc._windows_independent(xs) is not None            # the batched path is the one that ran above
+
+
+def test_dir_dropout_train_golden(hip):
+    """Train-time direction dropout: under torch.manual_seed(s) our modules make the reference's draws (same host
+    generator, same order) and produce its outputs, every branch of both classes."""
+    from paper_accurate_fast_cheap_amd.utils.class_utils import WENET_ATTENTION_CLASSES
+    g = load_golden("dir_dropout_train")
+    sd = _sd(g)
+    x = g["x"].cuda()
+    mods = {}
+    seen = set()
+    for c in g["cases"]:
+        if c["kind"] not in mods:
+            m = WENET_ATTENTION_CLASSES[c["kind"]](64, 128, 4, "rwkv", "bi", 2048, True, 1)
+            m.load_state_dict(sd)
+            mods[c["kind"]] = m.cuda().train()
+        torch.manual_seed(c["manual_seed"])
+        with torch.no_grad():
+            y, cache = mods[c["kind"]](x, x, x)
+        assert y.dtype == c["y"].dtype
+        _assert_close(y, c["y"], True, f"{c['kind']} seed {c['manual_seed']} ({c['branch']})")
+        seen.add((c["both"], c["branch"]))
+    assert seen == {(False, "bi"), (False, "left"), (True, "bi"), (True, "left"), (True, "right")}
+    # and with autograd: the branch taken is the one that receives gradients
+    m = mods["rwkv_tmix60_dir_layer_drop"]
+    left_seed = next(c["manual_seed"] for c in g["cases"] if not c["both"] and c["branch"] == "left")
+    torch.manual_seed(left_seed)
+    m.zero_grad(set_to_none=True)
+    y, _ = m(x, x, x)
+    y.float().square().sum().backward()
+    assert m.rwkv_wrapper_forward.tmix_block.receptance.weight.grad is not None
+    assert m.rwkv_wrapper_backward.tmix_block.receptance.weight.grad is None
 
 
 def test_cpu_tensors_fail_loudly(hip):

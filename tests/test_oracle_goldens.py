@@ -155,6 +155,57 @@ def test_encoder_reduced_golden(variant):
         assert EO.ctc_greedy_search(logp.float(), enc_lens, 0) == g["greedy"]
 
 
+@pytest.mark.parametrize("variant", ["bf16slot", "f32", "uni_bf16slot"])
+def test_forward_chunk_by_chunk_golden(variant):
+    """BaseEncoder.forward_chunk_by_chunk (encoder.py:341-402) captured from the reference (make_goldens_r2.py)."""
+    g = load_golden("encoder_chunk_by_chunk")
+    c = g["cases"][variant]
+    sd = _sd(c)
+    for chunk, want in c["outs"].items():
+        ys, masks = EO.encoder_forward_chunk_by_chunk(g["xs"], chunk, sd, c["conf"], env={})
+        assert torch.equal(masks, want["masks"]) and ys.shape == want["ys"].shape == (1, 50, 128)
+        assert _close(ys, want["ys"], variant != "f32"), (variant, chunk)
+    # windows are independent full-context passes: a chunked pass differs from the whole-utterance pass
+    full, _ = EO.encoder_forward(g["xs"], torch.tensor([g["xs"].size(1)]), sd, c["conf"], env={})
+    assert full.shape == (1, 50, 128)
+    assert not torch.allclose(full.float(), c["outs"][16]["ys"].float(), atol=1e-2)
+
+
+def test_dir_dropout_train_golden():
+    """Train-time branch of the direction-dropout wrappers (…direction_dropout.py:59-69, …_both.py:55-71): same host
+    RNG draws as the reference under torch.manual_seed, same branch arithmetic; every branch occurs in the fixture."""
+    g = load_golden("dir_dropout_train")
+    sd = _sd(g)
+    seen = set()
+    for c in g["cases"]:
+        torch.manual_seed(c["manual_seed"])
+        keep, left_only = EO.draw_direction_dropout(c["both"])
+        branch = "bi" if keep else ("left" if (not c["both"] or left_only) else "right")
+        assert branch == c["branch"], c["manual_seed"]
+        y, _ = EO.rwkv_wrapper_dir_dropout_train(g["x"], sd, "", g["head_size"], True, c["both"], keep, left_only)
+        assert _close(y, c["y"], True), (c["kind"], c["manual_seed"])
+        seen.add((c["both"], branch))
+    assert seen == {(False, "bi"), (False, "left"), (True, "bi"), (True, "left"), (True, "right")}
+
+
+def test_whole_model_bf16_bidirectional_mode_is_defined_by_one_flag():
+    """The headline precision (whole-model bf16, bidirectional slot) cannot run in the reference: its wrapper returns
+    .float() (rwkv_wrapper_bidirectional.py:55-56) into a bf16 LayerNorm.  The oracle's `oracle_slot_out_as_query` is the
+    one change that defines it; for an fp32 query it changes nothing."""
+    g = load_golden("encoder_reduced_bf16slot")
+    sd = _sd(g)
+    a, _ = EO.encoder_forward(g["xs"], g["lens"], sd, g["conf"], env={})
+    b, _ = EO.encoder_forward(g["xs"], g["lens"], sd, dict(g["conf"], oracle_slot_out_as_query=True), env={})
+    assert torch.equal(a, b)
+    sdb = {k: v.bfloat16() for k, v in sd.items()}
+    with pytest.raises(RuntimeError):
+        EO.encoder_forward(g["xs"].bfloat16(), g["lens"], sdb, g["conf"], env={})
+    out, _ = EO.encoder_forward(g["xs"].bfloat16(), g["lens"], sdb, dict(g["conf"], oracle_slot_out_as_query=True), env={})
+    assert out.dtype == torch.bfloat16 and bool(torch.isfinite(out.float()).all())
+    d = (out.float() - g["out"]).abs()
+    assert float(d.max()) <= 0.4 and float(d.mean()) <= 2e-2      # the bf16 model is the fp32 + bf16-slot model, rounded
+
+
 def test_padding_dependence_is_reproduced():
     """The reference flips the whole padded tensor (rwkv_wrapper_bidirectional.py:44), so a short utterance's
     right-to-left state is warmed by its padding: valid-frame outputs depend on the batch it sits in."""

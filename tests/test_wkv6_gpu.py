@@ -220,3 +220,49 @@ def test_state_autograd_function(hip):
     torch.testing.assert_close(s_param.grad.cpu().double(), ref[5].grad, rtol=1e-3, atol=3e-4 * float(ref[5].grad.abs().max()))
     torch.testing.assert_close(leaves[3].grad[:, :-1].cpu().double(), ref[3].grad[:, :-1], rtol=1e-3,
                                atol=3e-4 * float(ref[3].grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype,suffix", [(torch.bfloat16, ""), (torch.float32, "_fp32")])
+def test_torch_ops_wkv6_as_the_reference_calls_them(hip, dtype, suffix):
+    """INTEGRATION route C: `torch.ops.wkv6.forward(B, T, C, H, r, k, v, w, u, y)` and `.backward(..., gy, gr, gk, gv, gw,
+    gu)` with caller-allocated outputs and gu summed over the batch by the caller -- the call pattern of the reference's
+    WKV_6 / WKV_6_FP32 (wenet/rwkv_v6/src/model.py:108-152,161-214) -- against the C restatement of its CUDA kernels."""
+    from paper_accurate_fast_cheap_amd.rwkv_v6 import torch_ops
+    torch_ops.register()
+    fwd_op, bwd_op = getattr(torch.ops.wkv6, "forward" + suffix), getattr(torch.ops.wkv6, "backward" + suffix)
+
+    class WKV(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, r, k, v, w, u):
+            B, T, C = r.size()
+            H = C // 64
+            ctx.dims = (B, T, C, H)
+            ctx.save_for_backward(r, k, v, w, u)
+            y = torch.empty((B, T, C), device=r.device, dtype=dtype, memory_format=torch.contiguous_format)
+            fwd_op(B, T, C, H, r, k, v, w, u, y)
+            return y
+
+        @staticmethod
+        def backward(ctx, gy):
+            B, T, C, H = ctx.dims
+            r, k, v, w, u = ctx.saved_tensors
+            gr, gk, gv, gw = (torch.empty((B, T, C), device=gy.device, dtype=dtype) for _ in range(4))
+            gu = torch.empty((B, C), device=gy.device, dtype=dtype)
+            bwd_op(B, T, C, H, r, k, v, w, u, gy.contiguous(), gr, gk, gv, gw, gu)
+            return gr, gk, gv, gw, torch.sum(gu, 0).view(H, C // H)
+
+    B, T, C, H = 3, 211, 128, 2
+    a = _inputs(B, T, C, H, 4242, dtype)
+    gy = synth.randn((B, T, C), 4250, 0.5).to(dtype)
+    leaves = [t.cuda().requires_grad_() for t in a]
+    y = WKV.apply(*leaves)
+    y.backward(gy.cuda())
+    torch.testing.assert_close(y.detach().cpu().float(), WO.forward(*a).float(), **_tol(dtype))
+    ref = WO.backward(*a, gy)
+    for name, got, want in zip("gr gk gv gw gu".split(), [t.grad for t in leaves], ref):
+        scale = max(float(want.float().abs().max()), 1e-3)
+        bar = (2e-3 if dtype == torch.float32 else 3e-2) * scale
+        assert float((got.cpu().float() - want.float()).abs().max()) <= bar, name
+    with pytest.raises(Exception):      # checked, not asserted: a transposed (non-contiguous) operand is refused
+        fwd_op(B, T, C, H, leaves[0].detach().transpose(0, 1).contiguous().transpose(0, 1), *[t.detach() for t in leaves[1:]],
+               torch.empty_like(y))

@@ -3,8 +3,11 @@ the bf16 time-mix slot (the YAML default), CTC objective, forward + backward (WK
 all-reduce (RCCL when launched with torch.distributed.run) + clip + Adam.  Not the headline metric: a measurement of
 the training path, printed as one JSON line.
 
-  python tools/bench_train_step.py [--steps 5 --warmup 2 --batch 32]
-  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train_step.py
+  python tools/bench_train_step.py [--gpus N --steps 5 --warmup 2 --batch 32 --amp bf16 --grad-sync allreduce|rs_ag|bf16|fp16]
+
+--gpus N > 1 starts N ranks itself (a child torchrun, before the parent touches the GPU), as bench.py does; under a
+launcher (WORLD_SIZE set) it is one of the ranks.  With N > 1 the line also carries `exposed_allreduce_ms`: the step
+timed again under DDP's no_sync() (same kernels, no collective) and subtracted.
 """
 import argparse, json, os, sys, time
 import torch
@@ -14,19 +17,37 @@ import bench as B   # noqa: E402  (model / waveform helpers of the headline benc
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--grad-sync", default="allreduce", choices=["allreduce", "rs_ag", "bf16", "fp16"])
+    ap.add_argument("--ddp", action="store_true", help="wrap in DistributedDataParallel even with one rank (RCCL init + "
+                                                       "bucketing + the all-reduce kernels on a 1-GPU box)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of N > 1 on one GPU with "
                                                            "PAFC_BENCH_ONE_GPU=1)")
     ap.add_argument("--amp", default="none", choices=["none", "bf16"],
                     help="bf16: forward under torch.autocast(bfloat16) (the reference's `dtype: bf16`), fp32 master weights")
     args = ap.parse_args()
+    one_gpu = os.environ.get("PAFC_BENCH_ONE_GPU") == "1"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        have = torch.cuda.device_count()
+        if have < args.gpus and not one_gpu:
+            sys.exit(f"bench_train_step.py: --gpus {args.gpus} but this node shows {have} GPU(s)")
+        sys.exit(B.spawn_ranks(args.gpus, sys.argv[1:], script=os.path.abspath(__file__)))
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(args.dist_backend)
-    if os.environ.get("PAFC_BENCH_ONE_GPU") == "1":
+    if world != args.gpus:
+        sys.exit(f"bench_train_step.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+    use_ddp = world > 1 or args.ddp
+    if use_ddp:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29641")
+            dist.init_process_group(args.dist_backend, rank=0, world_size=1)
+        else:
+            dist.init_process_group(args.dist_backend)
+    if one_gpu:
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -34,8 +55,8 @@ def main():
     from paper_accurate_fast_cheap_amd.utils.train_utils import train_step, wrap_model_ddp
     _lib.lib()
     model, _ = B.build_model("fp32", device)          # fp32 parameters, bf16 slot: conf/rwkv/*.yaml as shipped
-    if world > 1:
-        model = wrap_model_ddp(model, device)
+    if use_ddp:
+        model = wrap_model_ddp(model, device, grad_sync=args.grad_sync)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     g = torch.Generator().manual_seed(777 + rank)
     lens = torch.randint(100, 2001, (args.batch,), generator=g)
@@ -64,9 +85,18 @@ def main():
         if os.environ.get("PAFC_BENCH_TRACE_LOSS") == "1" and rank == 0:
             print(f"step {i}: loss {float(info['loss']):.3f} grad_norm {float(info['grad_norm']):.2f}", file=sys.stderr)
     sync(); dt = time.perf_counter() - t0
+    dt_nosync = None
+    if use_ddp:        # the same steps without the gradient exchange: the difference is the all-reduce time not hidden by backward
+        with model.no_sync():
+            train_step(model, batch, opt, device, step_index=0, amp_dtype=amp)
+            sync(); t0 = time.perf_counter()
+            for i in range(args.steps):
+                train_step(model, batch, opt, device, step_index=i, amp_dtype=amp)
+            sync(); dt_nosync = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t)
+        t = torch.tensor([dt, dt_nosync], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); dt, dt_nosync = float(t[0]), float(t[1])
+    nparam = sum(p.numel() for p in model.parameters() if p.requires_grad)
     frames = int(lens.sum()) * world * args.steps
     if rank == 0:
         print(json.dumps({"metric": "training audio-sec/sec (c4: fwd + bwd + all-reduce + clip + Adam, CTC objective)",
@@ -74,7 +104,13 @@ def main():
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
                           "utts_per_gpu": args.batch, "frames_per_gpu_step": int(lens.sum()),
                           "loss": float(info["loss"]), "grad_norm": float(info["grad_norm"]), "dtype": "fp32 + bf16 slot" + (", bf16 autocast" if amp else ""),
-                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
+                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                          "ddp": use_ddp, "grad_sync": args.grad_sync if use_ddp else None, "backend": args.dist_backend if use_ddp else None,
+                          "gradient_message_MB": round(nparam * 4 / 1e6, 1),
+                          "ms_per_step_no_sync": round(dt_nosync / args.steps * 1e3, 2) if dt_nosync else None,
+                          "exposed_allreduce_ms": round((dt - dt_nosync) / args.steps * 1e3, 2) if dt_nosync else None}))
+    if use_ddp:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

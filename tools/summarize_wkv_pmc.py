@@ -6,7 +6,9 @@ Input directory: stats/ (--kernel-trace --stats), fetch/ (--pmc FETCH_SIZE), wri
 counters), each from `python tools/bench_wkv6_one.py 1 44998 bf16`.  HBM bytes follow MI355X_MICROARCH.md: rocprofv3
 reports KB; on gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes, so reads are doubled; WRITE_SIZE is exact.
 """
-import csv, json, shutil, sys
+import csv, json, os, shutil, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (scan_source_sha: the kernels the counters were taken on)
 from collections import defaultdict
 
 src, dst = sys.argv[1], sys.argv[2]
@@ -44,6 +46,7 @@ for r in csv.DictReader(open(f"{src}/stats/run_kernel_stats.csv")):
 out = {
     "command": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_* (separate passes) -- "
                "python tools/bench_wkv6_one.py 1 44998 bf16",
+    "scan_source_sha": bench.scan_source_sha(),
     "shape": {"B": B, "T": T, "C": C, "H": H, "ndir": ndir, "elem_bytes": eb},
     "units": "rocprofv3 reports KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at "
              "64 B); WRITE_SIZE exact",
