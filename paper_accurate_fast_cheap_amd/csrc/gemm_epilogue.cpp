@@ -1,175 +1,208 @@
-// Linear + bias (+ SiLU) (+ residual) as ONE library GEMM with a fused epilogue (C ABI: include/pafc_encoder_ops.h).
+// Linear + bias (+ SiLU) (+ residual) as ONE library GEMM with a fused epilogue, behind an explicit context / plan API
+// (C ABI: include/pafc_encoder_ops.h).  Used where the hand-written GEMM (gemm_bf16.hip / gemm_ph.hip) is not the
+// faster kernel or does not apply: fp32 models, the subsampling Linear(9728, 512), the CTC head.
 //
 // Replaces `activation(w_1(x))` of PositionwiseFeedForward.forward (wenet/transformer/positionwise_feed_forward.py:47-55,
-// activation swish = SiLU): in the reference (and through torch) that is a GEMM+bias kernel followed by an
-// element-wise SiLU kernel over the (rows, 2048) hidden tensor -- its largest per-layer activation, read and
-// written once more.  hipBLASLt's SWISH_BIAS epilogue applies bias and x*sigmoid(x) to the fp32 accumulator before
-// the single bf16 rounding.  This is a plain library GEMM (no hand-written tiling here), so it lives in a .cpp.
+// activation swish = SiLU): hipBLASLt's SWISH_BIAS epilogue applies bias and x*sigmoid(x) to the fp32 accumulator before
+// the single rounding.  With `residual` the same call computes  out = residual + alpha * x.W^T + bias  (beta = 1,
+// C = residual): the residual adds of ConformerEncoderLayer.forward (wenet/transformer/encoder_layer.py:201-259) happen
+// on the fp32 accumulator.
 //
-// With `residual` the same call computes  out = residual + alpha * x.W^T + bias  (beta = 1, C = residual): the
-// `x = residual + ff_scale * ff(x)` / `x = residual + branch(x)` adds of ConformerEncoderLayer.forward
-// (wenet/transformer/encoder_layer.py:201-259) happen on the fp32 accumulator, and the pre-norm pass that follows
-// reads one tensor instead of two.
+// Ownership and state (round-1 review: the previous version hid a process-global handle / plan map behind a mutex,
+// allocated and synchronised inside the hot call and timed library kernels there):
+//   * pafc_gemm_ctx     owns the hipBLASLt handle of ONE device; created and destroyed by the caller.
+//   * pafc_linear_plan  owns the descriptors and the chosen algorithm of ONE problem (dtype, rows, N, K, epilogue);
+//                       created from a context (host work only), destroyed by the caller.  No global state anywhere.
+//   * pafc_linear_plan_run   is asynchronous on the given stream, allocates nothing, takes no lock, never synchronises.
+//   * pafc_linear_plan_tune  is the ONLY place library candidates are measured: explicit, blocking, on caller-provided
+//                            scratch, refused while the stream is capturing.  Only candidates that need NO workspace are
+//                            ever launched (see below), so `run` needs no workspace either.
+// A plan is used by one thread at a time (its descriptor carries the bias pointer of the call in flight).
 //
-// The hipBLASLt handle and the algorithm choice per (rows, N, K, epilogue) are cached per process and device: they are
-// library objects, not state of the computation.  For large problems the choice is MEASURED once (the library's
-// heuristic ranks its kernels without running them and its first pick is often not the fastest on this shape): up to
-// 16 candidates run on the call's own operands (into a scratch output when the call is in place) and the fastest is
-// kept -- what MIOpen's "find" does for convolutions.  PAFC_GEMM_TUNE=0 keeps the heuristic's first pick.
+// Why no workspace-using candidate is ever launched -- the round-1 GPU memory-access fault, diagnosed
+// (tools/micro/hipblaslt_batched_probe.cpp, profiles/r02_hipblaslt_batched_probe_*.log): inside a torch process the
+// hipBLASLt that gets bound is the one bundled with torch (1.0.0, ROCm 7.0.2), not /opt/rocm's.  For the strided-batched
+// problem (6, 44998, 512) x (6, 512, 512)^T its heuristic returns stream-K kernels, among them the hand-written
+// `Custom_Cijk_Alik_Bljk_BBS_BH_Bias_HA_S_SAV_NTD_SK3_UserArgs_MT256x256x64_MI16x16x1_shortname0_gfx950` (solution index
+// 618464, workspace 65 011 712 B), which does not implement the batch dimension: it computes batch 0 and leaves the other
+// five sixths of the output unwritten.  It is offered at 44 998 rows and not at 7 499 -- exactly the shape dependence of
+// the fault -- while the caller's layouts are vindicated by the 15 other candidates, which agree bit for bit and write
+// nothing outside their output or their reported workspace.  The defect is the library's; the remedy here is structural:
+// no batched problems at all (the stacked projections run on the hand-written batched GEMM), and no stream-K /
+// workspace candidates, ever.
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
 
-#include <stdlib.h>
-
-#include <map>
-#include <mutex>
-#include <tuple>
+#include <new>
 
 #include "../../include/pafc_encoder_ops.h"
 
-namespace {
+struct pafc_gemm_ctx {
+    hipblasLtHandle_t handle = nullptr;
+    int device = 0;
+};
 
-struct Plan {
+struct pafc_linear_plan {
+    pafc_gemm_ctx *ctx = nullptr;
     hipblasLtMatmulDesc_t desc = nullptr;
     hipblasLtMatrixLayout_t a = nullptr, b = nullptr, d = nullptr;
     hipblasLtMatmulAlgo_t algo;
-    size_t ws = 0;
-    bool ok = false;
+    int dtype = 0, N = 0, K = 0, act = 0, has_bias = 0, has_residual = 0, tuned = 0;
+    long rows = 0;
 };
 
-std::mutex g_mu;
-std::map<int, hipblasLtHandle_t> g_handles;                                   // per device
-std::map<std::tuple<int, int, long, int, int, int, int>, Plan> g_plans;   // (device, dtype, rows, N, K, act | bias | residual, batch)
+namespace {
 
-constexpr size_t kMaxWorkspace = 64u << 20;
+void destroy_plan(pafc_linear_plan *p) {
+    if (!p) return;
+    if (p->a) hipblasLtMatrixLayoutDestroy(p->a);
+    if (p->b) hipblasLtMatrixLayoutDestroy(p->b);
+    if (p->d) hipblasLtMatrixLayoutDestroy(p->d);
+    if (p->desc) hipblasLtMatmulDescDestroy(p->desc);
+    delete p;
+}
+
+// candidates the library's heuristic ranks for this plan, workspace-free ones only, best-ranked first
+int candidates(pafc_linear_plan *p, hipblasLtMatmulHeuristicResult_t *res, int cap) {
+    hipblasLtMatmulPreference_t pref;
+    if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return 0;
+    const uint64_t maxws = 0;          // never offer workspace: no split-K / stream-K kernels in the list
+    hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &maxws, sizeof(maxws));
+    int found = 0;
+    const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(p->ctx->handle, p->desc, p->a, p->b, p->d, p->d, pref, cap, res, &found);
+    hipblasLtMatmulPreferenceDestroy(pref);
+    if (st != HIPBLAS_STATUS_SUCCESS) return 0;
+    int n = 0;
+    for (int i = 0; i < found; ++i)
+        if (res[i].workspaceSize == 0 && res[i].state == HIPBLAS_STATUS_SUCCESS) res[n++] = res[i];
+    return n;
+}
 
 }  // namespace
 
 extern "C" {
 
-size_t pafc_linear_act_workspace_bytes(void) { return kMaxWorkspace; }
+int pafc_gemm_ctx_create(pafc_gemm_ctx **out) {
+    if (!out) return PAFC_ERR_NULL_POINTER;
+    *out = nullptr;
+    pafc_gemm_ctx *c = new (std::nothrow) pafc_gemm_ctx;
+    if (!c) return PAFC_ERR_LAUNCH;
+    if (hipGetDevice(&c->device) != hipSuccess || hipblasLtCreate(&c->handle) != HIPBLAS_STATUS_SUCCESS) {
+        delete c;
+        return PAFC_ERR_LAUNCH;
+    }
+    *out = c;
+    return PAFC_OK;
+}
 
-static int linear_impl(int dtype, int batch, long rows, int N, int K, const void *x, const void *weight, const void *bias,
-                       void *out, int act, float alpha, const void *residual, void *workspace, size_t workspace_bytes,
-                       pafc_stream_t stream) {
-    if (!x || !weight || !out) return PAFC_ERR_NULL_POINTER;
-    if (rows <= 0 || N <= 0 || K <= 0 || batch <= 0) return PAFC_ERR_BAD_DIMS;
-    if (batch > 1 && bias) return PAFC_ERR_UNSUPPORTED;
+void pafc_gemm_ctx_destroy(pafc_gemm_ctx *c) {
+    if (!c) return;
+    if (c->handle) hipblasLtDestroy(c->handle);
+    delete c;
+}
+
+int pafc_linear_plan_create(pafc_gemm_ctx *ctx, pafc_linear_plan **out, int dtype, long rows, int N, int K, int has_bias,
+                            int act, int has_residual) {
+    if (!ctx || !out) return PAFC_ERR_NULL_POINTER;
+    *out = nullptr;
+    if (rows <= 0 || N <= 0 || K <= 0) return PAFC_ERR_BAD_DIMS;
     if (dtype != PAFC_BF16 && dtype != PAFC_F32) return PAFC_ERR_DTYPE;
     if (act != 0 && act != 1) return PAFC_ERR_UNSUPPORTED;   // 0: identity, 1: SiLU
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return PAFC_ERR_LAUNCH;
+    pafc_linear_plan *p = new (std::nothrow) pafc_linear_plan;
+    if (!p) return PAFC_ERR_LAUNCH;
+    p->ctx = ctx; p->dtype = dtype; p->rows = rows; p->N = N; p->K = K; p->act = act;
+    p->has_bias = has_bias != 0; p->has_residual = has_residual != 0;
     const hipDataType dt = dtype == PAFC_BF16 ? HIP_R_16BF : HIP_R_32F;
-
-    std::lock_guard<std::mutex> lock(g_mu);
-    hipblasLtHandle_t &handle = g_handles[dev];
-    if (!handle && hipblasLtCreate(&handle) != HIPBLAS_STATUS_SUCCESS) return PAFC_ERR_LAUNCH;
-    Plan &p = g_plans[std::make_tuple(dev, dtype, rows, N, K, act | (bias ? 2 : 0) | (residual ? 4 : 0), batch)];
-    if (!p.ok) {
-        // row-major out (rows, N) = x (rows, K) . W(N, K)^T   <=>   column-major D (N, rows) = W_cm(K, N)^T . x_cm(K, rows)
-        if (hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return PAFC_ERR_LAUNCH;
+    // row-major out (rows, N) = x (rows, K) . W(N, K)^T   <=>   column-major D (N, rows) = W_cm(K, N)^T . x_cm(K, rows)
+    bool ok = hipblasLtMatmulDescCreate(&p->desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
+    if (ok) {
         const hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
-        hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta));
-        hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb));
-        hipblasLtEpilogue_t epi = bias ? (act ? HIPBLASLT_EPILOGUE_SWISH_BIAS_EXT : HIPBLASLT_EPILOGUE_BIAS)
-                                       : (act ? HIPBLASLT_EPILOGUE_SWISH_EXT : HIPBLASLT_EPILOGUE_DEFAULT);
-        hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi));
-        if (bias) {
+        hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta));
+        hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb));
+        const hipblasLtEpilogue_t epi = has_bias ? (act ? HIPBLASLT_EPILOGUE_SWISH_BIAS_EXT : HIPBLASLT_EPILOGUE_BIAS)
+                                                 : (act ? HIPBLASLT_EPILOGUE_SWISH_EXT : HIPBLASLT_EPILOGUE_DEFAULT);
+        hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi));
+        if (has_bias) {
             const int32_t bt = (int32_t)dt;
-            hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt));
+            hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt));
+            const void *probe = (const void *)16;   // the heuristic's validity check looks at the pointer being non-null
+            hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &probe, sizeof(probe));
         }
         if (act) {
             const float one = 1.f;   // Swish(x, 1) = SiLU
-            hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE_ACT_ARG0_EXT, &one, sizeof(one));
+            hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_EPILOGUE_ACT_ARG0_EXT, &one, sizeof(one));
         }
-        hipblasLtMatrixLayoutCreate(&p.a, dt, K, N, K);       // W as column-major (K, N), ld K
-        hipblasLtMatrixLayoutCreate(&p.b, dt, K, rows, K);    // x as column-major (K, rows)
-        hipblasLtMatrixLayoutCreate(&p.d, dt, N, rows, N);    // out as column-major (N, rows)
-        if (batch > 1) {   // contiguous stacks: weight (batch, N, K), x (batch, rows, K), out / residual (batch, rows, N)
-            const int32_t bc = batch;
-            const int64_t sa = (int64_t)N * K, sb = (int64_t)rows * K, sd = (int64_t)rows * N;
-            hipblasLtMatrixLayoutSetAttribute(p.a, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc));
-            hipblasLtMatrixLayoutSetAttribute(p.b, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc));
-            hipblasLtMatrixLayoutSetAttribute(p.d, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc));
-            hipblasLtMatrixLayoutSetAttribute(p.a, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &sa, sizeof(sa));
-            hipblasLtMatrixLayoutSetAttribute(p.b, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &sb, sizeof(sb));
-            hipblasLtMatrixLayoutSetAttribute(p.d, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &sd, sizeof(sd));
-        }
-        hipblasLtMatmulPreference_t pref;
-        hipblasLtMatmulPreferenceCreate(&pref);
-        const uint64_t maxws = kMaxWorkspace;
-        hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &maxws, sizeof(maxws));
-        // the bias pointer takes part in the heuristic's validity check
-        if (bias) hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
-        constexpr int kMaxAlgos = 16;
-        hipblasLtMatmulHeuristicResult_t res[kMaxAlgos];
-        int found = 0;
-        const char *te = getenv("PAFC_GEMM_TUNE");
-        // batched problems keep the heuristic's first pick: one of the library's lower-ranked strided-batched candidates
-        // faulted on this GPU (memory access fault at (6, 44998, 512) x (6, 512, 512)); only candidates that need no
-        // workspace (no split-K / stream-K bookkeeping) are ever timed
-        // and only long-form problems (rows >= 32768) are measured at all: that is where the first pick was seen to lose
-        // (FFN w_1 at 44 998 rows: 176 -> 140 us), and it keeps the set of library kernels ever launched small
-        const char *me = getenv("PAFC_GEMM_TUNE_MIN_ROWS");      // A/B measurements only
-        const long min_rows = me ? atol(me) : 32768;
-        const bool tune = !(te && te[0] == '0') && batch == 1 && rows >= min_rows && workspace &&
-                          workspace_bytes >= kMaxWorkspace;
-        const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.a, p.b, p.d, p.d, pref, tune ? kMaxAlgos : 1,
-                                                                   res, &found);
-        hipblasLtMatmulPreferenceDestroy(pref);
-        if (st != HIPBLAS_STATUS_SUCCESS || found < 1) return PAFC_ERR_UNSUPPORTED;
-        int best = 0;
-        if (tune && found > 1) {
-            // time every candidate on the real operands; an in-place call (out == residual, beta = 1) writes to a scratch
-            // output meanwhile so that the residual is not accumulated into more than once
-            hipStream_t hs = (hipStream_t)stream;
-            void *scratch = nullptr;
-            void *dst = out;
-            const size_t esz = dtype == PAFC_BF16 ? 2 : 4;
-            if (residual == out && hipMalloc(&scratch, (size_t)batch * rows * N * esz) == hipSuccess) dst = scratch;
-            if (residual != out || scratch) {
-                hipEvent_t e0, e1;
-                (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-                const float tbeta = residual ? 1.f : 0.f;
-                const void *tc = residual ? residual : dst;
-                float best_ms = 1e30f, first_ms = 1e30f;
-                for (int i = 0; i < found; ++i) {
-                    if (i > 0 && res[i].workspaceSize > 0) continue;
-                    bool ok = true;
-                    for (int rep = 0; rep < 7 && ok; ++rep) {       // first run warms the code object, the other six are timed
-                        if (rep == 1) (void)hipEventRecord(e0, hs);
-                        ok = hipblasLtMatmul(handle, p.desc, &alpha, weight, p.a, x, p.b, &tbeta, tc, p.d, dst, p.d, &res[i].algo,
-                                             workspace, res[i].workspaceSize, hs) == HIPBLAS_STATUS_SUCCESS;
-                    }
-                    (void)hipEventRecord(e1, hs);
-                    (void)hipEventSynchronize(e1);
-                    float ms = 0.f;
-                    (void)hipEventElapsedTime(&ms, e0, e1);
-                    if (ok && i == 0) first_ms = ms;
-                    if (ok && ms < best_ms) { best_ms = ms; best = i; }
-                }
-                if (best_ms > 0.95f * first_ms) best = 0;           // leave the heuristic's pick unless clearly beaten
-                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-            }
-            if (scratch) (void)hipFree(scratch);
-        }
-        p.algo = res[best].algo;
-        p.ws = res[best].workspaceSize;
-        p.ok = true;
+        ok = hipblasLtMatrixLayoutCreate(&p->a, dt, K, N, K) == HIPBLAS_STATUS_SUCCESS &&        // W as column-major (K, N)
+             hipblasLtMatrixLayoutCreate(&p->b, dt, K, rows, K) == HIPBLAS_STATUS_SUCCESS &&     // x as column-major (K, rows)
+             hipblasLtMatrixLayoutCreate(&p->d, dt, N, rows, N) == HIPBLAS_STATUS_SUCCESS;       // out as column-major (N, rows)
     }
-    if (p.ws > 0 && (!workspace || workspace_bytes < p.ws)) return PAFC_ERR_WORKSPACE;
-    if (bias) hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
+    hipblasLtMatmulHeuristicResult_t first[4];
+    if (!ok || candidates(p, first, 4) < 1) {
+        destroy_plan(p);
+        return ok ? PAFC_ERR_UNSUPPORTED : PAFC_ERR_LAUNCH;
+    }
+    p->algo = first[0].algo;
+    *out = p;
+    return PAFC_OK;
+}
+
+void pafc_linear_plan_destroy(pafc_linear_plan *p) { destroy_plan(p); }
+
+int pafc_linear_plan_run(pafc_linear_plan *p, const void *x, const void *weight, const void *bias, void *out, float alpha,
+                         const void *residual, pafc_stream_t stream) {
+    if (!p || !x || !weight || !out) return PAFC_ERR_NULL_POINTER;
+    if ((p->has_bias != 0) != (bias != nullptr) || (p->has_residual != 0) != (residual != nullptr)) return PAFC_ERR_UNSUPPORTED;
+    if (bias) hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
     const float beta = residual ? 1.f : 0.f;
     const void *c = residual ? residual : out;
-    const hipblasStatus_t st = hipblasLtMatmul(handle, p.desc, &alpha, weight, p.a, x, p.b, &beta, c, p.d, out, p.d,
-                                               &p.algo, workspace, p.ws, (hipStream_t)stream);
+    const hipblasStatus_t st = hipblasLtMatmul(p->ctx->handle, p->desc, &alpha, weight, p->a, x, p->b, &beta, c, p->d, out, p->d,
+                                               &p->algo, nullptr, 0, (hipStream_t)stream);
     return st == HIPBLAS_STATUS_SUCCESS ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 
-int pafc_linear_bias_act(int dtype, long rows, int N, int K, const void *x, const void *weight, const void *bias,
-                         void *out, int act, float alpha, const void *residual, void *workspace,
-                         size_t workspace_bytes, pafc_stream_t stream) {
-    return linear_impl(dtype, 1, rows, N, K, x, weight, bias, out, act, alpha, residual, workspace, workspace_bytes, stream);
+int pafc_linear_plan_tune(pafc_linear_plan *p, const void *x, const void *weight, const void *bias, void *scratch_out,
+                          float alpha, const void *residual, int max_candidates, pafc_stream_t stream) {
+    if (!p || !x || !weight || !scratch_out) return PAFC_ERR_NULL_POINTER;
+    if ((p->has_bias != 0) != (bias != nullptr) || (p->has_residual != 0) != (residual != nullptr)) return PAFC_ERR_UNSUPPORTED;
+    if (scratch_out == residual) return PAFC_ERR_UNSUPPORTED;      // beta = 1 would accumulate once per timed run
+    hipStream_t hs = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(hs, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+        return PAFC_ERR_UNSUPPORTED;                               // measuring synchronises: never inside a graph capture
+    constexpr int kMax = 16;
+    hipblasLtMatmulHeuristicResult_t res[kMax];
+    const int found = candidates(p, res, max_candidates < 1 ? 1 : (max_candidates > kMax ? kMax : max_candidates));
+    if (found < 1) return PAFC_ERR_UNSUPPORTED;
+    if (bias) hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return PAFC_ERR_LAUNCH;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return PAFC_ERR_LAUNCH; }
+    const float beta = residual ? 1.f : 0.f;
+    const void *c = residual ? residual : scratch_out;
+    float best_ms = 1e30f, first_ms = 1e30f;
+    int best = 0;
+    for (int i = 0; i < found; ++i) {
+        bool ok = true;
+        for (int rep = 0; rep < 7 && ok; ++rep) {       // first run warms the code object, the other six are timed
+            if (rep == 1) (void)hipEventRecord(e0, hs);
+            ok = hipblasLtMatmul(p->ctx->handle, p->desc, &alpha, weight, p->a, x, p->b, &beta, c, p->d, scratch_out, p->d,
+                                 &res[i].algo, nullptr, 0, hs) == HIPBLAS_STATUS_SUCCESS;
+        }
+        (void)hipEventRecord(e1, hs);
+        if (hipEventSynchronize(e1) != hipSuccess) { ok = false; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ok && i == 0) first_ms = ms;
+        if (ok && ms < best_ms) { best_ms = ms; best = i; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (best_ms > 0.95f * first_ms) best = 0;           // leave the heuristic's pick unless clearly beaten
+    p->algo = res[best].algo;
+    p->tuned = 1;
+    return PAFC_OK;
 }
+
+int pafc_linear_plan_is_tuned(const pafc_linear_plan *p) { return p ? p->tuned : 0; }
 
 }  // extern "C"

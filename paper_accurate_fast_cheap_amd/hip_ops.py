@@ -457,7 +457,62 @@ def mix4_train(x: torch.Tensor, m: torch.Tensor, maa4: torch.Tensor, reverse: bo
     return _Mix4Train.apply(x.contiguous(), m, maa4, reverse)
 
 
-_gemm_ws = {}
+class _LinearPlans:
+    """Host-side owner of the library-GEMM objects of one device (include/pafc_encoder_ops.h: pafc_gemm_ctx,
+    pafc_linear_plan): one context, and a BOUNDED least-recently-used table of plans keyed by the exact problem -- a
+    ragged workload (c2: a new row count per batch) recycles plans instead of growing without limit; evicted plans are
+    destroyed.  Measuring the library's candidates (pafc_linear_plan_tune) is explicit: `tune_min_rows` rows and more
+    (long-form shapes, where the heuristic's first pick was seen to lose 20 %), never while a graph is being captured,
+    on a scratch output of the call's own shape.  PAFC_GEMM_TUNE=0 switches it off, PAFC_GEMM_TUNE_MIN_ROWS moves the
+    threshold."""
+    CAP = 256
+
+    def __init__(self, device):
+        import os
+        from collections import OrderedDict
+        from ctypes import POINTER, byref, c_float, c_long
+        L = _bind2()
+        if not getattr(L, "_pafc_plan_bound", False):
+            P, I = c_void_p, c_int
+            _lib._sig(L.pafc_gemm_ctx_create, I, POINTER(P))
+            _lib._sig(L.pafc_gemm_ctx_destroy, None, P)
+            _lib._sig(L.pafc_linear_plan_create, I, P, POINTER(P), I, c_long, I, I, I, I, I)
+            _lib._sig(L.pafc_linear_plan_destroy, None, P)
+            _lib._sig(L.pafc_linear_plan_run, I, P, P, P, P, P, c_float, P, P)
+            _lib._sig(L.pafc_linear_plan_tune, I, P, P, P, P, P, c_float, P, I, P)
+            _lib._sig(L.pafc_linear_plan_is_tuned, I, P)
+            L._pafc_plan_bound = True
+        self.L, self.byref = L, byref
+        self.plans = OrderedDict()
+        self.ctx = c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(L.pafc_gemm_ctx_create(byref(self.ctx)), "pafc_gemm_ctx_create")
+        self.tune = os.environ.get("PAFC_GEMM_TUNE", "1") != "0"
+        self.tune_min_rows = int(os.environ.get("PAFC_GEMM_TUNE_MIN_ROWS", "32768"))
+
+    def get(self, key):
+        plan = self.plans.get(key)
+        if plan is not None:
+            self.plans.move_to_end(key)
+            return plan
+        plan = c_void_p()
+        _lib.check(self.L.pafc_linear_plan_create(self.ctx, self.byref(plan), *key), "pafc_linear_plan_create")
+        self.plans[key] = plan
+        while len(self.plans) > self.CAP:
+            _, old = self.plans.popitem(last=False)
+            self.L.pafc_linear_plan_destroy(old)
+        return plan
+
+    def __del__(self):
+        try:
+            for plan in self.plans.values():
+                self.L.pafc_linear_plan_destroy(plan)
+            self.L.pafc_gemm_ctx_destroy(self.ctx)
+        except Exception:
+            pass
+
+
+_linear_plans = {}
 
 
 def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: str = "silu",
@@ -465,32 +520,35 @@ def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
     """act(alpha * x @ weight.T + residual + bias) as one hipBLASLt GEMM with fused epilogue (act: 'silu' or 'none').
     bias is added as given (not scaled by alpha).  inplace: write the result over ``residual``."""
     _lib.require_gpu(x, weight, bias, residual)
-    L = _bind2()
-    if not getattr(L, "_pafc_gemm_bound", False):
-        from ctypes import c_float, c_long, c_size_t
-        _lib._sig(L.pafc_linear_act_workspace_bytes, c_size_t)
-        _lib._sig(L.pafc_linear_bias_act, c_int, c_int, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                  c_float, c_void_p, c_void_p, c_size_t, c_void_p)
-        L._pafc_gemm_bound = True
     N, K = weight.shape
     rows = x.numel() // K
     if x.shape[-1] != K or weight.dtype != x.dtype or (bias is not None and bias.dtype != x.dtype):
         raise _lib.PafcError("linear_bias_act: shape/dtype mismatch")
     if residual is not None and (residual.dtype != x.dtype or residual.numel() != rows * N):
         raise _lib.PafcError("linear_bias_act: residual must be (rows, N) in the activation dtype")
-    ws = _gemm_ws.get(x.device)
-    if ws is None:
-        ws = _gemm_ws[x.device] = torch.empty(L.pafc_linear_act_workspace_bytes(), dtype=torch.uint8, device=x.device)
+    if act not in ("silu", "none"):
+        raise _lib.PafcError("linear_bias_act: act is 'silu' or 'none'")
+    plans = _linear_plans.get(x.device)
+    if plans is None:
+        plans = _linear_plans[x.device] = _LinearPlans(x.device)
+    L = plans.L
+    plan = plans.get((_lib.dtype_code(x.dtype), rows, N, K, int(bias is not None), int(act == "silu"), int(residual is not None)))
     if inplace and residual is not None:
         out = residual
     else:
         out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+    stream = _lib.stream_of(x)
+    if (plans.tune and rows >= plans.tune_min_rows and not L.pafc_linear_plan_is_tuned(plan)
+            and not torch.cuda.is_current_stream_capturing()):
+        scratch = torch.empty(rows, N, dtype=x.dtype, device=x.device)
+        _lib.check(L.pafc_linear_plan_tune(plan, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(scratch), float(alpha),
+                                           _lib.ptr(residual), 16, stream), "pafc_linear_plan_tune")
+        del scratch
     from .profiling import op_timer
     with op_timer("linear_%dx%d" % (K, N), sample=12, flops=2.0 * rows * N * K):
-        rc = L.pafc_linear_bias_act(_lib.dtype_code(x.dtype), rows, N, K, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias),
-                                    _lib.ptr(out), 1 if act == "silu" else 0, float(alpha), _lib.ptr(residual),
-                                    _lib.ptr(ws), ws.numel(), _lib.stream_of(x))
-    _lib.check(rc, "pafc_linear_bias_act")
+        rc = L.pafc_linear_plan_run(plan, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out), float(alpha),
+                                    _lib.ptr(residual), stream)
+    _lib.check(rc, "pafc_linear_plan_run")
     return out
 
 

@@ -188,7 +188,8 @@ def test_encoder_matches_oracle_on_fresh_inputs(hip):
 def test_config_c1_full_size_fp32_vs_oracle(hip):
     """BASELINE configs[0] on the GPU: 10 utterances with the config's own length filter (100..2000 frames, conf yaml
     :113; the longest is exactly 2000), the FULL 12-layer 512-d bidirectional encoder in fp32 + CTC head: HIP path vs
-    the CPU restatement ELEMENT-wise within 1e-3 relative (absolute floor 5e-2 * 1e-3 for values near zero), masks
+    the CPU restatement ELEMENT-wise: |err| <= 1e-3 * |ref| + 2.5e-4 (outputs are LayerNorm rows of unit RMS: the
+    absolute term, a quarter of 1e-3 of that RMS, covers the elements near zero, where a relative error means nothing), masks
     exact, CTC greedy token ids identical on every frame the oracle decides by more than the numerical noise."""
     import bench
     from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
@@ -219,7 +220,7 @@ def test_config_c1_full_size_fp32_vs_oracle(hip):
     valid = ref_masks.squeeze(1)
     got = out.cpu()[valid]
     want = ref[valid]
-    _assert_close(got, want, False, "c1 encoder output, valid frames")
+    torch.testing.assert_close(got, want, rtol=1e-3, atol=2.5e-4)
     flips = _token_parity(logp, ref_logp, valid, 1e-3 * float(ref_logp.abs().max()), "c1 fp32")
     if flips == 0:
         assert toks == EO.ctc_greedy_search(ref_logp, ref_lens, 0)

@@ -124,6 +124,42 @@ def test_linear_bias_silu_epilogue(hip, dtype):
     torch.testing.assert_close(buf.cpu().float(), res.float() + F.linear(x.float(), w.float()), **tol)
 
 
+def test_linear_plans_are_bounded_explicit_and_capture_safe(hip, monkeypatch):
+    """The library-GEMM objects (pafc_gemm_ctx / pafc_linear_plan): a ragged workload recycles a bounded table of plans;
+    candidates are measured only by the explicit tune call, never while a graph is being captured (a first sight of a
+    shape inside a capture keeps the heuristic's pick and the capture stays valid); results are the same either way."""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    hip_ops._linear_plans.pop(dev, None)
+    monkeypatch.setattr(hip_ops._LinearPlans, "CAP", 8)
+    monkeypatch.setenv("PAFC_GEMM_TUNE_MIN_ROWS", "64")
+    w = synth.randn((128, 64), 2, 0.1).to(torch.bfloat16).cuda()
+    b = synth.randn((128,), 3, 0.2).to(torch.bfloat16).cuda()
+    for rows in range(40, 72):                                   # 32 distinct problems through an 8-entry table
+        x = synth.randn((rows, 64), rows).to(torch.bfloat16).cuda()
+        got = hip_ops.linear_bias_act(x, w, b, "silu")
+        torch.testing.assert_close(got.float(), F.silu(F.linear(x.float(), w.float(), b.float())), rtol=2 ** -7, atol=1e-2)
+    plans = hip_ops._linear_plans[dev]
+    assert len(plans.plans) == 8
+    L = plans.L
+    tuned = {k[1]: bool(L.pafc_linear_plan_is_tuned(p)) for k, p in plans.plans.items()}
+    assert all(tuned[r] for r in tuned) and min(tuned) >= 64      # rows >= 64 were measured, by the explicit call
+    # first sight of a shape inside a capture: no measuring, the capture survives, the replay is right
+    x = synth.randn((300, 64), 7).to(torch.bfloat16).cuda()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            y = hip_ops.linear_bias_act(x, w, b, "none")
+    key = next(k for k in plans.plans if k[1] == 300)
+    assert not L.pafc_linear_plan_is_tuned(plans.plans[key])
+    graph.replay()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y.float(), F.linear(x.float(), w.float(), b.float()), rtol=2 ** -7, atol=1e-2)
+    hip_ops._linear_plans.pop(dev, None)                          # plans and context are destroyed with their owner
+
+
 def test_lora_mix4_fused_equals_two_step(hip):
     """pafc_tmix_lora_mix4_bf16 (LoRA up-projection on MFMA inside the lerp pass) vs bmm + pafc_tmix_mix4."""
     from paper_accurate_fast_cheap_amd.hip_ops import tmix_lora_mix4, tmix_mix4
