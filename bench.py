@@ -346,6 +346,7 @@ def main():
             if fl:
                 tf = fl / (rec["avg_ms"] * 1e-3) / 1e12
                 label = ("subsampling conv2 (hand-written implicit GEMM)" if name == "conv3x3s2"
+                         else "hand-written GEMM K x N [x batch] = " + name.split("_", 1)[1] if name.startswith("gemm_")
                          else "library GEMM K x N = " + name.split("_", 1)[1])
                 mfma["kernels"][label] = {"achieved": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
                                           "avg_us": round(rec["avg_ms"] * 1e3, 1), "launches": rec["n"]}

@@ -223,21 +223,30 @@ int pafc_mamba2_scan_skip_bf16(int B, int L, int H, const void *xbc, long ldx, c
 int pafc_mamba2_gate_norm(int dtype, long rows, int d_inner, const void *y, const void *z, long ld_z,
                           const void *norm_weight, float eps, void *out, pafc_stream_t stream);
 
-/* Hand-written bf16 GEMM with fused epilogue (csrc/gemm_bf16.hip), batched:
+/* Hand-written bf16 GEMM with fused epilogue, batched (csrc/gemm_bf16.hip: 128 x 128 tiles, two blocks per CU;
+ * csrc/gemm_ph.hip: persistent 256-wide phase-pipelined tiles for problems that fill the chip with them -- the entry point
+ * picks):
  *   out[z][m][n] = act(alpha * sum_k A[z][m][k] * W[z][n][k] + bias[z][n] + residual[z][m][n]),   z < batch
  * A: (M, K) rows lda apart; W: (N, K) = nn.Linear.weight layout, rows ldw apart; out / residual: (M, N), rows ldo / ldr
  * apart; stride*: elements between consecutive batch entries (strideBias = 0 shares one bias); bias, residual may be
- * NULL; residual may alias out.  act: 0 none, 1 SiLU, 2 tanh, 3 ReLU, 4 GLU (out has N / 2 columns: within every block of
- * 128 weight rows the first 64 are the value rows and the last 64 the gate rows of the same 64 output channels,
- * out[m][64 t + c] = a * sigmoid(b) with a, b = columns 128 t + c, 128 t + 64 + c; N % 128 == 0, no residual -- F.glu
- * after pointwise_conv1, convolution.py:118-128, with the weight rows interleaved by the caller).  bias is added as given (not scaled by alpha);
- * everything is applied to the fp32 accumulator, one rounding to bf16.  N % 8 == 0 (tiles are 128 wide), K % 64 == 0, all leading
+ * NULL; residual may alias out.  act: 0 none, 1 SiLU, 2 tanh, 3 ReLU, 4 GLU (out has N / 2 columns: the weight rows come
+ * in blocks of 2h rows, h value rows followed by the h gate rows of the same h output channels,
+ * out[m][h t + c] = a * sigmoid(b) with a, b = columns 2h t + c, 2h t + h + c; h = pafc_gemm_bf16_glu_half(M, N, K, batch)
+ * = 64 or 32 by the kernel the problem goes to; N % 256 == 0 (h = 32) or N % 128 == 0 (h = 64), no residual -- F.glu after
+ * pointwise_conv1, convolution.py:118-128, with the weight rows interleaved by the caller).  bias is added as given (not
+ * scaled by alpha); everything is applied to the fp32 accumulator, one rounding to bf16.  N % 8 == 0, K % 64 == 0, all leading
  * dimensions / strides multiples of 8 elements, pointers 16-byte aligned.  Replaces the Linear / 1x1-Conv1d calls of
  * PositionwiseFeedForward, ConvolutionModule, RWKV_Tmix_x060c and the residual adds of ConformerEncoderLayer.forward
  * (positionwise_feed_forward.py:47-55, convolution.py:118-141, rwkv_v6/src/model.py:286-324, encoder_layer.py:201-259). */
 int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, long lda, long strideA, const void *W, long ldw,
                    long strideW, const void *bias, long strideBias, const void *residual, long ldr, long strideR,
                    void *out, long ldo, long strideO, float alpha, int act, pafc_stream_t stream);
+int pafc_gemm_bf16_glu_half(long M, int N, int K, int batch);
+/* The phase-pipelined kernel by itself (A/B measurements, tests): tile_n 256 or 128 columns, tile_m 256 / 192 / 128 / 64 rows
+ * per tile; K >= 128; a residual excludes an activation; GLU blocks are tile_n / 4 rows (h = tile_n / 8). */
+int pafc_gemm_bf16_ph(long M, int N, int K, int batch, const void *A, long lda, long strideA, const void *W, long ldw,
+                      long strideW, const void *bias, long strideBias, const void *residual, long ldr, long strideR,
+                      void *out, long ldo, long strideO, float alpha, int act, int tile_n, int tile_m, pafc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -245,6 +245,37 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 }  // namespace
 }  // namespace pafc
 
+extern "C" int pafc_gemm_bf16_ph(long M, int N, int K, int batch, const void *A, long lda, long strideA, const void *W, long ldw,
+                                 long strideW, const void *bias, long strideBias, const void *residual, long ldr, long strideR,
+                                 void *out, long ldo, long strideO, float alpha, int act, int tile_n, int tile_m,
+                                 pafc_stream_t stream);
+
+// Which kernel takes a problem: the phase-pipelined 256-wide one (gemm_ph.hip; returns its rows per tile, 256 or 192) when its
+// big tiles still fill the chip, else 0 = the 128 x 128 kernel below.  Rows per tile: the count that needs the fewest
+// rounds of one-tile-per-CU work, weighted by the rows a round costs plus a fixed per-tile part (prologue, epilogue) worth
+// about 64 rows (measured at the 30-minute shapes: tools/bench_gemm_tiles.py).
+static int ph_tile_m(long M, int N, int K, int batch, int act, bool has_residual) {
+    if (N % 8 || K % 64 || K < 128 || N < 256) return 0;
+    if (act == 4 && N % 256) return 0;
+    if (has_residual && act != 0) return 0;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    const long nt = (N + 255) / 256;
+    if (((M + 255) / 256) * nt * batch < (long)cus * 3 / 4) return 0;      // too few big tiles: the small-tile kernel fills the chip better
+    long best_cost = -1;
+    int best = 0;
+    for (int tm = 256; tm >= 192; tm -= 64) {
+        const long tiles = ((M + tm - 1) / tm) * nt * batch;
+        const long cost = ((tiles + cus - 1) / cus) * (tm + 64);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = tm; }
+    }
+    return best;
+}
+
+// GLU row order the dispatcher wants for this problem: 64 (the 128 x 128 kernel's blocks) or 32 (the phase-pipelined one's).
+extern "C" int pafc_gemm_bf16_glu_half(long M, int N, int K, int batch) { return ph_tile_m(M, N, K, batch, 4, false) ? 32 : 64; }
+
 extern "C" int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, long lda, long strideA, const void *W,
                               long ldw, long strideW, const void *bias, long strideBias, const void *residual, long ldr,
                               long strideR, void *out, long ldo, long strideO, float alpha, int act,
@@ -253,6 +284,11 @@ extern "C" int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, lo
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535) return PAFC_ERR_BAD_DIMS;
     if (N % 8 || K % pafc::GBK) return PAFC_ERR_UNSUPPORTED;
     if (act < 0 || act > 4) return PAFC_ERR_UNSUPPORTED;
+    if (const int tm = ph_tile_m(M, N, K, batch, act, residual != nullptr)) {
+        const int rc = pafc_gemm_bf16_ph(M, N, K, batch, A, lda, strideA, W, ldw, strideW, bias, strideBias, residual, ldr, strideR,
+                                         out, ldo, strideO, alpha, act, 256, tm, stream);
+        if (rc != PAFC_ERR_UNSUPPORTED) return rc;        // (extents beyond its 31-bit offsets fall through)
+    }
     const bool glu = act == 4;
     if (glu && (N % pafc::GBN || residual)) return PAFC_ERR_UNSUPPORTED;
     if (lda < K || ldw < K || ldo < (glu ? N / 2 : N) || (residual && ldr < N)) return PAFC_ERR_BAD_DIMS;

@@ -642,12 +642,58 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
         raise _lib.PafcError("gemm_bf16: bias must be (N) or (Z, N) bf16")
     sb = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
     bs = lambda t: t.stride(0) if batched else 0
-    rc = L.pafc_gemm_bf16(M, N, K, Z, _lib.ptr(a), a.stride(-2), bs(a), _lib.ptr(w), w.stride(-2), bs(w),
-                          _lib.ptr(bias), sb, _lib.ptr(residual), residual.stride(-2) if residual is not None else 0,
-                          bs(residual) if residual is not None else 0, _lib.ptr(out), out.stride(-2), bs(out),
-                          float(alpha), _ACTS[act], _lib.stream_of(a))
+    from .profiling import op_timer
+    with op_timer("gemm_%dx%d%s" % (K, N, "x%d" % Z if batched else ""), sample=12, flops=2.0 * Z * M * N * K):
+        rc = L.pafc_gemm_bf16(M, N, K, Z, _lib.ptr(a), a.stride(-2), bs(a), _lib.ptr(w), w.stride(-2), bs(w),
+                              _lib.ptr(bias), sb, _lib.ptr(residual), residual.stride(-2) if residual is not None else 0,
+                              bs(residual) if residual is not None else 0, _lib.ptr(out), out.stride(-2), bs(out),
+                              float(alpha), _ACTS[act], _lib.stream_of(a))
     _lib.check(rc, "pafc_gemm_bf16")
     return out
+
+
+def gemm_bf16_ph(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
+                 alpha: float = 1.0, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                 tile_n: int = 256, tile_m: int = 256):
+    """The phase-pipelined tile_m x tile_n kernel (csrc/gemm_ph.hip) by itself -- same arguments as gemm_bf16, which picks
+    it for the long-form shapes; act "glu" wants glu_interleave(w, tile_n // 8)."""
+    _lib.require_gpu(bias)
+    for t in (a, w, residual, out):
+        if t is not None and (not t.is_cuda or t.dtype != torch.bfloat16 or t.stride(-1) != 1):
+            raise _lib.PafcError("gemm_bf16_ph: bf16 GPU tensors with unit stride in the last dimension")
+    L = _bind2()
+    if not getattr(L, "_pafc_gemm_ph_bound", False):
+        from ctypes import c_float, c_long
+        P, I, G = c_void_p, c_int, c_long
+        _lib._sig(L.pafc_gemm_bf16_ph, I, G, I, I, I, P, G, G, P, G, G, P, G, P, G, G, P, G, G, c_float, I, I, I, P)
+        L._pafc_gemm_ph_bound = True
+    batched = a.dim() == 3
+    Z = a.shape[0] if batched else 1
+    M, K = a.shape[-2], a.shape[-1]
+    N = w.shape[-2]
+    if w.shape[-1] != K or (batched and (w.dim() != 3 or w.shape[0] != Z)) or (not batched and (a.dim() != 2 or w.dim() != 2)):
+        raise _lib.PafcError("gemm_bf16_ph: a (M, K) x w (N, K), or both with a leading batch")
+    No = N // 2 if act == "glu" else N
+    if out is None:
+        out = torch.empty((Z, M, No) if batched else (M, No), dtype=a.dtype, device=a.device)
+    sb = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
+    bs = lambda t: t.stride(0) if batched else 0
+    rc = L.pafc_gemm_bf16_ph(M, N, K, Z, _lib.ptr(a), a.stride(-2), bs(a), _lib.ptr(w), w.stride(-2), bs(w),
+                             _lib.ptr(bias), sb, _lib.ptr(residual), residual.stride(-2) if residual is not None else 0,
+                             bs(residual) if residual is not None else 0, _lib.ptr(out), out.stride(-2), bs(out),
+                             float(alpha), _ACTS[act], int(tile_n), int(tile_m), _lib.stream_of(a))
+    _lib.check(rc, "pafc_gemm_bf16_ph")
+    return out
+
+
+def gemm_glu_half(M: int, N: int, K: int, batch: int = 1) -> int:
+    """Row-block half size (64 or 32) pafc_gemm_bf16 wants for act "glu" on this problem (it depends on the kernel chosen)."""
+    L = _bind2()
+    if not getattr(L, "_pafc_gluhalf_bound", False):
+        from ctypes import c_long
+        _lib._sig(L.pafc_gemm_bf16_glu_half, c_int, c_long, c_int, c_int, c_int)
+        L._pafc_gluhalf_bound = True
+    return int(L.pafc_gemm_bf16_glu_half(M, N, K, batch))
 
 
 def log_softmax_rows(x: torch.Tensor, inplace: bool = False) -> torch.Tensor:
@@ -665,14 +711,16 @@ def log_softmax_rows(x: torch.Tensor, inplace: bool = False) -> torch.Tensor:
     return out
 
 
-def glu_interleave(t: torch.Tensor) -> torch.Tensor:
+def glu_interleave(t: torch.Tensor, half: int = 64) -> torch.Tensor:
     """(2C, ...) parameter of a Linear followed by F.glu (values = rows [0, C), gates = rows [C, 2C)) -> the row order
-    pafc_gemm_bf16 wants for act "glu": blocks of 64 value rows followed by the 64 gate rows of the same channels."""
+    the GEMM kernels want for act "glu": blocks of `half` value rows followed by the `half` gate rows of the same channels
+    (half = 64: pafc_gemm_bf16's 128 x 128 kernel; 32 / 16: the phase-pipelined kernel at tile_n 256 / 128, where a wave's
+    columns are one block)."""
     C = t.shape[0] // 2
-    if C % 64:
-        raise _lib.PafcError("glu_interleave: channels must be a multiple of 64")
-    v = t[:C].reshape(C // 64, 64, *t.shape[1:])
-    g = t[C:].reshape(C // 64, 64, *t.shape[1:])
+    if C % half:
+        raise _lib.PafcError(f"glu_interleave: channels must be a multiple of {half}")
+    v = t[:C].reshape(C // half, half, *t.shape[1:])
+    g = t[C:].reshape(C // half, half, *t.shape[1:])
     return torch.cat([v, g], dim=1).reshape(t.shape).contiguous()
 
 

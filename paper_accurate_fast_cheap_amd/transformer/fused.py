@@ -10,8 +10,10 @@ arithmetic as ConformerEncoderLayer.forward / RWKV_Tmix_x060c.forward (reference
   * r/k/v projections of both directions are one batched GEMM, the decay LoRA one batched GEMM pair;
   * GLU is fused into the channels-last depthwise convolution.
 
-The GEMMs themselves stay with hipBLASLt via torch.  Used only under torch.no_grad() on GPU tensors; training
-goes through the plain module path (autograd)."""
+Every bf16 projection of the layer runs on the hand-written GEMM (csrc/gemm_ph.hip for the long-form shapes,
+csrc/gemm_bf16.hip otherwise) with its bias / activation / GLU / residual as the epilogue; fp32 projections go to the
+library GEMM (hip_ops.linear_bias_act).  Used only under torch.no_grad() on GPU tensors; training goes through the plain
+module path (autograd)."""
 from typing import List, Optional, Tuple
 
 import torch
@@ -66,11 +68,11 @@ class LayerPlan:
             self.b2 = (L.feed_forward.w_2.bias * L.ff_scale).contiguous()
             # pointwise_conv1 with its rows interleaved (64 values, 64 gates, ...) so that F.glu is a GEMM epilogue
             pw1 = L.conv_module.pointwise_conv1
-            self.pw1_glu = None
-            if pw1.weight.dtype == torch.bfloat16 and pw1.weight.is_cuda and pw1.weight.shape[0] % 128 == 0 \
+            self.pw1_glu = None                # {block half: (weight, bias)} in the two row orders the GEMM kernels want
+            if pw1.weight.dtype == torch.bfloat16 and pw1.weight.is_cuda and pw1.weight.shape[0] % 256 == 0 \
                     and pw1.weight.shape[1] % 64 == 0:
-                self.pw1_glu = (hip_ops.glu_interleave(pw1.weight.squeeze(-1)),
-                                hip_ops.glu_interleave(pw1.bias) if pw1.bias is not None else None)
+                self.pw1_glu = {h: (hip_ops.glu_interleave(pw1.weight.squeeze(-1), h),
+                                    hip_ops.glu_interleave(pw1.bias, h) if pw1.bias is not None else None) for h in (64, 32)}
         self._stamp = stamp
 
     def _refresh_rwkv(self, bl):
@@ -86,6 +88,9 @@ class LayerPlan:
         # q-major, direction-minor: [r_0, r_1, k_0, k_1, v_0, v_1], each W^T (C_in, C_out)
         self.Wrkv = torch.stack([getattr(b, n).weight.t() for n in ("receptance", "key", "value") for b in bl]
                                 ).contiguous()
+        self.Wrkv_n = torch.stack([getattr(b, n).weight for n in ("receptance", "key", "value") for b in bl]
+                                  ).contiguous()                                        # the same in nn.Linear layout (N, K)
+        self.D2n = torch.stack([b.time_decay_w2.t() for b in bl]).contiguous()         # (nd, C, 64)
         self.D1 = torch.stack([b.time_decay_w1 for b in bl]).contiguous()              # (nd, C, 64)
         self.D2 = torch.stack([b.time_decay_w2 for b in bl]).contiguous()              # (nd, 64, C)
         self.time_decay = torch.stack([b.time_decay.reshape(1, -1) for b in bl]).contiguous()  # (nd, 1, C)
@@ -107,16 +112,37 @@ def eligible(layer: nn.Module) -> bool:
             and layer.size % 8 == 0 and layer.size <= 1024)
 
 
-def _ffn(ff: nn.Module, h: torch.Tensor) -> torch.Tensor:
-    # w_1 + bias + SiLU is one GEMM with a fused epilogue (no separate pass over the (rows, 2048) hidden tensor)
-    return F.linear(hip_ops.linear_bias_act(h, ff.w_1.weight, ff.w_1.bias, "silu"), ff.w_2.weight, ff.w_2.bias)
+def _own_gemm(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """bf16 projections run on the hand-written GEMM (csrc/gemm_ph.hip / gemm_bf16.hip); fp32 ones on the library."""
+    return x.dtype == torch.bfloat16 and w.shape[-1] % 64 == 0 and w.shape[-2] % 8 == 0
+
+
+def proj(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: str = "none", alpha: float = 1.0,
+         residual: Optional[torch.Tensor] = None, inplace: bool = False) -> torch.Tensor:
+    """act(alpha * x w^T + bias + residual) as ONE GEMM with a fused epilogue; w in nn.Linear layout (N, K)."""
+    if _own_gemm(x, w):
+        N, K = w.shape
+        x2 = x.reshape(-1, K)
+        r2 = residual.reshape(-1, N) if residual is not None else None
+        out = hip_ops.gemm_bf16(x2, w, bias, act, alpha=alpha, residual=r2, out=r2 if (inplace and r2 is not None) else None)
+        return out.view(x.shape[:-1] + (N,))
+    return hip_ops.linear_bias_act(x, w, bias, act, alpha=alpha, residual=residual, inplace=inplace)
 
 
 def _ffn_residual(ff: nn.Module, h: torch.Tensor, x: torch.Tensor, scale: float, b2_scaled: torch.Tensor,
                   inplace: bool) -> torch.Tensor:
-    """x + scale * ff(h): the add rides on the w_2 GEMM (beta = 1), so the pre-norm that follows reads ONE tensor."""
-    hid = hip_ops.linear_bias_act(h, ff.w_1.weight, ff.w_1.bias, "silu")
-    return hip_ops.linear_bias_act(hid, ff.w_2.weight, b2_scaled, "none", alpha=scale, residual=x, inplace=inplace)
+    """x + scale * ff(h): bias + SiLU ride on the w_1 GEMM, the residual add on the w_2 GEMM, so the hidden tensor is
+    written once and the pre-norm that follows reads ONE tensor."""
+    hid = proj(h, ff.w_1.weight, ff.w_1.bias, "silu")
+    return proj(hid, ff.w_2.weight, b2_scaled, "none", alpha=scale, residual=x, inplace=inplace)
+
+
+def _pw1_glu(plan: "LayerPlan", h2: torch.Tensor) -> torch.Tensor:
+    """pointwise_conv1 + F.glu as one GEMM: the weight rows in the block order the kernel picked for this row count wants."""
+    w64 = plan.pw1_glu[64][0]
+    half = hip_ops.gemm_glu_half(h2.shape[0], w64.shape[0], w64.shape[1])
+    w, b = plan.pw1_glu[half]
+    return hip_ops.gemm_bf16(h2, w, b, act="glu")
 
 
 def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -137,9 +163,13 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
         for d in range(nd):
             torch.bmm(t[d].view(M, 4, -1).transpose(0, 1), plan.W2[d], out=m[d])
         z = hip_ops.tmix_mix4(h, m, plan.maa4)                                              # (4, nd, M, C)
-    rkv = torch.bmm(z[:3].view(3 * nd, M, C), plan.Wrkv)                                    # (3nd, M, C)
-    td = hip_ops.gemm_bf16(z[3], plan.D1n, act="tanh") if own_gemm else torch.tanh(torch.bmm(z[3], plan.D1))
-    w = torch.bmm(td, plan.D2)                                                              # (nd, M, C) decay LoRA
+    if own_gemm:
+        rkv = hip_ops.gemm_bf16(z[:3].view(3 * nd, M, C), plan.Wrkv_n)                      # (3nd, M, C), one launch
+        td = hip_ops.gemm_bf16(z[3], plan.D1n, act="tanh")
+        w = hip_ops.gemm_bf16(td, plan.D2n)                                                 # (nd, M, C) decay LoRA
+    else:
+        rkv = torch.bmm(z[:3].view(3 * nd, M, C), plan.Wrkv)
+        w = torch.bmm(torch.tanh(torch.bmm(z[3], plan.D1)), plan.D2)
     if nd == 1:
         w = w + plan.time_decay            # uni: one extra pass; bi: time_decay is added inside the scan kernel
     ycat = torch.empty((M, nd * C), dtype=h.dtype, device=h.device)
@@ -155,8 +185,8 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
         ln = plan.blocks[d].ln_x
         hip_ops.add_layernorm(y.view(M, C), None, 1.0, ln.weight, ln.bias, out1=ycat[:, d * C:(d + 1) * C], eps=ln.eps)
     if residual is not None:
-        return hip_ops.linear_bias_act(ycat, plan.Wo, None, "none", residual=residual.view(M, C), inplace=True).view(B, T, C)
-    return F.linear(ycat, plan.Wo).view(B, T, C)
+        return proj(ycat, plan.Wo, None, "none", residual=residual.view(M, C), inplace=True).view(B, T, C)
+    return proj(ycat, plan.Wo, None).view(B, T, C)
 
 
 def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optional[torch.Tensor],
@@ -193,18 +223,17 @@ def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optio
         left_pad, Tc = 0, T + cm.lorder
     if plan.pw1_glu is not None and h.dtype == torch.bfloat16:
         # F.glu rides on pointwise_conv1 (half the write, and the depthwise kernel no longer recomputes sigmoids)
-        p = hip_ops.gemm_bf16(h.view(B * Tc, C), plan.pw1_glu[0], plan.pw1_glu[1], act="glu").view(B, Tc, C)
+        p = _pw1_glu(plan, h.view(B * Tc, C)).view(B, Tc, C)
         dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, left_pad, T)
     else:
         p = F.linear(h, cm.pointwise_conv1.weight.squeeze(-1), cm.pointwise_conv1.bias)
         dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, left_pad, T, glu=True)
     _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
     if not masked:
-        x = hip_ops.linear_bias_act(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none",
-                                    residual=x, inplace=True)
+        x = proj(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none", residual=x, inplace=True)
         _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff.weight, L.norm_ff.bias, want_x=False, eps=L.norm_ff.eps)
     else:   # padded frames of the conv branch count as zero (convolution.py:140-141): the add stays in the norm pass
-        c = F.linear(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias)
+        c = proj(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias)
         x, h, _ = hip_ops.add_layernorm(x, c, 1.0, L.norm_ff.weight, L.norm_ff.bias, lens=lens, T=T, mask_y=True, eps=L.norm_ff.eps)
     x = _ffn_residual(L.feed_forward, h, x, L.ff_scale, plan.b2, inplace=True)
     if next_norm is not None and next_norm.eps != L.norm_final.eps:      # the one-pass pair shares one epsilon
@@ -252,8 +281,8 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict])
     xxx = hip_ops.tmix_shift_mix(hx, plan.maa_x[0], None)
     t = hip_ops.gemm_bf16(xxx.view(1, M1, C), plan.W1n, act="tanh")
     z = hip_ops.tmix_lora_mix4(hx, t, plan.W2t, plan.maa4)                                    # (4, 1, B, T + 1, C)
-    rkv = torch.bmm(z[:3].view(3, M1, C), plan.Wrkv).view(3, B, T + 1, C)
-    w = (torch.bmm(hip_ops.gemm_bf16(z[3].view(1, M1, C), plan.D1n, act="tanh"), plan.D2) + plan.time_decay).view(B, T + 1, C)
+    rkv = hip_ops.gemm_bf16(z[:3].view(3, M1, C), plan.Wrkv_n).view(3, B, T + 1, C)
+    w = (hip_ops.gemm_bf16(hip_ops.gemm_bf16(z[3].view(1, M1, C), plan.D1n, act="tanh"), plan.D2n) + plan.time_decay).view(B, T + 1, C)
     if B == 1:
         r_, k_, v_, w_ = rkv[0, :, 1:], rkv[1, :, 1:], rkv[2, :, 1:], w[:, 1:]                # contiguous views
     else:
@@ -261,7 +290,7 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict])
     y, s_out = wkv6_forward(r_, k_, v_, w_, plan.u[0], s_in=carry.get("wkv"), want_state=True)
     ln = plan.blocks[0].ln_x
     _, yn, _ = hip_ops.add_layernorm(y.view(M, C), None, 1.0, ln.weight, ln.bias, eps=ln.eps, want_x=False)
-    x = hip_ops.linear_bias_act(yn, plan.Wo, None, "none", residual=x.view(M, C), inplace=True).view(B, T, C)
+    x = proj(yn, plan.Wo, None, "none", residual=x.view(M, C), inplace=True).view(B, T, C)
     new = {"shift": h[:, -1:].clone(), "wkv": s_out}
     cm = L.conv_module
     _, hc, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_conv.weight, L.norm_conv.bias, want_x=False, eps=L.norm_conv.eps)
@@ -270,14 +299,13 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict])
     cx = torch.cat([left, hc], dim=1)                                                         # (B, lorder + T, C)
     new["cnn"] = cx[:, -cm.lorder:, :].transpose(1, 2)
     if plan.pw1_glu is not None:
-        p = hip_ops.gemm_bf16(cx.view(-1, C), plan.pw1_glu[0], plan.pw1_glu[1], act="glu").view(B, -1, C)
+        p = _pw1_glu(plan, cx.view(-1, C)).view(B, -1, C)
         dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, 0, T)
     else:
         p = F.linear(cx, cm.pointwise_conv1.weight.squeeze(-1), cm.pointwise_conv1.bias)
         dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, 0, T, glu=True)
     _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
-    x = hip_ops.linear_bias_act(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none",
-                                residual=x, inplace=True)
+    x = proj(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none", residual=x, inplace=True)
     _, h2, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff.weight, L.norm_ff.bias, want_x=False, eps=L.norm_ff.eps)
     x = _ffn_residual(L.feed_forward, h2, x, L.ff_scale, plan.b2, inplace=True)
     _, out, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False, eps=L.norm_final.eps)

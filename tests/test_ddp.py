@@ -64,13 +64,16 @@ tot = 0.0
 for r in range(world):
     tot = tot + ref(shard(r), dev)["loss"]
 (tot / world).backward()
-tol = {"allreduce": 2e-3, "rs_ag": 2e-3, "bf16": 2e-2, "fp16": 5e-3}[sync]
+# two passes of the same bf16-slot model through kernels whose reductions are not all order-fixed (the library's convolution
+# and CTC backward use atomics) differ by a few 1e-3 of a gradient's scale on the front-end weights, which see all of it;
+# a wrong average would be off by O(1)
+tol = {"allreduce": 2e-2, "rs_ag": 2e-2, "bf16": 3e-2, "fp16": 2e-2}[sync]
 checked = 0
 for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
     assert p.grad is not None and q.grad is not None, n
     scale = max(float(q.grad.float().abs().max()), 1e-4)
     err = float((p.grad.float() - q.grad.float()).abs().max())
-    bar = (tol if p.dtype == torch.float32 else max(tol, 2e-2)) * scale
+    bar = tol * scale
     assert err <= bar, f"{n}: {err:.3e} > {bar:.3e}"
     checked += 1
 assert checked > 100
@@ -100,7 +103,10 @@ def _launch(tmp_path, nproc, env_extra, port, timeout=600):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
-    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    if out.returncode != 0:      # the launcher's own summary buries the rank's traceback: show that first
+        err = out.stderr
+        at = max(err.find("Traceback (most recent call last)"), 0)
+        raise AssertionError(f"rank failed (rc {out.returncode}):\n{err[at:at + 3000]}\n--- stdout tail ---\n{out.stdout[-800:]}")
     assert "DDP_ENCODER_OK" in out.stdout
     return out.stdout
 

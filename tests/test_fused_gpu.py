@@ -493,3 +493,47 @@ def test_tmix_block_training_path_equals_framework_autograd(hip, dtype, reverse,
     for n in gp_f:
         s = max(float(gp_f[n].abs().max()), 1e-6)
         assert float((gp_k[n] - gp_f[n]).abs().max()) <= (0.08 if lo else 2e-3) * s, n
+
+
+@pytest.mark.parametrize("tile_n,tile_m", [(256, 256), (128, 256), (256, 192), (128, 128), (256, 64)])
+@pytest.mark.parametrize("M,N,K,Z,act", [(256, 256, 128, 1, "none"), (1000, 512, 512, 1, "silu"), (513, 264, 192, 1, "tanh"),
+                                         (300, 1024, 256, 2, "relu"), (2049, 512, 1024, 1, "none"), (777, 2048, 512, 1, "silu"),
+                                         (260, 512, 2048, 3, "none")])
+def test_gemm_phase_pipelined(hip, tile_n, tile_m, M, N, K, Z, act):
+    """csrc/gemm_ph.hip (tile_m x tile_n tiles, 8 waves, counted LDS-DMA waits) vs fp32 torch: tails in M and N, an odd and
+    an even number of K-steps down to the minimum of two, batching, every epilogue including the in-place residual, row
+    counts per tile from the full 256 down to one MFMA tile."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_bf16_ph
+    bf = torch.bfloat16
+    shp = (lambda *s: (Z, *s)) if Z > 1 else (lambda *s: s)
+    a = synth.randn(shp(M, K), 11).to(bf)
+    w = synth.randn(shp(N, K), 12, 1.0 / K ** 0.5).to(bf)
+    b = synth.randn(shp(N), 13, 0.3).to(bf)
+    r = synth.randn(shp(M, N), 14).to(bf)
+    lin = torch.matmul(a.float(), w.float().transpose(-1, -2))
+    f = {"none": lambda t: t, "silu": F.silu, "tanh": torch.tanh, "relu": F.relu}[act]
+    want = f(lin + (b.float().unsqueeze(-2) if Z > 1 else b.float()))
+    got = gemm_bf16_ph(a.cuda(), w.cuda(), b.cuda(), act, tile_n=tile_n, tile_m=tile_m)
+    torch.testing.assert_close(got.cpu().float(), want, rtol=2 ** -7, atol=2e-2)
+    got = gemm_bf16_ph(a.cuda(), w.cuda(), None, "none", alpha=0.5, residual=r.cuda(), tile_n=tile_n, tile_m=tile_m)
+    torch.testing.assert_close(got.cpu().float(), r.float() + 0.5 * lin, rtol=2 ** -7, atol=2e-2)
+    buf = r.cuda().clone()
+    same = gemm_bf16_ph(a.cuda(), w.cuda(), b.cuda(), "none", residual=buf, out=buf, tile_n=tile_n, tile_m=tile_m)
+    assert same.data_ptr() == buf.data_ptr()
+    torch.testing.assert_close(buf.cpu().float(), r.float() + lin + (b.float().unsqueeze(-2) if Z > 1 else b.float()),
+                               rtol=2 ** -7, atol=2e-2)
+
+
+@pytest.mark.parametrize("tile_n", [256, 128])
+@pytest.mark.parametrize("M,N,K", [(700, 1024, 512), (256, 256, 128), (1025, 512, 192)])
+def test_gemm_phase_pipelined_glu(hip, tile_n, M, N, K):
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_bf16_ph, glu_interleave
+    bf = torch.bfloat16
+    a = synth.randn((M, K), 21).to(bf)
+    w = synth.randn((N, K), 22, 1.0 / K ** 0.5).to(bf)
+    b = synth.randn((N,), 23, 0.3).to(bf)
+    want = F.glu(F.linear(a.float(), w.float(), b.float()), dim=-1)
+    half = tile_n // 8
+    got = gemm_bf16_ph(a.cuda(), glu_interleave(w.cuda(), half), glu_interleave(b.cuda(), half), act="glu", tile_n=tile_n)
+    assert got.shape == (M, N // 2)
+    torch.testing.assert_close(got.cpu().float(), want, rtol=2 ** -7, atol=2e-2)

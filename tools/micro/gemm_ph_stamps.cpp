@@ -1,0 +1,82 @@
+// Diagnostic build of csrc/gemm_ph.hip with in-kernel shader-clock stamps (PH_STAMPS): where a tile's cycles go --
+// prologue fill, each K-step, re-join, residual DMA, accumulator -> LDS, LDS -> global.  Stamps go to a buffer no other
+// code reads; in the shipped library no stamp executes.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -I paper_accurate_fast_cheap_amd/csrc tools/micro/gemm_ph_stamps.cpp -o build_exp/gemm_ph_stamps
+//   build_exp/gemm_ph_stamps M N K residual(0/1) tile_n tile_m
+#define PH_STAMPS 1
+#include "../../paper_accurate_fast_cheap_amd/csrc/gemm_ph.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+__global__ void fill_rand(unsigned short *p, size_t n, unsigned seed) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)(i * 2654435761u) ^ seed;
+        h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+        const float f = ((int)(h & 0xffff) - 32768) / 32768.0f;
+        unsigned u; memcpy(&u, &f, 4);
+        p[i] = (unsigned short)(u >> 16);
+    }
+}
+
+int main(int argc, char **argv) {
+    const long M = argc > 1 ? atol(argv[1]) : 44998;
+    const int N = argc > 2 ? atoi(argv[2]) : 2048, K = argc > 3 ? atoi(argv[3]) : 512, res = argc > 4 ? atoi(argv[4]) : 0;
+    const int tn = argc > 5 ? atoi(argv[5]) : 256, tm = argc > 6 ? atoi(argv[6]) : 256;
+    unsigned short *A, *W, *O, *R, *B;
+    hipMalloc(&A, M * K * 2); hipMalloc(&W, (size_t)N * K * 2); hipMalloc(&O, M * N * 2); hipMalloc(&R, M * N * 2); hipMalloc(&B, N * 2);
+    fill_rand<<<2048, 256>>>(A, M * K, 1); fill_rand<<<512, 256>>>(W, (size_t)N * K, 2); fill_rand<<<2048, 256>>>(R, M * N, 3);
+    fill_rand<<<8, 256>>>(B, N, 4);
+    const long mt = (M + tm - 1) / tm, nt = (N + tn - 1) / tn, nblk = mt * nt;
+    unsigned long long *st;
+    hipMalloc(&st, nblk * 2 * 64 * 8);
+    hipMemset(st, 0, nblk * 2 * 64 * 8);
+    pafc::PhParams p{};
+    p.A = A; p.W = W; p.bias = B; p.res = res ? R : nullptr; p.out = O;
+    p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldo = N; p.ldr = N; p.alpha = 1.f;
+    p.mtiles = (int)mt; p.ntiles = (int)nt; p.tm = tm; p.stamps = st; p.batch = 1;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0, 0);
+        int rc;
+        if (tn == 256) rc = res ? pafc::launch_ph<256, 1, 0>(p, 1, 0) : pafc::launch_ph<256, 0, 1>(p, 1, 0);
+        else rc = res ? pafc::launch_ph<128, 1, 0>(p, 1, 0) : pafc::launch_ph<128, 0, 1>(p, 1, 0);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rc) { printf("launch failed %d\n", rc); return 1; }
+    }
+    std::vector<unsigned long long> h(nblk * 2 * 64);
+    hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
+    const int nk = K / 64;
+    printf("M %ld N %d K %d residual %d tile %d x %d: %ld tiles, %.1f us with stamps (%.0f TF/s)\n", M, N, K, res, tm, tn, nblk, ms * 1e3,
+           2.0 * M * N * K / ms / 1e9);
+    for (int g = 0; g < 2; ++g) {
+        // medians over the blocks of: prologue, mean K-step, first / last K-step, re-join, residual DMA, acc -> LDS, store, total
+        std::vector<double> pro, ks, k0, kl, rj, rd, wr, so, tot;
+        for (long b = 0; b < nblk; ++b) {
+            const unsigned long long *s = &h[(b * 2 + g) * 64];
+            if (!s[53]) continue;
+            pro.push_back((double)(s[1] - s[0]));
+            ks.push_back((double)(s[1 + nk] - s[1]) / nk);
+            k0.push_back((double)(s[2] - s[1]));
+            kl.push_back((double)(s[1 + nk] - s[nk]));
+            rj.push_back((double)(s[50] - s[1 + nk]));
+            rd.push_back((double)(s[51] - s[50]));
+            wr.push_back((double)(s[52] - s[51]));
+            so.push_back((double)(s[53] - s[52]));
+            tot.push_back((double)(s[53] - s[0]));
+        }
+        auto med = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+        printf("  wave %d (median cycles over %zu tiles): prologue %.0f | K-step mean %.0f (first %.0f, last %.0f; ideal %d) x %d | re-join %.0f | "
+               "residual DMA %.0f | acc->LDS %.0f | LDS->global %.0f | tile total %.0f\n",
+               g * 4, tot.size(), med(pro), med(ks), med(k0), med(kl), tn == 256 ? 2048 : 1024, nk, med(rj), med(rd), med(wr), med(so), med(tot));
+    }
+    // how the tiles of one CU follow each other: start times of the first blocks
+    return 0;
+}
