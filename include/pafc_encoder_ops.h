@@ -242,6 +242,11 @@ int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, long lda, lon
                    long strideW, const void *bias, long strideBias, const void *residual, long ldr, long strideR,
                    void *out, long ldo, long strideO, float alpha, int act, pafc_stream_t stream);
 int pafc_gemm_bf16_glu_half(long M, int N, int K, int batch);
+/* pafc_conv3x3s2_nhwc_bf16 on the phase-pipelined kernel (implicit GEMM: K-step = one tap x 64 input channels; Ci / 64 a
+ * power of two): the entry point above dispatches here for problems that fill the chip; exported for tests and A/B runs.
+ * tile_m 256 / 192 / 128.  PAFC_ERR_UNSUPPORTED: take the other kernel. */
+int pafc_conv3x3s2_nhwc_bf16_ph(int B, int T1, int F1, int Ci, int Co, const void *in, const void *w_tap_co_ci, const void *bias,
+                                void *out, int relu, int tile_m, pafc_stream_t stream);
 /* The phase-pipelined kernel by itself (A/B measurements, tests): tile_n 256 or 128 columns, tile_m 256 / 192 / 128 / 64 rows
  * per tile; K >= 128; a residual excludes an activation; GLU blocks are tile_n / 4 rows (h = tile_n / 8). */
 int pafc_gemm_bf16_ph(long M, int N, int K, int batch, const void *A, long lda, long strideA, const void *W, long ldw,

@@ -30,7 +30,7 @@
  * Pinning: the reference has NO executable implementation of this arithmetic
  * outside CUDA (model.py:296-299 always calls the CUDA op) and no tests, so
  * this file is pinned by (i) line-by-line restatement of the .cu source and
- * (ii) an independent float64 closed-form check in tests/test_oracle_wkv6.py.
+ * (ii) an independent float64 closed-form check in tests/test_oracle_goldens.py.
  * Everything *around* the op is pinned by goldens captured from the reference
  * Python (tests/golden/make_goldens.py), which runs with this file as the op.
  *
@@ -264,7 +264,7 @@ DEFINE_BACKWARD(wkv6_oracle_backward_f32, float, LD_F32, ST_F32)
 DEFINE_BACKWARD(wkv6_oracle_backward_bf16, uint16_t, LD_BF16, ST_BF16)
 
 /* Independent float64 closed form of the forward, used only to pin the float
- * restatement above (tests/test_oracle_wkv6.py):
+ * restatement above (tests/test_oracle_goldens.py):
  *   y_t[i] = sum_j r_t[j] * ( u[j] k_t[j] v_t[i]
  *                             + sum_{s<t} (prod_{s<q<t} d_q[j]) k_s[j] v_s[i] )
  * evaluated directly (O(T^2)), no running state. */

@@ -527,10 +527,21 @@ int launch_conv(ConvParams &p, hipStream_t stream) {
 }  // namespace
 }  // namespace pafc
 
+extern "C" int pafc_conv3x3s2_nhwc_bf16_ph(int B, int T1, int F1, int Ci, int Co, const void *in, const void *w_tap_co_ci,
+                                           const void *bias, void *out, int relu, int tile_m, pafc_stream_t stream);
+
 extern "C" int pafc_conv3x3s2_nhwc_bf16(int B, int T1, int F1, int Ci, int Co, const void *in, const void *w_tap_co_ci,
                                         const void *bias, void *out, int relu, pafc_stream_t stream) {
     if (!in || !w_tap_co_ci || !out) return PAFC_ERR_NULL_POINTER;
     if (B <= 0 || T1 < 3 || F1 < 3 || Ci <= 0 || Co <= 0 || Ci % pafc::BK || Co % 128) return PAFC_ERR_BAD_DIMS;
+    {   // problems that fill the chip with 256-wide tiles: the phase-pipelined implicit GEMM (csrc/gemm_ph.hip);
+        // PAFC_CONV_TILE (A/B measurements) keeps the kernels of this file
+        const long M_ = (long)B * ((T1 - 3) / 2 + 1) * ((F1 - 3) / 2 + 1);
+        if (!getenv("PAFC_CONV_TILE") && Co % 256 == 0 && ((M_ + 255) / 256) * (Co / 256) >= 512) {
+            const int rc = pafc_conv3x3s2_nhwc_bf16_ph(B, T1, F1, Ci, Co, in, w_tap_co_ci, bias, out, relu, 256, stream);
+            if (rc != PAFC_ERR_UNSUPPORTED) return rc;
+        }
+    }
     pafc::ConvParams p{};
     p.in = (const pafc::bf16_t *)in; p.wt = (const pafc::bf16_t *)w_tap_co_ci; p.bias = (const pafc::bf16_t *)bias;
     p.out = (pafc::bf16_t *)out;

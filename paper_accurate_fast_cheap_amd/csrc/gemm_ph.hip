@@ -48,6 +48,10 @@ struct PhParams {
     int mtiles, ntiles;
     int tm;                           // rows per tile actually used: 256, 192, 128 or 64 (balances the grid over the CUs)
     int batch;
+    // implicit-GEMM mode (CONV): A is an NHWC image (B, T1, F1, Ci), row m = output position (b, t2, f2) of a 3 x 3 stride-2
+    // convolution, K = 9 taps x Ci; W is (9, N, Ci) tap-major.  K-step kt = (tap, 64-channel slice).
+    int T1, F1, T2, F2, Ci, kshift;   // kshift = log2(Ci / 64)
+    long in_bytes;                    // bytes of the whole image tensor
 #ifdef PH_STAMPS
     unsigned long long *stamps;       // diagnostic build only: [block][2 waves][64] shader-clock stamps (s_memtime)
 #endif
@@ -95,8 +99,8 @@ constexpr int PBM = 256, PBK = 64;
 
 // EPI: 0 plain, 1 residual, 2 GLU (weight rows in blocks of 64 = 32 values + the 32 gates of the same channels: a wave's
 // 64 columns are one block, its column half 0 the values and half 1 the gates; the output has N / 2 columns)
-// ACT: 0 none, 1 SiLU, 2 tanh, 3 ReLU (EPI 0 only)
-template <int BN, int EPI, int ACT>
+// ACT: 0 none, 1 SiLU, 2 tanh, 3 ReLU (EPI 0 only).  CONV: the second subsampling convolution as an implicit GEMM.
+template <int BN, int EPI, int ACT, bool CONV = false>
 __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     constexpr int UA = 128 * 128;                 // bytes of an A unit: 128 rows x 64 k
     constexpr int UB = (BN / 2) * 128;            // bytes of a B unit
@@ -128,8 +132,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     auto flush_stores = [&]() {
         // branch-free through a buffer descriptor: a chunk outside the tile's valid rows / the matrix's columns gets an offset
         // beyond the descriptor's extent, and the hardware drops the store
+        // (the descriptor starts at the tile's first row: offsets stay small whatever the size of the output)
         const int ncol = EPI == 2 ? p.N / 2 : p.N;
-        const __amdgpu_buffer_rsrc_t Or = make_rsrc(p.out + pz * p.sO, ((p.M - 1) * p.ldo + ncol) * 2);
+        const __amdgpu_buffer_rsrc_t Or = make_rsrc(p.out + pz * p.sO + pm0 * p.ldo, ((p.M - 1 - pm0) * p.ldo + ncol) * 2);
         int stid = tid;
         asm volatile("" : "+v"(stid));
 #pragma unroll
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
             const int c = pc ^ (row & (EPI == 2 ? 7 : 15));
             const int col = (EPI == 2 ? pn0 / 2 : pn0) + c * 8;
             const bool ok = row < pvr && col < ncol;
-            const unsigned off = ok ? (unsigned)(((pm0 + row) * p.ldo + col) * 2) : 0x7ffffff0u;
+            const unsigned off = ok ? (unsigned)(((long)row * p.ldo + col) * 2) : 0xC0000000u;
             __builtin_amdgcn_raw_buffer_store_b128(u32x4p{img[q].x, img[q].y, img[q].z, img[q].w}, Or, off, 0, 0);
         }
     };
@@ -163,8 +168,18 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     // ---- LDS-DMA sources: lane (sub = lane >> 3, pch = lane & 7) fills LDS chunk pch of row `sub` of its 8-row piece with
     //      source chunk pch ^ sub; unit row u = (wave * D + j) * 8 + sub
     const int sub = lane >> 3, pch = lane & 7;
-    const __amdgpu_buffer_rsrc_t Ar = make_rsrc(p.A + z * p.sA, ((p.M - 1) * p.lda + p.K) * 2);
-    const __amdgpu_buffer_rsrc_t Wr = make_rsrc(p.W + z * p.sW, ((long)(p.N - 1) * p.ldw + p.K) * 2);
+    // CONV: input offset of output position m (its tap (0, 0) pixel); the descriptor starts at this tile's first pixel, so the
+    // 32-bit lane offsets stay small however long the recording is
+    auto pix_off = [&](long m) -> long {
+        const long tf = (long)p.T2 * p.F2;
+        const long bb = m / tf, rem = m - bb * tf;
+        const long t2 = rem / p.F2, f2 = rem - t2 * p.F2;
+        return (((bb * p.T1 + 2 * t2) * p.F1 + 2 * f2) * p.Ci) * 2;
+    };
+    const long a_base = CONV ? pix_off(m0) : 0;
+    const long a_bytes = CONV ? p.in_bytes - a_base : ((p.M - 1) * p.lda + p.K) * 2;
+    const __amdgpu_buffer_rsrc_t Ar = make_rsrc(reinterpret_cast<const unsigned char *>(p.A + z * p.sA) + a_base, a_bytes);
+    const __amdgpu_buffer_rsrc_t Wr = make_rsrc(p.W + z * p.sW, CONV ? (long)9 * p.N * p.Ci * 2 : ((long)(p.N - 1) * p.ldw + p.K) * 2);
     unsigned a_off[2][DA], b_off[2][DB];          // byte offsets of this lane's 16-byte source chunks (K-step 0)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -172,24 +187,36 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         for (int j = 0; j < DA; ++j) {
             const int u = (wave * DA + j) * 8 + sub;                         // 0..127: wave-row group u >> 6, row u & 63
             const long m = m0 + min((u >> 6) * 128 + h * 64 + (u & 63), vr - 1);   // clamp: loaded, never stored
-            a_off[h][j] = (unsigned)(m * p.lda * 2 + 16 * (pch ^ sub));
+            a_off[h][j] = CONV ? (unsigned)(pix_off(m) - a_base + 16 * (pch ^ sub)) : (unsigned)(m * p.lda * 2 + 16 * (pch ^ sub));
         }
 #pragma unroll
         for (int j = 0; j < DB; ++j) {
             const int u = (wave * DB + j) * 8 + sub;                         // 0..BN/2-1: wave column u / (WN/2)
             const int n = min(n0 + (u / (WN / 2)) * WN + h * (WN / 2) + (u % (WN / 2)), p.N - 1);
-            b_off[h][j] = (unsigned)((long)n * p.ldw * 2 + 16 * (pch ^ sub));
+            b_off[h][j] = (unsigned)((long)n * (CONV ? p.Ci : p.ldw) * 2 + 16 * (pch ^ sub));
         }
     }
+    // wave-uniform byte offset of K-step kt inside a row of A / W
+    auto a_soff = [&](int kt) -> unsigned {
+        if constexpr (!CONV) return kt * 128;
+        const int tap = kt >> p.kshift, kc = kt - (tap << p.kshift);
+        const int dt = (tap * 11) >> 5, df = tap - 3 * dt;                  // tap / 3, tap % 3 for tap < 9
+        return (unsigned)(((dt * p.F1 + df) * p.Ci) * 2 + kc * 128);
+    };
+    auto w_soff = [&](int kt) -> unsigned {
+        if constexpr (!CONV) return kt * 128;
+        const int tap = kt >> p.kshift, kc = kt - (tap << p.kshift);
+        return (unsigned)(tap * p.N * p.Ci * 2 + kc * 128);
+    };
     auto stage_a = [&](int h, int buf, int kt) {
 #pragma unroll
         for (int j = 0; j < DA; ++j)
-            dma16(Ar, a_off[h][j], kt * 128, lds + buf * STEP + (h ? OFF_A1 : OFF_A0) + (wave * DA + j) * 1024);
+            dma16(Ar, a_off[h][j], a_soff(kt), lds + buf * STEP + (h ? OFF_A1 : OFF_A0) + (wave * DA + j) * 1024);
     };
     auto stage_b = [&](int h, int buf, int kt) {
 #pragma unroll
         for (int j = 0; j < DB; ++j)
-            dma16(Wr, b_off[h][j], kt * 128, lds + buf * STEP + (h ? OFF_B1 : OFF_B0) + (wave * DB + j) * 1024);
+            dma16(Wr, b_off[h][j], w_soff(kt), lds + buf * STEP + (h ? OFF_B1 : OFF_B0) + (wave * DB + j) * 1024);
     };
 
     // this lane's bias values, packed as they lie in memory: 4 consecutive columns per (column half, tile); fetched here so
@@ -462,11 +489,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     if (st_pending) flush_stores();
 }
 
-template <int BN, int EPI, int ACT>
+template <int BN, int EPI, int ACT, bool CONV = false>
 int launch_ph(const PhParams &p, int batch, hipStream_t s) {
     constexpr size_t step = 2 * 128 * 128 + 2 * (BN / 2) * 128;
     constexpr size_t lds = 2 * step > (size_t)PBM * BN * 2 ? 2 * step : (size_t)PBM * BN * 2;
-    auto kern = gemm_ph_kernel<BN, EPI, ACT>;
+    auto kern = gemm_ph_kernel<BN, EPI, ACT, CONV>;
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PAFC_ERR_LAUNCH;
     int dev = 0, cus = 0;
@@ -501,8 +528,7 @@ extern "C" int pafc_gemm_bf16_ph(long M, int N, int K, int batch, const void *A,
     if ((lda | ldw | ldo | strideA | strideW | strideO) % 8 || (residual && ((ldr | strideR) % 8))) return PAFC_ERR_ALIGNMENT;
     if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)residual) & 15) != 0) return PAFC_ERR_ALIGNMENT;
     // 31-bit byte extents inside one batch entry of A / W / residual (buffer descriptors)
-    if ((double)M * lda * 2 >= 2.0e9 || (double)N * ldw * 2 >= 2.0e9 || (residual && (double)M * ldr * 2 >= 2.0e9) ||
-        (double)M * ldo * 2 >= 2.0e9)
+    if ((double)M * lda * 2 >= 2.0e9 || (double)N * ldw * 2 >= 2.0e9 || (residual && (double)M * ldr * 2 >= 2.0e9))
         return PAFC_ERR_UNSUPPORTED;
     pafc::PhParams p{};
     p.A = (const pafc::bf16_t *)A; p.W = (const pafc::bf16_t *)W; p.bias = (const pafc::bf16_t *)bias;
@@ -531,4 +557,32 @@ extern "C" int pafc_gemm_bf16_ph(long M, int N, int K, int batch, const void *A,
     if (tile_n == 256) PH_DISPATCH(256);
     PH_DISPATCH(128);
 #undef PH_DISPATCH
+}
+
+// The second subsampling convolution, Conv2d(Ci, Co, 3, stride 2) + bias (+ ReLU) on NHWC bf16 (wenet/transformer/
+// subsampling.py:187-192), as an implicit GEMM on the phase-pipelined kernel: same contract as pafc_conv3x3s2_nhwc_bf16,
+// which dispatches here when the problem fills the chip with 256-wide tiles.  PAFC_ERR_UNSUPPORTED = take the other kernel.
+extern "C" int pafc_conv3x3s2_nhwc_bf16_ph(int B, int T1, int F1, int Ci, int Co, const void *in, const void *w_tap_co_ci,
+                                           const void *bias, void *out, int relu, int tile_m, pafc_stream_t stream) {
+    if (!in || !w_tap_co_ci || !out) return PAFC_ERR_NULL_POINTER;
+    if (B <= 0 || T1 < 3 || F1 < 3 || Ci <= 0 || Co <= 0) return PAFC_ERR_BAD_DIMS;
+    if (Ci % 64 || (Ci / 64) & (Ci / 64 - 1) || Co % 8) return PAFC_ERR_UNSUPPORTED;       // 64-channel K-steps, a power of two per tap
+    if (tile_m != 256 && tile_m != 192 && tile_m != 128) return PAFC_ERR_UNSUPPORTED;
+    if ((((uintptr_t)in | (uintptr_t)w_tap_co_ci | (uintptr_t)out) & 15) != 0) return PAFC_ERR_ALIGNMENT;
+    const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+    const long M = (long)B * T2 * F2;
+    if ((double)9 * Co * Ci * 2 >= 2.0e9) return PAFC_ERR_UNSUPPORTED;
+    pafc::PhParams p{};
+    p.A = (const pafc::bf16_t *)in; p.W = (const pafc::bf16_t *)w_tap_co_ci; p.bias = (const pafc::bf16_t *)bias; p.out = (pafc::bf16_t *)out;
+    p.M = M; p.N = Co; p.K = 9 * Ci; p.lda = Ci; p.ldw = Ci; p.ldo = Co; p.alpha = 1.f;
+    p.T1 = T1; p.F1 = F1; p.T2 = T2; p.F2 = F2; p.Ci = Ci;
+    p.in_bytes = (long)B * T1 * F1 * Ci * 2;
+    int ks = 0;
+    while ((64 << ks) < Ci) ++ks;
+    p.kshift = ks;
+    p.tm = tile_m;
+    p.mtiles = (int)((M + tile_m - 1) / tile_m);
+    p.ntiles = (Co + 255) / 256;
+    hipStream_t s = (hipStream_t)stream;
+    return relu ? pafc::launch_ph<256, 0, 3, true>(p, 1, s) : pafc::launch_ph<256, 0, 0, true>(p, 1, s);
 }

@@ -496,17 +496,23 @@ class _LinearPlans:
             self.plans.move_to_end(key)
             return plan
         plan = c_void_p()
-        _lib.check(self.L.pafc_linear_plan_create(self.ctx, self.byref(plan), *key), "pafc_linear_plan_create")
+        rc = self.L.pafc_linear_plan_create(self.ctx, self.byref(plan), *key)
+        if rc == -7:      # PAFC_ERR_UNSUPPORTED: the library has no workspace-free kernel for this problem
+            self.plans[key] = None
+            return None
+        _lib.check(rc, "pafc_linear_plan_create")
         self.plans[key] = plan
         while len(self.plans) > self.CAP:
             _, old = self.plans.popitem(last=False)
-            self.L.pafc_linear_plan_destroy(old)
+            if old is not None:
+                self.L.pafc_linear_plan_destroy(old)
         return plan
 
     def __del__(self):
         try:
             for plan in self.plans.values():
-                self.L.pafc_linear_plan_destroy(plan)
+                if plan is not None:
+                    self.L.pafc_linear_plan_destroy(plan)
             self.L.pafc_gemm_ctx_destroy(self.ctx)
         except Exception:
             pass
@@ -533,6 +539,22 @@ def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
         plans = _linear_plans[x.device] = _LinearPlans(x.device)
     L = plans.L
     plan = plans.get((_lib.dtype_code(x.dtype), rows, N, K, int(bias is not None), int(act == "silu"), int(residual is not None)))
+    if plan is None:
+        # no workspace-free library kernel for this problem (seen for some row counts at N = 5000): the framework's own
+        # GEMM + separate epilogue ops -- still on the GPU, just not fused
+        y = torch.nn.functional.linear(x, weight)
+        if alpha != 1.0:
+            y = y * alpha
+        if bias is not None:
+            y = y + bias
+        if act == "silu":
+            y = torch.nn.functional.silu(y)
+        if residual is not None:
+            y = y + residual.view(y.shape)
+            if inplace:
+                residual.view(y.shape).copy_(y)
+                return residual
+        return y
     if inplace and residual is not None:
         out = residual
     else:
@@ -550,6 +572,15 @@ def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
                                     _lib.ptr(residual), stream)
     _lib.check(rc, "pafc_linear_plan_run")
     return out
+
+
+def linear_fused(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: str = "none") -> torch.Tensor:
+    """act(x @ weight.T + bias) with the epilogue fused: bf16 operands on the hand-written GEMM (K % 64 == 0, N % 8 == 0),
+    anything else on the library GEMM."""
+    N, K = weight.shape
+    if x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and K % 64 == 0 and N % 8 == 0:
+        return gemm_bf16(x.reshape(-1, K), weight, bias, act).view(x.shape[:-1] + (N,))
+    return linear_bias_act(x, weight, bias, act)
 
 
 def tmix_lora_mix4(x: torch.Tensor, t: torch.Tensor, w2t: torch.Tensor, maa: torch.Tensor, reverse0: bool = False):
@@ -584,6 +615,26 @@ def conv3x3s2_nhwc(x: torch.Tensor, w_tap_co_ci: torch.Tensor, bias: Optional[to
         rc = L.pafc_conv3x3s2_nhwc_bf16(B, T1, F1, Ci, Co, _lib.ptr(x), _lib.ptr(w_tap_co_ci), _lib.ptr(bias),
                                         _lib.ptr(out), int(relu), _lib.stream_of(x))
     _lib.check(rc, "pafc_conv3x3s2_nhwc_bf16")
+    return out
+
+
+def conv3x3s2_nhwc_ph(x: torch.Tensor, w_tap_co_ci: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = True,
+                      tile_m: int = 256):
+    """The phase-pipelined implicit GEMM (csrc/gemm_ph.hip) by itself -- same arguments as conv3x3s2_nhwc, which picks it
+    for the long-form shapes."""
+    _lib.require_gpu(x, w_tap_co_ci, bias)
+    L = _bind2()
+    if not getattr(L, "_pafc_convph_bound", False):
+        _lib._sig(L.pafc_conv3x3s2_nhwc_bf16_ph, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                  c_void_p, c_int, c_int, c_void_p)
+        L._pafc_convph_bound = True
+    B, T1, F1, Ci = x.shape
+    Co = w_tap_co_ci.shape[1]
+    if x.dtype != torch.bfloat16 or w_tap_co_ci.shape != (9, Co, Ci) or w_tap_co_ci.dtype != x.dtype:
+        raise _lib.PafcError("conv3x3s2_nhwc_ph: bf16 NHWC input and a (9, Co, Ci) weight")
+    out = torch.empty((B, (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1, Co), dtype=x.dtype, device=x.device)
+    _lib.check(L.pafc_conv3x3s2_nhwc_bf16_ph(B, T1, F1, Ci, Co, _lib.ptr(x), _lib.ptr(w_tap_co_ci), _lib.ptr(bias), _lib.ptr(out),
+                                             int(relu), int(tile_m), _lib.stream_of(x)), "pafc_conv3x3s2_nhwc_bf16_ph")
     return out
 
 

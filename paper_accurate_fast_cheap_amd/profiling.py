@@ -20,6 +20,12 @@ def enable(flag: bool = True):
         _calls.clear()
 
 
+def enable_recording(flag: bool):
+    """Stop (or resume) recording without dropping what was recorded."""
+    global _enabled
+    _enabled = flag
+
+
 @contextlib.contextmanager
 def op_timer(name: str, sample: int = 1, **meta):
     """sample = n: time only every n-th call of this name (frequent ops: the events themselves cost ~2 us each)."""

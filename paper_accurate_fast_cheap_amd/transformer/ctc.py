@@ -26,8 +26,8 @@ class CTC(torch.nn.Module):
         normalised in place by one kernel that reads them once; with autograd (training) the framework op is used."""
         if hs_pad.is_cuda and not torch.is_grad_enabled() and hs_pad.dtype in (torch.float32, torch.bfloat16) \
                 and hs_pad.dtype == self.ctc_lo.weight.dtype:
-            from ..hip_ops import linear_bias_act, log_softmax_rows
-            logits = linear_bias_act(hs_pad.contiguous(), self.ctc_lo.weight, self.ctc_lo.bias, "none")
+            from ..hip_ops import linear_fused, log_softmax_rows
+            logits = linear_fused(hs_pad.contiguous(), self.ctc_lo.weight, self.ctc_lo.bias, "none")
             return log_softmax_rows(logits, inplace=True)
         return F.log_softmax(self.ctc_lo(hs_pad), dim=2)
 

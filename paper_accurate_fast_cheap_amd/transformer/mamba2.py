@@ -71,7 +71,7 @@ class Mamba2(nn.Module):
         in_proj's output; the six scan operand planes in one pass; residual terms + gate + RMSNorm in one pass) instead
         of ~40 framework kernels and their (L, 1024) fp32 temporaries."""
         from .. import hip_ops
-        lin = lambda t, m: hip_ops.linear_bias_act(t.contiguous(), m.weight, m.bias, "none")   # library GEMM, measured pick
+        lin = lambda t, m: hip_ops.linear_fused(t.contiguous(), m.weight, m.bias, "none")   # hand-written GEMM for bf16
         zxbcdt = lin(u, self.in_proj)                                                  # (B, L, 2 d_inner + 2 N + H)
         di, N, H = self.d_inner, self.d_state, self.nheads
         z = zxbcdt[..., :di]

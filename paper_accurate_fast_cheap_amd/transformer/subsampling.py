@@ -59,8 +59,8 @@ class Conv2dSubsampling4(BaseSubsampling):
             y = conv3x3s2_c1_nhwc(x.contiguous(), c1.weight, c1.bias, relu=True)            # (B, T1, F1, C)
             y = conv3x3s2_nhwc(y, self._w_c2_taps, c2.bias, relu=True)                       # (B, T', F', C)
             b, t, f, c = y.shape
-            from ..hip_ops import linear_bias_act
-            return linear_bias_act(y.view(b, t, f * c), self._w_lin, lin.bias, "none")
+            from ..hip_ops import linear_fused
+            return linear_fused(y.view(b, t, f * c), self._w_lin, lin.bias, "none")
         if x.dtype == torch.float32 and self._w_c2_split is not None and C % 128 == 0 and 256 % (C // 8) == 0:
             # fp32 model: both convolutions on the bf16 matrix cores with hi + lo split operands (fp32 accumulation,
             # ~1e-5 relative to the fp32 convolution) instead of the fp32 MFMA path (57 ms -> 13 ms per 30-minute file)

@@ -190,6 +190,24 @@ def test_conv3x3s2_implicit_gemm(hip, B, T1, F1, C):
     assert float((got.float() - ref).abs().mean()) < 3e-3
 
 
+@pytest.mark.parametrize("tile_m", [256, 192])
+@pytest.mark.parametrize("B,T1,F1,C", [(2, 37, 19, 256), (3, 11, 9, 128), (1, 203, 39, 512), (2, 9, 7, 64)])
+def test_conv3x3s2_phase_pipelined(hip, tile_m, B, T1, F1, C):
+    """The second subsampling convolution as an implicit GEMM on the phase-pipelined kernel (tap x 64-channel K-steps,
+    tiles that run across batch entries, 1 / 2 / 4 / 8 K-steps per tap) vs torch conv2d in fp32, with and without ReLU."""
+    from paper_accurate_fast_cheap_amd.hip_ops import conv3x3s2_nhwc_ph
+    x = synth.randn((B, T1, F1, C), 1).bfloat16()
+    w = (synth.randn((C, C, 3, 3), 2) / (3 * C ** 0.5)).bfloat16()
+    b = synth.randn((C,), 3, 0.1).bfloat16()
+    lin = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), b.float(), stride=2).permute(0, 2, 3, 1)
+    taps = w.permute(2, 3, 0, 1).reshape(9, C, C).contiguous().cuda()
+    got = conv3x3s2_nhwc_ph(x.cuda(), taps, b.cuda(), relu=True, tile_m=tile_m).cpu()
+    assert got.shape == lin.shape
+    torch.testing.assert_close(got.float(), F.relu(lin), rtol=2 ** -7, atol=2e-2)
+    got = conv3x3s2_nhwc_ph(x.cuda(), taps, None, relu=False, tile_m=tile_m).cpu()
+    torch.testing.assert_close(got.float(), lin - b.float(), rtol=2 ** -7, atol=2e-2)
+
+
 @pytest.mark.parametrize("M,N,K,Z", [(300, 128, 64, 1), (129, 256, 512, 1), (1000, 64, 512, 2), (257, 2048, 512, 1),
                                      (128, 512, 2048, 1), (77, 512, 512, 6), (5, 8, 64, 1)])
 @pytest.mark.parametrize("act", ["none", "silu", "tanh", "relu"])
