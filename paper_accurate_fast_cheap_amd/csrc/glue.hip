@@ -3,6 +3,8 @@
 // element-wise kernels, each a full (B,T,C) round trip; here each chain is one pass.  bf16 rounding points
 // are those of the op-by-op PyTorch chain (every intermediate that PyTorch would materialise in bf16 is
 // rounded to bf16 in registers), so the fused result tracks the reference's numerics, not a re-association.
+#include <stdlib.h>
+
 #include "pafc_common.h"
 #include "../../include/pafc_encoder_ops.h"
 
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(256) void tmix_mix4_kernel(int T, int C, long rows,
 //   x: (rows, C); t: (ndir, rows, 128); w2t: (ndir, 4, C, 32) (W2 with K innermost); maa: (ndir, 4, C); z: (4, ndir, rows, C)
 typedef float f32x4g __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8g __attribute__((ext_vector_type(8)));
+template <bool LDSW>
 __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long rows, int ndir, int rev0,
                                                              const bf16_t *__restrict__ x, const bf16_t *__restrict__ t,
                                                              const bf16_t *__restrict__ w2t,
@@ -241,6 +244,18 @@ __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long 
     // segments per 8 lanes, so z is stored in full lines
     constexpr int LDZ = 64 + 8;
     __shared__ __attribute__((aligned(16))) bf16_t s_z[4][16][LDZ];   // [wave][row][col]: one map's tile at a time
+    // the block's slice of W2 (this block's 64 columns x 32 LoRA inputs, 4 maps, both directions = 32 KiB) goes through LDS
+    // once: its four waves (64 rows) would otherwise each fetch the same 16 KiB per direction from L2 (720 MB per layer at the
+    // 30-minute shape, more than the kernel's HBM traffic)
+    __shared__ __attribute__((aligned(16))) bf16_t s_w2[LDSW ? 2 : 1][LDSW ? 4 : 1][LDSW ? 64 : 1][32];
+    if constexpr (LDSW) {
+        for (int i = threadIdx.x; i < ndir * 4 * 64 * 4; i += 256) {          // 16-byte chunks: [d][q][col][4 chunks of 8]
+            const int ck = i & 3, col = (i >> 2) & 63, dq = i >> 8;           // dq = d * 4 + q
+            *reinterpret_cast<uint4 *>(&s_w2[0][0][0][0] + ((size_t)dq * 64 + col) * 32 + 8 * ck) =
+                *reinterpret_cast<const uint4 *>(w2t + ((size_t)dq * C + blockIdx.y * 64 + col) * 32 + 8 * ck);
+        }
+        __syncthreads();
+    }
     for (int d = 0; d < ndir; ++d) {
         const bool rev = (d == 0) ? (rev0 != 0) : true;
         const bool has_nb = rev ? (tt < T - 1) : (tt > 0);
@@ -268,9 +283,16 @@ __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long 
                 const int cb = blockIdx.y * 2 + cbi;
                 const int col = cb * 32 + 8 * qq;
                 const int colA = cb * 32 + 8 * (r16 >> 2) + (r16 & 3);  // column whose W2 row this lane feeds (slot r16)
-                const bf16_t *wq = w2t + ((size_t)(d * 4 + q) * C) * 32 + 8 * qq;
-                const uint4 a1 = *reinterpret_cast<const uint4 *>(wq + (size_t)colA * 32);
-                const uint4 a2 = *reinterpret_cast<const uint4 *>(wq + (size_t)(colA + 4) * 32);
+                uint4 a1, a2;
+                if constexpr (LDSW) {
+                    const int colL = colA - blockIdx.y * 64;             // column inside this block's 64
+                    a1 = *reinterpret_cast<const uint4 *>(&s_w2[d][q][colL][8 * qq]);
+                    a2 = *reinterpret_cast<const uint4 *>(&s_w2[d][q][colL + 4][8 * qq]);
+                } else {
+                    const bf16_t *wq = w2t + ((size_t)(d * 4 + q) * C) * 32 + 8 * qq;
+                    a1 = *reinterpret_cast<const uint4 *>(wq + (size_t)colA * 32);
+                    a2 = *reinterpret_cast<const uint4 *>(wq + (size_t)(colA + 4) * 32);
+                }
                 const f32x4g m1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8g, a1),
                                                                          __builtin_bit_cast(bf16x8g, tb[q]), zero, 0, 0, 0);
                 const f32x4g m2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8g, a2),
@@ -383,9 +405,15 @@ int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const 
     if (B <= 0 || T <= 0 || C <= 0 || C % 64 || ndir < 1 || ndir > 2) return PAFC_ERR_BAD_DIMS;
     const long rows = (long)B * T;
     dim3 grid((unsigned)((rows + 63) / 64), C / 64), block(256);
-    hipLaunchKernelGGL(pafc::tmix_lora_mix4_kernel, grid, block, 0, (hipStream_t)stream, T, C, rows, ndir, reverse0,
-                       (const pafc::bf16_t *)x, (const pafc::bf16_t *)t, (const pafc::bf16_t *)w2t,
-                       (const pafc::bf16_t *)maa, (pafc::bf16_t *)z);
+    const char *e = getenv("PAFC_LORA_LDSW");      // A/B measurements: 1 = the block's W2 slice staged through LDS
+    if (e && e[0] == '1')
+        hipLaunchKernelGGL(pafc::tmix_lora_mix4_kernel<true>, grid, block, 0, (hipStream_t)stream, T, C, rows, ndir, reverse0,
+                           (const pafc::bf16_t *)x, (const pafc::bf16_t *)t, (const pafc::bf16_t *)w2t,
+                           (const pafc::bf16_t *)maa, (pafc::bf16_t *)z);
+    else
+        hipLaunchKernelGGL(pafc::tmix_lora_mix4_kernel<false>, grid, block, 0, (hipStream_t)stream, T, C, rows, ndir, reverse0,
+                           (const pafc::bf16_t *)x, (const pafc::bf16_t *)t, (const pafc::bf16_t *)w2t,
+                           (const pafc::bf16_t *)maa, (pafc::bf16_t *)z);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 
