@@ -331,34 +331,57 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         constexpr int PAR = decltype(parc)::value;
         const int last = nt - 1 - kt;
         const bool pend = st_pending && kt == 0;
+#ifdef PH_STAMPS
+#define PH_FINE(i) do { if (stamp_on && kt == 4) st[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PH_FINE(i) do { } while (0)
+#endif
         // phase 1: quadrant (rows 0-63, column half 0)
+        PH_FINE(20);
         read_b(0, PAR, bf0);
         read_a(0, PAR);
         if (last >= 1) stage_b(1, PAR ^ 1, kt + 1);
         else if constexpr (RESPRE) stage_res((PAR ^ 1) * STEP + OFF_B1);
+        PH_FINE(21);
         PH_SYNC(1);
+        PH_FINE(22);
         mma(0, 0, bf0);
+        PH_FINE(23);
         PH_END();
+        PH_FINE(24);
         // phase 2: (rows 0-63, column half 1)
         read_b(1, PAR, bf1);
         if (last >= 1) stage_a(1, PAR ^ 1, kt + 1);
         else if constexpr (RESPRE) stage_res((PAR ^ 1) * STEP + OFF_A1);
+        PH_FINE(25);
         PH_SYNC(2);
+        PH_FINE(26);
         mma(0, 1, bf1);
+        PH_FINE(27);
         PH_END();
+        PH_FINE(28);
         // phase 3: (rows 64-127, column half 1)
         read_a(1, PAR);
         if (last >= 2) stage_a(0, PAR, kt + 2);
         else if constexpr (RESPRE) stage_res(PAR * STEP + OFF_A0);
+        PH_FINE(29);
         PH_SYNC(3);
+        PH_FINE(30);
         mma(1, 1, bf1);
+        PH_FINE(31);
         PH_END();
+        PH_FINE(32);
         // phase 4: (rows 64-127, column half 0)
         if (last >= 2) stage_b(0, PAR, kt + 2);
         else if constexpr (RESPRE) stage_res(PAR * STEP + OFF_B0);
+        PH_FINE(33);
         PH_SYNC(4);
+        PH_FINE(34);
         mma(1, 0, bf0);
+        PH_FINE(35);
         PH_END();
+        PH_FINE(36);
+#undef PH_FINE
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void tmix_mix4_kernel(int T, int C, long rows,
 //   x: (rows, C); t: (ndir, rows, 128); w2t: (ndir, 4, C, 32) (W2 with K innermost); maa: (ndir, 4, C); z: (4, ndir, rows, C)
 typedef float f32x4g __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8g __attribute__((ext_vector_type(8)));
-template <bool LDSW>
+template <bool LDSW, bool FULLROW = false>
 __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long rows, int ndir, int rev0,
                                                              const bf16_t *__restrict__ x, const bf16_t *__restrict__ t,
                                                              const bf16_t *__restrict__ w2t,

@@ -289,13 +289,27 @@ bool use_mfma() {
     return !(e && e[0] == 'v');
 }
 
+// Pass A (chunk-local end states): bf16 I/O runs the channel-lane kernel; PAFC_WKV6_PASS_A=lt keeps the time-lane one
+// (same results up to fp32 rounding; for A/B measurements).
+template <typename ET>
+void launch_pass_a(const FwdParams &p, dim3 grid, hipStream_t stream) {
+    if constexpr (sizeof(ET) == 2) {
+        const char *e = getenv("PAFC_WKV6_PASS_A");
+        if (!(e && e[0] == 'l')) {
+            hipLaunchKernelGGL(wkv6_pass_a_cl_kernel, grid, dim3(64), 0, stream, p);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((wkv6_mfma_kernel<ET, false>), grid, dim3(64), 0, stream, p);
+}
+
 template <typename ET>
 int launch_fwd(FwdParams &p, int ndir, bool any_final, hipStream_t stream) {
     const bool mfma = use_mfma();
     if (p.NC > 1) {
         p.nc_local = any_final ? p.NC : p.NC - 1;
         dim3 ga(p.nc_local, p.B * p.H, ndir);
-        if (mfma) hipLaunchKernelGGL((wkv6_mfma_kernel<ET, false>), ga, dim3(64), 0, stream, p);
+        if (mfma) launch_pass_a<ET>(p, ga, stream);
         else hipLaunchKernelGGL((wkv6_chunk_kernel<ET, false>), ga, dim3(64), 0, stream, p);
         dim3 gb(16, p.B * p.H, ndir);
         hipLaunchKernelGGL(wkv6_scan_kernel, gb, dim3(256), 0, stream, p);
@@ -652,7 +666,7 @@ int launch_bwd(int B, int T, int C, int H, const void *r, const void *k, const v
     fp.nc_local = gs ? NC : NC - 1;     // the adjoint of the initial state is the FINAL state of the reverse-time sweep
     fp.ws_state = ws_state; fp.ws_decay = ws_decay;
     if (NC > 1) {
-        if (mfma) hipLaunchKernelGGL((wkv6_mfma_kernel<ET, false>), dim3(fp.nc_local, B * H, 2), dim3(64), 0, stream, fp);
+        if (mfma) launch_pass_a<ET>(fp, dim3(fp.nc_local, B * H, 2), stream);
         else hipLaunchKernelGGL((wkv6_chunk_kernel<ET, false>), dim3(fp.nc_local, B * H, 2), dim3(64), 0, stream, fp);
         hipLaunchKernelGGL(wkv6_scan_kernel, dim3(16, B * H, 2), dim3(256), 0, stream, fp);
     }

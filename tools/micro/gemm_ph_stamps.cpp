@@ -77,6 +77,21 @@ int main(int argc, char **argv) {
                "residual DMA %.0f | acc->LDS %.0f | LDS->global %.0f | tile total %.0f\n",
                g * 4, tot.size(), med(pro), med(ks), med(k0), med(kl), tn == 256 ? 2048 : 1024, nk, med(rj), med(rd), med(wr), med(so), med(tot));
     }
-    // how the tiles of one CU follow each other: start times of the first blocks
+    // inside K-step 4: per phase, median cycles of [reads + DMA issue] [counted wait + barrier] [16 MFMAs] [closing barrier]
+    if (nk > 4)
+        for (int g = 0; g < 2; ++g) {
+            printf("  wave %d, K-step 4:", g * 4);
+            for (int ph = 0; ph < 4; ++ph) {
+                std::vector<double> d[4];
+                for (long b = 0; b < nblk; ++b) {
+                    const unsigned long long *s = &h[(b * 2 + g) * 64] + 20 + 4 * ph;
+                    if (!s[0] || !s[4]) continue;
+                    for (int i = 0; i < 4; ++i) d[i].push_back((double)(s[i + 1] - s[i]));
+                }
+                auto med = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+                printf("  p%d: issue %.0f | wait+barrier %.0f | mfma %.0f | barrier %.0f", ph + 1, med(d[0]), med(d[1]), med(d[2]), med(d[3]));
+            }
+            printf("\n");
+        }
     return 0;
 }
