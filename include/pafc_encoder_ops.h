@@ -94,6 +94,14 @@ int pafc_tmix_mix4(int dtype, int B, int T, int C, int ndir, int reverse0, const
 int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const void *x, const void *t, const void *w2t,
                              const void *maa, void *z, pafc_stream_t stream);
 
+/* The decay LoRA of the time-mix in one pass (bf16): w = bf16( bf16(tanh(zw @ time_decay_w1)) @ time_decay_w2 ) [+ bias]
+ * (src/model.py:286-287: ww = tanh(xw @ time_decay_w1) @ time_decay_w2; w = time_decay + ww).  zw: (ndir, rows, C) the
+ * fourth lerp; d1n: (ndir, H, C) = time_decay_w1^T, d2n: (ndir, C, H) = time_decay_w2^T (K innermost); bias: (ndir, C)
+ * time_decay or null (the bidirectional scan adds it itself); w: (ndir, rows, C).  Both weight matrices stay in LDS and the
+ * H-wide hidden tensor never exists in memory.  Built for C = 512, H = 64 (PAFC_ERR_UNSUPPORTED otherwise: two GEMMs). */
+int pafc_decay_lora_bf16(long rows, int C, int H, int ndir, const void *zw, const void *d1n, const void *d2n,
+                         const void *bias, void *w, pafc_stream_t stream);
+
 /* Backward of the two element-wise groups of the time-mix block for the training step (config c4; the reference
  * differentiates src/model.py:274-284 op by op through autograd).  One direction per call (reverse: the shift is
  * x_{t+1}); sums in fp32, maa gradients in float32 summed in a fixed order (deterministic).

@@ -324,6 +324,202 @@ __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long 
     }
 }
 
+
+// Weight-stationary form of tmix_lora_mix4_kernel: a block keeps ONE 64-column slice of W2 and maa of ONE direction in
+// registers (16 MFMA A fragments + the lerp coefficients) and walks over row tiles with it, so the weights are read from L2
+// once per block instead of once per 16 rows (720 MB of fragment reads per layer at the 30-minute shape otherwise).
+// grid = (G, C / 64, ndir); a wave takes the 16-row tiles blockIdx.x * 4 + wave, + 4 G, ...
+template <int NW, int WCOLS>   // waves per block; how many of them sit side by side on one row tile (adjacent 64-column slices)
+__global__ __launch_bounds__(NW * 64) void tmix_lora_mix4_ws_kernel(int T, int C, long rows, int ndir, int rev0,
+                                                                const bf16_t *__restrict__ x, const bf16_t *__restrict__ t,
+                                                                const bf16_t *__restrict__ w2t,
+                                                                const bf16_t *__restrict__ maa, bf16_t *__restrict__ z) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, qq = lane >> 4;
+    constexpr int WROWS = NW / WCOLS;
+    const int cy = blockIdx.y * WCOLS + wave % WCOLS, d = blockIdx.z;
+    const int wrow = wave / WCOLS;
+    const bool rev = (d == 0) ? (rev0 != 0) : true;
+    const f32x4g zero = {0.f, 0.f, 0.f, 0.f};
+    constexpr int LDZ = 64 + 8;
+    __shared__ __attribute__((aligned(16))) bf16_t s_z[NW][16][LDZ];
+    const int colslot = 8 * (r16 >> 2) + (r16 & 3);
+    uint4 a1[4][2], a2[4][2], av[4][2];       // [map][32-column block]: W2 rows (MFMA A operands), maa of my 8 columns (packed)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int cbi = 0; cbi < 2; ++cbi) {
+            const int cb = cy * 2 + cbi;
+            const bf16_t *wq = w2t + ((size_t)(d * 4 + q) * C + cb * 32 + colslot) * 32 + 8 * qq;
+            a1[q][cbi] = *reinterpret_cast<const uint4 *>(wq);
+            a2[q][cbi] = *reinterpret_cast<const uint4 *>(wq + 4 * 32);
+            av[q][cbi] = *reinterpret_cast<const uint4 *>(maa + ((size_t)d * 4 + q) * C + cb * 32 + 8 * qq);
+        }
+    const long ntiles = (rows + 15) / 16;
+    for (long tile = (long)blockIdx.x * WROWS + wrow; tile < ntiles; tile += (long)gridDim.x * WROWS) {
+        const long row = tile * 16 + r16;
+        const long rowc = row < rows ? row : rows - 1;     // clamp (every lane takes part in the MFMAs), skip the store
+        const int tt = (int)(rowc % T);
+        const bool has_nb = rev ? (tt < T - 1) : (tt > 0);
+        const long nb = has_nb ? (rev ? rowc + 1 : rowc - 1) : rowc;
+        uint4 tb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            tb[q] = *reinterpret_cast<const uint4 *>(t + ((size_t)d * rows + rowc) * 128 + 32 * q + 8 * qq);
+        float xc[2][VEC], xx[2][VEC];
+#pragma unroll
+        for (int cbi = 0; cbi < 2; ++cbi) {
+            const int col = (cy * 2 + cbi) * 32 + 8 * qq;
+            float xn[VEC];
+            load8<bf16_t>(x + rowc * C + col, xc[cbi]);
+            load8<bf16_t>(x + nb * C + col, xn);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) xx[cbi][e] = round_bf16((has_nb ? xn[e] : 0.f) - xc[cbi][e]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int cbi = 0; cbi < 2; ++cbi) {
+                const f32x4g m1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8g, a1[q][cbi]),
+                                                                         __builtin_bit_cast(bf16x8g, tb[q]), zero, 0, 0, 0);
+                const f32x4g m2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8g, a2[q][cbi]),
+                                                                         __builtin_bit_cast(bf16x8g, tb[q]), zero, 0, 0, 0);
+                const unsigned aw[4] = {av[q][cbi].x, av[q][cbi].y, av[q][cbi].z, av[q][cbi].w};
+                float o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float a = (e & 1) ? __uint_as_float(aw[e >> 1] & 0xffff0000u) : __uint_as_float(aw[e >> 1] << 16);
+                    const float mv = round_bf16(e < 4 ? m1[e] : m2[e - 4]);
+                    o[e] = round_bf16(xc[cbi][e] + round_bf16(xx[cbi][e] * round_bf16(a + mv)));
+                }
+                store8<bf16_t>(&s_z[wave][r16][cbi * 32 + 8 * qq], o);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int rr = half * 8 + (lane >> 3), cc = (lane & 7) * 8;
+                const long orow = tile * 16 + rr;
+                if (orow < rows)
+                    *reinterpret_cast<uint4 *>(z + (((size_t)q * ndir + d) * rows + orow) * C + cy * 64 + cc) =
+                        *reinterpret_cast<const uint4 *>(&s_z[wave][rr][cc]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// The decay LoRA in one pass (bf16):  w = bf16( bf16(tanh(z_w D1)) . D2 ) [+ time_decay]   (src/model.py:286-287)
+// z_w: (ndir, rows, C) the fourth lerp; d1n: (ndir, 64, C) = time_decay_w1^T; d2n: (ndir, C, 64) = time_decay_w2^T.
+// Both weight matrices of a direction (2 x 64 KiB) stay in LDS in MFMA-fragment order (one lane-linear ds_read_b128 per
+// fragment, conflict-free); a wave takes 16 rows at a time: the transposed product td^T[n1][row] = sum_c D1^T[n1][c]
+// z_w^T[c][row] takes the row's own 16-byte pieces as its B operand straight from global memory, the accumulators (lane = row,
+// register = 4 consecutive n1) become after tanh + rounding the B operand of w^T[c][row] = sum_n1 D2^T[c][n1] td^T[n1][row]
+// with the k-slots of a step taken as (4 of tile 2p | 4 of tile 2p+1), and w leaves through a per-wave LDS tile in full
+// lines.  The 64-wide hidden tensor never exists in memory and z_w / w cross HBM once each (two library-shaped GEMMs: 83 us
+// for 206 MB at the 30-minute shape).
+typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float tanh_as_gemm_epilogue(float v) {   // the form gemm_bf16.hip / gemm_ph.hip apply (act 2)
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * v) + 1.f);
+}
+__device__ __forceinline__ unsigned pack_bf16_exact(float lo, float hi) {   // both already bf16 values
+    return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+}
+constexpr int DL_C = 512, DL_H = 64;      // model width and LoRA width this kernel is built for (checked on the host)
+constexpr int DL_WAVES = 8;
+__global__ __launch_bounds__(DL_WAVES * 64) void decay_lora_kernel(long rows, int ndir, const bf16_t *__restrict__ zw,
+                                                                   const bf16_t *__restrict__ d1n,
+                                                                   const bf16_t *__restrict__ d2n,
+                                                                   const bf16_t *__restrict__ bias, bf16_t *__restrict__ wout) {
+    constexpr int C = DL_C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, qq = lane >> 4;
+    const f32x4g zero = {0.f, 0.f, 0.f, 0.f};
+    constexpr int LDZ = 64 + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dl_lds[];
+    uint4 *s_d1 = reinterpret_cast<uint4 *>(dl_lds);                       // [ks 16][tau 4][lane 64]   64 KiB
+    uint4 *s_d2 = s_d1 + 16 * 4 * 64;                                      // [cb 16][a 2][p 2][lane 64] 64 KiB
+    bf16_t(*s_z)[16][LDZ] = reinterpret_cast<bf16_t(*)[16][LDZ]>(s_d2 + 16 * 2 * 2 * 64);   // [wave][row][col]
+    const int colslot = 8 * (r16 >> 2) + (r16 & 3);   // column (in a 32-block) whose weight row this lane feeds as MFMA row r16
+    const long ntiles = (rows + 15) / 16;
+    {
+        const int d = blockIdx.y;                       // a block serves one direction: its weights are staged once
+        for (int f = wave; f < 64; f += DL_WAVES) {     // fragment (ks, tau): lane (r16, qq) <- D1^T[16 tau + r16][32 ks + 8 qq ..]
+            const int ks = f >> 2, tau = f & 3;
+            s_d1[f * 64 + lane] = *reinterpret_cast<const uint4 *>(d1n + ((size_t)d * DL_H + 16 * tau + r16) * C + 32 * ks + 8 * qq);
+        }
+        for (int f = wave; f < 64; f += DL_WAVES) {     // fragment (cb, a, p): the row of column cb*32 + colslot + 4a, k-slots of step p
+            const int cb = f >> 2, a = (f >> 1) & 1, p = f & 1;
+            const bf16_t *dq = d2n + ((size_t)d * C + cb * 32 + colslot + 4 * a) * DL_H + 32 * p + 4 * qq;
+            const uint2 lo = *reinterpret_cast<const uint2 *>(dq), hi = *reinterpret_cast<const uint2 *>(dq + 16);
+            s_d2[f * 64 + lane] = uint4{lo.x, lo.y, hi.x, hi.y};
+        }
+        __syncthreads();
+        for (long tile = (long)blockIdx.x * DL_WAVES + wave; tile < ntiles; tile += (long)gridDim.x * DL_WAVES) {
+            const long row = tile * 16 + r16;
+            const long rowc = row < rows ? row : rows - 1;     // clamp (every lane takes part in the MFMAs), skip the store
+            const bf16_t *zr = zw + ((size_t)d * rows + rowc) * C + 8 * qq;
+            uint4 zf[16];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) zf[ks] = *reinterpret_cast<const uint4 *>(zr + 32 * ks);
+            f32x4g acc1[4] = {zero, zero, zero, zero};
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+                for (int tau = 0; tau < 4; ++tau)
+                    acc1[tau] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8g, s_d1[(ks * 4 + tau) * 64 + lane]),
+                                                                         __builtin_bit_cast(bf16x8g, zf[ks]), acc1[tau], 0, 0, 0);
+            // tanh + rounding; k-step p of the second product takes n1 = 32 p + 4 qq + e (e < 4) | 32 p + 16 + 4 qq + e - 4
+            u32x4g b2[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = round_bf16(tanh_as_gemm_epilogue(acc1[2 * p + (e >> 2)][e & 3]));
+                b2[p] = u32x4g{pack_bf16_exact(v[0], v[1]), pack_bf16_exact(v[2], v[3]),
+                               pack_bf16_exact(v[4], v[5]), pack_bf16_exact(v[6], v[7])};
+            }
+            for (int cy = 0; cy < C / 64; ++cy) {
+#pragma unroll
+                for (int cbi = 0; cbi < 2; ++cbi) {
+                    const int cb = cy * 2 + cbi;
+                    f32x4g o[2];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        o[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8g, s_d2[((cb * 2 + a) * 2 + 0) * 64 + lane]),
+                                                                       __builtin_bit_cast(bf16x8g, b2[0]), zero, 0, 0, 0);
+                        o[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8g, s_d2[((cb * 2 + a) * 2 + 1) * 64 + lane]),
+                                                                       __builtin_bit_cast(bf16x8g, b2[1]), o[a], 0, 0, 0);
+                    }
+                    float ov[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) ov[e] = e < 4 ? o[0][e] : o[1][e - 4];
+                    if (bias) {   // w = time_decay + ww, each rounded where the reference's op chain rounds it
+                        float bv[VEC];
+                        load8<bf16_t>(bias + (size_t)d * C + cb * 32 + 8 * qq, bv);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) ov[e] = bv[e] + round_bf16(ov[e]);
+                    }
+                    store8<bf16_t>(&s_z[wave][r16][cbi * 32 + 8 * qq], ov);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int rr = half * 8 + (lane >> 3), cc = (lane & 7) * 8;
+                    const long orow = tile * 16 + rr;
+                    if (orow < rows)
+                        *reinterpret_cast<uint4 *>(wout + ((size_t)d * rows + orow) * C + cy * 64 + cc) =
+                            *reinterpret_cast<const uint4 *>(&s_z[wave][rr][cc]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
 template <typename EX>
 int launch_ln(int dtype_out, const LnArgs &a, hipStream_t s) {
     dim3 grid((a.rows + 3) / 4), block(256);
@@ -405,7 +601,24 @@ int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const 
     if (B <= 0 || T <= 0 || C <= 0 || C % 64 || ndir < 1 || ndir > 2) return PAFC_ERR_BAD_DIMS;
     const long rows = (long)B * T;
     dim3 grid((unsigned)((rows + 63) / 64), C / 64), block(256);
-    const char *e = getenv("PAFC_LORA_LDSW");      // A/B measurements: 1 = the block's W2 slice staged through LDS
+    const char *e = getenv("PAFC_LORA_LDSW");      // A/B measurements: 1 = the block's W2 slice staged through LDS, 0 = reloaded per 16 rows
+    const long ntiles = (rows + 15) / 16;
+    if (!e && ntiles >= 256) {                      // weight-stationary: each wave walks over row tiles with its W2 slice
+        const char *g = getenv("PAFC_LORA_WS_BLOCKS");
+        const char *wc = getenv("PAFC_LORA_WS_WCOLS");
+        const int wcols = wc ? atoi(wc) : 1;
+        long G = g ? atol(g) : 2048 / ((C / 64) * ndir);   // measured at the 30-minute shape: 512 blocks 145 us, 1024: 128, 2048: 123
+        if (G < 1) G = 1;
+#define PAFC_WS(NW, WCOLS)                                                                                               \
+    hipLaunchKernelGGL((pafc::tmix_lora_mix4_ws_kernel<NW, WCOLS>), dim3((unsigned)G, (C / 64) / WCOLS, ndir), dim3(NW * 64), 0, \
+                       (hipStream_t)stream, T, C, rows, ndir, reverse0, (const pafc::bf16_t *)x, (const pafc::bf16_t *)t,  \
+                       (const pafc::bf16_t *)w2t, (const pafc::bf16_t *)maa, (pafc::bf16_t *)z)
+        if (wcols == 8 && (C / 64) % 8 == 0) PAFC_WS(8, 8);
+        else if (wcols == 4 && (C / 64) % 4 == 0) PAFC_WS(4, 4);
+        else PAFC_WS(4, 1);
+#undef PAFC_WS
+        return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+    }
     if (e && e[0] == '1')
         hipLaunchKernelGGL(pafc::tmix_lora_mix4_kernel<true>, grid, block, 0, (hipStream_t)stream, T, C, rows, ndir, reverse0,
                            (const pafc::bf16_t *)x, (const pafc::bf16_t *)t, (const pafc::bf16_t *)w2t,
@@ -417,4 +630,27 @@ int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const 
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 
+int pafc_decay_lora_bf16(long rows, int C, int H, int ndir, const void *zw, const void *d1n, const void *d2n, const void *bias,
+                         void *w, pafc_stream_t stream) {
+    if (!zw || !d1n || !d2n || !w) return PAFC_ERR_NULL_POINTER;
+    if (rows <= 0 || ndir < 1 || ndir > 2) return PAFC_ERR_BAD_DIMS;
+    if (C != pafc::DL_C || H != pafc::DL_H) return PAFC_ERR_UNSUPPORTED;
+    const size_t lds = 2 * 65536 + pafc::DL_WAVES * 16 * (64 + 8) * sizeof(pafc::bf16_t);
+    if (hipFuncSetAttribute((const void *)pafc::decay_lora_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+        return PAFC_ERR_LAUNCH;
+    const long ntiles = (rows + 15) / 16;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0)
+        return PAFC_ERR_LAUNCH;
+    long grid = cus / ndir;                       // one block per CU in all (128 KiB of LDS each)
+    if (grid > (ntiles + pafc::DL_WAVES - 1) / pafc::DL_WAVES) grid = (ntiles + pafc::DL_WAVES - 1) / pafc::DL_WAVES;
+    hipLaunchKernelGGL(pafc::decay_lora_kernel, dim3((unsigned)grid, ndir), dim3(pafc::DL_WAVES * 64), lds, (hipStream_t)stream, rows, ndir,
+                       (const pafc::bf16_t *)zw, (const pafc::bf16_t *)d1n, (const pafc::bf16_t *)d2n,
+                       (const pafc::bf16_t *)bias, (pafc::bf16_t *)w);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
 }  // extern "C"
+

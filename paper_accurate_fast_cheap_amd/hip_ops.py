@@ -1,4 +1,5 @@
 """torch-tensor front ends of the glue kernels in include/pafc_encoder_ops.h (GPU only, no fallback)."""
+import ctypes
 from typing import Optional
 
 import torch
@@ -595,6 +596,36 @@ def tmix_lora_mix4(x: torch.Tensor, t: torch.Tensor, w2t: torch.Tensor, maa: tor
                                            _lib.ptr(maa), _lib.ptr(z), _lib.stream_of(x))
     _lib.check(rc, "pafc_tmix_lora_mix4_bf16")
     return z
+
+
+def decay_lora(zw: torch.Tensor, d1n: torch.Tensor, d2n: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """bf16: w = bf16(bf16(tanh(zw d1n^T)) d2n^T) [+ bias] in one pass.  zw (ndir, rows, C), d1n (ndir, H, C), d2n (ndir, C, H),
+    bias (ndir, C) or None -> (ndir, rows, C).  C = 512, H = 64 run the fused kernel (weights resident in LDS); other sizes
+    take two GEMMs with the same roundings."""
+    _lib.require_gpu(zw, d1n, d2n, bias)
+    L = _bind2()
+    if not getattr(L, "_pafc_decay_bound", False):
+        _lib._sig(L.pafc_decay_lora_bf16, ctypes.c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                  c_void_p)
+        L._pafc_decay_bound = True
+    ndir, rows, C = zw.shape
+    H = d1n.shape[1]
+    if zw.dtype != torch.bfloat16 or d1n.shape != (ndir, H, C) or d2n.shape != (ndir, C, H) or \
+            (bias is not None and bias.numel() != ndir * C):
+        raise _lib.PafcError("decay_lora: bf16 only, zw (ndir, rows, C), d1n (ndir, H, C), d2n (ndir, C, H), bias (ndir, C)")
+    for a in (zw, d1n, d2n) + ((bias,) if bias is not None else ()):
+        if not a.is_contiguous() or a.dtype != torch.bfloat16:
+            raise _lib.PafcError("decay_lora: contiguous bf16 tensors")
+    if C == 512 and H == 64:
+        w = torch.empty_like(zw)
+        from .profiling import op_timer
+        with op_timer("decay_lora"):
+            rc = L.pafc_decay_lora_bf16(rows, C, H, ndir, _lib.ptr(zw), _lib.ptr(d1n), _lib.ptr(d2n), _lib.ptr(bias),
+                                        _lib.ptr(w), _lib.stream_of(zw))
+        _lib.check(rc, "pafc_decay_lora_bf16")
+        return w
+    w = gemm_bf16(gemm_bf16(zw, d1n, act="tanh"), d2n)
+    return w if bias is None else w + bias.view(ndir, 1, C)
 
 
 def conv3x3s2_nhwc(x: torch.Tensor, w_tap_co_ci: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = True):

@@ -16,6 +16,8 @@ library GEMM (hip_ops.linear_bias_act).  Used only under torch.no_grad() on GPU 
 module path (autograd)."""
 from typing import List, Optional, Tuple
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -165,12 +167,12 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
         z = hip_ops.tmix_mix4(h, m, plan.maa4)                                              # (4, nd, M, C)
     if own_gemm:
         rkv = hip_ops.gemm_bf16(z[:3].view(3 * nd, M, C), plan.Wrkv_n)                      # (3nd, M, C), one launch
-        td = hip_ops.gemm_bf16(z[3], plan.D1n, act="tanh")
-        w = hip_ops.gemm_bf16(td, plan.D2n)                                                 # (nd, M, C) decay LoRA
+        # decay LoRA in one pass (the 64-wide hidden tensor stays on chip); uni: time_decay rides along
+        w = hip_ops.decay_lora(z[3], plan.D1n, plan.D2n, plan.time_decay.view(nd, C) if nd == 1 else None)
     else:
         rkv = torch.bmm(z[:3].view(3 * nd, M, C), plan.Wrkv)
         w = torch.bmm(torch.tanh(torch.bmm(z[3], plan.D1)), plan.D2)
-    if nd == 1:
+    if nd == 1 and not own_gemm:
         w = w + plan.time_decay            # uni: one extra pass; bi: time_decay is added inside the scan kernel
     ycat = torch.empty((M, nd * C), dtype=h.dtype, device=h.device)
     if nd == 2:
@@ -282,7 +284,7 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict])
     t = hip_ops.gemm_bf16(xxx.view(1, M1, C), plan.W1n, act="tanh")
     z = hip_ops.tmix_lora_mix4(hx, t, plan.W2t, plan.maa4)                                    # (4, 1, B, T + 1, C)
     rkv = hip_ops.gemm_bf16(z[:3].view(3, M1, C), plan.Wrkv_n).view(3, B, T + 1, C)
-    w = (hip_ops.gemm_bf16(hip_ops.gemm_bf16(z[3].view(1, M1, C), plan.D1n, act="tanh"), plan.D2n) + plan.time_decay).view(B, T + 1, C)
+    w = hip_ops.decay_lora(z[3].view(1, M1, C), plan.D1n, plan.D2n, plan.time_decay.view(1, C)).view(B, T + 1, C)
     if B == 1:
         r_, k_, v_, w_ = rkv[0, :, 1:], rkv[1, :, 1:], rkv[2, :, 1:], w[:, 1:]                # contiguous views
     else:

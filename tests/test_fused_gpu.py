@@ -160,10 +160,11 @@ def test_linear_plans_are_bounded_explicit_and_capture_safe(hip, monkeypatch):
     hip_ops._linear_plans.pop(dev, None)                          # plans and context are destroyed with their owner
 
 
-def test_lora_mix4_fused_equals_two_step(hip):
-    """pafc_tmix_lora_mix4_bf16 (LoRA up-projection on MFMA inside the lerp pass) vs bmm + pafc_tmix_mix4."""
+@pytest.mark.parametrize("B,T,C,nd", [(2, 37, 128, 2), (2, 2101, 128, 2), (1, 4099, 64, 1)])
+def test_lora_mix4_fused_equals_two_step(hip, B, T, C, nd):
+    """pafc_tmix_lora_mix4_bf16 (LoRA up-projection on MFMA inside the lerp pass) vs bmm + pafc_tmix_mix4; from 256 row tiles
+    on, the weight-stationary kernel (a block keeps its W2 slice in registers and walks over row tiles)."""
     from paper_accurate_fast_cheap_amd.hip_ops import tmix_lora_mix4, tmix_mix4
-    B, T, C, nd = 2, 37, 128, 2
     x = synth.randn((B, T, C), 1).bfloat16().cuda()
     t = torch.tanh(synth.randn((nd, B * T, 128), 2)).bfloat16().cuda()
     w2 = (synth.randn((nd, 4, 32, C), 3) * 0.2).bfloat16().cuda()
@@ -174,6 +175,31 @@ def test_lora_mix4_fused_equals_two_step(hip):
     # identical op chain; the only freedom is the K = 32 summation order inside the MFMA vs the library GEMM
     torch.testing.assert_close(got.float(), ref.float(), rtol=2 ** -7, atol=2 ** -7)
     assert float((got.float() - ref.float()).abs().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("rows,C,nd,with_bias", [(37, 512, 2, False), (4099, 512, 2, False), (300, 512, 1, True),
+                                                 (1, 512, 1, False), (70, 128, 2, True)])
+def test_decay_lora_equals_two_gemms(hip, rows, C, nd, with_bias):
+    """pafc_decay_lora_bf16 (both LoRA matrices resident in LDS, the 64-wide hidden tensor never in memory) vs the two GEMMs it
+    replaces: the hidden values are rounded to bf16 at the same place, so w differs only by the fp32 summation order of the two
+    products (and, rarely, a hidden value that rounds the other way).  C = 128 takes the two-GEMM fallback of the wrapper."""
+    from paper_accurate_fast_cheap_amd.hip_ops import decay_lora, gemm_bf16
+    zw = synth.randn((nd, rows, C), 1).bfloat16().cuda()
+    d1n = (synth.randn((nd, 64, C), 5) * (2.0 / C ** 0.5)).bfloat16().cuda()
+    d2n = (synth.randn((nd, C, 64), 6) * 0.3).bfloat16().cuda()
+    bias = (synth.randn((nd, C), 7) - 3).bfloat16().cuda() if with_bias else None
+    w_ref = gemm_bf16(gemm_bf16(zw, d1n, act="tanh"), d2n)
+    td32 = torch.tanh(zw.float() @ d1n.float().transpose(1, 2)).bfloat16().float()
+    w32 = td32 @ d2n.float().transpose(1, 2)
+    if with_bias:
+        w_ref = w_ref + bias.view(nd, 1, C)
+        w32 = (w32.bfloat16() + bias.view(nd, 1, C)).float()
+    w = decay_lora(zw, d1n, d2n, bias)
+    assert w.shape == (nd, rows, C) and torch.isfinite(w.float()).all()
+    # a hidden value that rounds the other way moves w by at most |D2| * ulp(td); everything else is summation order
+    torch.testing.assert_close(w.float(), w_ref.float(), rtol=2 ** -6, atol=3e-2)
+    assert float((w.float() - w_ref.float()).abs().mean()) < 2e-3
+    torch.testing.assert_close(w.float(), w32, rtol=2 ** -6, atol=3e-2)     # the same chain in fp32 on the bf16 inputs
 
 
 @pytest.mark.parametrize("B,T1,F1,C", [(1, 9, 39, 128), (2, 37, 39, 128), (1, 201, 39, 512), (3, 5, 7, 256)])
