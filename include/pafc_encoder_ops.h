@@ -94,6 +94,14 @@ int pafc_tmix_mix4(int dtype, int B, int T, int C, int ndir, int reverse0, const
 int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const void *x, const void *t, const void *w2t,
                              const void *maa, void *z, pafc_stream_t stream);
 
+/* Token shift + the first lerp + the LoRA down-projection + tanh in one pass (bf16; src/model.py:273-277):
+ * t = bf16(tanh((x + (x_neighbour - x) * maa_x) @ time_maa_rkvw_w1)).  x: (B, T, C); maa_x: (ndir, C); w1n: (ndir, N, C) =
+ * time_maa_rkvw_w1^T (K innermost); t: (ndir, B*T, N).  Direction 0 looks back (or forward with reverse0), direction 1
+ * forward, as pafc_tmix_shift_mix.  The weights stay in LDS and xxx never exists in memory.  Built for C = 512, N = 128
+ * (PAFC_ERR_UNSUPPORTED otherwise: pafc_tmix_shift_mix + a GEMM). */
+int pafc_tmix_lora_down_bf16(int B, int T, int C, int N, int ndir, int reverse0, const void *x, const void *maa_x,
+                             const void *w1n, void *t, pafc_stream_t stream);
+
 /* The decay LoRA of the time-mix in one pass (bf16): w = bf16( bf16(tanh(zw @ time_decay_w1)) @ time_decay_w2 ) [+ bias]
  * (src/model.py:286-287: ww = tanh(xw @ time_decay_w1) @ time_decay_w2; w = time_decay + ww).  zw: (ndir, rows, C) the
  * fourth lerp; d1n: (ndir, H, C) = time_decay_w1^T, d2n: (ndir, C, H) = time_decay_w2^T (K innermost); bias: (ndir, C)

@@ -520,6 +520,79 @@ __global__ __launch_bounds__(DL_WAVES * 64) void decay_lora_kernel(long rows, in
     }
 }
 
+// Token shift + the first lerp + the LoRA down-projection + tanh in one pass (bf16):
+//   xx = x_neighbour - x;  xxx = x + xx * maa_x;  t = bf16(tanh(xxx W1))            (src/model.py:273-277)
+// x: (rows, C); maa_x: (ndir, C); w1n: (ndir, 128, C) = time_maa_rkvw_w1^T (K innermost); t: (ndir, rows, 128).
+// W1 of a direction (128 KiB) stays in LDS in MFMA-fragment order; a wave takes 16 rows at a time and forms its B operand --
+// 8 consecutive columns of ITS row of xxx per K-step -- in registers from x and the neighbouring row, so xxx (2 x 46 MB
+// written and read back at the 30-minute shape) never exists in memory.  Transposed product t^T[n][row]; the weight rows of
+// a pair of MFMAs are interleaved so that a lane ends up with 8 consecutive n of its row = one 16-byte store.
+constexpr int LD_C = 512, LD_N = 128;
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void tmix_lora_down_kernel(int T, long rows, int rev0, const bf16_t *__restrict__ x,
+                                                                       const bf16_t *__restrict__ maa_x,
+                                                                       const bf16_t *__restrict__ w1n, bf16_t *__restrict__ tout) {
+    constexpr int C = LD_C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, qq = lane >> 4;
+    const f32x4g zero = {0.f, 0.f, 0.f, 0.f};
+    extern __shared__ __attribute__((aligned(16))) unsigned char dl_lds[];
+    uint4 *s_w1 = reinterpret_cast<uint4 *>(dl_lds);                       // [ks 16][np 4][a 2][lane 64]   128 KiB
+    const int colslot = 8 * (r16 >> 2) + (r16 & 3);
+    const int d = blockIdx.y;                           // a block serves one direction: its weights are staged once
+    const bool rev = (d == 0) ? (rev0 != 0) : true;
+    for (int f = wave; f < 128; f += NW) {        // fragment (ks, np, a): lane (r16, qq) <- W1^T[32 np + colslot + 4 a][32 ks + 8 qq ..]
+        const int ks = f >> 3, np = (f >> 1) & 3, a = f & 1;
+        s_w1[f * 64 + lane] = *reinterpret_cast<const uint4 *>(w1n + ((size_t)d * LD_N + 32 * np + colslot + 4 * a) * C + 32 * ks + 8 * qq);
+    }
+    __syncthreads();
+    const long ntiles = (rows + 15) / 16;
+    for (long tile = (long)blockIdx.x * NW + wave; tile < ntiles; tile += (long)gridDim.x * NW) {
+        const long row = tile * 16 + r16;
+        const long rowc = row < rows ? row : rows - 1;     // clamp (every lane takes part in the MFMAs), skip the store
+        const int tt = (int)(rowc % T);
+        const bool has_nb = rev ? (tt < T - 1) : (tt > 0);
+        const long nb = has_nb ? (rev ? rowc + 1 : rowc - 1) : rowc;
+        const bf16_t *xr = x + rowc * C + 8 * qq, *xnr = x + nb * C + 8 * qq, *mr = maa_x + (size_t)d * C + 8 * qq;
+        f32x4g acc[4][2];
+#pragma unroll
+        for (int np = 0; np < 4; ++np) { acc[np][0] = zero; acc[np][1] = zero; }
+#pragma unroll 1
+        for (int kc = 0; kc < 16; kc += 4)   // four K-steps at a time: their 12 loads are in flight together, no more
+#pragma unroll
+        for (int ks = kc; ks < kc + 4; ++ks) {
+            float xc[VEC], xn[VEC], mm[VEC];
+            load8<bf16_t>(xr + 32 * ks, xc);
+            load8<bf16_t>(xnr + 32 * ks, xn);                // branch-free: select after the load
+            load8<bf16_t>(mr + 32 * ks, mm);
+            float o[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xx = round_bf16((has_nb ? xn[e] : 0.f) - xc[e]);
+                o[e] = round_bf16(xc[e] + round_bf16(xx * mm[e]));
+            }
+            const u32x4g bq = {pack_bf16_exact(o[0], o[1]), pack_bf16_exact(o[2], o[3]), pack_bf16_exact(o[4], o[5]),
+                               pack_bf16_exact(o[6], o[7])};
+#pragma unroll
+            for (int np = 0; np < 4; ++np)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    acc[np][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8g, s_w1[((ks * 4 + np) * 2 + a) * 64 + lane]), __builtin_bit_cast(bf16x8g, bq),
+                        acc[np][a], 0, 0, 0);
+        }
+        if (row < rows) {
+#pragma unroll
+            for (int np = 0; np < 4; ++np) {
+                float o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = tanh_as_gemm_epilogue(e < 4 ? acc[np][0][e] : acc[np][1][e - 4]);
+                store8<bf16_t>(tout + ((size_t)d * rows + row) * LD_N + 32 * np + 8 * qq, o);
+            }
+        }
+    }
+}
+
 template <typename EX>
 int launch_ln(int dtype_out, const LnArgs &a, hipStream_t s) {
     dim3 grid((a.rows + 3) / 4), block(256);
@@ -649,6 +722,36 @@ int pafc_decay_lora_bf16(long rows, int C, int H, int ndir, const void *zw, cons
     hipLaunchKernelGGL(pafc::decay_lora_kernel, dim3((unsigned)grid, ndir), dim3(pafc::DL_WAVES * 64), lds, (hipStream_t)stream, rows, ndir,
                        (const pafc::bf16_t *)zw, (const pafc::bf16_t *)d1n, (const pafc::bf16_t *)d2n,
                        (const pafc::bf16_t *)bias, (pafc::bf16_t *)w);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+int pafc_tmix_lora_down_bf16(int B, int T, int C, int N, int ndir, int reverse0, const void *x, const void *maa_x,
+                             const void *w1n, void *t, pafc_stream_t stream) {
+    if (!x || !maa_x || !w1n || !t) return PAFC_ERR_NULL_POINTER;
+    if (B <= 0 || T <= 0 || ndir < 1 || ndir > 2) return PAFC_ERR_BAD_DIMS;
+    if (C != pafc::LD_C || N != pafc::LD_N) return PAFC_ERR_UNSUPPORTED;
+    const size_t lds = 2 * 65536;
+    const long rows = (long)B * T, ntiles = (rows + 15) / 16;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0)
+        return PAFC_ERR_LAUNCH;
+    const char *e = getenv("PAFC_LORA_DOWN_WAVES");      // A/B measurements: 8 or 16 waves per block (one block per CU)
+    const int nw = e ? atoi(e) : 16;
+    long grid = cus / ndir;                       // one block per CU in all (128 KiB of LDS each)
+    if (grid > (ntiles + nw - 1) / nw) grid = (ntiles + nw - 1) / nw;
+#define PAFC_DOWN(NW)                                                                                                      \
+    do {                                                                                                                   \
+        if (hipFuncSetAttribute((const void *)pafc::tmix_lora_down_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)lds) != hipSuccess)                                                                   \
+            return PAFC_ERR_LAUNCH;                                                                                        \
+        hipLaunchKernelGGL(pafc::tmix_lora_down_kernel<NW>, dim3((unsigned)grid, ndir), dim3(NW * 64), lds, (hipStream_t)stream, T, \
+                           rows, reverse0, (const pafc::bf16_t *)x, (const pafc::bf16_t *)maa_x, (const pafc::bf16_t *)w1n, \
+                           (pafc::bf16_t *)t);                                                                             \
+    } while (0)
+    if (nw == 8) PAFC_DOWN(8);
+    else PAFC_DOWN(16);
+#undef PAFC_DOWN
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 

@@ -598,6 +598,35 @@ def tmix_lora_mix4(x: torch.Tensor, t: torch.Tensor, w2t: torch.Tensor, maa: tor
     return z
 
 
+def tmix_lora_down(x: torch.Tensor, maa_x: torch.Tensor, w1n: torch.Tensor, reverse0: bool = False):
+    """bf16: t = tanh((x + (x_nb - x) * maa_x) w1n^T) in one pass.  x (B, T, C), maa_x (ndir, C), w1n (ndir, N, C) ->
+    (ndir, B*T, N).  C = 512, N = 128 run the fused kernel (weights resident in LDS); other sizes take the shift/lerp pass and
+    a GEMM with the same roundings."""
+    _lib.require_gpu(x, maa_x, w1n)
+    L = _bind2()
+    if not getattr(L, "_pafc_down_bound", False):
+        _lib._sig(L.pafc_tmix_lora_down_bf16, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                  c_void_p)
+        L._pafc_down_bound = True
+    B, T, C = x.shape
+    ndir, N = w1n.shape[0], w1n.shape[1]
+    if x.dtype != torch.bfloat16 or w1n.shape != (ndir, N, C) or maa_x.shape != (ndir, C):
+        raise _lib.PafcError("tmix_lora_down: bf16 only, maa_x (ndir, C), w1n (ndir, N, C)")
+    for a in (x, maa_x, w1n):
+        if not a.is_contiguous() or a.dtype != torch.bfloat16:
+            raise _lib.PafcError("tmix_lora_down: contiguous bf16 tensors")
+    if C == 512 and N == 128:
+        t = torch.empty((ndir, B * T, N), dtype=x.dtype, device=x.device)
+        from .profiling import op_timer
+        with op_timer("tmix_lora_down"):
+            rc = L.pafc_tmix_lora_down_bf16(B, T, C, N, ndir, int(reverse0), _lib.ptr(x), _lib.ptr(maa_x), _lib.ptr(w1n),
+                                            _lib.ptr(t), _lib.stream_of(x))
+        _lib.check(rc, "pafc_tmix_lora_down_bf16")
+        return t
+    xxx = tmix_shift_mix(x, maa_x[0], maa_x[1] if ndir == 2 else None, reverse0=reverse0)
+    return gemm_bf16(xxx.view(ndir, B * T, C), w1n, act="tanh")
+
+
 def decay_lora(zw: torch.Tensor, d1n: torch.Tensor, d2n: torch.Tensor, bias: Optional[torch.Tensor] = None):
     """bf16: w = bf16(bf16(tanh(zw d1n^T)) d2n^T) [+ bias] in one pass.  zw (ndir, rows, C), d1n (ndir, H, C), d2n (ndir, C, H),
     bias (ndir, C) or None -> (ndir, rows, C).  C = 512, H = 64 run the fused kernel (weights resident in LDS); other sizes

@@ -79,6 +79,7 @@ class LayerPlan:
 
     def _refresh_rwkv(self, bl):
         self.maa_x = [b.time_maa_x.reshape(-1).contiguous() for b in bl]
+        self.maa_x_n = torch.stack(self.maa_x).contiguous()                            # (nd, C)
         self.W1 = torch.stack([b.time_maa_rkvw_w1 for b in bl]).contiguous()           # (nd, C, 128)
         self.W1n = torch.stack([b.time_maa_rkvw_w1.t() for b in bl]).contiguous()      # (nd, 128, C): Linear layout
         self.D1n = torch.stack([b.time_decay_w1.t() for b in bl]).contiguous()         # (nd, 64, C)
@@ -152,11 +153,11 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
     With ``residual`` (same dtype) the result is residual + slot output, written over ``residual``."""
     B, T, C = h.shape
     M, nd = B * T, plan.ndir
-    xxx = hip_ops.tmix_shift_mix(h, plan.maa_x[0], plan.maa_x[1] if nd == 2 else None)
     own_gemm = h.dtype == torch.bfloat16 and C % 64 == 0
-    if own_gemm:   # tanh rides on the down-projection (hand-written GEMM, one rounding)
-        t = hip_ops.gemm_bf16(xxx.view(nd, M, C), plan.W1n, act="tanh")                     # (nd, M, 128)
+    if own_gemm:   # token shift, first lerp, down-projection and tanh in one pass (one rounding of the product, then tanh)
+        t = hip_ops.tmix_lora_down(h, plan.maa_x_n, plan.W1n)                               # (nd, M, 128)
     else:
+        xxx = hip_ops.tmix_shift_mix(h, plan.maa_x[0], plan.maa_x[1] if nd == 2 else None)
         t = torch.tanh(torch.bmm(xxx.view(nd, M, C), plan.W1))
     if h.dtype == torch.bfloat16 and t.shape[-1] == 128 and C % 64 == 0:
         z = hip_ops.tmix_lora_mix4(h, t, plan.W2t, plan.maa4)      # LoRA up-projection on MFMA inside the lerp pass
@@ -280,8 +281,7 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict])
         shift = h.new_zeros(B, 1, C)
     hx = torch.cat([shift.to(h.dtype), h], dim=1)                                            # (B, T + 1, C)
     M1 = B * (T + 1)
-    xxx = hip_ops.tmix_shift_mix(hx, plan.maa_x[0], None)
-    t = hip_ops.gemm_bf16(xxx.view(1, M1, C), plan.W1n, act="tanh")
+    t = hip_ops.tmix_lora_down(hx, plan.maa_x_n, plan.W1n)
     z = hip_ops.tmix_lora_mix4(hx, t, plan.W2t, plan.maa4)                                    # (4, 1, B, T + 1, C)
     rkv = hip_ops.gemm_bf16(z[:3].view(3, M1, C), plan.Wrkv_n).view(3, B, T + 1, C)
     w = hip_ops.decay_lora(z[3].view(1, M1, C), plan.D1n, plan.D2n, plan.time_decay.view(1, C)).view(B, T + 1, C)

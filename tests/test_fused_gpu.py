@@ -177,6 +177,26 @@ def test_lora_mix4_fused_equals_two_step(hip, B, T, C, nd):
     assert float((got.float() - ref.float()).abs().mean()) < 1e-3
 
 
+@pytest.mark.parametrize("B,T,C,nd,rev0", [(2, 37, 512, 2, False), (1, 4099, 512, 2, False), (3, 65, 512, 1, True),
+                                           (1, 1, 512, 1, False), (2, 19, 128, 2, False)])
+def test_tmix_lora_down_equals_shift_mix_plus_gemm(hip, B, T, C, nd, rev0):
+    """pafc_tmix_lora_down_bf16 (token shift + first lerp + LoRA down-projection + tanh, W1 resident in LDS) vs
+    pafc_tmix_shift_mix followed by the tanh-epilogue GEMM: xxx is formed with the same roundings, so t differs only by the
+    fp32 summation order of the K = C product.  C = 128 takes the two-step fallback of the wrapper."""
+    from paper_accurate_fast_cheap_amd.hip_ops import tmix_lora_down, tmix_shift_mix, gemm_bf16
+    x = synth.randn((B, T, C), 1).bfloat16().cuda()
+    maa = synth.randn((nd, C), 2, 0.5).bfloat16().cuda()
+    w1n = (synth.randn((nd, 128, C), 3) * (1.5 / C ** 0.5)).bfloat16().cuda()
+    xxx = tmix_shift_mix(x, maa[0], maa[1] if nd == 2 else None, reverse0=rev0)
+    ref = gemm_bf16(xxx.view(nd, B * T, C), w1n, act="tanh")
+    got = tmix_lora_down(x, maa, w1n, reverse0=rev0)
+    assert got.shape == (nd, B * T, 128) and torch.isfinite(got.float()).all()
+    torch.testing.assert_close(got.float(), ref.float(), rtol=2 ** -7, atol=2 ** -8)
+    assert float((got.float() - ref.float()).abs().mean()) < 2e-4
+    ref32 = torch.tanh(xxx.view(nd, B * T, C).float() @ w1n.float().transpose(1, 2))
+    torch.testing.assert_close(got.float(), ref32, rtol=2 ** -7, atol=2 ** -8)
+
+
 @pytest.mark.parametrize("rows,C,nd,with_bias", [(37, 512, 2, False), (4099, 512, 2, False), (300, 512, 1, True),
                                                  (1, 512, 1, False), (70, 128, 2, True)])
 def test_decay_lora_equals_two_gemms(hip, rows, C, nd, with_bias):
