@@ -1,5 +1,8 @@
 """torch-tensor front ends of the glue kernels in include/pafc_encoder_ops.h (GPU only, no fallback)."""
+import contextlib
 import ctypes
+import os
+import weakref
 from typing import Optional
 
 import torch
@@ -194,6 +197,57 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, out_dtype: torch.dtype = torch.fl
     return (dw, db) if want_bias else dw
 
 
+# bf16 copies of fp32 master weights for the training step.  Under autocast every projection casts its weight and bias on
+# every step (~400 small launches).  Inside `with train_shadows():` (utils.train_utils.train_step wraps the forward pass in
+# it) the copy is kept beside the parameter and ALL copies are brought up to date by one multi-tensor copy when the context
+# is entered -- unconditionally: fused optimizers update parameters without touching Tensor._version, so nothing cheaper can
+# tell a stale copy.  Outside the context every use casts, as before.
+_shadows = {}      # id(parameter) -> [weak reference to the parameter, bf16 copy]  (tensors compare element-wise: they cannot
+                   # be keys of a WeakKeyDictionary)
+_shadows_on = False
+
+
+def _bf16_shadow(p: torch.Tensor) -> torch.Tensor:
+    if p.dtype == torch.bfloat16:
+        return p
+    if not _shadows_on:
+        return p.to(torch.bfloat16)
+    ent = _shadows.get(id(p))
+    if ent is not None and ent[0]() is p and ent[1].device == p.device and ent[1].shape == p.shape:
+        return ent[1]                                # refreshed when the context was entered
+    sh = p.detach().to(torch.bfloat16)
+    _shadows[id(p)] = [weakref.ref(p), sh]
+    return sh
+
+
+def refresh_train_shadows() -> None:
+    """Bring every registered bf16 weight copy up to date with its parameter in one multi-tensor copy."""
+    live, dead = [], []
+    for key, ent in _shadows.items():
+        p = ent[0]()
+        if p is None or ent[1].device != p.device or ent[1].shape != p.shape:
+            dead.append(key)
+        else:
+            live.append((p, ent[1]))
+    for key in dead:
+        del _shadows[key]
+    if live:
+        with torch.no_grad():
+            torch._foreach_copy_([sh for _, sh in live], [p.detach() for p, _ in live])
+
+
+@contextlib.contextmanager
+def train_shadows():
+    """The forward pass of one training step: projections take refreshed bf16 copies of their fp32 weights."""
+    global _shadows_on
+    refresh_train_shadows()
+    prev, _shadows_on = _shadows_on, True
+    try:
+        yield
+    finally:
+        _shadows_on = prev
+
+
 class _LinearTrainBf16(torch.autograd.Function):
     """nn.Linear for the bf16 training step: forward and input gradient through the library GEMM, the weight gradient
     through gemm_tn (the library's pick for that layout runs at 5 % of the matrix peak), straight into the weight's
@@ -201,8 +255,8 @@ class _LinearTrainBf16(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        wb = weight if weight.dtype == torch.bfloat16 else weight.to(torch.bfloat16)
-        bb = None if bias is None else (bias if bias.dtype == torch.bfloat16 else bias.to(torch.bfloat16))
+        wb = _bf16_shadow(weight)
+        bb = None if bias is None else _bf16_shadow(bias)
         ctx.save_for_backward(x, wb)
         ctx.w_dtype = weight.dtype
         ctx.b_dtype = None if bias is None else bias.dtype

@@ -3,6 +3,7 @@
 all-reduce overlaps here: RCCL over xGMI through torch.distributed backend "nccl") -> clip_grad_norm_ -> skip the
 update when the norm is not finite -> optimizer step -> scheduler step.  One process per GPU; the trainer loop,
 logging, snapshotting and DeepSpeed engines around it are out of scope."""
+import contextlib
 from typing import Optional
 
 import torch
@@ -64,6 +65,41 @@ def wrap_model_ddp(model: torch.nn.Module, device: Optional[torch.device] = None
     return ddp
 
 
+def clip_grad_norm_(params, max_norm: float) -> torch.Tensor:
+    """torch.nn.utils.clip_grad_norm_(params, max_norm) (L2; the reference's call, wenet/utils/train_utils.py:700) with the
+    same arithmetic in far fewer launches when gradient dtypes are mixed: torch multiplies every (device, dtype) group by the
+    fp32 clip-coefficient TENSOR, and `_foreach_mul_` then falls to one kernel per tensor for each group that is not fp32 (the
+    bf16 time-mix slot: ~400 launches per step).  Here every group is multiplied by the coefficient in the group's own dtype,
+    which takes the multi-tensor kernel and is the same product (bit for bit: tests/test_train_step.py).  The coefficient is
+    read back once (the caller tests the norm for inf / nan on the host right afterwards anyway): a coefficient of 1 (no
+    clipping) multiplies nothing.  Returns the total norm (fp32 tensor), like torch."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return torch.zeros(())
+    from torch.utils._foreach_utils import _group_tensors_by_device_and_dtype
+    # torch's own grouping, so that the norms are stacked -- and summed -- in the same order
+    groups = {key: gs[0] for key, (gs, _) in _group_tensors_by_device_and_dtype([grads]).items()}
+    first = grads[0].device
+    norms = []
+    for gs in groups.values():
+        norms.extend(torch._foreach_norm(gs, 2.0))
+    total = torch.linalg.vector_norm(torch.stack([n.to(first) for n in norms]), 2.0)
+    coef_t = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    coef = float(coef_t)
+    if coef < 1.0:        # nan compares false: nothing is scaled, the caller drops the update
+        for (dev, dt), gs in groups.items():
+            if dt == torch.float32:
+                torch._foreach_mul_(gs, coef_t.to(dev))
+            elif dev.type == "cuda":
+                # on the GPU g.mul_(fp32 0-dim tensor) rounds the coefficient to g's dtype first (measured, torch 2.10): the
+                # multi-tensor kernel with the coefficient already in that dtype is the same product
+                torch._foreach_mul_(gs, coef_t.to(device=dev, dtype=dt))
+            else:
+                for g in gs:                       # the CPU kernel keeps the fp32 coefficient: torch's own per-tensor path
+                    g.mul_(coef_t)
+    return total
+
+
 def train_step(model: torch.nn.Module, batch: dict, optimizer: torch.optim.Optimizer, device: torch.device,
                grad_clip: float = 0.1, accum_grad: int = 1, scheduler=None, step_index: int = 0,
                amp_dtype: Optional[torch.dtype] = None, scaler=None, clip_hard_maxvalue: float = float("inf"),
@@ -81,7 +117,10 @@ def train_step(model: torch.nn.Module, batch: dict, optimizer: torch.optim.Optim
     model.train()
     if scaler is not None and amp_dtype is None:
         amp_dtype = torch.float16
-    with torch.autocast(device_type=device.type, dtype=amp_dtype, enabled=amp_dtype is not None):
+    from .. import hip_ops
+    # bf16 copies of the fp32 master weights, refreshed by one launch instead of a cast per weight (GPU training kernels only)
+    shadows = hip_ops.train_shadows() if (device.type == "cuda" and amp_dtype == torch.bfloat16) else contextlib.nullcontext()
+    with shadows, torch.autocast(device_type=device.type, dtype=amp_dtype, enabled=amp_dtype is not None):
         out = model(batch, device)
     loss = out["loss"]
     scaled = loss / accum_grad
@@ -91,13 +130,13 @@ def train_step(model: torch.nn.Module, batch: dict, optimizer: torch.optim.Optim
         params = [p for p in model.parameters() if p.requires_grad]
         if scaler is not None:
             scaler.unscale_(optimizer)
-            grad_norm = torch.nn.utils.clip_grad_norm_(params, grad_clip)
+            grad_norm = clip_grad_norm_(params, grad_clip)
             scale_before = scaler.get_scale()
             scaler.step(optimizer)              # skips the update itself when the un-scaled gradients overflowed
             scaler.update()
             info["updated"] = bool(torch.isfinite(grad_norm)) and scaler.get_scale() >= scale_before
         else:
-            grad_norm = torch.nn.utils.clip_grad_norm_(params, grad_clip)
+            grad_norm = clip_grad_norm_(params, grad_clip)
             if torch.isfinite(grad_norm):       # train_utils.py:702-711: skip the update on inf / nan
                 if (clip_hard_maxvalue == float("inf") or step_index < clip_hard_warmup
                         or float(grad_norm) <= clip_hard_maxvalue):

@@ -402,3 +402,59 @@ def test_subsampling_training_path_equals_framework_autograd(hip, monkeypatch, C
         # within bf16 noise of the fp32 gradient, and no further from it than the library's own bf16 path plus slack
         assert err_k <= 0.2 * s, (n, err_k, s)           # both bf16 paths sit 6-12 % (max-norm) from the fp32 gradient here
         assert err_k <= 1.5 * err_f + 1e-2 * s, (n, err_k, err_f, s)
+
+
+def _mixed_grads(device, seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [((7, 5), torch.float32), ((33,), torch.bfloat16), ((4, 4, 4), torch.bfloat16), ((3,), torch.float32),
+              ((129, 64), torch.bfloat16), ((1, 1, 64), torch.bfloat16)]
+    return [(torch.randn(s, generator=g) * 3).to(dt).to(device) for s, dt in shapes]
+
+
+def _check_clip_equals_torch(device):
+    from paper_accurate_fast_cheap_amd.utils.train_utils import clip_grad_norm_
+    for max_norm in (0.1, 7.0, 1e4):
+        grads = _mixed_grads(device, 5)
+        ours = [torch.nn.Parameter(torch.zeros_like(g)) for g in grads]
+        theirs = [torch.nn.Parameter(torch.zeros_like(g)) for g in grads]
+        for p, q, g in zip(ours, theirs, grads):
+            p.grad, q.grad = g.clone(), g.clone()
+        n_ref = torch.nn.utils.clip_grad_norm_(theirs, max_norm)
+        n = clip_grad_norm_(ours, max_norm)
+        assert torch.equal(n.cpu(), n_ref.cpu())
+        for p, q in zip(ours, theirs):
+            assert torch.equal(p.grad, q.grad), (max_norm, p.dtype, p.shape)
+
+
+def test_clip_grad_norm_equals_torch_cpu():
+    """train_utils.clip_grad_norm_ (one multi-tensor launch per dtype group) is torch.nn.utils.clip_grad_norm_ bit for bit on
+    fp32 + bf16 gradients, clipping or not."""
+    _check_clip_equals_torch(torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_clip_grad_norm_equals_torch_gpu():
+    _check_clip_equals_torch(torch.device("cuda"))
+
+
+@pytest.mark.gpu
+def test_bf16_weight_shadows_follow_the_parameter():
+    """The bf16 copies the training projections use instead of a cast per step: only inside train_shadows(), refreshed on
+    entry whatever changed the parameter (a fused optimizer does not touch Tensor._version); outside, a fresh cast."""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    w = torch.nn.Parameter(torch.randn(64, 64, device="cuda"))
+    w.grad = torch.randn_like(w)
+    opt = torch.optim.Adam([w], lr=0.1, fused=True)
+    a = hip_ops._bf16_shadow(w)
+    assert a.dtype == torch.bfloat16 and torch.equal(a, w.detach().bfloat16()) and id(w) not in hip_ops._shadows
+    with hip_ops.train_shadows():
+        s0 = hip_ops._bf16_shadow(w)
+        assert torch.equal(s0, w.detach().bfloat16()) and hip_ops._bf16_shadow(w) is s0     # one cast, then the copy
+    opt.step()                                                                               # in place, version untouched
+    assert not torch.equal(s0, w.detach().bfloat16())
+    with hip_ops.train_shadows():
+        assert hip_ops._bf16_shadow(w) is s0 and torch.equal(s0, w.detach().bfloat16())      # refreshed on entry
+    assert hip_ops._bf16_shadow(w) is not s0                                                 # outside: a fresh cast
+    b = torch.nn.Parameter(torch.randn(64, device="cuda").bfloat16())
+    with hip_ops.train_shadows():
+        assert hip_ops._bf16_shadow(b) is b                                                  # bf16 parameters as they are

@@ -1,0 +1,34 @@
+"""Host-side view of one training step (torch.profiler): which ATen ops are called how often and what they cost on the CPU --
+the step is launch-bound on a slow host, so the op COUNT is what to cut.  python tools/prof_train_ops.py"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as B
+from paper_accurate_fast_cheap_amd import _lib
+from paper_accurate_fast_cheap_amd.utils.train_utils import train_step
+
+device = torch.device("cuda", 0)
+_lib.lib()
+model, _ = B.build_model("fp32", device)
+opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+g = torch.Generator().manual_seed(777)
+lens = torch.randint(100, 2001, (32,), generator=g)
+feats, _ = B.front_end(B.synthetic_waveform(60.0, 777), device)
+src = feats[0]
+fb = torch.zeros(32, int(lens.max()), 80, device=device)
+for j, n in enumerate(lens.tolist()):
+    off = (j * 7919) % (src.shape[0] - 2001)
+    fb[j, :n] = src[off:off + n]
+tl = torch.randint(1, 161, (32,), generator=g)
+tl = torch.minimum(tl, ((lens - 1) // 2 - 1) // 2 // 2).clamp(min=1)
+target = torch.randint(1, 4999, (32, int(tl.max())), generator=g)
+batch = {"feats": fb, "feats_lengths": lens.to(device), "target": target.to(device), "target_lengths": tl.to(device)}
+for i in range(3):
+    train_step(model, batch, opt, device, amp_dtype=torch.bfloat16, step_index=i)
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
+    train_step(model, batch, opt, device, amp_dtype=torch.bfloat16, step_index=3)
+    torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60))
+print(prof.key_averages(group_by_input_shape=True).table(sort_by="count", row_limit=40, max_name_column_width=50))
