@@ -75,9 +75,14 @@ class _DepthwiseConvCL(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, left_pad, out_len):
-        ctx.save_for_backward(x, weight)
+        # parameters in the activation dtype (what autocast does for nn.Conv1d); the cast sits inside the Function so that the
+        # gradients come back in the parameters' own dtype without a cast node each, and bf16 takes the kept copies
+        w = _param_as(weight, x.dtype)
+        b = None if bias is None else _param_as(bias, x.dtype)
+        ctx.save_for_backward(x, w)
         ctx.left_pad, ctx.has_bias = left_pad, bias is not None
-        return depthwise_conv1d_cl(x, weight, bias, left_pad, out_len)
+        ctx.w_dtype, ctx.b_dtype = weight.dtype, (None if bias is None else bias.dtype)
+        return depthwise_conv1d_cl(x, w, b, left_pad, out_len)
 
     @staticmethod
     def backward(ctx, dy):
@@ -89,8 +94,8 @@ class _DepthwiseConvCL(torch.autograd.Function):
             dx = depthwise_conv1d_cl(dy, weight.flip(-1).contiguous(), None, K - 1 - ctx.left_pad, x.shape[1])
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = depthwise_conv1d_cl_wgrad(x, dy, K, ctx.left_pad, want_bias=ctx.has_bias)
-            dw = dw.to(weight.dtype)
-            db = db.to(weight.dtype) if db is not None else None
+            dw = dw.to(ctx.w_dtype)
+            db = db.to(ctx.b_dtype) if db is not None else None
         return dx, dw, db, None, None
 
 
@@ -98,9 +103,7 @@ def depthwise_conv1d_cl_autograd(x: torch.Tensor, weight: torch.Tensor, bias: Op
                                  out_len: int) -> torch.Tensor:
     """Training-side entry: parameters are cast to the activation dtype (what autocast does for nn.Conv1d), gradients
     come back in the parameters' dtype."""
-    w = weight.to(x.dtype)
-    b = bias.to(x.dtype) if bias is not None else None
-    return _DepthwiseConvCL.apply(x.contiguous(), w, b, left_pad, out_len)
+    return _DepthwiseConvCL.apply(x.contiguous(), weight, bias, left_pad, out_len)
 
 
 def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float):
@@ -136,8 +139,7 @@ class _LayerNormTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, eps, out_dtype):
-        g = weight if weight.dtype == x.dtype else weight.to(x.dtype)
-        b = bias if bias.dtype == x.dtype else bias.to(x.dtype)
+        g, b = _param_as(weight, x.dtype), _param_as(bias, x.dtype)
         _, y, _ = add_layernorm(x, None, 1.0, g, b, out_dtype=out_dtype, want_x=False, eps=eps)
         ctx.save_for_backward(x, g)
         ctx.eps, ctx.w_dtype, ctx.b_dtype = eps, weight.dtype, bias.dtype
@@ -218,6 +220,15 @@ def _bf16_shadow(p: torch.Tensor) -> torch.Tensor:
     sh = p.detach().to(torch.bfloat16)
     _shadows[id(p)] = [weakref.ref(p), sh]
     return sh
+
+
+def _param_as(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """A parameter in the dtype a training kernel wants (no autograd through the cast: callers sit inside Functions)."""
+    if p.dtype == dtype:
+        return p.detach()
+    if dtype == torch.bfloat16 and p.dtype == torch.float32 and isinstance(p, torch.nn.Parameter):
+        return _bf16_shadow(p).detach()
+    return p.detach().to(dtype)
 
 
 def refresh_train_shadows() -> None:

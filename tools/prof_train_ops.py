@@ -31,4 +31,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     train_step(model, batch, opt, device, amp_dtype=torch.bfloat16, step_index=3)
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60))
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="count", row_limit=40, max_name_column_width=50))
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::copy_", "aten::_to_copy", "aten::clone", "aten::mul", "aten::mul_", "aten::add_", "aten::add", "aten::sum", "aten::contiguous")]
+rows.sort(key=lambda e: -e.count)
+for e in rows[:60]:
+    print(f"{e.key:16s} {e.count:5d}  cpu {e.cpu_time_total / 1e3:7.2f} ms  {str(e.input_shapes)[:150]}")
