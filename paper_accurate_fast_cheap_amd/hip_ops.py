@@ -663,6 +663,12 @@ def tmix_lora_mix4(x: torch.Tensor, t: torch.Tensor, w2t: torch.Tensor, maa: tor
     return z
 
 
+# The one-pass LoRA kernels stage 128 KiB of weights into LDS per block: worth it from a few thousand rows on (30-minute
+# file: 45 k rows, a c2 batch: ~16 k); a streaming chunk (65 rows x streams) keeps the small-GEMM path (measured: 2.1 vs 2.8 ms
+# per 12-layer chunk step with one stream, 4.2 vs 4.8 ms with 64).  PAFC_LDS_RESIDENT_MIN_ROWS overrides (tests, A/B).
+_LDS_RESIDENT_MIN_ROWS = int(os.environ.get("PAFC_LDS_RESIDENT_MIN_ROWS", "8192"))
+
+
 def tmix_lora_down(x: torch.Tensor, maa_x: torch.Tensor, w1n: torch.Tensor, reverse0: bool = False):
     """bf16: t = tanh((x + (x_nb - x) * maa_x) w1n^T) in one pass.  x (B, T, C), maa_x (ndir, C), w1n (ndir, N, C) ->
     (ndir, B*T, N).  C = 512, N = 128 run the fused kernel (weights resident in LDS); other sizes take the shift/lerp pass and
@@ -680,7 +686,7 @@ def tmix_lora_down(x: torch.Tensor, maa_x: torch.Tensor, w1n: torch.Tensor, reve
     for a in (x, maa_x, w1n):
         if not a.is_contiguous() or a.dtype != torch.bfloat16:
             raise _lib.PafcError("tmix_lora_down: contiguous bf16 tensors")
-    if C == 512 and N == 128:
+    if C == 512 and N == 128 and B * T >= _LDS_RESIDENT_MIN_ROWS:
         t = torch.empty((ndir, B * T, N), dtype=x.dtype, device=x.device)
         from .profiling import op_timer
         with op_timer("tmix_lora_down"):
@@ -710,7 +716,7 @@ def decay_lora(zw: torch.Tensor, d1n: torch.Tensor, d2n: torch.Tensor, bias: Opt
     for a in (zw, d1n, d2n) + ((bias,) if bias is not None else ()):
         if not a.is_contiguous() or a.dtype != torch.bfloat16:
             raise _lib.PafcError("decay_lora: contiguous bf16 tensors")
-    if C == 512 and H == 64:
+    if C == 512 and H == 64 and rows >= _LDS_RESIDENT_MIN_ROWS:
         w = torch.empty_like(zw)
         from .profiling import op_timer
         with op_timer("decay_lora"):

@@ -179,11 +179,13 @@ def test_lora_mix4_fused_equals_two_step(hip, B, T, C, nd):
 
 @pytest.mark.parametrize("B,T,C,nd,rev0", [(2, 37, 512, 2, False), (1, 4099, 512, 2, False), (3, 65, 512, 1, True),
                                            (1, 1, 512, 1, False), (2, 19, 128, 2, False)])
-def test_tmix_lora_down_equals_shift_mix_plus_gemm(hip, B, T, C, nd, rev0):
+def test_tmix_lora_down_equals_shift_mix_plus_gemm(hip, monkeypatch, B, T, C, nd, rev0):
     """pafc_tmix_lora_down_bf16 (token shift + first lerp + LoRA down-projection + tanh, W1 resident in LDS) vs
     pafc_tmix_shift_mix followed by the tanh-epilogue GEMM: xxx is formed with the same roundings, so t differs only by the
     fp32 summation order of the K = C product.  C = 128 takes the two-step fallback of the wrapper."""
+    from paper_accurate_fast_cheap_amd import hip_ops
     from paper_accurate_fast_cheap_amd.hip_ops import tmix_lora_down, tmix_shift_mix, gemm_bf16
+    monkeypatch.setattr(hip_ops, "_LDS_RESIDENT_MIN_ROWS", 1)       # the one-pass kernel at every size (product: from 8192 rows)
     x = synth.randn((B, T, C), 1).bfloat16().cuda()
     maa = synth.randn((nd, C), 2, 0.5).bfloat16().cuda()
     w1n = (synth.randn((nd, 128, C), 3) * (1.5 / C ** 0.5)).bfloat16().cuda()
@@ -199,11 +201,13 @@ def test_tmix_lora_down_equals_shift_mix_plus_gemm(hip, B, T, C, nd, rev0):
 
 @pytest.mark.parametrize("rows,C,nd,with_bias", [(37, 512, 2, False), (4099, 512, 2, False), (300, 512, 1, True),
                                                  (1, 512, 1, False), (70, 128, 2, True)])
-def test_decay_lora_equals_two_gemms(hip, rows, C, nd, with_bias):
+def test_decay_lora_equals_two_gemms(hip, monkeypatch, rows, C, nd, with_bias):
     """pafc_decay_lora_bf16 (both LoRA matrices resident in LDS, the 64-wide hidden tensor never in memory) vs the two GEMMs it
     replaces: the hidden values are rounded to bf16 at the same place, so w differs only by the fp32 summation order of the two
     products (and, rarely, a hidden value that rounds the other way).  C = 128 takes the two-GEMM fallback of the wrapper."""
+    from paper_accurate_fast_cheap_amd import hip_ops
     from paper_accurate_fast_cheap_amd.hip_ops import decay_lora, gemm_bf16
+    monkeypatch.setattr(hip_ops, "_LDS_RESIDENT_MIN_ROWS", 1)       # the one-pass kernel at every size (product: from 8192 rows)
     zw = synth.randn((nd, rows, C), 1).bfloat16().cuda()
     d1n = (synth.randn((nd, 64, C), 5) * (2.0 / C ** 0.5)).bfloat16().cuda()
     d2n = (synth.randn((nd, C, 64), 6) * 0.3).bfloat16().cuda()
