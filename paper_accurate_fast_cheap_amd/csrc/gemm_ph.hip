@@ -209,11 +209,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         return (unsigned)(tap * p.N * p.Ci * 2 + kc * 128);
     };
     auto stage_a = [&](int h, int buf, int kt) {
+#ifdef PH_ABL_NODMA
+        return;
+#endif
 #pragma unroll
         for (int j = 0; j < DA; ++j)
             dma16(Ar, a_off[h][j], a_soff(kt), lds + buf * STEP + (h ? OFF_A1 : OFF_A0) + (wave * DA + j) * 1024);
     };
     auto stage_b = [&](int h, int buf, int kt) {
+#ifdef PH_ABL_NODMA
+        return;
+#endif
 #pragma unroll
         for (int j = 0; j < DB; ++j)
             dma16(Wr, b_off[h][j], w_soff(kt), lds + buf * STEP + (h ? OFF_B1 : OFF_B0) + (wave * DB + j) * 1024);
@@ -250,6 +256,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     bf16x8p af[4][2], bf0[TN][2], bf1[TN][2];
 
     auto read_a = [&](int h, int buf) {
+#ifdef PH_ABL_NOREAD
+        return;
+#endif
         const unsigned char *base = lds + buf * STEP + (h ? OFF_A1 : OFF_A0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -258,6 +267,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         }
     };
     auto read_b = [&](int h, int buf, bf16x8p (&dst)[TN][2]) {
+#ifdef PH_ABL_NOREAD
+        return;
+#endif
         const unsigned char *base = lds + buf * STEP + (h ? OFF_B1 : OFF_B0);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -267,7 +279,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     };
     auto mma = [&](int mi, int nj, const bf16x8p (&bq)[TN][2]) {
         __builtin_amdgcn_s_setprio(1);
+#ifdef PH_ABL_NOMFMA
+        if (false) {
+#else
         if (half_on[mi]) {   // wave-uniform, one branch per phase: a 64-row half beyond the tile's rows costs nothing
+#endif
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -309,6 +325,19 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     // PH_SYNC(PHASE): the counted wait of a phase, then its barrier.  Base count by (tile shape, K-steps left, phase); the
     // first K-step of a tile that follows another one in this block adds that tile's output stores, which were issued behind
     // the prologue units and ahead of everything the loop issues (`pend`).
+// Ablation switches of the diagnostic build (tools/micro/gemm_ph_stamps.cpp; results are then WRONG, only the timing means
+// something): PH_ABL_NOEND drops the closing barrier of a phase, PH_ABL_NOBAR the barrier after the counted wait, PH_ABL_NOMFMA
+// the matrix instructions, PH_ABL_NODMA the global -> LDS units, PH_ABL_NOREAD the fragment reads.
+#ifdef PH_ABL_NOBAR
+#define PH_BAR1() do { } while (0)
+#else
+#define PH_BAR1() __builtin_amdgcn_s_barrier()
+#endif
+#ifdef PH_ABL_NOEND
+#define PH_BAR2() do { } while (0)
+#else
+#define PH_BAR2() __builtin_amdgcn_s_barrier()
+#endif
 #define PH_SYNC(PHASE)                                                             \
     do {                                                                           \
         constexpr int W1c = DB == 2 ? (PHASE == 3 ? 6 : PHASE == 4 ? 4 : 8) : (PHASE == 3 ? 4 : PHASE == 4 ? 3 : 6); \
@@ -317,13 +346,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         if (RESPRE || last >= 2) { if (pend) wait_vm<WS + NST>(); else wait_vm<WS>(); }        \
         else if (last == 1) { if (pend) wait_vm<W1c + NST>(); else wait_vm<W1c>(); }           \
         else { if (pend) wait_vm<W0c + NST>(); else wait_vm<W0c>(); }              \
-        __builtin_amdgcn_s_barrier();                                              \
+        PH_BAR1();                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                         \
     } while (0)
 #define PH_END()                                                                   \
     do {                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                         \
-        __builtin_amdgcn_s_barrier();                                              \
+        PH_BAR2();                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                         \
     } while (0)
 
@@ -331,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         constexpr int PAR = decltype(parc)::value;
         const int last = nt - 1 - kt;
         const bool pend = st_pending && kt == 0;
-#ifdef PH_STAMPS
+#if defined(PH_STAMPS) && defined(PH_FINE_STAMPS)   // (needs K / 64 <= 18: the indices sit above the per-K-step stamps)
 #define PH_FINE(i) do { if (stamp_on && kt == 4) st[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PH_FINE(i) do { } while (0)
