@@ -676,8 +676,8 @@ def tmix_lora_down(x: torch.Tensor, maa_x: torch.Tensor, w1n: torch.Tensor, reve
     _lib.require_gpu(x, maa_x, w1n)
     L = _bind2()
     if not getattr(L, "_pafc_down_bound", False):
-        _lib._sig(L.pafc_tmix_lora_down_bf16, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                  c_void_p)
+        _lib._sig(L.pafc_tmix_lora_down_bf16, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                  c_void_p, c_void_p)
         L._pafc_down_bound = True
     B, T, C = x.shape
     ndir, N = w1n.shape[0], w1n.shape[1]
@@ -705,8 +705,8 @@ def decay_lora(zw: torch.Tensor, d1n: torch.Tensor, d2n: torch.Tensor, bias: Opt
     _lib.require_gpu(zw, d1n, d2n, bias)
     L = _bind2()
     if not getattr(L, "_pafc_decay_bound", False):
-        _lib._sig(L.pafc_decay_lora_bf16, ctypes.c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                  c_void_p)
+        _lib._sig(L.pafc_decay_lora_bf16, c_int, ctypes.c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                  c_void_p, c_void_p)
         L._pafc_decay_bound = True
     ndir, rows, C = zw.shape
     H = d1n.shape[1]
