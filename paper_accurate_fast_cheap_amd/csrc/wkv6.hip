@@ -303,6 +303,19 @@ void launch_pass_a(const FwdParams &p, dim3 grid, hipStream_t stream) {
     hipLaunchKernelGGL((wkv6_mfma_kernel<ET, false>), grid, dim3(64), 0, stream, p);
 }
 
+// Pass C (outputs): bf16 I/O runs the channel-lane kernel; PAFC_WKV6_PASS_C=lt keeps the time-lane one (A/B measurements).
+template <typename ET>
+void launch_pass_c(const FwdParams &p, dim3 grid, hipStream_t stream) {
+    if constexpr (sizeof(ET) == 2) {
+        const char *e = getenv("PAFC_WKV6_PASS_C");
+        if (!(e && e[0] == 'l')) {
+            hipLaunchKernelGGL(wkv6_pass_c_cl_kernel, grid, dim3(64), 0, stream, p);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((wkv6_mfma_kernel<ET, true>), grid, dim3(64), 0, stream, p);
+}
+
 template <typename ET>
 int launch_fwd(FwdParams &p, int ndir, bool any_final, hipStream_t stream) {
     const bool mfma = use_mfma();
@@ -315,7 +328,7 @@ int launch_fwd(FwdParams &p, int ndir, bool any_final, hipStream_t stream) {
         hipLaunchKernelGGL(wkv6_scan_kernel, gb, dim3(256), 0, stream, p);
     }
     dim3 gc(p.NC, p.B * p.H, ndir);
-    if (mfma) hipLaunchKernelGGL((wkv6_mfma_kernel<ET, true>), gc, dim3(64), 0, stream, p);
+    if (mfma) launch_pass_c<ET>(p, gc, stream);
     else hipLaunchKernelGGL((wkv6_chunk_kernel<ET, true>), gc, dim3(64), 0, stream, p);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
@@ -674,7 +687,7 @@ int launch_bwd(int B, int T, int C, int H, const void *r, const void *k, const v
     fg.d[0] = fp.d[1];
     fg.ws_state = ws_state + (size_t)B * H * NC * (N * N);
     fg.ws_decay = ws_decay + (size_t)B * H * NC * N;
-    if (mfma) hipLaunchKernelGGL((wkv6_mfma_kernel<ET, true>), dim3(NC, B * H, 1), dim3(64), 0, stream, fg);
+    if (mfma) launch_pass_c<ET>(fg, dim3(NC, B * H, 1), stream);
     else hipLaunchKernelGGL((wkv6_chunk_kernel<ET, true>), dim3(NC, B * H, 1), dim3(64), 0, stream, fg);
 
     RowParams rp{};
