@@ -15,7 +15,7 @@ src, dst = sys.argv[1], sys.argv[2]
 B, T, C, H, ndir, eb = 1, 44998, 512, 8, 2, 2
 PASS = {"wkv6_mfma_kernel<unsigned short, false>": "pass_A_chunk_state", "wkv6_pass_a_cl_kernel": "pass_A_chunk_state",
         "wkv6_scan_kernel": "pass_B_state_scan",
-        "wkv6_mfma_kernel<unsigned short, true>": "pass_C_output"}
+        "wkv6_mfma_kernel<unsigned short, true>": "pass_C_output", "wkv6_pass_c_cl_kernel": "pass_C_output"}
 
 
 def which(name):
