@@ -258,11 +258,6 @@ int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, long lda, lon
                    long strideW, const void *bias, long strideBias, const void *residual, long ldr, long strideR,
                    void *out, long ldo, long strideO, float alpha, int act, pafc_stream_t stream);
 int pafc_gemm_bf16_glu_half(long M, int N, int K, int batch);
-/* The two-blocks-per-CU kernel by itself (csrc/gemm_p2.hip: 128 x 256 tiles, 4 waves, three-slot ring of 32-deep K-steps, so
- * that one block's epilogue runs under the other block's multiplies): K % 32 == 0, K >= 128; GLU blocks of 64 rows (h = 32). */
-int pafc_gemm_bf16_p2(long M, int N, int K, int batch, const void *A, long lda, long strideA, const void *W, long ldw,
-                      long strideW, const void *bias, long strideBias, const void *residual, long ldr, long strideR,
-                      void *out, long ldo, long strideO, float alpha, int act, pafc_stream_t stream);
 /* pafc_conv3x3s2_nhwc_bf16 on the phase-pipelined kernel (implicit GEMM: K-step = one tap x 64 input channels; Ci / 64 a
  * power of two): the entry point above dispatches here for problems that fill the chip; exported for tests and A/B runs.
  * tile_m 256 / 192 / 128.  PAFC_ERR_UNSUPPORTED: take the other kernel. */

@@ -868,39 +868,6 @@ def gemm_bf16_ph(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
     return out
 
 
-def gemm_bf16_p2(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
-                 alpha: float = 1.0, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
-    """The two-blocks-per-CU 128 x 256 kernel (csrc/gemm_p2.hip) by itself -- same arguments as gemm_bf16, which picks it for
-    the short-K long-form shapes; act "glu" wants glu_interleave(w, 32)."""
-    _lib.require_gpu(bias)
-    for t in (a, w, residual, out):
-        if t is not None and (not t.is_cuda or t.dtype != torch.bfloat16 or t.stride(-1) != 1):
-            raise _lib.PafcError("gemm_bf16_p2: bf16 GPU tensors with unit stride in the last dimension")
-    L = _bind2()
-    if not getattr(L, "_pafc_gemm_p2_bound", False):
-        from ctypes import c_float, c_long
-        P, I, G = c_void_p, c_int, c_long
-        _lib._sig(L.pafc_gemm_bf16_p2, I, G, I, I, I, P, G, G, P, G, G, P, G, P, G, G, P, G, G, c_float, I, P)
-        L._pafc_gemm_p2_bound = True
-    batched = a.dim() == 3
-    Z = a.shape[0] if batched else 1
-    M, K = a.shape[-2], a.shape[-1]
-    N = w.shape[-2]
-    if w.shape[-1] != K or (batched and (w.dim() != 3 or w.shape[0] != Z)) or (not batched and (a.dim() != 2 or w.dim() != 2)):
-        raise _lib.PafcError("gemm_bf16_p2: a (M, K) x w (N, K), or both with a leading batch")
-    No = N // 2 if act == "glu" else N
-    if out is None:
-        out = torch.empty((Z, M, No) if batched else (M, No), dtype=a.dtype, device=a.device)
-    sb = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
-    bs = lambda t: t.stride(0) if batched else 0
-    rc = L.pafc_gemm_bf16_p2(M, N, K, Z, _lib.ptr(a), a.stride(-2), bs(a), _lib.ptr(w), w.stride(-2), bs(w),
-                             _lib.ptr(bias), sb, _lib.ptr(residual), residual.stride(-2) if residual is not None else 0,
-                             bs(residual) if residual is not None else 0, _lib.ptr(out), out.stride(-2), bs(out),
-                             float(alpha), _ACTS[act], _lib.stream_of(a))
-    _lib.check(rc, "pafc_gemm_bf16_p2")
-    return out
-
-
 def gemm_glu_half(M: int, N: int, K: int, batch: int = 1) -> int:
     """Row-block half size (64 or 32) pafc_gemm_bf16 wants for act "glu" on this problem (it depends on the kernel chosen)."""
     L = _bind2()

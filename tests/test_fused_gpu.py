@@ -607,41 +607,3 @@ def test_gemm_phase_pipelined_glu(hip, tile_n, M, N, K):
     torch.testing.assert_close(got.cpu().float(), want, rtol=2 ** -7, atol=2e-2)
 
 
-@pytest.mark.parametrize("M,N,K,Z,act", [(128, 256, 128, 1, "none"), (1000, 512, 512, 1, "silu"), (513, 264, 160, 1, "tanh"),
-                                         (300, 1024, 256, 2, "relu"), (2049, 512, 1024, 1, "none"), (777, 2048, 512, 1, "silu"),
-                                         (260, 512, 2048, 3, "none"), (5000, 512, 224, 1, "none")])
-def test_gemm_two_blocks_per_cu(hip, M, N, K, Z, act):
-    """csrc/gemm_p2.hip (128 x 256 tiles, two co-resident blocks per CU, three-slot ring of 32-deep K-steps) vs fp32 torch:
-    tails in M and N, K-step counts 4 .. 64 in all residues mod 3 (the ring), batching, every epilogue, several tiles per
-    block (deferred stores)."""
-    from paper_accurate_fast_cheap_amd.hip_ops import gemm_bf16_p2
-    bf = torch.bfloat16
-    shp = (lambda *s: (Z, *s)) if Z > 1 else (lambda *s: s)
-    a = synth.randn(shp(M, K), 11).to(bf)
-    w = synth.randn(shp(N, K), 12, 1.0 / K ** 0.5).to(bf)
-    b = synth.randn(shp(N), 13, 0.3).to(bf)
-    r = synth.randn(shp(M, N), 14).to(bf)
-    lin = torch.matmul(a.float(), w.float().transpose(-1, -2))
-    f = {"none": lambda t: t, "silu": F.silu, "tanh": torch.tanh, "relu": F.relu}[act]
-    bb = b.float().unsqueeze(-2) if Z > 1 else b.float()
-    got = gemm_bf16_p2(a.cuda(), w.cuda(), b.cuda(), act)
-    torch.testing.assert_close(got.cpu().float(), f(lin + bb), rtol=2 ** -7, atol=2e-2)
-    got = gemm_bf16_p2(a.cuda(), w.cuda(), None, "none", alpha=0.5, residual=r.cuda())
-    torch.testing.assert_close(got.cpu().float(), r.float() + 0.5 * lin, rtol=2 ** -7, atol=2e-2)
-    buf = r.cuda().clone()
-    same = gemm_bf16_p2(a.cuda(), w.cuda(), b.cuda(), "none", residual=buf, out=buf)
-    assert same.data_ptr() == buf.data_ptr()
-    torch.testing.assert_close(buf.cpu().float(), r.float() + lin + bb, rtol=2 ** -7, atol=2e-2)
-
-
-@pytest.mark.parametrize("M,N,K", [(700, 1024, 512), (128, 256, 128), (40000, 512, 192)])
-def test_gemm_two_blocks_per_cu_glu(hip, M, N, K):
-    from paper_accurate_fast_cheap_amd.hip_ops import gemm_bf16_p2, glu_interleave
-    bf = torch.bfloat16
-    a = synth.randn((M, K), 21).to(bf)
-    w = synth.randn((N, K), 22, 1.0 / K ** 0.5).to(bf)
-    b = synth.randn((N,), 23, 0.3).to(bf)
-    want = F.glu(F.linear(a.float(), w.float(), b.float()), dim=-1)
-    got = gemm_bf16_p2(a.cuda(), glu_interleave(w.cuda(), 32), glu_interleave(b.cuda(), 32), act="glu")
-    assert got.shape == (M, N // 2)
-    torch.testing.assert_close(got.cpu().float(), want, rtol=2 ** -7, atol=2e-2)

@@ -3,7 +3,7 @@ library's measured pick: variants interleaved round by round in ONE process, med
 run-to-run spread is larger than the differences of interest).   python tools/bench_gemm_tiles.py [M]"""
 import statistics, sys
 import torch
-from paper_accurate_fast_cheap_amd.hip_ops import gemm_bf16, gemm_bf16_p2, gemm_bf16_ph, linear_bias_act
+from paper_accurate_fast_cheap_amd.hip_ops import gemm_bf16, gemm_bf16_ph, linear_bias_act
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 44998
 dev, bf = "cuda", torch.bfloat16
 
@@ -34,7 +34,6 @@ for (K, N, Z, act, res, name) in [(512, 2048, 1, "silu", False, "ffn w_1 + SiLU"
     al = 0.5 if res else 1.0
     v = {f"ph {tm}x{tn}": (lambda tn=tn, tm=tm: gemm_bf16_ph(x, w, b, act, alpha=al, residual=r, tile_n=tn, tile_m=tm))
          for tn in (256,) for tm in (256, 192)}
-    v["p2 128x256 (2 blocks/CU)"] = lambda: gemm_bf16_p2(x, w, b, act, alpha=al, residual=r)
     v["dispatch"] = lambda: gemm_bf16(x, w, b, act, alpha=al, residual=r)
     if Z == 1:
         v["library"] = lambda: linear_bias_act(x, w, b, act, alpha=al, residual=r)
