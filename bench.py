@@ -184,6 +184,7 @@ def main():
     ap.add_argument("--batch-size", type=int, default=8)
     ap.add_argument("--cpu-sample-frames", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the fp32-model / bf16-slot timing reported under 'extra'")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     args = ap.parse_args()
 
@@ -378,6 +379,26 @@ def main():
                       "audio_sec_per_sec_encoder_plus_fbank": round(
                           frames_per_step / 100.0 / (elapsed / args.steps + fbank_ms * 1e-3), 2)},
     }
+    # the precision mode the reference itself can run (fp32 model, bf16 time-mix slot: the YAML default) beside the headline:
+    # same file, same timed region, a few steps after the headline's (N = 1, c3 only; --no-extra skips it)
+    out["extra"] = None
+    if rank == 0 and world == 1 and args.workload == "c3" and args.dtype == "bf16" and args.chunk_size <= 0 and not args.no_extra:
+        del batches
+        m2, _ = build_model("bf16slot", device)
+        fb2, ln2 = feats32.to(device), torch.tensor([feats32.shape[1]], dtype=torch.int32, device=device)
+        with torch.no_grad():
+            for _ in range(2):
+                m2.ctc_logprobs(m2._forward_encoder(fb2, ln2)[0])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                m2.ctc_logprobs(m2._forward_encoder(fb2, ln2)[0])
+            torch.cuda.synchronize()
+            ms2 = (time.perf_counter() - t0) / 3 * 1e3
+        out["extra"] = {"f32_model_bf16_slot_ms_per_step": round(ms2, 3),
+                        "f32_model_bf16_slot_audio_sec_per_sec": round(frames_per_step / 100.0 / (ms2 * 1e-3), 1),
+                        "note": "rwkv_do_bfloat16 on an fp32 model (conf/rwkv/*.yaml as shipped): fp32 library GEMMs outside the slot"}
+        del m2, fb2
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, feats32, conf, min(args.cpu_sample_frames, FRAMES))
     else:
