@@ -124,6 +124,8 @@ def cpu_baseline(model, feats_cpu_f32, conf, sample_frames: int):
         EO.ctc_log_softmax(out, csd)
         dt = time.time() - t0
     return {"value": round(sample_frames / 100.0 / dt, 3), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
+            "precision": "f32 model + bf16 time-mix slot (the reference's YAML default; the GPU headline is whole-model bf16, "
+                         "the GPU figure in this precision is extra.f32_model_bf16_slot_*)",
             "sample": f"first {sample_frames / 100:.0f} s of the same synthetic file, one sequence, fp32 graph with the "
                       f"bf16 time-mix slot, {threads} torch/OpenMP threads, {dt:.1f} s wall"}
 
@@ -204,13 +206,21 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(args.dist_backend)  # RCCL; only used for the timing barrier and the max-reduce
     if one_gpu:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)              # before the process group: RCCL binds its communicator to THIS device
     device = torch.device("cuda", local_rank)
+    rccl_ranks = None
+    if world > 1:
+        import torch.distributed as dist
+        # RCCL; only used for the timing barrier and the max-reduce (wenet/utils/train_utils.py:208 is the reference's call)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend)
+        ones = torch.ones(1, device=device if args.dist_backend == "nccl" else torch.device("cpu"))
+        dist.all_reduce(ones)                      # proof for the record that the collective saw every rank
+        rccl_ranks = int(ones.item())
 
     from paper_accurate_fast_cheap_amd import _lib, profiling
     _lib.lib()  # fail loudly, before anything else, if the HIP extension is missing
@@ -273,15 +283,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def rss_mb():
+        import resource
+        return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0     # Linux: KiB
+
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
         barrier()
+        torch.cuda.reset_peak_memory_stats(device)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         barrier()
         elapsed = time.perf_counter() - t0
+        max_vram_mb = torch.cuda.max_memory_allocated(device) / 1024 / 1024    # encoder-rtf.py:544 (MB, this rank)
         # per-kernel event timers (roofline / mfma objects) run on extra steps OUTSIDE the timed region: recording events
         # on the hot stream costs a few microseconds per timed op, which the headline number should not carry
         profiling.enable(True)
@@ -373,6 +389,13 @@ def main():
                                + ", 12-layer bidirectional RWKV-v6 Conformer encoder (512d, 8x64 heads) + CTC(5000) "
                                  "log-softmax; random-init weights (seed 777)",
                    "frames_per_step": frames_per_step, "parallelism": f"dp{world} (independent files, no collective)"},
+        # the reference harness's own quantities (wenet/bin/encoder-rtf.py:526-549): final_rtf = wall / audio seconds,
+        # "minutes of audio processed per sec", max VRAM (torch allocator peak over the timed region) and max host RSS
+        "rtf_harness": {"final_rtf": round(elapsed / audio_s, 9), "minutes_per_sec": round(audio_s / 60.0 / elapsed, 3),
+                        "total_frames": int(total_frames * args.steps), "total_elapsed": round(elapsed, 6),
+                        "max_vram_GB": round(max_vram_mb / 1024.0, 3), "max_vram_MB": round(max_vram_mb, 2),
+                        "max_cpu_ram_MB": round(rss_mb(), 2)},
+        "rccl_ranks": rccl_ranks,
         "roofline": roofline, "mfma": mfma,
         "front_end": {"kernel": "fbank (HIP, fp32 MFMA DFT)", "ms_per_file": round(fbank_ms, 3),
                       "audio_sec_per_sec": round(frames_per_step / 100.0 / (fbank_ms * 1e-3), 1),

@@ -222,20 +222,29 @@ def conv_module(x, mask_pad, sd: SD, p: str, kernel_size: int):
 
 
 def conformer_layer(x, mask_pad, sd: SD, p: str, conf: dict, layer_id: int, env=None):
-    """ConformerEncoderLayer.forward, wenet/transformer/encoder_layer.py:165-261 with normalize_before,
-    macaron FFN (ff_scale 0.5, :149-151), conv module, eval-mode dropout."""
+    """ConformerEncoderLayer.forward, wenet/transformer/encoder_layer.py:165-261: macaron FFN (ff_scale 0.5,
+    :149-151), conv module, eval-mode dropout; normalize_before (the paper's configs) puts each LayerNorm in front of its
+    branch, otherwise behind the residual add (:203-208, :212-213/:233-234, :241-247, :251-256)."""
     head_size = conf["output_size"] // conf["attention_heads"]
-    r = x
-    x = r + 0.5 * positionwise_ff(layer_norm(x, sd, p + "norm_ff_macaron."), sd, p + "feed_forward_macaron.")
-    r = x
-    a, _ = self_attn(layer_norm(x, sd, p + "norm_mha."), sd, p + "self_attn.", conf["selfattention_layer_type"],
-                     head_size, conf.get("rwkv_do_bfloat16", True), layer_id, env=env,
-                     out_as_query=bool(conf.get("oracle_slot_out_as_query", False)))
-    x = r + a
-    r = x
-    x = r + conv_module(layer_norm(x, sd, p + "norm_conv."), mask_pad, sd, p + "conv_module.", conf["cnn_module_kernel"])
-    r = x
-    x = r + 0.5 * positionwise_ff(layer_norm(x, sd, p + "norm_ff."), sd, p + "feed_forward.")
+    pre = bool(conf.get("normalize_before", True))
+
+    def slot(h):
+        return self_attn(h, sd, p + "self_attn.", conf["selfattention_layer_type"], head_size,
+                         conf.get("rwkv_do_bfloat16", True), layer_id, env=env,
+                         out_as_query=bool(conf.get("oracle_slot_out_as_query", False)))[0]
+    for norm, scale, fn in (("norm_ff_macaron.", 0.5, lambda h: positionwise_ff(h, sd, p + "feed_forward_macaron.")),
+                            ("norm_mha.", None, slot),
+                            ("norm_conv.", None, lambda h: conv_module(h, mask_pad, sd, p + "conv_module.", conf["cnn_module_kernel"])),
+                            ("norm_ff.", 0.5, lambda h: positionwise_ff(h, sd, p + "feed_forward."))):
+        if not pre and norm == "norm_conv." and mask_pad.size(2) > 0:
+            # post-norm hands the residual stream itself to the conv module, whose masked_fill_ is IN PLACE on a view of
+            # its input (convolution.py:105-109): the residual loses its padded frames as well
+            x = x.masked_fill(~mask_pad.transpose(1, 2), 0.0)
+        r = x
+        y = fn(layer_norm(x, sd, p + norm) if pre else x)
+        x = r + (y if scale is None else scale * y)
+        if not pre:
+            x = layer_norm(x, sd, p + norm)
     return layer_norm(x, sd, p + "norm_final.")
 
 
@@ -255,16 +264,29 @@ def global_cmvn(x, sd: SD, p: str = "global_cmvn."):
     return (x - sd[p + "mean"]) * sd[p + "istd"]
 
 
-def conv2d_subsampling4(x, x_mask, sd: SD, p: str = "embed."):
+def abs_position_rows(offset: int, size: int, d_model: int):
+    """Rows [offset, offset + size) of PositionalEncoding's sin/cos table, wenet/transformer/embedding.py:39-56."""
+    pos = torch.arange(offset, offset + size, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * -(math.log(10000.0) / d_model))
+    pe = torch.zeros(size, d_model)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.unsqueeze(0)
+
+
+def conv2d_subsampling4(x, x_mask, sd: SD, p: str = "embed.", pos_enc: str = "rel_pos", offset: int = 0):
     """Conv2dSubsampling4.forward, wenet/transformer/subsampling.py:201-226, followed by
     RelPositionalEncoding.forward, embedding.py:133-147 (x * sqrt(d_model); pos_emb is returned by the
-    reference but never read by the RWKV slot, so it is not produced here)."""
+    reference but never read by the RWKV slot, so it is not produced here) or, for pos_enc 'abs_pos',
+    PositionalEncoding.forward, embedding.py:58-77 (x * sqrt(d_model) + pe[offset : offset + T'])."""
     x = x.unsqueeze(1)
     x = F.relu(F.conv2d(x, sd[p + "conv.0.weight"], sd[p + "conv.0.bias"], stride=2))
     x = F.relu(F.conv2d(x, sd[p + "conv.2.weight"], sd[p + "conv.2.bias"], stride=2))
     b, c, t, f = x.shape
     x = F.linear(x.transpose(1, 2).contiguous().view(b, t, c * f), sd[p + "out.0.weight"], sd[p + "out.0.bias"])
     x = x * math.sqrt(x.shape[-1])
+    if pos_enc in ("abs_pos", "embed"):
+        x = x + abs_position_rows(offset, x.shape[1], x.shape[-1]).to(x.dtype)
     return x, x_mask[:, :, 2::2][:, :, 2::2]
 
 
@@ -275,27 +297,29 @@ def encoder_forward(xs, xs_lens, sd: SD, conf: dict, env=None, return_layers: bo
     T = xs.size(1)
     masks = ~make_pad_mask(xs_lens, T).unsqueeze(1)
     xs = global_cmvn(xs, sd)
-    xs, masks = conv2d_subsampling4(xs, masks, sd)
+    xs, masks = conv2d_subsampling4(xs, masks, sd, pos_enc=conf.get("pos_enc_layer_type", "rel_pos"))
     layers = []
     for i in range(conf["num_blocks"]):
         xs = conformer_layer(xs, masks, sd, f"encoders.{i}.", conf, i, env)
         layers.append(xs)
-    xs = layer_norm(xs, sd, "after_norm.")
+    if conf.get("normalize_before", True):       # encoder.py:145-146
+        xs = layer_norm(xs, sd, "after_norm.")
     return (xs, masks, layers) if return_layers else (xs, masks)
 
 
-def encoder_forward_chunk(xs, sd: SD, conf: dict, env=None):
+def encoder_forward_chunk(xs, sd: SD, conf: dict, env=None, offset: int = 0):
     """BaseEncoder.forward_chunk, encoder.py:231-339, as it behaves with an RWKV slot and a non-causal
     conv module: B == 1, all-ones masks, att_cache comes back (0,0,0,0) and cnn_cache (num_blocks,0,0,0)
      -- i.e. an independent full-context pass over the chunk."""
     assert xs.size(0) == 1
     masks = torch.ones(1, 1, xs.size(1), dtype=torch.bool)
     xs = global_cmvn(xs, sd)
-    xs, _ = conv2d_subsampling4(xs, masks, sd)
+    xs, _ = conv2d_subsampling4(xs, masks, sd, pos_enc=conf.get("pos_enc_layer_type", "rel_pos"), offset=offset)
     empty_mask = torch.ones((0, 0, 0), dtype=torch.bool)
     for i in range(conf["num_blocks"]):
         xs = conformer_layer(xs, empty_mask, sd, f"encoders.{i}.", conf, i, env)
-    xs = layer_norm(xs, sd, "after_norm.")
+    if conf.get("normalize_before", True):       # encoder.py:328-329
+        xs = layer_norm(xs, sd, "after_norm.")
     return xs, torch.zeros((0, 0, 0, 0)), torch.zeros((conf["num_blocks"], 0, 0, 0))
 
 
@@ -310,9 +334,11 @@ def encoder_forward_chunk_by_chunk(xs, decoding_chunk_size: int, sd: SD, conf: d
     stride = subsampling * decoding_chunk_size
     window = (decoding_chunk_size - 1) * subsampling + context
     outs = []
+    offset = 0          # encoder.py:377,399: the running count of output frames is the next window's positional offset
     for cur in range(0, xs.size(1) - context + 1, stride):
-        y, _, _ = encoder_forward_chunk(xs[:, cur:min(cur + window, xs.size(1))], sd, conf, env)
+        y, _, _ = encoder_forward_chunk(xs[:, cur:min(cur + window, xs.size(1))], sd, conf, env, offset)
         outs.append(y)
+        offset += y.size(1)
     ys = torch.cat(outs, 1)
     return ys, torch.ones((1, 1, ys.size(1)), dtype=torch.bool)
 

@@ -42,6 +42,11 @@ def lib():
         raise PafcError(
             f"{SO_PATH} is missing: the HIP extension has not been built "
             "(python -m paper_accurate_fast_cheap_amd.csrc.build). There is no CPU fallback.")
+    from .csrc import build as _build
+    if _build.built_key() != _build.source_key():
+        raise PafcError(
+            f"{SO_PATH} was not built from the sources in this tree (libpafc_hip.so.json: {_build.built_key()}, sources: "
+            f"{_build.source_key()}): rebuild with python -m paper_accurate_fast_cheap_amd.csrc.build")
     L = ctypes.CDLL(SO_PATH)
     P, I, Z = c_void_p, c_int, c_size_t
     _sig(L.pafc_abi_version, I)

@@ -1,47 +1,103 @@
 """Build libpafc_hip.so (the C-ABI library of include/*.h) for gfx950 with hipcc.
 
-    python -m paper_accurate_fast_cheap_amd.csrc.build [--force]
+    python -m paper_accurate_fast_cheap_amd.csrc.build [--force] [-v]
 
-hipcc cross-compiles without a GPU.  The .so is written next to the package
-(paper_accurate_fast_cheap_amd/libpafc_hip.so): in-tree, git-ignored, shipped to
-the GPU box with the snapshot.
+hipcc cross-compiles without a GPU.  Every source becomes one object, keyed by the sha256 of its text, of every header /
+.inc it could include and of the flags: an object is rebuilt exactly when that key changes (content, not mtime), objects
+compile in parallel, and the link writes `libpafc_hip.so` next to the package (in-tree, git-ignored, shipped to the GPU box
+with the snapshot) together with `libpafc_hip.so.json`: the key of the sources it was linked from.  `_lib.lib()` compares
+that key with the sources in the tree and refuses a stale library.
 """
 import glob
+import hashlib
+import json
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 OUT = os.path.join(PKG, "libpafc_hip.so")
+MANIFEST = OUT + ".json"
+OBJ = os.path.join(HERE, "_obj")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-         "-I", os.path.join(ROOT, "include"), "-I", HERE]
+_CFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]   # these enter the keys
+CFLAGS = _CFLAGS + ["-I", os.path.join(ROOT, "include"), "-I", HERE]      # (the include paths depend on where the tree lies)
+LDFLAGS = ["-shared", "-fPIC", f"--offload-arch={ARCH}", "-L/opt/rocm/lib", "-lhipblaslt", "-Wl,-rpath,/opt/rocm/lib"]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(HERE, "*.hip"))) + sorted(glob.glob(os.path.join(HERE, "*.cpp")))
 
 
-def stale():
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    deps = sources() + glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(HERE, "*.inc")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+def _headers():
+    return sorted(glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(HERE, "*.inc"))
+                  + glob.glob(os.path.join(ROOT, "include", "*.h")))
+
+
+def _sha(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def source_key() -> str:
+    """Key of everything the library is built from (sources, headers, flags)."""
+    return _sha(sources() + _headers(), " ".join(_CFLAGS + LDFLAGS))
+
+
+def built_key():
+    try:
+        with open(MANIFEST) as f:
+            return json.load(f).get("source_key")
+    except (OSError, ValueError):
+        return None
+
+
+def stale() -> bool:
+    return not os.path.exists(OUT) or built_key() != source_key()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", OUT + ".tmp"] + sources() + ["-L/opt/rocm/lib", "-lhipblaslt", "-Wl,-rpath,/opt/rocm/lib"]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_key = _sha(_headers(), " ".join(_CFLAGS))
+    jobs, objs = [], []
+    for src in sources():
+        key = _sha([src], hdr_key)
+        obj = os.path.join(OBJ, f"{os.path.basename(src)}.{key}.o")
+        objs.append(obj)
+        if force or not os.path.exists(obj):
+            cmd = [hipcc] + CFLAGS + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-c", src, "-o", obj + ".tmp"]
+            jobs.append((cmd, obj))
+
+    def run(job):
+        cmd, obj = job
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        os.replace(obj + ".tmp", obj)
+
+    workers = max(1, min(len(jobs), int(os.environ.get("PAFC_BUILD_JOBS", str(min(8, os.cpu_count() or 1))))))
+    if jobs:
+        with ThreadPoolExecutor(workers) as ex:
+            list(ex.map(run, jobs))
+    subprocess.check_call([hipcc] + objs + LDFLAGS + ["-o", OUT + ".tmp"])
     os.replace(OUT + ".tmp", OUT)
+    with open(MANIFEST, "w") as f:
+        json.dump({"source_key": source_key(), "arch": ARCH, "objects": [os.path.basename(o) for o in objs],
+                   "compiled_now": len(jobs)}, f, indent=1)
+    keep = set(objs)                                   # objects of older source versions
+    for old in glob.glob(os.path.join(OBJ, "*.o")):
+        if old not in keep:
+            os.remove(old)
     return OUT
 
 

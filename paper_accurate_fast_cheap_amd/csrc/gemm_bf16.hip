@@ -258,9 +258,7 @@ static int ph_tile_m(long M, int N, int K, int batch, int act, bool has_residual
     if (N % 8 || K % 64 || K < 128 || N < 256) return 0;
     if (act == 4 && N % 256) return 0;
     if (has_residual && act != 0) return 0;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (cus <= 0) cus = 256;
+    const int cus = pafc::device_cus();
     const long nt = (N + 255) / 256;
     if (((M + 255) / 256) * nt * batch < (long)cus * 3 / 4) return 0;      // too few big tiles: the small-tile kernel fills the chip better
     long best_cost = -1;
@@ -288,6 +286,9 @@ extern "C" int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, lo
         const int rc = pafc_gemm_bf16_ph(M, N, K, batch, A, lda, strideA, W, ldw, strideW, bias, strideBias, residual, ldr, strideR,
                                          out, ldo, strideO, alpha, act, 256, tm, stream);
         if (rc != PAFC_ERR_UNSUPPORTED) return rc;        // (extents beyond its 31-bit offsets fall through)
+        // ... except GLU: the caller laid the weight rows out in the order pafc_gemm_bf16_glu_half announced for THIS kernel
+        // (blocks of 32), the 128 x 128 kernel below reads blocks of 64 -- refuse rather than compute something else
+        if (act == 4) return PAFC_ERR_UNSUPPORTED;
     }
     const bool glu = act == 4;
     if (glu && (N % pafc::GBN || residual)) return PAFC_ERR_UNSUPPORTED;

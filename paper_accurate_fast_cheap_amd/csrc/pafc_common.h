@@ -44,6 +44,19 @@ template <> struct Elem<bf16_t> {
     __device__ static __forceinline__ float round(float v) { return round_bf16(v); }
 };
 
+// Compute units of the current device, asked once per device and process (host side; 256 if the query fails).
+inline int device_cus() {
+    static int cached[64];                 // 0 = not asked yet; a racing first call writes the same value twice
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int c = cached[dev];
+    if (c <= 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        cached[dev] = c;
+    }
+    return c;
+}
+
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);

@@ -553,6 +553,10 @@ class _LinearPlans:
         self.ctx = c_void_p()
         with torch.cuda.device(device):
             _lib.check(L.pafc_gemm_ctx_create(byref(self.ctx)), "pafc_gemm_ctx_create")
+        # a plan's descriptor carries the CALL's bias pointer between pafc_linear_plan_run's write and its launch, and ctypes
+        # releases the GIL: one thread at a time per device (include/pafc_encoder_ops.h: "a plan is used by one thread at a time")
+        import threading
+        self.lock = threading.Lock()
         self.tune = os.environ.get("PAFC_GEMM_TUNE", "1") != "0"
         self.tune_min_rows = int(os.environ.get("PAFC_GEMM_TUNE_MIN_ROWS", "32768"))
 
@@ -604,7 +608,8 @@ def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
     if plans is None:
         plans = _linear_plans[x.device] = _LinearPlans(x.device)
     L = plans.L
-    plan = plans.get((_lib.dtype_code(x.dtype), rows, N, K, int(bias is not None), int(act == "silu"), int(residual is not None)))
+    with plans.lock:
+        plan = plans.get((_lib.dtype_code(x.dtype), rows, N, K, int(bias is not None), int(act == "silu"), int(residual is not None)))
     if plan is None:
         # no workspace-free library kernel for this problem (seen for some row counts at N = 5000): the framework's own
         # GEMM + separate epilogue ops -- still on the GPU, just not fused
@@ -613,29 +618,30 @@ def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
             y = y * alpha
         if bias is not None:
             y = y + bias
+        if residual is not None:           # act(alpha * x W^T + residual + bias), as the fused kernels compute it
+            y = y + residual.view(y.shape)
         if act == "silu":
             y = torch.nn.functional.silu(y)
-        if residual is not None:
-            y = y + residual.view(y.shape)
-            if inplace:
-                residual.view(y.shape).copy_(y)
-                return residual
+        if residual is not None and inplace:
+            residual.view(y.shape).copy_(y)
+            return residual
         return y
     if inplace and residual is not None:
         out = residual
     else:
         out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
     stream = _lib.stream_of(x)
-    if (plans.tune and rows >= plans.tune_min_rows and not L.pafc_linear_plan_is_tuned(plan)
-            and not torch.cuda.is_current_stream_capturing()):
-        scratch = torch.empty(rows, N, dtype=x.dtype, device=x.device)
-        _lib.check(L.pafc_linear_plan_tune(plan, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(scratch), float(alpha),
-                                           _lib.ptr(residual), 16, stream), "pafc_linear_plan_tune")
-        del scratch
     from .profiling import op_timer
-    with op_timer("linear_%dx%d" % (K, N), sample=12, flops=2.0 * rows * N * K):
-        rc = L.pafc_linear_plan_run(plan, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out), float(alpha),
-                                    _lib.ptr(residual), stream)
+    with plans.lock:
+        if (plans.tune and rows >= plans.tune_min_rows and not L.pafc_linear_plan_is_tuned(plan)
+                and not torch.cuda.is_current_stream_capturing()):
+            scratch = torch.empty(rows, N, dtype=x.dtype, device=x.device)
+            _lib.check(L.pafc_linear_plan_tune(plan, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(scratch),
+                                               float(alpha), _lib.ptr(residual), 16, stream), "pafc_linear_plan_tune")
+            del scratch
+        with op_timer("linear_%dx%d" % (K, N), sample=12, flops=2.0 * rows * N * K):
+            rc = L.pafc_linear_plan_run(plan, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out), float(alpha),
+                                        _lib.ptr(residual), stream)
     _lib.check(rc, "pafc_linear_plan_run")
     return out
 

@@ -260,7 +260,13 @@ class BaseEncoder(torch.nn.Module):
 
     def _windows_independent(self, xs: torch.Tensor):
         """The fused plan when the windows of forward_chunk_by_chunk do not depend on each other: recurrent slot (its
-        att_cache stays empty) and a non-causal conv module (its cnn_cache stays empty) -- the paper's configs."""
+        att_cache stays empty), a non-causal conv module (its cnn_cache stays empty) and a positional encoding that
+        leaves xs independent of the window's offset (rel_pos / no_pos; abs_pos adds pe[offset : offset + T] into xs,
+        embedding.py:64-77, so its windows keep the window-by-window path with the running offset) -- the paper's configs."""
+        from .embedding import NoPositionalEncoding, PositionalEncoding, RelPositionalEncoding
+        pos = getattr(self.embed, "pos_enc", None)
+        if isinstance(pos, PositionalEncoding) or not isinstance(pos, (RelPositionalEncoding, NoPositionalEncoding)):
+            return None
         plan = self._fused(xs)
         if plan is None or any(l.conv_module is not None and l.conv_module.lorder > 0 for l in self.encoders):
             return None

@@ -16,8 +16,6 @@ class ConformerEncoderLayer(nn.Module):
                  feed_forward_macaron: Optional[nn.Module] = None, conv_module: Optional[nn.Module] = None,
                  dropout_rate: float = 0.1, normalize_before: bool = True):
         super().__init__()
-        if not normalize_before:
-            raise NotImplementedError("post-norm layers (normalize_before: false) are outside the accelerated path")
         self.self_attn = self_attn
         self.feed_forward = feed_forward
         self.feed_forward_macaron = feed_forward_macaron
@@ -33,13 +31,15 @@ class ConformerEncoderLayer(nn.Module):
             self.norm_conv = LayerNorm(size, eps=1e-5)
             self.norm_final = LayerNorm(size, eps=1e-5)
         # pre-norm branches whose first operation is a projection (FFN w_1, pointwise_conv1) or the slot's own cast
-        # to bf16: the consumer takes bf16 under autocast (layer_norm.py)
-        self.norm_ff.consumer_casts = True
-        if feed_forward_macaron is not None:
-            self.norm_ff_macaron.consumer_casts = True
-        if self.conv_module is not None:
-            self.norm_conv.consumer_casts = True
-        self.norm_mha.consumer_casts = bool(getattr(self_attn, "do_bfloat16", False))
+        # to bf16: the consumer takes bf16 under autocast (layer_norm.py).  A post-norm layer's norms feed the residual
+        # stream itself, which stays in the stream's dtype.
+        if normalize_before:
+            self.norm_ff.consumer_casts = True
+            if feed_forward_macaron is not None:
+                self.norm_ff_macaron.consumer_casts = True
+            if self.conv_module is not None:
+                self.norm_conv.consumer_casts = True
+            self.norm_mha.consumer_casts = bool(getattr(self_attn, "do_bfloat16", False))
         self.dropout = nn.Dropout(dropout_rate)
         self.size = size
         self.normalize_before = normalize_before
@@ -53,19 +53,33 @@ class ConformerEncoderLayer(nn.Module):
         """-> (x, mask, new_att_cache, new_cnn_cache), the tuple of the reference's layer (encoder_layer.py:165-261).
         A chain of pre-norm residual branches -- half-step macaron FFN, slot, conv module, half-step FFN -- closed by
         norm_final when there is a conv module.  The recurrent slot hands `att_cache` back untouched."""
-        drop = self.dropout
+        drop, pre = self.dropout, self.normalize_before
+        side = {}
+
+        def branch(x, norm, fn, scale=1.0):
+            # pre-norm: x + scale * fn(norm(x));  post-norm: norm(x + scale * fn(x))   (encoder_layer.py:201-256)
+            y = fn(norm(x) if pre else x)
+            if isinstance(y, tuple):
+                y, side["cache"] = y
+            x = x + (drop(y) if scale == 1.0 else scale * drop(y))
+            return x if pre else norm(x)
+
         if self.feed_forward_macaron is not None:
-            x = x + self.ff_scale * drop(self.feed_forward_macaron(self.norm_ff_macaron(x)))
-        h = self.norm_mha(x)
-        att, new_att_cache = self.self_attn(h, h, h, mask, pos_emb, att_cache)
-        x = x + drop(att)
-        if self.conv_module is None:
-            x = x + self.ff_scale * drop(self.feed_forward(self.norm_ff(x)))
-            return x, mask, new_att_cache, x.new_zeros((0, 0, 0))
-        c, new_cnn_cache = self.conv_module(self.norm_conv(x), mask_pad, cnn_cache)
-        x = x + drop(c)
-        x = x + self.ff_scale * drop(self.feed_forward(self.norm_ff(x)))
-        return self.norm_final(x), mask, new_att_cache, new_cnn_cache
+            x = branch(x, self.norm_ff_macaron, self.feed_forward_macaron, self.ff_scale)
+        x = branch(x, self.norm_mha, lambda h: self.self_attn(h, h, h, mask, pos_emb, att_cache))
+        new_att_cache = side.pop("cache")
+        new_cnn_cache = x.new_zeros((0, 0, 0))
+        if self.conv_module is not None:
+            if not pre and mask_pad.size(2) > 0:
+                # the reference's conv module zeroes padded frames IN PLACE on a view of its input (convolution.py:105-109);
+                # post-norm hands it the residual stream itself, which therefore loses them too
+                x = x.masked_fill(~mask_pad.transpose(1, 2), 0.0)
+            x = branch(x, self.norm_conv, lambda h: self.conv_module(h, mask_pad, cnn_cache))
+            new_cnn_cache = side.pop("cache")
+        x = branch(x, self.norm_ff, self.feed_forward, self.ff_scale)
+        if self.conv_module is not None:
+            x = self.norm_final(x)
+        return x, mask, new_att_cache, new_cnn_cache
 
     def forward_carry(self, x: torch.Tensor, carry: Optional[dict]) -> Tuple[torch.Tensor, dict]:
         """One chunk WITH recurrent-state carry (uni-directional slot only): what the reference's forward_chunk
@@ -76,6 +90,8 @@ class ConformerEncoderLayer(nn.Module):
         slot = self.self_attn
         if type(slot) is not RWKV_TmixWrapper:
             raise NotImplementedError("state carry is defined for the uni-directional slot (rwkv_tmix60)")
+        if not self.normalize_before:
+            raise NotImplementedError("state carry is defined for pre-norm layers")
         carry = carry or {}
         if self.feed_forward_macaron is not None:
             x = x + self.ff_scale * self.feed_forward_macaron(self.norm_ff_macaron(x))

@@ -71,10 +71,12 @@ class LayerPlan:
             # pointwise_conv1 with its rows interleaved (64 values, 64 gates, ...) so that F.glu is a GEMM epilogue
             pw1 = L.conv_module.pointwise_conv1
             self.pw1_glu = None                # {block half: (weight, bias)} in the two row orders the GEMM kernels want
-            if pw1.weight.dtype == torch.bfloat16 and pw1.weight.is_cuda and pw1.weight.shape[0] % 256 == 0 \
+            rows2 = pw1.weight.shape[0]                      # 2C: h = 64 blocks need 2C % 128 == 0, h = 32 blocks 2C % 256 == 0
+            if pw1.weight.dtype == torch.bfloat16 and pw1.weight.is_cuda and rows2 % 128 == 0 \
                     and pw1.weight.shape[1] % 64 == 0:
                 self.pw1_glu = {h: (hip_ops.glu_interleave(pw1.weight.squeeze(-1), h),
-                                    hip_ops.glu_interleave(pw1.bias, h) if pw1.bias is not None else None) for h in (64, 32)}
+                                    hip_ops.glu_interleave(pw1.bias, h) if pw1.bias is not None else None)
+                                for h in ((64, 32) if rows2 % 256 == 0 else (64,))}
         self._stamp = stamp
 
     def _refresh_rwkv(self, bl):
@@ -150,7 +152,7 @@ def _ffn_residual(ff: nn.Module, h: torch.Tensor, x: torch.Tensor, scale: float,
 def _pw1_glu(plan: "LayerPlan", h2: torch.Tensor) -> torch.Tensor:
     """pointwise_conv1 + F.glu as one GEMM: the weight rows in the block order the kernel picked for this row count wants."""
     w64 = plan.pw1_glu[64][0]
-    half = hip_ops.gemm_glu_half(h2.shape[0], w64.shape[0], w64.shape[1])
+    half = hip_ops.gemm_glu_half(h2.shape[0], w64.shape[0], w64.shape[1])   # 32 only when 2C % 256 == 0 (ph_tile_m)
     w, b = plan.pw1_glu[half]
     return hip_ops.gemm_bf16(h2, w, b, act="glu")
 
@@ -173,12 +175,14 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
         for d in range(nd):
             torch.bmm(t[d].view(M, 4, -1).transpose(0, 1), plan.W2[d], out=m[d])
         z = hip_ops.tmix_mix4(h, m, plan.maa4)                                              # (4, nd, M, C)
-    if own_gemm:
+    if own_gemm and M >= _OWN_GEMM_MIN_ROWS:     # short inputs: the library's small-problem kernels, as in proj()
         rkv = hip_ops.gemm_bf16(z[:3].view(3 * nd, M, C), plan.Wrkv_n)                      # (3nd, M, C), one launch
+    else:
+        rkv = torch.bmm(z[:3].view(3 * nd, M, C), plan.Wrkv)
+    if own_gemm:
         # decay LoRA in one pass (the 64-wide hidden tensor stays on chip); uni: time_decay rides along
         w = hip_ops.decay_lora(z[3], plan.D1n, plan.D2n, plan.time_decay.view(nd, C) if nd == 1 else None)
     else:
-        rkv = torch.bmm(z[:3].view(3 * nd, M, C), plan.Wrkv)
         w = torch.bmm(torch.tanh(torch.bmm(z[3], plan.D1)), plan.D2)
     if nd == 1 and not own_gemm:
         w = w + plan.time_decay            # uni: one extra pass; bi: time_decay is added inside the scan kernel

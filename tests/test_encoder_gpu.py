@@ -365,6 +365,31 @@ def test_forward_chunk_by_chunk_golden(hip, variant):
         assert enc._windows_independent(xs) is not None            # the batched path is the one that ran above
 
 
+@pytest.mark.parametrize("case", ["postnorm_f32", "postnorm_bf16slot", "abspos_f32", "abspos_bf16slot"])
+def test_postnorm_and_abspos_goldens(hip, case):
+    """Configurations outside the paper's YAMLs that the reference's classes support (tests/golden/make_goldens_r3.py):
+    post-norm layers (module path; the fused executor is pre-norm only) and abs_pos, whose forward_chunk_by_chunk windows
+    carry the running output offset and therefore must NOT take the batched-window path."""
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_postnorm_abspos")
+    c = g["cases"][case]
+    enc = ConformerEncoder(80, **c["conf"])
+    enc.load_state_dict(_sd(c))
+    enc = enc.cuda().eval()
+    bf = case.endswith("bf16slot")
+    with torch.no_grad():
+        out, masks = enc(g["xs"].cuda(), g["lens"].cuda())
+        assert torch.equal(masks.cpu(), c["masks"]) and out.dtype == c["out"].dtype
+        _assert_close(out, c["out"], bf, case)
+        if case.startswith("postnorm"):
+            assert enc._fused(out) is None
+        for chunk, want in c.get("chunks", {}).items():
+            assert enc._windows_independent(out) is None
+            ys, m = enc.forward_chunk_by_chunk(g["long"].cuda(), chunk, -1)
+            assert torch.equal(m.cpu(), want["masks"])
+            _assert_close(ys, want["ys"], bf, f"{case} chunk {chunk}")
+
+
 def test_dir_dropout_train_golden(hip):
     """Train-time direction dropout: under torch.manual_seed(s) our modules make the reference's draws (same host
     generator, same order) and produce its outputs, every branch of both classes."""

@@ -294,3 +294,23 @@ def test_state_recurrence_f64_agrees_with_the_pinned_c_restatement():
     y_p, s_p = WO.state_recurrence_f64(r, k, v, w, u, s)
     torch.testing.assert_close(y_p.float(), y_c, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(s_p.float(), s_c, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", ["postnorm_f32", "postnorm_bf16slot", "abspos_f32", "abspos_bf16slot"])
+def test_postnorm_and_abspos_goldens(case):
+    """Post-norm layers (encoder_layer.py:207-256) and abs_pos windows with their running offset (embedding.py:58-77,
+    encoder.py:377-399), captured from the reference (make_goldens_r3.py)."""
+    g = load_golden("encoder_postnorm_abspos")
+    c = g["cases"][case]
+    sd = _sd(c)
+    bf = case.endswith("bf16slot")
+    out, masks = EO.encoder_forward(g["xs"], g["lens"], sd, c["conf"], env={})
+    assert torch.equal(masks, c["masks"]) and _close(out, c["out"], bf), case
+    for chunk, want in c.get("chunks", {}).items():
+        ys, m = EO.encoder_forward_chunk_by_chunk(g["long"], chunk, sd, c["conf"], env={})
+        assert torch.equal(m, want["masks"]) and _close(ys, want["ys"], bf), (case, chunk)
+        # the offset matters: the same windows embedded at offset 0 give something else
+        ys0 = torch.cat([EO.encoder_forward_chunk(g["long"][:, cur:min(cur + (chunk - 1) * 4 + 7, g["long"].size(1))], sd,
+                                                  c["conf"], env={})[0]
+                         for cur in range(0, g["long"].size(1) - 6, 4 * chunk)], 1)
+        assert not torch.allclose(ys0.float(), want["ys"].float(), atol=1e-2)

@@ -41,17 +41,18 @@ def main():
         sys.exit(f"bench_train_step.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
     use_ddp = world > 1 or args.ddp
+    if one_gpu:
+        local = 0
+    torch.cuda.set_device(local)                  # before the process group: RCCL binds its communicator to this device
+    device = torch.device("cuda", local)
     if use_ddp:
+        kw = dict(device_id=device) if args.dist_backend == "nccl" else {}
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29641")
-            dist.init_process_group(args.dist_backend, rank=0, world_size=1)
+            dist.init_process_group(args.dist_backend, rank=0, world_size=1, **kw)
         else:
-            dist.init_process_group(args.dist_backend)
-    if one_gpu:
-        local = 0
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+            dist.init_process_group(args.dist_backend, **kw)
     from paper_accurate_fast_cheap_amd import _lib
     from paper_accurate_fast_cheap_amd.utils.train_utils import train_step, wrap_model_ddp
     _lib.lib()
