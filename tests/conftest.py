@@ -15,6 +15,11 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    from tests import parity_log
+    parity_log.flush()
+
+
 def load_golden(name):
     return torch.load(os.path.join(GOLDEN, name + ".pt"), weights_only=False)
 

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import encoder_oracle as EO
-from tests import synth
+from tests import parity_log, synth
 from tests.conftest import load_golden
 
 pytestmark = pytest.mark.gpu
@@ -21,6 +21,9 @@ def _assert_close(got, ref, bf16_path, what="", whole_model_bf16=False):
     shows against ITSELF when only its GEMM summation order changes (tests/test_oracle_goldens.py:_close)."""
     got, ref = got.float().cpu(), ref.float().cpu()
     mx, mean = _stats(got, ref)
+    if what:
+        parity_log.record(f"golden/{what}", max_abs_err=mx, mean_abs_err=mean, ref_abs_max=float(ref.abs().max()),
+                          mode="whole-bf16" if whole_model_bf16 else "bf16-inside" if bf16_path else "fp32")
     if whole_model_bf16:
         # every op of every layer rounds to bf16 (ulp 0.03 at |x| = 4) and CPU / GPU differ in each op's internal
         # order, not only in the GEMMs: bound the drift at ~10 ulp max, ~0.5 ulp mean
@@ -51,7 +54,7 @@ def test_uni_wrapper(hip, tag):
     with torch.no_grad():
         y, cache = m(x, x, x, torch.ones((0, 0, 0), dtype=torch.bool), torch.empty(0), torch.zeros((0, 0, 0, 0)))
     assert y.dtype == g["y"].dtype and tuple(cache.shape) == g["cache_shape"]
-    _assert_close(y, g["y"], g["do_bfloat16"], tag)
+    _assert_close(y, g["y"], g["do_bfloat16"], f"uni_wrapper/{tag}")
 
 
 @pytest.mark.parametrize("key", ["rwkv_tmix60_bidirectional", "rwkv_tmix60_bidirectional2"])
@@ -68,7 +71,7 @@ def test_bi_wrapper(hip, key, tag):
         y_none, _ = m(x, None, None, None, None, None)  # bidirectional2 calls its inner wrappers with None
     assert y.dtype == torch.float32 and tuple(cache.shape) == g["cache_shape"]
     assert torch.equal(y, y_none)
-    _assert_close(y, g["y"], g["do_bfloat16"], tag)
+    _assert_close(y, g["y"], g["do_bfloat16"], f"{key}/{tag}")
 
 
 def test_dir_dropout_eval(hip, monkeypatch):
@@ -109,7 +112,7 @@ def test_encoder_reduced(hip, variant):
     wm = variant == "uni_bf16model"
 
     def _assert_close(a, b, bfp, what):  # noqa: F811 -- same check, whole-model flag bound per variant
-        globals()["_assert_close"](a, b, bfp, what, whole_model_bf16=wm)
+        globals()["_assert_close"](a, b, bfp, f"encoder_reduced_{variant}/{what}", whole_model_bf16=wm)
     with torch.no_grad():
         out, masks, layers = enc.forward_return_layers(g["xs"].cuda(), g["lens"].cuda(), want_layers=True)
         assert torch.equal(masks.cpu(), g["masks"])
@@ -160,6 +163,9 @@ def _token_parity(logp, ref_logp, valid, logp_tol, what):
     decided = (margin > 2 * e) & valid
     assert bool((same | ~decided).all()), f"{what}: token differs on a frame the reference decides by more than 2e = {2 * e:.4g}"
     flips = int((~same & valid).sum())
+    parity_log.record(f"tokens/{what}", max_abs_dlogp=e, flipped_frames=flips, valid_frames=int(valid.sum()),
+                      largest_margin_among_flipped=float(margin[~same & valid].max()) if flips else 0.0,
+                      undecided_frames_margin_le_2e=int(((margin <= 2 * e) & valid).sum()))
     print(f"[token parity] {what}: {flips} of {int(valid.sum())} valid frames flipped, all with reference top-2 margin "
           f"<= {2 * e:.4g} (max |dlogp| {e:.4g}); largest margin among flipped frames "
           f"{float(margin[~same & valid].max()) if flips else 0.0:.4g}")
@@ -221,9 +227,12 @@ def test_config_c1_full_size_fp32_vs_oracle(hip):
     got = out.cpu()[valid]
     want = ref[valid]
     torch.testing.assert_close(got, want, rtol=1e-3, atol=2.5e-4)
+    d = (got - want).abs()
+    parity_log.record("c1 fp32 full size", max_abs_err=float(d.max()), mean_abs_err=float(d.mean()),
+                      max_rel_err_where_ref_ge_0p05=float((d / want.abs().clamp_min(5e-2)).max()))
     flips = _token_parity(logp, ref_logp, valid, 1e-3 * float(ref_logp.abs().max()), "c1 fp32")
-    if flips == 0:
-        assert toks == EO.ctc_greedy_search(ref_logp, ref_lens, 0)
+    assert flips == 0                                   # fp32: token ids are bit-exact, no margin rule
+    assert toks == EO.ctc_greedy_search(ref_logp, ref_lens, 0)
 
 
 def _bf16_headline(xs, lens, enc, ctc, conf, what):
@@ -253,6 +262,9 @@ def _bf16_headline(xs, lens, enc, ctc, conf, what):
     o, r, x = out.float().cpu()[valid], ref.float()[valid], exact[valid]
     d_ref = (o - r).abs()
     e_hip, e_ref = (o - x).abs(), (r - x).abs()
+    parity_log.record(f"headline bf16/{what}", vs_matched_oracle_max=float(d_ref.max()), vs_matched_oracle_mean=float(d_ref.mean()),
+                      hip_vs_exact_max=float(e_hip.max()), hip_vs_exact_mean=float(e_hip.mean()),
+                      oracle_bf16_vs_exact_max=float(e_ref.max()), oracle_bf16_vs_exact_mean=float(e_ref.mean()))
     print(f"[headline bf16] {what}: vs matched-precision oracle max {float(d_ref.max()):.4g} mean {float(d_ref.mean()):.4g}; "
           f"vs exact model: HIP max {float(e_hip.max()):.4g} mean {float(e_hip.mean()):.4g}, oracle-bf16 max "
           f"{float(e_ref.max()):.4g} mean {float(e_ref.mean()):.4g}")
@@ -275,6 +287,7 @@ def _bf16_headline(xs, lens, enc, ctc, conf, what):
     ex_top = exact_logp.argmax(-1)
     fer_hip = float(((logp.float().cpu().argmax(-1) != ex_top) & valid).sum()) / float(valid.sum())
     fer_ref = float(((ref_logp.float().argmax(-1) != ex_top) & valid).sum()) / float(valid.sum())
+    parity_log.record(f"headline bf16/{what}", frame_error_vs_exact_hip=fer_hip, frame_error_vs_exact_oracle_bf16=fer_ref)
     print(f"[headline bf16] {what}: frames whose token differs from the exact model's: HIP {fer_hip:.4f}, oracle-bf16 {fer_ref:.4f}")
     assert fer_hip <= fer_ref + 0.02
 
@@ -310,6 +323,25 @@ def test_headline_bf16_bidirectional_full_size_c2_batch_vs_oracle(hip):
     _bf16_headline(xs, lens, enc, ctc, conf, "full-size 12-layer, c2-shaped ragged B=8")
 
 
+def test_headline_bf16_full_size_five_minute_file_vs_oracle(hip):
+    """A 5-minute file (T = 30 000 frames, T' = 7 499) as ONE sequence through the bench's model and precision: the whole
+    fused encoder + CTC head vs the matched-precision oracle and the exact model, element-wise and by token (the long-T
+    whole-encoder comparison; the 30-minute shape itself is covered kernel by kernel in test_wkv6_gpu / test_fused_gpu)."""
+    import bench
+    from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    conf = bench.encoder_conf()
+    torch.manual_seed(777)
+    enc = ConformerEncoder(80, **conf).eval()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.02)
+    ctc = CTC(200, 512).eval()
+    xs = synth.randn((1, 30000, 80), 904, 2.0)
+    _bf16_headline(xs, torch.tensor([30000]), enc, ctc, conf, "full-size 12-layer, 5-minute file as one sequence")
+
+
 def test_bf16slot_full_size_vs_oracle(hip):
     """The YAML-default precision (fp32 model, bf16 slot returning fp32 -- what the reference CAN run) at full size on
     the same ragged batch: HIP fused path vs the oracle, bf16-inside tolerance, token rule as above."""
@@ -336,6 +368,7 @@ def test_bf16slot_full_size_vs_oracle(hip):
     assert out.dtype == torch.float32 and torch.equal(masks.cpu(), ref_masks)
     valid = ref_masks.squeeze(1)
     d = (out.cpu()[valid] - ref[valid]).abs()
+    parity_log.record("bf16slot full size", max_abs_err=float(d.max()), mean_abs_err=float(d.mean()))
     print(f"[bf16slot full size] max {float(d.max()):.4g} mean {float(d.mean()):.4g}")
     assert float(d.mean()) <= 1.5e-2 and float(d.max()) <= 0.4      # 24 bf16 slots deep (2-layer goldens: 6e-3 / 0.1)
     _token_parity(logp, ref_logp, valid, 0.5, "bf16slot full size")

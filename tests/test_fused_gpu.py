@@ -607,3 +607,52 @@ def test_gemm_phase_pipelined_glu(hip, tile_n, M, N, K):
     torch.testing.assert_close(got.cpu().float(), want, rtol=2 ** -7, atol=2e-2)
 
 
+
+
+@pytest.mark.parametrize("K,N,Z,act,res,name", [
+    (512, 2048, 1, "silu", False, "ffn w_1 + SiLU"), (2048, 512, 1, "none", True, "ffn w_2 + residual"),
+    (512, 1024, 1, "glu", False, "pointwise_conv1 + GLU"), (512, 512, 1, "none", True, "pointwise_conv2 + residual"),
+    (1024, 512, 1, "none", True, "slot output + residual"), (512, 512, 6, "none", False, "r,k,v stack"),
+    (512, 5000, 1, "none", False, "CTC head")])
+def test_gemm_at_the_production_shape(hip, K, N, Z, act, res, name):
+    """The dispatching entry point (pafc_gemm_bf16 -> the phase-pipelined kernel) at the bench's row count, M = 44 998
+    (176 row tiles, tile_m balancing, the descriptor extents), element-wise against an fp32 product of the same bf16
+    operands computed on the GPU: every layer shape of the 30-minute pass and the CTC head."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_bf16, gemm_glu_half, glu_interleave
+    from tests import parity_log
+    M, bf, dev = 44998, torch.bfloat16, "cuda"
+    g = torch.Generator(device=dev).manual_seed(1234 + K + N)
+    shp = (lambda *s: (Z, *s)) if Z > 1 else (lambda *s: s)
+    a = torch.randn(shp(M, K), device=dev, generator=g).to(bf)
+    w = (torch.randn(shp(N, K), device=dev, generator=g) / K ** 0.5).to(bf)
+    b = None if Z > 1 else (torch.randn(N, device=dev, generator=g) * 0.3).to(bf)
+    r = torch.randn(shp(M, N), device=dev, generator=g).to(bf) if res else None
+    lin = torch.matmul(a.float(), w.float().transpose(-1, -2))
+    if b is not None:
+        lin = lin + b.float()
+    alpha = 0.5 if res else 1.0
+    if act == "glu":
+        half = gemm_glu_half(M, N, K)
+        got = gemm_bf16(a, glu_interleave(w, half), glu_interleave(b, half), act="glu")
+        want = F.glu(lin, dim=-1)
+    elif res:
+        wb = alpha * (lin - (b.float() if b is not None else 0)) + (b.float() if b is not None else 0) + r.float()
+        got = gemm_bf16(a, w, b, "none", alpha=alpha, residual=r)
+        want = wb
+    else:
+        got = gemm_bf16(a, w, b, act)
+        want = {"none": lambda t: t, "silu": F.silu}[act](lin)
+    assert got.shape == want.shape and got.dtype == bf
+    d = (got.float() - want).abs()
+    tol = 2 ** -7 * want.abs() + 2e-2
+    parity_log.record(f"gemm M=44998/{name}", max_abs_err=float(d.max()), mean_abs_err=float(d.mean()),
+                      worst_err_over_tol=float((d / tol).max()), want_abs_max=float(want.abs().max()))
+    assert bool((d <= tol).all()), (name, float(d.max()))
+    # the last row tile is ragged (44 998 = 175 * 256 + 198): nothing may be written past the matrix
+    if res:
+        buf = torch.cat([r.reshape(-1, N), torch.full((64, N), 7.0, device=dev, dtype=bf)]) if Z == 1 else None
+        if buf is not None:
+            view = buf[:M]
+            gemm_bf16(a, w, b, "none", alpha=alpha, residual=view, out=view)
+            assert bool((buf[M:] == 7.0).all())
+            torch.testing.assert_close(view, got)
