@@ -1,31 +1,45 @@
-// The long-form projections as a phase-pipelined bf16 GEMM (gfx950): 256 x BN tiles, 8 waves, K-step 64.
+// The long-form projections as a phase-pipelined bf16 GEMM (gfx950): 256 x 256 tiles, 8 waves, K-step 64.
 // C ABI: include/pafc_encoder_ops.h: pafc_gemm_bf16 dispatches here for large problems (see gemm_bf16.hip for the
-// 128 x 128 kernel that keeps the small and oddly shaped ones).
+// 128 x 128 kernel that keeps the small and oddly shaped ones); pafc_gemm_ph_ex is the general entry point.
 //
 //   out[z][m][n] = act(alpha * sum_k A[z][m][k] * W[z][n][k] + bias[z][n] + residual[z][m][n])
 // nn.Linear (weight (N, K), K contiguous) with bias, SiLU / tanh / ReLU / GLU, ff_scale and the residual add applied to
 // the fp32 accumulator before the single rounding: the FFN, 1x1-conv, r/k/v and output projections of
 // ConformerEncoderLayer, ConvolutionModule and RWKV_Tmix_x060c (wenet/transformer/positionwise_feed_forward.py:47-55,
-// convolution.py:118-141, rwkv_v6/src/model.py:286-324, encoder_layer.py:201-259) at the 30-minute shape (44 998 rows),
-// where the library's kernels ran at 25-39 % of the matrix peak (round-1 review).
+// convolution.py:118-141, rwkv_v6/src/model.py:286-324, encoder_layer.py:201-259) at the 30-minute shape (44 998 rows).
 //
 // Why this structure.  With one 512-thread block per CU every SIMD hosts two waves.  The two waves of a SIMD run the SAME
 // program one barrier apart (waves 4-7 take one extra barrier at the start): while one multiplies (16 MFMAs = 256 cycles of
 // the SIMD's matrix pipe) the other reads its next operand fragments from LDS and issues the block's next LDS-DMA piece,
-// then they swap.  A K-step of a wave is four such phases, one per quadrant of its 128 x (BN / 4) output.
+// then they swap.  A K-step of a wave is four such phases, one per quadrant of its 128 x 64 output.
 //
-// LDS holds two K-steps (2 x 64 KiB at BN = 256), each cut into four UNITS by the phase in which they are read:
+// LDS holds two K-steps (2 x 64 KiB), each cut into four UNITS by the phase in which they are read:
 //   A_m0 (the first 64 rows of every wave's 128; read in phase 1)   B_n0 (first half of every wave's columns; phase 1)
 //   B_n1 (second half of the columns; phase 2)                       A_m1 (the other 64 rows; phase 3)
 // A unit is dead two phases after its read phase, so it is re-filled for the K-step after next right then: every phase issues
-// exactly one unit (2 LDS-DMA instructions per thread at BN = 256), four to six phases (1 000+ cycles) ahead of its use, and
-// waits only `vmcnt(8)` -- the unit issued four phases ago -- never vmcnt(0).  Barriers are raw s_barrier (a
-// __syncthreads() would drain the DMA queue); the XOR swizzle of the 16-byte chunks sits on the SOURCE address, the LDS
-// image is lane-linear, and the fragment reads apply the same XOR (conflict-free ds_read_b128).
+// exactly one unit (2 LDS-DMA instructions per thread), four to six phases (1 000+ cycles) ahead of its use, and waits only
+// `vmcnt(8)` -- the unit issued four phases ago -- never vmcnt(0).  Barriers are raw s_barrier (a __syncthreads() would
+// drain the DMA queue); the XOR swizzle of the 16-byte chunks sits on the SOURCE address, the LDS image is lane-linear, and
+// the fragment reads apply the same XOR (conflict-free ds_read_b128).
 //
-// The product is formed transposed (W fragment as the first MFMA operand): a lane then owns 4 CONSECUTIVE output columns of
-// one row, so the epilogue packs 8-byte pieces into a swizzled [256][BN] bf16 image in LDS (in place over the residual
-// tile, which arrives by LDS-DMA) and the tile leaves as whole 512-byte rows.
+// Round 3: the epilogue leaves from registers.  The product is formed transposed (W fragment as the first MFMA operand), so
+// a lane owns 4 consecutive output columns of one row per accumulator; the weight rows of a wave's column half are dealt to
+// the MFMA's n index so that the lane's two accumulators of a half are 8 CONSECUTIVE columns (row r of the half's LDS image
+// holds weight row (r & 15 >> 2) * 8 + (r >> 4) * 4 + (r & 3): a permutation of the LDS-DMA source rows, free): one 16-byte
+// store per row group and half, four lanes cover 64 contiguous bytes of a row.  No output image in LDS, no barrier in the
+// epilogue -- so LDS is free as soon as the K loop ends and the NEXT tile's prologue (six units = 96 KiB in flight) is issued
+// before this tile's epilogue arithmetic: a K = 512 tile used to spend 6 500 cycles waiting for its first operands and
+// 10 500 cycles in its epilogue (profiles/r02a_gemm_ph_cycle_stamps.log), the two now overlap.  A bf16 residual still arrives
+// by LDS-DMA in the staging slots the last two K-steps leave empty and is read back from LDS per lane; an fp32 residual
+// (fp32 models) is loaded to registers.  Output bf16, fp32, or fp32 as two bf16 planes hi | lo (the split-operand form the
+// next GEMM of an fp32 model reads as ITS A operand, see below).
+//
+// fp32 activations on the bf16 matrix cores (fp32 models; the reference's default precision is an fp32 model around the bf16
+// slot, rwkv_wrapper_bidirectional.py:40-56): x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 significant bits), the
+// same for the weight, and x w = hi_x hi_w + lo_x hi_w + hi_x lo_w (+ 2^-16 relative).  As a GEMM: A stored as [hi | lo]
+// (M x 2K), W' = [hi_w | hi_w | lo_w] (N x 3K), and the K walk of A wraps back to column 0 after 2K (`a_wrap`): three
+// bf16 products on the fast path instead of one fp32 product at 1/16 of the rate.
+#include <climits>
 #include <type_traits>
 
 #include "pafc_common.h"
@@ -36,18 +50,23 @@ namespace {
 
 typedef float f32x4p __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8p __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
 
 struct PhParams {
-    const bf16_t *A, *W, *bias, *res;
-    bf16_t *out;
+    const bf16_t *A, *W;
+    const void *bias;                 // bf16 (OUT 0) or fp32 (OUT 1, 2)
+    const void *res;                  // bf16 (RES 1) or fp32 (RES 2)
+    void *out;                        // bf16 / fp32 / bf16 planes hi | lo
     long M;
-    int N, K;
-    long lda, ldw, ldo, ldr;          // row strides (elements)
+    int N, K;                         // K = columns walked by the K loop (3 x the logical K for a split-operand A)
+    long lda, ldw, ldo, ldr;          // row strides (elements of the respective type)
     long sA, sW, sO, sB, sR;          // batch strides (elements); sB = 0 shares the bias
     float alpha;
     int mtiles, ntiles;
     int tm;                           // rows per tile actually used: 256, 192, 128 or 64 (balances the grid over the CUs)
     int batch;
+    int a_wrap;                       // K-step at which the walk over A's columns starts again at 0 (INT_MAX: never)
+    long lo_off;                      // OUT 2: column offset of the lo plane inside an output row
     // implicit-GEMM mode (CONV): A is an NHWC image (B, T1, F1, Ci), row m = output position (b, t2, f2) of a 3 x 3 stride-2
     // convolution, K = 9 taps x Ci; W is (9, N, Ci) tap-major.  K-step kt = (tap, 64-channel slice).
     int T1, F1, T2, F2, Ci, kshift;   // kshift = log2(Ci / 64)
@@ -95,23 +114,33 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-constexpr int PBM = 256, PBK = 64;
+constexpr int PBM = 256, PBN = 256, PBK = 64;
+constexpr unsigned PH_OOB = 0xC0000000u;       // a byte offset beyond every descriptor: the hardware drops the access
 
-// EPI: 0 plain, 1 residual, 2 GLU (weight rows in blocks of 64 = 32 values + the 32 gates of the same channels: a wave's
-// 64 columns are one block, its column half 0 the values and half 1 the gates; the output has N / 2 columns)
-// ACT: 0 none, 1 SiLU, 2 tanh, 3 ReLU (EPI 0 only).  CONV: the second subsampling convolution as an implicit GEMM.
-template <int BN, int EPI, int ACT, bool CONV = false>
+// GLU: weight rows in blocks of 64 = 32 values + the 32 gates of the same channels (a wave's 64 columns are one block, its
+//      column half 0 the values and half 1 the gates; the output has N / 2 columns).
+// ACT: 0 none, 1 SiLU, 2 tanh, 3 ReLU (not with GLU or a residual).
+// RES: 0 none, 1 bf16 residual (through LDS, hidden in the K loop's tail), 2 fp32 residual (registers).
+// OUT: 0 bf16, 1 fp32, 2 fp32 as bf16 planes hi | lo.  With OUT != 0 the bias is fp32.
+// CONV: the second subsampling convolution as an implicit GEMM.
+template <bool GLU, int ACT, int RES, int OUT, bool CONV = false>
 __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
+    constexpr int BN = PBN;
     constexpr int UA = 128 * 128;                 // bytes of an A unit: 128 rows x 64 k
     constexpr int UB = (BN / 2) * 128;            // bytes of a B unit
     constexpr int STEP = 2 * UA + 2 * UB;         // one K-step in LDS
     constexpr int OFF_A0 = 0, OFF_A1 = UA, OFF_B0 = 2 * UA, OFF_B1 = 2 * UA + UB;
-    constexpr int WN = BN / 4;                    // columns per wave
-    constexpr int TN = WN / 32;                   // 16-column tiles per column half (2 at BN = 256, 1 at BN = 128)
+    constexpr int TN = 2;                         // 16-column tiles per column half
     constexpr int DA = UA / 8192;                 // LDS-DMA instructions per thread for an A unit (2)
-    constexpr int DB = UB / 8192;                 // ... for a B unit (2 / 1)
-    constexpr int NST = (PBM * (EPI == 2 ? BN / 2 : BN) * 2 / 16) / 512;    // output stores per thread and tile (16 / 8 / 4)
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // 2 x STEP; reused by the epilogue
+    constexpr int DB = UB / 8192;                 // ... for a B unit (2)
+    constexpr int OSZ = OUT == 1 ? 4 : 2;         // bytes per stored element
+    constexpr bool BIASF32 = OUT != 0;
+    // 16-byte stores per lane and tile, ALWAYS issued (rows / columns outside the matrix go to an out-of-range offset): the
+    // counted waits of the next tile's first K-step rely on the exact number
+    constexpr int NST = 8 * (GLU ? 1 : 2) * (OUT == 0 ? 1 : 2);
+    static_assert(!(GLU && (ACT != 0 || RES != 0)), "GLU excludes an activation and a residual");
+    static_assert(!(RES != 0 && ACT != 0), "the layer never pairs a residual with an activation");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // 2 x STEP
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,49 +150,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     const long nblk = (long)p.mtiles * p.ntiles;
     const long total = nblk * p.batch;
     const long per = total / 8;
-    // The output of a tile leaves LDS for registers at the end of its epilogue and goes to memory only AFTER the next tile's
-    // prologue DMA has been issued: the stores then drain under that tile's first K-step instead of in front of it.
-    constexpr int CPO = (EPI == 2 ? BN / 2 : BN) * 2 / 16;                  // output chunks per row
-    bool st_pending = false;
-    uint4 img[NST];
-    long pm0 = 0;
-    int pn0 = 0, pvr = 0, pz = 0;
-    typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
-    auto flush_stores = [&]() {
-        // branch-free through a buffer descriptor: a chunk outside the tile's valid rows / the matrix's columns gets an offset
-        // beyond the descriptor's extent, and the hardware drops the store
-        // (the descriptor starts at the tile's first row: offsets stay small whatever the size of the output)
-        const int ncol = EPI == 2 ? p.N / 2 : p.N;
-        const __amdgpu_buffer_rsrc_t Or = make_rsrc(p.out + pz * p.sO + pm0 * p.ldo, ((p.M - 1 - pm0) * p.ldo + ncol) * 2);
-        int stid = tid;
-        asm volatile("" : "+v"(stid));
-#pragma unroll
-        for (int q = 0; q < NST; ++q) {
-            const int idx = q * 512 + stid;
-            const int row = idx / CPO, pc = idx % CPO;
-            const int c = pc ^ (row & (EPI == 2 ? 7 : 15));
-            const int col = (EPI == 2 ? pn0 / 2 : pn0) + c * 8;
-            const bool ok = row < pvr && col < ncol;
-            const unsigned off = ok ? (unsigned)(((long)row * p.ldo + col) * 2) : 0xC0000000u;
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4p{img[q].x, img[q].y, img[q].z, img[q].w}, Or, off, 0, 0);
-        }
-    };
-    for (long t = blockIdx.x; t < total; t += gridDim.x) {
-    long tt = t;
-    if (tt < per * 8) tt = (tt % 8) * per + tt / 8;
-    const int z = (int)(tt / nblk);
-    const long bid = tt % nblk;
-    const int mt0 = (int)(bid / p.ntiles), nt0 = (int)(bid % p.ntiles);
-    const long m0 = (long)mt0 * p.tm;
-    const int n0 = nt0 * BN;
-#ifdef PH_STAMPS
-    const bool stamp_on = (wave == 0 || wave == 4) && lane == 0 && z == 0;
-    unsigned long long *st = p.stamps + ((size_t)t * 2 + (wave >> 2)) * 64;
-    PH_STAMP(0);
-#endif
-    const int vr = (int)min((long)p.tm, p.M - m0);       // valid rows of this tile
-    const int nrt = (vr + 15) >> 4;                       // ... in 16-row tiles (epilogue) ...
-    const bool half_on[2] = {wr * 128 < vr, wr * 128 + 64 < vr};   // ... and which 64-row halves of this wave multiply at all
+    const int nt = p.K / PBK;                     // K-steps per tile, >= 2 (checked on the host)
 
     // ---- LDS-DMA sources: lane (sub = lane >> 3, pch = lane & 7) fills LDS chunk pch of row `sub` of its 8-row piece with
     //      source chunk pch ^ sub; unit row u = (wave * D + j) * 8 + sub
@@ -176,29 +163,64 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         const long t2 = rem / p.F2, f2 = rem - t2 * p.F2;
         return (((bb * p.T1 + 2 * t2) * p.F1 + 2 * f2) * p.Ci) * 2;
     };
-    const long a_base = CONV ? pix_off(m0) : 0;
-    const long a_bytes = CONV ? p.in_bytes - a_base : ((p.M - 1) * p.lda + p.K) * 2;
-    const __amdgpu_buffer_rsrc_t Ar = make_rsrc(reinterpret_cast<const unsigned char *>(p.A + z * p.sA) + a_base, a_bytes);
-    const __amdgpu_buffer_rsrc_t Wr = make_rsrc(p.W + z * p.sW, CONV ? (long)9 * p.N * p.Ci * 2 : ((long)(p.N - 1) * p.ldw + p.K) * 2);
+
+    // ---- the tile this block works on (set by setup(); while a tile's epilogue runs these already describe the next one)
+    long m0 = 0;
+    int n0 = 0, z = 0, vr = 0;
+    bool half_on[2] = {false, false};             // which 64-row halves of this wave multiply at all
+    __amdgpu_buffer_rsrc_t Ar = make_rsrc(p.A, 0), Wr = make_rsrc(p.W, 0);
     unsigned a_off[2][DA], b_off[2][DB];          // byte offsets of this lane's 16-byte source chunks (K-step 0)
+    uint4 bq[2][BIASF32 ? 2 : 1];                 // bias of the lane's 8 consecutive columns per column half
+    auto setup = [&](long t) {
+        long tt = t;
+        if (tt < per * 8) tt = (tt % 8) * per + tt / 8;
+        z = (int)(tt / nblk);
+        const long bid = tt % nblk;
+        const int mt0 = (int)(bid / p.ntiles), nt0 = (int)(bid % p.ntiles);
+        m0 = (long)mt0 * p.tm;
+        n0 = nt0 * BN;
+        vr = (int)min((long)p.tm, p.M - m0);     // valid rows of this tile
+        half_on[0] = wr * 128 < vr;
+        half_on[1] = wr * 128 + 64 < vr;
+        const long a_base = CONV ? pix_off(m0) : 0;
+        const long a_bytes = CONV ? p.in_bytes - a_base : ((p.M - 1) * p.lda + (p.a_wrap == INT_MAX ? p.K : p.a_wrap * PBK)) * 2;
+        Ar = make_rsrc(reinterpret_cast<const unsigned char *>(p.A + z * p.sA) + a_base, a_bytes);
+        Wr = make_rsrc(p.W + z * p.sW, CONV ? (long)9 * p.N * p.Ci * 2 : ((long)(p.N - 1) * p.ldw + p.K) * 2);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int j = 0; j < DA; ++j) {
-            const int u = (wave * DA + j) * 8 + sub;                         // 0..127: wave-row group u >> 6, row u & 63
-            const long m = m0 + min((u >> 6) * 128 + h * 64 + (u & 63), vr - 1);   // clamp: loaded, never stored
-            a_off[h][j] = CONV ? (unsigned)(pix_off(m) - a_base + 16 * (pch ^ sub)) : (unsigned)(m * p.lda * 2 + 16 * (pch ^ sub));
+            for (int j = 0; j < DA; ++j) {
+                const int u = (wave * DA + j) * 8 + sub;                         // 0..127: wave-row group u >> 6, row u & 63
+                const long m = m0 + min((u >> 6) * 128 + h * 64 + (u & 63), vr - 1);   // clamp: loaded, never stored
+                a_off[h][j] = CONV ? (unsigned)(pix_off(m) - a_base + 16 * (pch ^ sub)) : (unsigned)(m * p.lda * 2 + 16 * (pch ^ sub));
+            }
+#pragma unroll
+            for (int j = 0; j < DB; ++j) {
+                const int u = (wave * DB + j) * 8 + sub;                         // 0..127: wave column group u >> 5, row u & 31
+                const int r = u & 31;                                            // MFMA tile r >> 4, its n index r & 15
+                const int pc = ((r & 15) >> 2) * 8 + (r >> 4) * 4 + (r & 3);     // -> column inside the half (see the head comment)
+                const int n = min(n0 + (u >> 5) * 64 + h * 32 + pc, p.N - 1);
+                b_off[h][j] = (unsigned)((long)n * (CONV ? p.Ci : p.ldw) * 2 + 16 * (pch ^ sub));
+            }
         }
+        // this lane's bias values as they lie in memory: 8 consecutive columns per column half; fetched here so that their
+        // latency is hidden by the main loop, not paid at the start of the epilogue
 #pragma unroll
-        for (int j = 0; j < DB; ++j) {
-            const int u = (wave * DB + j) * 8 + sub;                         // 0..BN/2-1: wave column u / (WN/2)
-            const int n = min(n0 + (u / (WN / 2)) * WN + h * (WN / 2) + (u % (WN / 2)), p.N - 1);
-            b_off[h][j] = (unsigned)((long)n * (CONV ? p.Ci : p.ldw) * 2 + 16 * (pch ^ sub));
+        for (int nj = 0; nj < 2; ++nj) {
+            const int n = min(n0 + wc * 64 + nj * 32 + 8 * (lane >> 4), p.N - 8);
+            if constexpr (BIASF32) {
+                const float *bz = p.bias ? reinterpret_cast<const float *>(p.bias) + z * p.sB : nullptr;
+                bq[nj][0] = bz ? *reinterpret_cast<const uint4 *>(bz + n) : uint4{0u, 0u, 0u, 0u};
+                bq[nj][1] = bz ? *reinterpret_cast<const uint4 *>(bz + n + 4) : uint4{0u, 0u, 0u, 0u};
+            } else {
+                const bf16_t *bz = p.bias ? reinterpret_cast<const bf16_t *>(p.bias) + z * p.sB : nullptr;
+                bq[nj][0] = bz ? *reinterpret_cast<const uint4 *>(bz + n) : uint4{0u, 0u, 0u, 0u};
+            }
         }
-    }
+    };
     // wave-uniform byte offset of K-step kt inside a row of A / W
     auto a_soff = [&](int kt) -> unsigned {
-        if constexpr (!CONV) return kt * 128;
+        if constexpr (!CONV) return (unsigned)(kt >= p.a_wrap ? kt - p.a_wrap : kt) * 128;
         const int tap = kt >> p.kshift, kc = kt - (tap << p.kshift);
         const int dt = (tap * 11) >> 5, df = tap - 3 * dt;                  // tap / 3, tap % 3 for tap < 9
         return (unsigned)(((dt * p.F1 + df) * p.Ci) * 2 + kc * 128);
@@ -225,36 +247,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
             dma16(Wr, b_off[h][j], w_soff(kt), lds + buf * STEP + (h ? OFF_B1 : OFF_B0) + (wave * DB + j) * 1024);
     };
 
-    // this lane's bias values, packed as they lie in memory: 4 consecutive columns per (column half, tile); fetched here so
-    // that their latency is hidden by the main loop, not paid at the start of the epilogue
-    const bf16_t *bz = p.bias ? p.bias + z * p.sB : nullptr;
-    uint2 bq[2][BN / 128];
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-        for (int j = 0; j < BN / 128; ++j) {
-            const int n = min(n0 + (wave & 3) * (BN / 4) + nj * (BN / 8) + j * 16 + 4 * (lane >> 4), p.N - 4);
-            bq[nj][j] = bz ? *reinterpret_cast<const uint2 *>(bz + n) : uint2{0u, 0u};
-        }
-
     // ---- fragment read addresses: row fr of a 16-row tile, k chunk (ks * 4 + kq) ^ (row & 7); (row & 7) == (fr & 7)
     const int fr = lane & 15, kq = lane >> 4;
     const unsigned frag = fr * 128 + ((kq ^ (fr & 7)) * 16);                 // ks = 1 flips bit 6
     const unsigned la = wr * (64 * 128) + frag;                              // + i * 2048 inside a unit
-    const unsigned lb = wc * ((WN / 2) * 128) + frag;                        // + j * 2048
-
-    f32x4p acc[2][2][4][TN];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[a][b][i][j] = f32x4p{0.f, 0.f, 0.f, 0.f};
+    const unsigned lb = wc * (32 * 128) + frag;                              // + j * 2048
 
     bf16x8p af[4][2], bf0[TN][2], bf1[TN][2];
-
     auto read_a = [&](int h, int buf) {
 #ifdef PH_ABL_NOREAD
         return;
@@ -277,33 +276,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
             dst[j][1] = *reinterpret_cast<const bf16x8p *>(base + (lb ^ 64) + j * 2048);
         }
     };
-    auto mma = [&](int mi, int nj, const bf16x8p (&bq)[TN][2]) {
-        __builtin_amdgcn_s_setprio(1);
-#ifdef PH_ABL_NOMFMA
-        if (false) {
-#else
-        if (half_on[mi]) {   // wave-uniform, one branch per phase: a 64-row half beyond the tile's rows costs nothing
-#endif
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)   // transposed product: D[n][m], a lane owns 4 consecutive n of one m
-                        acc[mi][nj][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j][ks], af[i][ks], acc[mi][nj][i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_s_setprio(0);
-    };
 
-    const int nt = p.K / PBK;                    // >= 2 (checked on the host)
-
-    // EPI 1 at BN = 256: the output image [256][512 B] is exactly the two K-step buffers, and a 16 KiB unit region is 32 image
-    // rows.  The staging slots the last two K-steps would leave empty (their units belong to K-steps that do not exist) carry
-    // the RESIDUAL rows of the regions they would have filled -- same regions, same phases, so the same hazards are already
+    // RES 1: the residual tile [256][512 B] is exactly the two K-step buffers, and a 16 KiB unit region is 32 rows of it.  The
+    // staging slots the last two K-steps would leave empty (their units belong to K-steps that do not exist) carry the
+    // RESIDUAL rows of the regions they would have filled -- same regions, same phases, so the same hazards are already
     // covered, and every phase keeps issuing exactly one unit (the waits stay at their steady-state counts).  Six of the
     // eight regions arrive this way during the last two K-steps; only the last two are fetched after the loop.
-    constexpr bool RESPRE = EPI == 1 && BN == 256;
-    const __amdgpu_buffer_rsrc_t Rr = make_rsrc(EPI == 1 ? p.res + z * p.sR : p.A, EPI == 1 ? ((p.M - 1) * p.ldr + p.N) * 2 : 0);
+    // LDS image: 16-byte chunk c of row r at chunk position c ^ (r & 15).
+    constexpr bool RESPRE = RES == 1;
+    __amdgpu_buffer_rsrc_t Rr = make_rsrc(p.A, 0);
     auto stage_res = [&](int region) {            // region: byte offset of a 16 KiB unit region = 32 rows of the image
         int ln = lane;
         asm volatile("" : "+v"(ln));              // addresses are formed where they are used, not hoisted out of the K loop
@@ -318,13 +299,58 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         }
     };
 
+    // The six units the steady state would have in flight or landed when K-step 0 starts
+    auto issue_prologue = [&]() {
+        stage_a(0, 0, 0); stage_b(0, 0, 0); stage_b(1, 0, 0); stage_a(1, 0, 0); stage_a(0, 1, 1); stage_b(0, 1, 1);
+    };
+
+    bool st_pending = false;                      // an earlier tile's NST stores sit behind this tile's prologue units
+    setup(blockIdx.x);
+    issue_prologue();
+
+    for (long t = blockIdx.x; t < total; t += gridDim.x) {
+#ifdef PH_STAMPS
+    const bool stamp_on = (wave == 0 || wave == 4) && lane == 0 && z == 0;
+    unsigned long long *st = p.stamps + ((size_t)t * 2 + (wave >> 2)) * 64;
+    PH_STAMP(0);
+#endif
+    if constexpr (RESPRE) Rr = make_rsrc(reinterpret_cast<const bf16_t *>(p.res) + z * p.sR, ((p.M - 1) * p.ldr + p.N) * 2);
+
+    f32x4p acc[2][2][4][TN];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[a][b][i][j] = f32x4p{0.f, 0.f, 0.f, 0.f};
+
+    auto mma = [&](int mi, int nj, const bf16x8p (&bqf)[TN][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#ifdef PH_ABL_NOMFMA
+        if (false) {
+#else
+        if (half_on[mi]) {   // wave-uniform, one branch per phase: a 64-row half beyond the tile's rows costs nothing
+#endif
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)   // transposed product: D[n][m], a lane owns 4 consecutive n of one m
+                        acc[mi][nj][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bqf[j][ks], af[i][ks], acc[mi][nj][i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
     // One K-step = four phases.  `last` = K-steps after this one: the units a phase issues belong to the next K-step (phases
     // 1, 2) or to the one after (phases 3, 4), so the tail issues less and waits for less -- a wave-uniform switch around the
     // same code (no separate tail code: the accumulators keep their registers).  Wait counts = LDS-DMA instructions of the
-    // units issued in the last four phases that may still be in flight (A unit: 2 per thread; B unit: 2 at BN = 256, 1 at 128).
-    // PH_SYNC(PHASE): the counted wait of a phase, then its barrier.  Base count by (tile shape, K-steps left, phase); the
-    // first K-step of a tile that follows another one in this block adds that tile's output stores, which were issued behind
-    // the prologue units and ahead of everything the loop issues (`pend`).
+    // units issued in the last four phases that may still be in flight (2 per thread and unit).
+    // PH_SYNC(PHASE): the counted wait of a phase, then its barrier.  Base count by (K-steps left, phase); the first K-step of
+    // a tile that follows another one in this block adds that tile's output stores, which were issued behind the prologue
+    // units and ahead of everything the loop issues (`pend`).
 // Ablation switches of the diagnostic build (tools/micro/gemm_ph_stamps.cpp; results are then WRONG, only the timing means
 // something): PH_ABL_NOEND drops the closing barrier of a phase, PH_ABL_NOBAR the barrier after the counted wait, PH_ABL_NOMFMA
 // the matrix instructions, PH_ABL_NODMA the global -> LDS units, PH_ABL_NOREAD the fragment reads.
@@ -340,9 +366,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
 #endif
 #define PH_SYNC(PHASE)                                                             \
     do {                                                                           \
-        constexpr int W1c = DB == 2 ? (PHASE == 3 ? 6 : PHASE == 4 ? 4 : 8) : (PHASE == 3 ? 4 : PHASE == 4 ? 3 : 6); \
+        constexpr int W1c = PHASE == 3 ? 6 : PHASE == 4 ? 4 : 8;                   \
         constexpr int W0c = PHASE == 1 ? 2 : 0;                                    \
-        constexpr int WS = DB == 2 ? 8 : 6;                                        \
+        constexpr int WS = 8;                                                      \
         if (RESPRE || last >= 2) { if (pend) wait_vm<WS + NST>(); else wait_vm<WS>(); }        \
         else if (last == 1) { if (pend) wait_vm<W1c + NST>(); else wait_vm<W1c>(); }           \
         else { if (pend) wait_vm<W0c + NST>(); else wait_vm<W0c>(); }              \
@@ -360,70 +386,42 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         constexpr int PAR = decltype(parc)::value;
         const int last = nt - 1 - kt;
         const bool pend = st_pending && kt == 0;
-#if defined(PH_STAMPS) && defined(PH_FINE_STAMPS)   // (needs K / 64 <= 18: the indices sit above the per-K-step stamps)
-#define PH_FINE(i) do { if (stamp_on && kt == 4) st[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define PH_FINE(i) do { } while (0)
-#endif
         // phase 1: quadrant (rows 0-63, column half 0)
-        PH_FINE(20);
         read_b(0, PAR, bf0);
         read_a(0, PAR);
         if (last >= 1) stage_b(1, PAR ^ 1, kt + 1);
         else if constexpr (RESPRE) stage_res((PAR ^ 1) * STEP + OFF_B1);
-        PH_FINE(21);
         PH_SYNC(1);
-        PH_FINE(22);
         mma(0, 0, bf0);
-        PH_FINE(23);
         PH_END();
-        PH_FINE(24);
         // phase 2: (rows 0-63, column half 1)
         read_b(1, PAR, bf1);
         if (last >= 1) stage_a(1, PAR ^ 1, kt + 1);
         else if constexpr (RESPRE) stage_res((PAR ^ 1) * STEP + OFF_A1);
-        PH_FINE(25);
         PH_SYNC(2);
-        PH_FINE(26);
         mma(0, 1, bf1);
-        PH_FINE(27);
         PH_END();
-        PH_FINE(28);
         // phase 3: (rows 64-127, column half 1)
         read_a(1, PAR);
         if (last >= 2) stage_a(0, PAR, kt + 2);
         else if constexpr (RESPRE) stage_res(PAR * STEP + OFF_A0);
-        PH_FINE(29);
         PH_SYNC(3);
-        PH_FINE(30);
         mma(1, 1, bf1);
-        PH_FINE(31);
         PH_END();
-        PH_FINE(32);
         // phase 4: (rows 64-127, column half 0)
         if (last >= 2) stage_b(0, PAR, kt + 2);
         else if constexpr (RESPRE) stage_res(PAR * STEP + OFF_B0);
-        PH_FINE(33);
         PH_SYNC(4);
-        PH_FINE(34);
         mma(1, 0, bf0);
-        PH_FINE(35);
         PH_END();
-        PH_FINE(36);
-#undef PH_FINE
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    // ---- prologue: the six units the steady state would have in flight or landed when K-step 0 starts
-    stage_a(0, 0, 0); stage_b(0, 0, 0); stage_b(1, 0, 0); stage_a(1, 0, 0); stage_a(0, 1, 1); stage_b(0, 1, 1);
+    // ---- the prologue units of this tile are in flight (issued before the previous tile's epilogue, or above)
     __builtin_amdgcn_sched_barrier(0);
-    if (st_pending) {
-        flush_stores();
-        wait_vm<(DB == 2 ? 8 : 6) + NST>();
-    } else {
-        wait_vm<(DB == 2 ? 8 : 6)>();
-    }
+    if (st_pending) wait_vm<8 + NST>();
+    else wait_vm<8>();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind waves 0-3
@@ -440,118 +438,187 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
 #undef PH_END
 
     // ---- epilogue ----------------------------------------------------------------------------------------------
-    // LDS image of the output tile: [256 rows][BN bf16], 16-byte chunk c of row r stored at chunk c ^ (r & 15)
-    constexpr int ROWB = BN * 2;                  // bytes per row (512 / 256)
-    constexpr int CPR = ROWB / 16;                // chunks per row (32 / 16)
-    constexpr int ON = EPI == 2 ? BN / 2 : BN;    // output columns of the tile
+    int etid = tid;
+    asm volatile("" : "+v"(etid));               // epilogue addresses are formed here, per tile, not hoisted out of the tile loop
+    const int efr = etid & 15, ekq = (etid >> 4) & 3;
+    uint4 rres[RES == 1 ? 16 : 1];               // RES 1: this lane's residual chunks, [row group][column half]
     if constexpr (RESPRE) {
         const int b = (nt - 1) & 1;               // the last K-step's buffer: its A_m1 and B_n1 regions are still to come
         stage_res(b * STEP + OFF_A1);
         stage_res(b * STEP + OFF_B1);
         PH_WAIT(0);
         __builtin_amdgcn_s_barrier();
-    } else if constexpr (EPI == 1) {
 #pragma unroll
-        for (int q = 0; q < (PBM * CPR) / 512; ++q) {
-            const int idx = q * 512 + tid;
-            const int row = idx / CPR, pc = idx % CPR;
-            const int c = pc ^ (row & 15);
-            const long m = m0 + min(row, vr - 1);
-            const int n = min(n0 + c * 8, p.N - 8);
-            dma16(Rr, (unsigned)((m * p.ldr + n) * 2), 0, lds + (q * 512 + wave * 64) * 16);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        PH_WAIT(0);
-        __builtin_amdgcn_s_barrier();
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+                const int row = wr * 128 + g * 16 + efr;                        // g = mi * 4 + i; row & 15 == efr
+                const int cidx = wc * 8 + nj * 4 + ekq;                         // the lane's 8 columns as a chunk of the row
+                rres[g * 2 + nj] = *reinterpret_cast<const uint4 *>(lds + row * 512 + ((cidx ^ efr) * 16));
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();             // LDS belongs to the next tile from here on
     }
     PH_STAMP(51);
-    int etid = tid;
-    asm volatile("" : "+v"(etid));               // epilogue addresses are formed here, per tile, not hoisted out of the tile loop
-    const int efr = etid & 15, ekq = (etid >> 4) & 3;
-    auto bias4 = [&](const uint2 &q, float (&b)[4]) {
-        b[0] = bf16_bits_to_f32(q.x & 0xffffu); b[1] = __uint_as_float(q.x & 0xffff0000u);
-        b[2] = bf16_bits_to_f32(q.y & 0xffffu); b[3] = __uint_as_float(q.y & 0xffff0000u);
+    // this tile's coordinates and bias (the tile state is about to describe the next tile)
+    const long e_m0 = m0;
+    const int e_n0 = n0, e_vr = vr, e_z = z;
+    uint4 eb[2][BIASF32 ? 2 : 1];
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int q = 0; q < (BIASF32 ? 2 : 1); ++q) {
+            eb[nj][q] = bq[nj][q];
+            // a use HERE: the compiler's wait for these loads (issued before the K loop) lands ahead of the next prologue's
+            // LDS-DMA -- behind it, it would be a vmcnt(0) that drains the prefetch
+            asm volatile("" : "+v"(eb[nj][q].x), "+v"(eb[nj][q].y), "+v"(eb[nj][q].z), "+v"(eb[nj][q].w));
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    const long tnext = t + gridDim.x;
+    if (tnext < total) {
+        setup(tnext);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_prologue();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    PH_STAMP(52);
+
+    const int ncol = GLU ? p.N / 2 : p.N;
+    const int nrt = (e_vr + 15) >> 4;             // 16-row groups with a valid row
+    // descriptors start at the tile's first row: offsets stay small whatever the size of the tensors
+    const __amdgpu_buffer_rsrc_t Or = make_rsrc(reinterpret_cast<unsigned char *>(p.out) + (e_z * p.sO + e_m0 * p.ldo) * OSZ,
+                                                ((p.M - 1 - e_m0) * p.ldo + (OUT == 2 ? p.lo_off : 0) + ncol) * OSZ);
+    __amdgpu_buffer_rsrc_t Fr = Or;               // RES 2: the fp32 residual, same rows
+    if constexpr (RES == 2)
+        Fr = make_rsrc(reinterpret_cast<const unsigned char *>(p.res) + (e_z * p.sR + e_m0 * p.ldr) * 4,
+                       ((p.M - 1 - e_m0) * p.ldr + p.N) * 4);
+    auto unpack8 = [&](const uint4 &q, float (&f)[8]) {
+        f[0] = bf16_bits_to_f32(q.x & 0xffffu); f[1] = __uint_as_float(q.x & 0xffff0000u);
+        f[2] = bf16_bits_to_f32(q.y & 0xffffu); f[3] = __uint_as_float(q.y & 0xffff0000u);
+        f[4] = bf16_bits_to_f32(q.z & 0xffffu); f[5] = __uint_as_float(q.z & 0xffff0000u);
+        f[6] = bf16_bits_to_f32(q.w & 0xffffu); f[7] = __uint_as_float(q.w & 0xffff0000u);
+    };
+    auto bias8 = [&](int nj, float (&f)[8]) {
+        if constexpr (BIASF32) {
+            f[0] = __uint_as_float(eb[nj][0].x); f[1] = __uint_as_float(eb[nj][0].y);
+            f[2] = __uint_as_float(eb[nj][0].z); f[3] = __uint_as_float(eb[nj][0].w);
+            f[4] = __uint_as_float(eb[nj][BIASF32 ? 1 : 0].x); f[5] = __uint_as_float(eb[nj][BIASF32 ? 1 : 0].y);
+            f[6] = __uint_as_float(eb[nj][BIASF32 ? 1 : 0].z); f[7] = __uint_as_float(eb[nj][BIASF32 ? 1 : 0].w);
+        } else {
+            unpack8(eb[nj][0], f);
+        }
+    };
+    // store the lane's 8 consecutive values o[] of (row, col): bf16 one 16-byte store, fp32 two, hi | lo planes two
+    auto store8 = [&](const float (&o)[8], bool live, int row, int col) {
+        const bool ok = row < e_vr && col < ncol;
+        const unsigned off = ok ? (unsigned)(((long)row * p.ldo + col) * OSZ) : PH_OOB;
+        if constexpr (OUT == 0) {
+            u32x4p w{0u, 0u, 0u, 0u};
+            if (live) w = u32x4p{pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+            __builtin_amdgcn_raw_buffer_store_b128(w, Or, off, 0, 0);
+        } else if constexpr (OUT == 1) {
+            u32x4p w0{0u, 0u, 0u, 0u}, w1{0u, 0u, 0u, 0u};
+            if (live) {
+                w0 = u32x4p{__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+                w1 = u32x4p{__float_as_uint(o[4]), __float_as_uint(o[5]), __float_as_uint(o[6]), __float_as_uint(o[7])};
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(w0, Or, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(w1, Or, ok ? off + 16 : PH_OOB, 0, 0);
+        } else {
+            u32x4p wh{0u, 0u, 0u, 0u}, wl{0u, 0u, 0u, 0u};
+            if (live) {
+                float lo[8];
+                wh = u32x4p{pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+                float hf[8];
+                unpack8(uint4{wh.x, wh.y, wh.z, wh.w}, hf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) lo[e] = o[e] - hf[e];
+                wl = u32x4p{pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(lo[4], lo[5]), pack_bf16(lo[6], lo[7])};
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(wh, Or, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(wl, Or, ok ? off + (unsigned)(p.lo_off * 2) : PH_OOB, 0, 0);
+        }
     };
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             __builtin_amdgcn_sched_barrier(0);    // one row group at a time: keeps the epilogue's registers few
-            if (wr * 8 + mi * 4 + i >= nrt) continue;
-            const int row = wr * 128 + mi * 64 + i * 16 + efr;
+            const int g = mi * 4 + i;
+            const bool live = wr * 8 + g < nrt;   // wave-uniform: a row group beyond the tile's rows computes nothing
+            const int row = wr * 128 + g * 16 + efr;
+            if constexpr (GLU) {
+                float o[8];
+                if (live) {
+                    float bv[8], bg[8];
+                    bias8(0, bv);
+                    bias8(1, bg);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if constexpr (EPI == 2) {
-                    const int oc = wc * (WN / 2) + j * 16 + 4 * ekq;          // output column inside the tile (BN / 2 wide)
-                    float bv[4], bg[4], o[4];
-                    bias4(bq[0][j], bv);
-                    bias4(bq[1][j], bg);
+                    for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float a = fmaf(acc[mi][0][i][j][g], p.alpha, bv[g]);
-                        const float b = fmaf(acc[mi][1][i][j][g], p.alpha, bg[g]);
-                        o[g] = a * __builtin_amdgcn_rcpf(1.f + __expf(-b));
-                    }
-                    uint2 w;
-                    w.x = pack_bf16(o[0], o[1]);
-                    w.y = pack_bf16(o[2], o[3]);
-                    const int c = oc >> 3;
-                    *reinterpret_cast<uint2 *>(lds + row * (ROWB / 2) + ((c ^ (row & 7)) * 16) + ((oc >> 2) & 1) * 8) = w;
-                } else {
-#pragma unroll
-                    for (int nj = 0; nj < 2; ++nj) {
-                        const int col = wc * WN + nj * (WN / 2) + j * 16 + 4 * ekq;
-                        unsigned char *dst = lds + row * ROWB + (((col >> 3) ^ (row & 15)) * 16) + ((col >> 2) & 1) * 8;
-                        float bv[4], o[4];
-                        bias4(bq[nj][j], bv);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) o[g] = act_apply<ACT>(fmaf(acc[mi][nj][i][j][g], p.alpha, bv[g]));
-                        if constexpr (EPI == 1) {
-                            const uint2 rq = *reinterpret_cast<const uint2 *>(dst);
-                            o[0] += bf16_bits_to_f32(rq.x & 0xffffu); o[1] += __uint_as_float(rq.x & 0xffff0000u);
-                            o[2] += bf16_bits_to_f32(rq.y & 0xffffu); o[3] += __uint_as_float(rq.y & 0xffff0000u);
+                        for (int e = 0; e < 4; ++e) {
+                            const float a = fmaf(acc[mi][0][i][j][e], p.alpha, bv[j * 4 + e]);
+                            const float b = fmaf(acc[mi][1][i][j][e], p.alpha, bg[j * 4 + e]);
+                            o[j * 4 + e] = a * __builtin_amdgcn_rcpf(1.f + __expf(-b));
                         }
-                        uint2 w;
-                        w.x = pack_bf16(o[0], o[1]);
-                        w.y = pack_bf16(o[2], o[3]);
-                        *reinterpret_cast<uint2 *>(dst) = w;
+                }
+                store8(o, live, row, e_n0 / 2 + wc * 32 + ekq * 8);
+            } else {
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj) {
+                    const int col = e_n0 + wc * 64 + nj * 32 + ekq * 8;
+                    float o[8];
+                    u32x4p r0{0u, 0u, 0u, 0u}, r1{0u, 0u, 0u, 0u};
+                    if constexpr (RES == 2) {     // out-of-range rows / columns read zeros
+                        const bool ok = row < e_vr && col < p.N;
+                        const unsigned off = ok ? (unsigned)(((long)row * p.ldr + col) * 4) : PH_OOB;
+                        r0 = __builtin_amdgcn_raw_buffer_load_b128(Fr, off, 0, 0);
+                        r1 = __builtin_amdgcn_raw_buffer_load_b128(Fr, ok ? off + 16 : PH_OOB, 0, 0);
                     }
+                    if (live) {
+                        float bv[8];
+                        bias8(nj, bv);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                o[j * 4 + e] = act_apply<ACT>(fmaf(acc[mi][nj][i][j][e], p.alpha, bv[j * 4 + e]));
+                        if constexpr (RES == 1) {
+                            float rv[8];
+                            unpack8(rres[g * 2 + nj], rv);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] += rv[e];
+                        } else if constexpr (RES == 2) {
+                            o[0] += __uint_as_float(r0.x); o[1] += __uint_as_float(r0.y);
+                            o[2] += __uint_as_float(r0.z); o[3] += __uint_as_float(r0.w);
+                            o[4] += __uint_as_float(r1.x); o[5] += __uint_as_float(r1.y);
+                            o[6] += __uint_as_float(r1.z); o[7] += __uint_as_float(r1.w);
+                        }
+                    }
+                    store8(o, live, row, col);
                 }
             }
         }
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    PH_STAMP(52);
-    // the image leaves LDS for registers (the accumulators' registers are free now); after the barrier the LDS belongs to the
-    // next tile
-#pragma unroll
-    for (int q = 0; q < NST; ++q) {
-        const int idx = q * 512 + etid;
-        const int row = idx / CPO, pc = idx % CPO;
-        img[q] = *reinterpret_cast<const uint4 *>(lds + row * (CPO * 16) + pc * 16);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    pm0 = m0; pn0 = n0; pvr = vr; pz = z;
     st_pending = true;
     PH_STAMP(53);
     }   // tile loop
-    if (st_pending) flush_stores();
 }
 
-template <int BN, int EPI, int ACT, bool CONV = false>
+template <bool GLU, int ACT, int RES, int OUT, bool CONV = false>
 int launch_ph(const PhParams &p, int batch, hipStream_t s) {
-    constexpr size_t step = 2 * 128 * 128 + 2 * (BN / 2) * 128;
-    constexpr size_t lds = 2 * step > (size_t)PBM * BN * 2 ? 2 * step : (size_t)PBM * BN * 2;
-    auto kern = gemm_ph_kernel<BN, EPI, ACT, CONV>;
-    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return PAFC_ERR_LAUNCH;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        cus <= 0)
-        return PAFC_ERR_LAUNCH;
+    constexpr size_t lds = 2 * (2 * 128 * 128 + 2 * (PBN / 2) * 128);        // 128 KiB
+    auto kern = gemm_ph_kernel<GLU, ACT, RES, OUT, CONV>;
+    static bool attr_set[64];                     // per device; a racing first call sets the same attribute twice
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return PAFC_ERR_LAUNCH;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PAFC_ERR_LAUNCH;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    const int cus = device_cus();
     PhParams q = p;
     q.batch = batch;
     const long total = (long)p.mtiles * p.ntiles * batch;
@@ -563,52 +630,81 @@ int launch_ph(const PhParams &p, int batch, hipStream_t s) {
 }  // namespace
 }  // namespace pafc
 
+// The general entry point of the phase-pipelined kernel (include/pafc_encoder_ops.h).
+//   a_split != 0: A holds an fp32 operand as two bf16 planes [hi | lo] (M x 2K, lda >= 2K) and W the matching
+//                 [hi_w | hi_w | lo_w] (N x 3K, ldw >= 3K): the kernel walks 3K columns, A's wrapping after 2K.
+//   out_kind: 0 bf16, 1 fp32, 2 fp32 as bf16 planes hi | lo (lo at column offset lo_off of the same row; ldo in bf16 elements).
+//   res_kind: 0 none, 1 bf16, 2 fp32 (with res_kind 2 / out_kind != 0 the bias is fp32).
+extern "C" int pafc_gemm_ph_ex(long M, int N, int K, int batch, const void *A, long lda, long strideA, int a_split, const void *W,
+                               long ldw, long strideW, const void *bias, long strideBias, const void *residual, int res_kind,
+                               long ldr, long strideR, void *out, int out_kind, long ldo, long lo_off, long strideO, float alpha,
+                               int act, int tile_m, pafc_stream_t stream) {
+    if (!A || !W || !out) return PAFC_ERR_NULL_POINTER;
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535) return PAFC_ERR_BAD_DIMS;
+    if (act < 0 || act > 4 || out_kind < 0 || out_kind > 2 || res_kind < 0 || res_kind > 2) return PAFC_ERR_UNSUPPORTED;
+    if (!residual) res_kind = 0;
+    else if (res_kind == 0) return PAFC_ERR_BAD_DIMS;
+    const bool glu = act == 4;
+    if (tile_m < 64 || tile_m > 256 || tile_m % 64) return PAFC_ERR_UNSUPPORTED;
+    if (N % 8 || K % 64 || K < 128) return PAFC_ERR_UNSUPPORTED;
+    if (glu && (N % 256 || residual)) return PAFC_ERR_UNSUPPORTED;
+    if (residual && act != 0) return PAFC_ERR_UNSUPPORTED;      // the layer never pairs a residual with an activation
+    if (res_kind == 1 && out_kind != 0) return PAFC_ERR_UNSUPPORTED;   // a bf16 residual stream has a bf16 output
+    if (res_kind == 2 && out_kind != 1) return PAFC_ERR_UNSUPPORTED;   // an fp32 residual stream stays fp32
+    const int Kw = a_split ? 3 * K : K;                         // columns the K loop walks
+    const int No = glu ? N / 2 : N;
+    if (lda < (a_split ? 2 * K : K) || ldw < Kw || (residual && ldr < N)) return PAFC_ERR_BAD_DIMS;
+    if (out_kind == 2 ? (lo_off < No || ldo < lo_off + No) : ldo < No) return PAFC_ERR_BAD_DIMS;
+    if ((lda | ldw | strideA | strideW) % 8 || (ldo | strideO | lo_off) % 8 || (residual && ((ldr | strideR) % 8))) return PAFC_ERR_ALIGNMENT;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)bias) & 15) != 0) return PAFC_ERR_ALIGNMENT;
+    // 31-bit byte extents inside one batch entry of A / W / a bf16 residual (buffer descriptors that start at the tensor), and
+    // inside one 256-row tile of the output / fp32 residual (descriptors that start at the tile)
+    if ((double)M * lda * 2 >= 2.0e9 || (double)N * ldw * 2 >= 2.0e9 || (res_kind == 1 && (double)M * ldr * 2 >= 2.0e9))
+        return PAFC_ERR_UNSUPPORTED;
+    if ((double)256 * ldo * 4 >= 2.0e9 || (res_kind == 2 && (double)256 * ldr * 4 >= 2.0e9)) return PAFC_ERR_UNSUPPORTED;
+    pafc::PhParams p{};
+    p.A = (const pafc::bf16_t *)A; p.W = (const pafc::bf16_t *)W; p.bias = bias; p.res = residual; p.out = out;
+    p.M = M; p.N = N; p.K = Kw;
+    p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr;
+    p.sA = strideA; p.sW = strideW; p.sO = strideO; p.sB = strideBias; p.sR = strideR;
+    p.alpha = alpha;
+    p.a_wrap = a_split ? 2 * K / 64 : INT_MAX;
+    p.lo_off = lo_off;
+    p.tm = tile_m;
+    p.mtiles = (int)((M + tile_m - 1) / tile_m);
+    p.ntiles = (N + 255) / 256;
+    if ((long)p.mtiles * p.ntiles > 0x7fffffffL) return PAFC_ERR_BAD_DIMS;
+    hipStream_t s = (hipStream_t)stream;
+    if (out_kind == 0) {
+        if (glu) return pafc::launch_ph<true, 0, 0, 0>(p, batch, s);
+        if (res_kind == 1) return pafc::launch_ph<false, 0, 1, 0>(p, batch, s);
+        switch (act) {
+            case 1: return pafc::launch_ph<false, 1, 0, 0>(p, batch, s);
+            case 2: return pafc::launch_ph<false, 2, 0, 0>(p, batch, s);
+            case 3: return pafc::launch_ph<false, 3, 0, 0>(p, batch, s);
+            default: return pafc::launch_ph<false, 0, 0, 0>(p, batch, s);
+        }
+    }
+    if (out_kind == 1) {
+        if (glu) return pafc::launch_ph<true, 0, 0, 1>(p, batch, s);
+        if (res_kind == 2) return pafc::launch_ph<false, 0, 2, 1>(p, batch, s);
+        if (act == 0) return pafc::launch_ph<false, 0, 0, 1>(p, batch, s);
+        return PAFC_ERR_UNSUPPORTED;
+    }
+    if (glu || residual) return PAFC_ERR_UNSUPPORTED;           // planes: the hidden tensor of an FFN, or a plain projection
+    if (act == 1) return pafc::launch_ph<false, 1, 0, 2>(p, batch, s);
+    if (act == 0) return pafc::launch_ph<false, 0, 0, 2>(p, batch, s);
+    return PAFC_ERR_UNSUPPORTED;
+}
+
 // Same contract as pafc_gemm_bf16 (which calls this for the shapes it suits); exported for A/B measurements.
 extern "C" int pafc_gemm_bf16_ph(long M, int N, int K, int batch, const void *A, long lda, long strideA, const void *W,
                                  long ldw, long strideW, const void *bias, long strideBias, const void *residual, long ldr,
                                  long strideR, void *out, long ldo, long strideO, float alpha, int act, int tile_n,
                                  int tile_m, pafc_stream_t stream) {
-    if (!A || !W || !out) return PAFC_ERR_NULL_POINTER;
-    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535) return PAFC_ERR_BAD_DIMS;
-    if (act < 0 || act > 4) return PAFC_ERR_UNSUPPORTED;
-    const bool glu = act == 4;
-    if (tile_n != 256 && tile_n != 128) return PAFC_ERR_UNSUPPORTED;
-    if (tile_m < 64 || tile_m > 256 || tile_m % 64) return PAFC_ERR_UNSUPPORTED;
-    if (N % 8 || K % 64 || K < 128) return PAFC_ERR_UNSUPPORTED;
-    if (glu && (N % tile_n || residual)) return PAFC_ERR_UNSUPPORTED;
-    if (lda < K || ldw < K || ldo < (glu ? N / 2 : N) || (residual && ldr < N)) return PAFC_ERR_BAD_DIMS;
-    if ((lda | ldw | ldo | strideA | strideW | strideO) % 8 || (residual && ((ldr | strideR) % 8))) return PAFC_ERR_ALIGNMENT;
-    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)residual) & 15) != 0) return PAFC_ERR_ALIGNMENT;
-    // 31-bit byte extents inside one batch entry of A / W / residual (buffer descriptors)
-    if ((double)M * lda * 2 >= 2.0e9 || (double)N * ldw * 2 >= 2.0e9 || (residual && (double)M * ldr * 2 >= 2.0e9))
-        return PAFC_ERR_UNSUPPORTED;
-    pafc::PhParams p{};
-    p.A = (const pafc::bf16_t *)A; p.W = (const pafc::bf16_t *)W; p.bias = (const pafc::bf16_t *)bias;
-    p.res = (const pafc::bf16_t *)residual; p.out = (pafc::bf16_t *)out;
-    p.M = M; p.N = N; p.K = K;
-    p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr;
-    p.sA = strideA; p.sW = strideW; p.sO = strideO; p.sB = strideBias; p.sR = strideR;
-    p.alpha = alpha;
-    p.tm = tile_m;
-    p.mtiles = (int)((M + tile_m - 1) / tile_m);
-    p.ntiles = (N + tile_n - 1) / tile_n;
-    if ((long)p.mtiles * p.ntiles > 0x7fffffffL) return PAFC_ERR_BAD_DIMS;
-    hipStream_t s = (hipStream_t)stream;
-    if (residual && act != 0) return PAFC_ERR_UNSUPPORTED;      // the layer never pairs a residual with an activation
-#define PH_DISPATCH(BN)                                                        \
-    do {                                                                       \
-        if (glu) return pafc::launch_ph<BN, 2, 0>(p, batch, s);                \
-        if (residual) return pafc::launch_ph<BN, 1, 0>(p, batch, s);           \
-        switch (act) {                                                         \
-            case 1: return pafc::launch_ph<BN, 0, 1>(p, batch, s);             \
-            case 2: return pafc::launch_ph<BN, 0, 2>(p, batch, s);             \
-            case 3: return pafc::launch_ph<BN, 0, 3>(p, batch, s);             \
-            default: return pafc::launch_ph<BN, 0, 0>(p, batch, s);            \
-        }                                                                      \
-    } while (0)
-    if (tile_n == 256) PH_DISPATCH(256);
-    PH_DISPATCH(128);
-#undef PH_DISPATCH
+    if (tile_n != 256) return PAFC_ERR_UNSUPPORTED;
+    return pafc_gemm_ph_ex(M, N, K, batch, A, lda, strideA, 0, W, ldw, strideW, bias, strideBias, residual, residual ? 1 : 0, ldr,
+                           strideR, out, 0, ldo, 0, strideO, alpha, act, tile_m, stream);
 }
 
 // The second subsampling convolution, Conv2d(Ci, Co, 3, stride 2) + bias (+ ReLU) on NHWC bf16 (wenet/transformer/
@@ -620,13 +716,14 @@ extern "C" int pafc_conv3x3s2_nhwc_bf16_ph(int B, int T1, int F1, int Ci, int Co
     if (B <= 0 || T1 < 3 || F1 < 3 || Ci <= 0 || Co <= 0) return PAFC_ERR_BAD_DIMS;
     if (Ci % 64 || (Ci / 64) & (Ci / 64 - 1) || Co % 8) return PAFC_ERR_UNSUPPORTED;       // 64-channel K-steps, a power of two per tap
     if (tile_m != 256 && tile_m != 192 && tile_m != 128) return PAFC_ERR_UNSUPPORTED;
-    if ((((uintptr_t)in | (uintptr_t)w_tap_co_ci | (uintptr_t)out) & 15) != 0) return PAFC_ERR_ALIGNMENT;
+    if ((((uintptr_t)in | (uintptr_t)w_tap_co_ci | (uintptr_t)out | (uintptr_t)bias) & 15) != 0) return PAFC_ERR_ALIGNMENT;
     const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
     const long M = (long)B * T2 * F2;
     if ((double)9 * Co * Ci * 2 >= 2.0e9) return PAFC_ERR_UNSUPPORTED;
     pafc::PhParams p{};
-    p.A = (const pafc::bf16_t *)in; p.W = (const pafc::bf16_t *)w_tap_co_ci; p.bias = (const pafc::bf16_t *)bias; p.out = (pafc::bf16_t *)out;
+    p.A = (const pafc::bf16_t *)in; p.W = (const pafc::bf16_t *)w_tap_co_ci; p.bias = bias; p.out = out;
     p.M = M; p.N = Co; p.K = 9 * Ci; p.lda = Ci; p.ldw = Ci; p.ldo = Co; p.alpha = 1.f;
+    p.a_wrap = INT_MAX;
     p.T1 = T1; p.F1 = F1; p.T2 = T2; p.F2 = F2; p.Ci = Ci;
     p.in_bytes = (long)B * T1 * F1 * Ci * 2;
     int ks = 0;
@@ -636,5 +733,5 @@ extern "C" int pafc_conv3x3s2_nhwc_bf16_ph(int B, int T1, int F1, int Ci, int Co
     p.mtiles = (int)((M + tile_m - 1) / tile_m);
     p.ntiles = (Co + 255) / 256;
     hipStream_t s = (hipStream_t)stream;
-    return relu ? pafc::launch_ph<256, 0, 3, true>(p, 1, s) : pafc::launch_ph<256, 0, 0, true>(p, 1, s);
+    return relu ? pafc::launch_ph<false, 3, 0, 0, true>(p, 1, s) : pafc::launch_ph<false, 0, 0, 0, true>(p, 1, s);
 }

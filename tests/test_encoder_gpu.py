@@ -26,8 +26,9 @@ def _assert_close(got, ref, bf16_path, what="", whole_model_bf16=False):
                           mode="whole-bf16" if whole_model_bf16 else "bf16-inside" if bf16_path else "fp32")
     if whole_model_bf16:
         # every op of every layer rounds to bf16 (ulp 0.03 at |x| = 4) and CPU / GPU differ in each op's internal
-        # order, not only in the GEMMs: bound the drift at ~10 ulp max, ~0.5 ulp mean
-        assert mx <= 0.4 and mean <= 2e-2, f"{what}: max {mx:.4g} mean {mean:.4g}"
+        # order, not only in the GEMMs.  Bounds = 2 x the largest values recorded in profiles/parity_r03.json
+        # (round 3: max 0.078, mean 0.0077 over the whole-bf16 goldens)
+        assert mx <= 0.16 and mean <= 1.6e-2, f"{what}: max {mx:.4g} mean {mean:.4g}"
     elif bf16_path:
         assert mx <= 0.1 and mean <= 6e-3, f"{what}: max {mx:.4g} mean {mean:.4g}"
     else:
@@ -141,7 +142,7 @@ def test_encoder_reduced(hip, variant):
         if not bf:
             assert ours == g["greedy"]
         else:
-            flips = _token_parity(logp, glogp, masks.squeeze(1), 0.1 if not wm else 0.4, f"encoder_reduced_{variant}")
+            flips = _token_parity(logp, glogp, masks.squeeze(1), 0.07, f"encoder_reduced_{variant}")   # recorded: 0.028-0.034
             if flips == 0:
                 assert ours == g["greedy"]
 
@@ -268,14 +269,15 @@ def _bf16_headline(xs, lens, enc, ctc, conf, what):
     print(f"[headline bf16] {what}: vs matched-precision oracle max {float(d_ref.max()):.4g} mean {float(d_ref.mean()):.4g}; "
           f"vs exact model: HIP max {float(e_hip.max()):.4g} mean {float(e_hip.mean()):.4g}, oracle-bf16 max "
           f"{float(e_ref.max()):.4g} mean {float(e_ref.mean()):.4g}")
-    # matched precision: two bf16 roundings of the same O(1) graph (ulp 0.03 at |x| = 4), 12 layers deep
+    # matched precision: two bf16 roundings of the same O(1) graph (ulp 0.03 at |x| = 4), 12 layers deep.  Bounds = 2 x the
+    # values recorded in profiles/parity_r03.json (12 layers: max 0.196 / mean 0.0177; 2 layers: 0.086 / 0.0068)
     deep = conf["num_blocks"] > 2
-    assert float(d_ref.mean()) <= (4e-2 if deep else 2e-2) and float(d_ref.max()) <= (1.0 if deep else 0.4)
+    assert float(d_ref.mean()) <= (3.6e-2 if deep else 1.4e-2) and float(d_ref.max()) <= (0.4 if deep else 0.18)
     # against the exact model the HIP path is no further away than the reference's own bf16 arithmetic
     assert float(e_hip.mean()) <= 1.1 * float(e_ref.mean()) + 1e-3
     assert float(e_hip.max()) <= 1.5 * float(e_ref.max()) + 1e-2
     # tokens: flips only where the oracle itself is undecided at the measured noise
-    flips = _token_parity(logp, ref_logp, valid, 1.5 if deep else 0.6, f"{what} vs matched-precision oracle")
+    flips = _token_parity(logp, ref_logp, valid, 0.25 if deep else 0.2, f"{what} vs matched-precision oracle")   # recorded 0.125 / 0.094
     # bf16 log-probs can tie EXACTLY; which maximiser a search returns is then implementation-defined (the reference's topk(1)
     # included), so whole token lists are compared only when neither side has a tie on a valid frame
     def _tied(lp):
@@ -370,8 +372,8 @@ def test_bf16slot_full_size_vs_oracle(hip):
     d = (out.cpu()[valid] - ref[valid]).abs()
     parity_log.record("bf16slot full size", max_abs_err=float(d.max()), mean_abs_err=float(d.mean()))
     print(f"[bf16slot full size] max {float(d.max()):.4g} mean {float(d.mean()):.4g}")
-    assert float(d.mean()) <= 1.5e-2 and float(d.max()) <= 0.4      # 24 bf16 slots deep (2-layer goldens: 6e-3 / 0.1)
-    _token_parity(logp, ref_logp, valid, 0.5, "bf16slot full size")
+    assert float(d.mean()) <= 1.6e-2 and float(d.max()) <= 0.12     # 24 bf16 slots deep; 2 x the recorded 0.0078 / 0.056
+    _token_parity(logp, ref_logp, valid, 0.08, "bf16slot full size")   # recorded 0.035
 
 
 @pytest.mark.parametrize("variant", ["bf16slot", "f32", "uni_bf16slot"])
