@@ -263,11 +263,26 @@ int pafc_gemm_bf16_glu_half(long M, int N, int K, int batch);
  * tile_m 256 / 192 / 128.  PAFC_ERR_UNSUPPORTED: take the other kernel. */
 int pafc_conv3x3s2_nhwc_bf16_ph(int B, int T1, int F1, int Ci, int Co, const void *in, const void *w_tap_co_ci, const void *bias,
                                 void *out, int relu, int tile_m, pafc_stream_t stream);
-/* The phase-pipelined kernel by itself (A/B measurements, tests): tile_n 256 or 128 columns, tile_m 256 / 192 / 128 / 64 rows
- * per tile; K >= 128; a residual excludes an activation; GLU blocks are tile_n / 4 rows (h = tile_n / 8). */
+/* The phase-pipelined kernel by itself (A/B measurements, tests): tile_n = 256 columns, tile_m 256 / 192 / 128 / 64 rows
+ * per tile; K % 128 == 0; a residual excludes an activation; GLU blocks are 64 rows (h = 32). */
 int pafc_gemm_bf16_ph(long M, int N, int K, int batch, const void *A, long lda, long strideA, const void *W, long ldw,
                       long strideW, const void *bias, long strideBias, const void *residual, long ldr, long strideR,
                       void *out, long ldo, long strideO, float alpha, int act, int tile_n, int tile_m, pafc_stream_t stream);
+/* The same kernel with every operand form it takes -- what an fp32 MODEL needs to run its projections on the bf16 matrix
+ * cores (the reference's default precision is an fp32 model around the bf16 slot: rwkv_wrapper_bidirectional.py:40-56,
+ * the rwkv_do_bfloat16 key of conf/rwkv):
+ *   a_split != 0: A holds an fp32 operand x as two bf16 planes [hi | lo] (M x 2K; hi = bf16(x), lo = bf16(x - hi)) and W the
+ *                 matching [hi_w | hi_w | lo_w] (N x 3K): x w = hi hi_w + lo hi_w + hi lo_w, three bf16 products, fp32
+ *                 accumulation, ~2^-16 relative.  K is the logical K.
+ *   out_kind:     0 bf16; 1 fp32; 2 fp32 written as planes hi | lo (lo at column offset lo_off of the same row; ldo counts
+ *                 bf16 elements) -- the form the next GEMM takes as its split A.
+ *   res_kind:     0 none; 1 bf16 residual (out_kind 0); 2 fp32 residual (out_kind 1).
+ *   bias:         bf16 for out_kind 0, fp32 otherwise; strides / leading dimensions in elements of each tensor's own type.
+ * act as pafc_gemm_bf16 (GLU: h = 32); out_kind 2 takes act 0 or 1 only, out_kind 1 act 0 or GLU. */
+int pafc_gemm_ph_ex(long M, int N, int K, int batch, const void *A, long lda, long strideA, int a_split, const void *W, long ldw,
+                    long strideW, const void *bias, long strideBias, const void *residual, int res_kind, long ldr, long strideR,
+                    void *out, int out_kind, long ldo, long lo_off, long strideO, float alpha, int act, int tile_m,
+                    pafc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -255,7 +255,7 @@ extern "C" int pafc_gemm_bf16_ph(long M, int N, int K, int batch, const void *A,
 // rounds of one-tile-per-CU work, weighted by the rows a round costs plus a fixed per-tile part (prologue, epilogue) worth
 // about 64 rows (measured at the 30-minute shapes: tools/bench_gemm_tiles.py).
 static int ph_tile_m(long M, int N, int K, int batch, int act, bool has_residual) {
-    if (N % 8 || K % 64 || K < 128 || N < 256) return 0;
+    if (N % 8 || K % 128 || N < 256) return 0;              // (an even number of 64-deep K-steps: gemm_ph.hip's tile loop)
     if (act == 4 && N % 256) return 0;
     if (has_residual && act != 0) return 0;
     const int cus = pafc::device_cus();

@@ -27,12 +27,13 @@
 // the MFMA's n index so that the lane's two accumulators of a half are 8 CONSECUTIVE columns (row r of the half's LDS image
 // holds weight row (r & 15 >> 2) * 8 + (r >> 4) * 4 + (r & 3): a permutation of the LDS-DMA source rows, free): one 16-byte
 // store per row group and half, four lanes cover 64 contiguous bytes of a row.  No output image in LDS, no barrier in the
-// epilogue -- so LDS is free as soon as the K loop ends and the NEXT tile's prologue (six units = 96 KiB in flight) is issued
-// before this tile's epilogue arithmetic: a K = 512 tile used to spend 6 500 cycles waiting for its first operands and
-// 10 500 cycles in its epilogue (profiles/r02a_gemm_ph_cycle_stamps.log), the two now overlap.  A bf16 residual still arrives
-// by LDS-DMA in the staging slots the last two K-steps leave empty and is read back from LDS per lane; an fp32 residual
-// (fp32 models) is loaded to registers.  Output bf16, fp32, or fp32 as two bf16 planes hi | lo (the split-operand form the
-// next GEMM of an fp32 model reads as ITS A operand, see below).
+// epilogue -- so LDS belongs to the operands alone and the pipeline runs THROUGH the tile boundary: the staging slots the
+// last two K-steps of a tile would leave empty (their units belong to K-steps that do not exist) carry the first six units of
+// the block's NEXT tile, in the same regions and phases as in the steady state.  A K = 512 tile used to spend 6 500 cycles
+// waiting for its first operands and 10 500 cycles in its epilogue (profiles/r02a_gemm_ph_cycle_stamps.log); now the operands
+// of K-step 0 have landed long before the previous epilogue ends.  The residual (bf16 or fp32) is loaded to registers in the
+// epilogue.  Output bf16, fp32, or fp32 as two bf16 planes hi | lo (the split-operand form the next GEMM of an fp32 model
+// reads as ITS A operand, see below).
 //
 // fp32 activations on the bf16 matrix cores (fp32 models; the reference's default precision is an fp32 model around the bf16
 // slot, rwkv_wrapper_bidirectional.py:40-56): x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 significant bits), the
@@ -114,13 +115,13 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-constexpr int PBM = 256, PBN = 256, PBK = 64;
+constexpr int PBN = 256, PBK = 64;      // tile columns, K-step (tile rows: PhParams::tm <= 256)
 constexpr unsigned PH_OOB = 0xC0000000u;       // a byte offset beyond every descriptor: the hardware drops the access
 
 // GLU: weight rows in blocks of 64 = 32 values + the 32 gates of the same channels (a wave's 64 columns are one block, its
 //      column half 0 the values and half 1 the gates; the output has N / 2 columns).
 // ACT: 0 none, 1 SiLU, 2 tanh, 3 ReLU (not with GLU or a residual).
-// RES: 0 none, 1 bf16 residual (through LDS, hidden in the K loop's tail), 2 fp32 residual (registers).
+// RES: 0 none, 1 bf16 residual, 2 fp32 residual (both loaded to registers in the epilogue).
 // OUT: 0 bf16, 1 fp32, 2 fp32 as bf16 planes hi | lo.  With OUT != 0 the bias is fp32.
 // CONV: the second subsampling convolution as an implicit GEMM.
 template <bool GLU, int ACT, int RES, int OUT, bool CONV = false>
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     constexpr int NST = 8 * (GLU ? 1 : 2) * (OUT == 0 ? 1 : 2);
     static_assert(!(GLU && (ACT != 0 || RES != 0)), "GLU excludes an activation and a residual");
     static_assert(!(RES != 0 && ACT != 0), "the layer never pairs a residual with an activation");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // 2 x STEP
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // 2 x STEP + 8 x 1 KiB (bias slots)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -150,13 +151,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     const long nblk = (long)p.mtiles * p.ntiles;
     const long total = nblk * p.batch;
     const long per = total / 8;
-    const int nt = p.K / PBK;                     // K-steps per tile, >= 2 (checked on the host)
+    const int nt = p.K / PBK;                     // K-steps per tile: even, >= 2 (checked on the host)
 
-    // ---- LDS-DMA sources: lane (sub = lane >> 3, pch = lane & 7) fills LDS chunk pch of row `sub` of its 8-row piece with
-    //      source chunk pch ^ sub; unit row u = (wave * D + j) * 8 + sub
-    const int sub = lane >> 3, pch = lane & 7;
-    // CONV: input offset of output position m (its tap (0, 0) pixel); the descriptor starts at this tile's first pixel, so the
-    // 32-bit lane offsets stay small however long the recording is
+    // CONV: input offset of output position m (its tap (0, 0) pixel)
     auto pix_off = [&](long m) -> long {
         const long tf = (long)p.T2 * p.F2;
         const long bb = m / tf, rem = m - bb * tf;
@@ -164,59 +161,65 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         return (((bb * p.T1 + 2 * t2) * p.F1 + 2 * f2) * p.Ci) * 2;
     };
 
-    // ---- the tile this block works on (set by setup(); while a tile's epilogue runs these already describe the next one)
-    long m0 = 0;
-    int n0 = 0, z = 0, vr = 0;
-    bool half_on[2] = {false, false};             // which 64-row halves of this wave multiply at all
-    __amdgpu_buffer_rsrc_t Ar = make_rsrc(p.A, 0), Wr = make_rsrc(p.W, 0);
-    unsigned a_off[2][DA], b_off[2][DB];          // byte offsets of this lane's 16-byte source chunks (K-step 0)
-    uint4 bq[2][BIASF32 ? 2 : 1];                 // bias of the lane's 8 consecutive columns per column half
-    auto setup = [&](long t) {
-        long tt = t;
+    // ---- a tile = its coordinates + the buffer descriptors of its operands, all wave-uniform (SGPRs).  The descriptors START
+    //      at the tile's first row of A / first row of W, so the per-lane byte offsets of the LDS-DMA sources are the same for
+    //      every tile (formed once, below); rows beyond the matrix lie beyond the descriptor's extent and read as zeros --
+    //      loaded, never stored -- so nothing is clamped.  A descriptor of extent 0 (no next tile) turns every access into a
+    //      no-op that still counts in vmcnt: the staging code is branch-free across the last tile.
+    struct Tile {
+        long m0;
+        int n0, z, vr;
+        __amdgpu_buffer_rsrc_t Ar, Wr;
+    };
+    auto make_tile = [&](long t, Tile &T) {
+        const bool real = t < total;
+        long tt = real ? t : 0;
         if (tt < per * 8) tt = (tt % 8) * per + tt / 8;
-        z = (int)(tt / nblk);
+        T.z = (int)(tt / nblk);
         const long bid = tt % nblk;
         const int mt0 = (int)(bid / p.ntiles), nt0 = (int)(bid % p.ntiles);
-        m0 = (long)mt0 * p.tm;
-        n0 = nt0 * BN;
-        vr = (int)min((long)p.tm, p.M - m0);     // valid rows of this tile
-        half_on[0] = wr * 128 < vr;
-        half_on[1] = wr * 128 + 64 < vr;
-        const long a_base = CONV ? pix_off(m0) : 0;
-        const long a_bytes = CONV ? p.in_bytes - a_base : ((p.M - 1) * p.lda + (p.a_wrap == INT_MAX ? p.K : p.a_wrap * PBK)) * 2;
-        Ar = make_rsrc(reinterpret_cast<const unsigned char *>(p.A + z * p.sA) + a_base, a_bytes);
-        Wr = make_rsrc(p.W + z * p.sW, CONV ? (long)9 * p.N * p.Ci * 2 : ((long)(p.N - 1) * p.ldw + p.K) * 2);
+        T.m0 = (long)mt0 * p.tm;
+        T.n0 = nt0 * BN;
+        T.vr = (int)min((long)p.tm, p.M - T.m0);     // valid rows of this tile
+        if constexpr (CONV) {
+            const long a_base = pix_off(T.m0);
+            T.Ar = make_rsrc(reinterpret_cast<const unsigned char *>(p.A) + a_base, real ? p.in_bytes - a_base : 0);
+            T.Wr = make_rsrc(p.W + (long)T.n0 * p.Ci, real ? ((long)8 * p.N + p.N - T.n0) * p.Ci * 2 : 0);
+        } else {
+            const long acols = p.a_wrap == INT_MAX ? p.K : (long)p.a_wrap * PBK;
+            T.Ar = make_rsrc(p.A + T.z * p.sA + T.m0 * p.lda, real ? ((p.M - 1 - T.m0) * p.lda + acols) * 2 : 0);
+            T.Wr = make_rsrc(p.W + T.z * p.sW + (long)T.n0 * p.ldw, real ? ((long)(p.N - 1 - T.n0) * p.ldw + p.K) * 2 : 0);
+        }
+    };
+
+    // ---- LDS-DMA sources: lane (sub = lane >> 3, pch = lane & 7) fills LDS chunk pch of row `sub` of its 8-row piece with
+    //      source chunk pch ^ sub; unit row u = (wave * D + j) * 8 + sub.  Byte offsets relative to the tile's descriptors.
+    unsigned a_off[2][DA], b_off[2][DB];
+    // A offsets of one 64-row half (unit A_m0 / A_m1).  Tile-invariant for a plain GEMM (formed once); CONV: a row's pixel is
+    // not affine in the row, so they are re-formed per tile.
+    auto a_offsets = [&](const Tile &T, int h) {
+        int sl = lane;
+        asm volatile("" : "+v"(sl));
+        const int sub = sl >> 3, pch = sl & 7;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int j = 0; j < DA; ++j) {
+            const int u = (wave * DA + j) * 8 + sub;                             // 0..127: wave-row group u >> 6, row u & 63
+            const int row = (u >> 6) * 128 + h * 64 + (u & 63);
+            a_off[h][j] = CONV ? (unsigned)(pix_off(T.m0 + row) - pix_off(T.m0) + 16 * (pch ^ sub))
+                               : (unsigned)((long)row * p.lda * 2 + 16 * (pch ^ sub));
+        }
+    };
+    auto b_offsets = [&]() {
+        const int sub = lane >> 3, pch = lane & 7;
 #pragma unroll
-            for (int j = 0; j < DA; ++j) {
-                const int u = (wave * DA + j) * 8 + sub;                         // 0..127: wave-row group u >> 6, row u & 63
-                const long m = m0 + min((u >> 6) * 128 + h * 64 + (u & 63), vr - 1);   // clamp: loaded, never stored
-                a_off[h][j] = CONV ? (unsigned)(pix_off(m) - a_base + 16 * (pch ^ sub)) : (unsigned)(m * p.lda * 2 + 16 * (pch ^ sub));
-            }
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < DB; ++j) {
                 const int u = (wave * DB + j) * 8 + sub;                         // 0..127: wave column group u >> 5, row u & 31
                 const int r = u & 31;                                            // MFMA tile r >> 4, its n index r & 15
                 const int pc = ((r & 15) >> 2) * 8 + (r >> 4) * 4 + (r & 3);     // -> column inside the half (see the head comment)
-                const int n = min(n0 + (u >> 5) * 64 + h * 32 + pc, p.N - 1);
-                b_off[h][j] = (unsigned)((long)n * (CONV ? p.Ci : p.ldw) * 2 + 16 * (pch ^ sub));
+                b_off[h][j] = (unsigned)((long)((u >> 5) * 64 + h * 32 + pc) * (CONV ? p.Ci : p.ldw) * 2 + 16 * (pch ^ sub));
             }
-        }
-        // this lane's bias values as they lie in memory: 8 consecutive columns per column half; fetched here so that their
-        // latency is hidden by the main loop, not paid at the start of the epilogue
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj) {
-            const int n = min(n0 + wc * 64 + nj * 32 + 8 * (lane >> 4), p.N - 8);
-            if constexpr (BIASF32) {
-                const float *bz = p.bias ? reinterpret_cast<const float *>(p.bias) + z * p.sB : nullptr;
-                bq[nj][0] = bz ? *reinterpret_cast<const uint4 *>(bz + n) : uint4{0u, 0u, 0u, 0u};
-                bq[nj][1] = bz ? *reinterpret_cast<const uint4 *>(bz + n + 4) : uint4{0u, 0u, 0u, 0u};
-            } else {
-                const bf16_t *bz = p.bias ? reinterpret_cast<const bf16_t *>(p.bias) + z * p.sB : nullptr;
-                bq[nj][0] = bz ? *reinterpret_cast<const uint4 *>(bz + n) : uint4{0u, 0u, 0u, 0u};
-            }
-        }
     };
     // wave-uniform byte offset of K-step kt inside a row of A / W
     auto a_soff = [&](int kt) -> unsigned {
@@ -230,21 +233,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         const int tap = kt >> p.kshift, kc = kt - (tap << p.kshift);
         return (unsigned)(tap * p.N * p.Ci * 2 + kc * 128);
     };
-    auto stage_a = [&](int h, int buf, int kt) {
+    auto stage_a = [&](const Tile &T, int h, int buf, int kt) {
 #ifdef PH_ABL_NODMA
         return;
 #endif
 #pragma unroll
         for (int j = 0; j < DA; ++j)
-            dma16(Ar, a_off[h][j], a_soff(kt), lds + buf * STEP + (h ? OFF_A1 : OFF_A0) + (wave * DA + j) * 1024);
+            dma16(T.Ar, a_off[h][j], a_soff(kt), lds + buf * STEP + (h ? OFF_A1 : OFF_A0) + (wave * DA + j) * 1024);
     };
-    auto stage_b = [&](int h, int buf, int kt) {
+    auto stage_b = [&](const Tile &T, int h, int buf, int kt) {
 #ifdef PH_ABL_NODMA
         return;
 #endif
 #pragma unroll
         for (int j = 0; j < DB; ++j)
-            dma16(Wr, b_off[h][j], w_soff(kt), lds + buf * STEP + (h ? OFF_B1 : OFF_B0) + (wave * DB + j) * 1024);
+            dma16(T.Wr, b_off[h][j], w_soff(kt), lds + buf * STEP + (h ? OFF_B1 : OFF_B0) + (wave * DB + j) * 1024);
     };
 
     // ---- fragment read addresses: row fr of a 16-row tile, k chunk (ks * 4 + kq) ^ (row & 7); (row & 7) == (fr & 7)
@@ -277,44 +280,57 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         }
     };
 
-    // RES 1: the residual tile [256][512 B] is exactly the two K-step buffers, and a 16 KiB unit region is 32 rows of it.  The
-    // staging slots the last two K-steps would leave empty (their units belong to K-steps that do not exist) carry the
-    // RESIDUAL rows of the regions they would have filled -- same regions, same phases, so the same hazards are already
-    // covered, and every phase keeps issuing exactly one unit (the waits stay at their steady-state counts).  Six of the
-    // eight regions arrive this way during the last two K-steps; only the last two are fetched after the loop.
-    // LDS image: 16-byte chunk c of row r at chunk position c ^ (r & 15).
-    constexpr bool RESPRE = RES == 1;
-    __amdgpu_buffer_rsrc_t Rr = make_rsrc(p.A, 0);
-    auto stage_res = [&](int region) {            // region: byte offset of a 16 KiB unit region = 32 rows of the image
-        int ln = lane;
-        asm volatile("" : "+v"(ln));              // addresses are formed where they are used, not hoisted out of the K loop
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int off = region + (wave * 2 + j) * 1024 + ln * 16;
-            const int row = off >> 9, pc = (off >> 4) & 31;
-            const int c = pc ^ (row & 15);
-            const long m = m0 + min(row, vr - 1);
-            const int n = min(n0 + c * 8, p.N - 8);
-            dma16(Rr, (unsigned)((m * p.ldr + n) * 2), 0, lds + region + (wave * 2 + j) * 1024);
-        }
-    };
-
-    // The six units the steady state would have in flight or landed when K-step 0 starts
-    auto issue_prologue = [&]() {
-        stage_a(0, 0, 0); stage_b(0, 0, 0); stage_b(1, 0, 0); stage_a(1, 0, 0); stage_a(0, 1, 1); stage_b(0, 1, 1);
-    };
-
-    bool st_pending = false;                      // an earlier tile's NST stores sit behind this tile's prologue units
-    setup(blockIdx.x);
-    issue_prologue();
+    // ---- first tile: the six units the steady state would have in flight or landed when K-step 0 starts
+    Tile cur, nxt;
+    make_tile(blockIdx.x, cur);
+    a_offsets(cur, 0);
+    a_offsets(cur, 1);
+    b_offsets();
+    stage_a(cur, 0, 0, 0); stage_b(cur, 0, 0, 0); stage_b(cur, 1, 0, 0); stage_a(cur, 1, 0, 0);
+    stage_a(cur, 0, 1, 1); stage_b(cur, 0, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vm<8>();
+    __builtin_amdgcn_sched_barrier(0);
+    bool first = true;                            // later tiles: NST stores + the bias DMA sit between the units of K-step 0 / 1 and the loop
 
     for (long t = blockIdx.x; t < total; t += gridDim.x) {
 #ifdef PH_STAMPS
-    const bool stamp_on = (wave == 0 || wave == 4) && lane == 0 && z == 0;
+    const bool stamp_on = (wave == 0 || wave == 4) && lane == 0 && cur.z == 0;
     unsigned long long *st = p.stamps + ((size_t)t * 2 + (wave >> 2)) * 64;
     PH_STAMP(0);
 #endif
-    if constexpr (RESPRE) Rr = make_rsrc(reinterpret_cast<const bf16_t *>(p.res) + z * p.sR, ((p.M - 1) * p.ldr + p.N) * 2);
+    // the next tile of this block: its first six units ride in the staging slots the last two K-steps of THIS tile would
+    // leave empty (their units belong to K-steps that do not exist) -- same regions, same phases, so the same hazards are
+    // already covered, every phase keeps issuing exactly one unit, the waits stay at their steady-state counts and the
+    // pipeline never drains between tiles.  (K / 64 is even: K-step 0 of the next tile lands in buffer 0 again.)
+    make_tile(CONV ? total : t + gridDim.x, nxt);
+    if constexpr (CONV) {
+        // implicit GEMM: 72 K-steps per tile and A offsets that are not affine in the row (they are re-formed per tile) -- the
+        // tile boundary is not worth the registers here: no next-tile units (the empty descriptors make the tail's staging a
+        // no-op that still counts), an explicit prologue per tile instead
+        if (!first) {
+            a_offsets(cur, 0);
+            a_offsets(cur, 1);
+            stage_a(cur, 0, 0, 0); stage_b(cur, 0, 0, 0); stage_b(cur, 1, 0, 0); stage_a(cur, 1, 0, 0);
+            stage_a(cur, 0, 1, 1); stage_b(cur, 0, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vm<8>();                         // (the previous tile's stores are older: done as well)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const bool after_stores = !CONV && !first;    // the previous tile's NST stores sit between this tile's first units and the loop
+    const bool half_on[2] = {wr * 128 < cur.vr, wr * 128 + 64 < cur.vr};   // which 64-row halves of this wave multiply at all
+    // The tile's bias row (256 columns: 512 B of bf16 or 1 KiB of fp32) comes by LDS-DMA too, one instruction per wave into
+    // a slot of the wave's own behind the two K-step buffers: an LDS-DMA stays where it is written (a register load could be
+    // moved to its use by the compiler, and the first K-step's counted waits rely on the exact sequence), it holds no
+    // registers across the K loop, and the wave reads it back in its epilogue, long after the K loop's waits retired it.
+    constexpr int NBL = 1;
+    {
+        const long esz = BIASF32 ? 4 : 2;
+        const __amdgpu_buffer_rsrc_t Br = make_rsrc(reinterpret_cast<const unsigned char *>(p.bias) + ((long)cur.z * p.sB + cur.n0) * esz,
+                                                    p.bias ? (long)(p.N - cur.n0) * esz : 0);
+        dma16(Br, lane * 16, 0, lds + 2 * STEP + wave * 1024);
+    }
 
     f32x4p acc[2][2][4][TN];
 #pragma unroll
@@ -344,13 +360,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         __builtin_amdgcn_s_setprio(0);
     };
 
-    // One K-step = four phases.  `last` = K-steps after this one: the units a phase issues belong to the next K-step (phases
-    // 1, 2) or to the one after (phases 3, 4), so the tail issues less and waits for less -- a wave-uniform switch around the
-    // same code (no separate tail code: the accumulators keep their registers).  Wait counts = LDS-DMA instructions of the
-    // units issued in the last four phases that may still be in flight (2 per thread and unit).
-    // PH_SYNC(PHASE): the counted wait of a phase, then its barrier.  Base count by (K-steps left, phase); the first K-step of
-    // a tile that follows another one in this block adds that tile's output stores, which were issued behind the prologue
-    // units and ahead of everything the loop issues (`pend`).
+    // One K-step = four phases; every phase issues one unit and waits `vmcnt(8)`: everything but the four units issued last
+    // has landed (2 LDS-DMA instructions per thread and unit).  The units a phase issues belong to the next K-step (phases 1,
+    // 2) or to the one after (phases 3, 4) -- of this tile, or, in the last two K-steps, of the next one.  In the first
+    // K-step of a tile that follows another one, the previous tile's NST output stores and this tile's bias DMA were issued
+    // after the units of K-step 0 / 1 and ahead of everything the loop issues: the count grows by them.
 // Ablation switches of the diagnostic build (tools/micro/gemm_ph_stamps.cpp; results are then WRONG, only the timing means
 // something): PH_ABL_NOEND drops the closing barrier of a phase, PH_ABL_NOBAR the barrier after the counted wait, PH_ABL_NOMFMA
 // the matrix instructions, PH_ABL_NODMA the global -> LDS units, PH_ABL_NOREAD the fragment reads.
@@ -364,14 +378,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
 #else
 #define PH_BAR2() __builtin_amdgcn_s_barrier()
 #endif
-#define PH_SYNC(PHASE)                                                             \
+#define PH_SYNC()                                                                  \
     do {                                                                           \
-        constexpr int W1c = PHASE == 3 ? 6 : PHASE == 4 ? 4 : 8;                   \
-        constexpr int W0c = PHASE == 1 ? 2 : 0;                                    \
-        constexpr int WS = 8;                                                      \
-        if (RESPRE || last >= 2) { if (pend) wait_vm<WS + NST>(); else wait_vm<WS>(); }        \
-        else if (last == 1) { if (pend) wait_vm<W1c + NST>(); else wait_vm<W1c>(); }           \
-        else { if (pend) wait_vm<W0c + NST>(); else wait_vm<W0c>(); }              \
+        if (kt == 0) { if (after_stores) wait_vm<8 + NST + NBL>(); else wait_vm<8 + NBL>(); } \
+        else wait_vm<8>();                                                         \
         PH_BAR1();                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                         \
     } while (0)
@@ -385,44 +395,38 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     auto kstep = [&](auto parc, int kt) {
         constexpr int PAR = decltype(parc)::value;
         const int last = nt - 1 - kt;
-        const bool pend = st_pending && kt == 0;
         // phase 1: quadrant (rows 0-63, column half 0)
         read_b(0, PAR, bf0);
         read_a(0, PAR);
-        if (last >= 1) stage_b(1, PAR ^ 1, kt + 1);
-        else if constexpr (RESPRE) stage_res((PAR ^ 1) * STEP + OFF_B1);
-        PH_SYNC(1);
+        if (last >= 1) stage_b(cur, 1, PAR ^ 1, kt + 1);
+        else stage_b(nxt, 1, PAR ^ 1, 0);
+        PH_SYNC();
         mma(0, 0, bf0);
         PH_END();
         // phase 2: (rows 0-63, column half 1)
         read_b(1, PAR, bf1);
-        if (last >= 1) stage_a(1, PAR ^ 1, kt + 1);
-        else if constexpr (RESPRE) stage_res((PAR ^ 1) * STEP + OFF_A1);
-        PH_SYNC(2);
+        if (last >= 1) stage_a(cur, 1, PAR ^ 1, kt + 1);
+        else stage_a(nxt, 1, PAR ^ 1, 0);
+        PH_SYNC();
         mma(0, 1, bf1);
         PH_END();
         // phase 3: (rows 64-127, column half 1)
         read_a(1, PAR);
-        if (last >= 2) stage_a(0, PAR, kt + 2);
-        else if constexpr (RESPRE) stage_res(PAR * STEP + OFF_A0);
-        PH_SYNC(3);
+        if (last >= 2) stage_a(cur, 0, PAR, kt + 2);
+        else stage_a(nxt, 0, PAR, 1 - last);
+        PH_SYNC();
         mma(1, 1, bf1);
         PH_END();
         // phase 4: (rows 64-127, column half 0)
-        if (last >= 2) stage_b(0, PAR, kt + 2);
-        else if constexpr (RESPRE) stage_res(PAR * STEP + OFF_B0);
-        PH_SYNC(4);
+        if (last >= 2) stage_b(cur, 0, PAR, kt + 2);
+        else stage_b(nxt, 0, PAR, 1 - last);
+        PH_SYNC();
         mma(1, 0, bf0);
         PH_END();
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    // ---- the prologue units of this tile are in flight (issued before the previous tile's epilogue, or above)
-    __builtin_amdgcn_sched_barrier(0);
-    if (st_pending) wait_vm<8 + NST>();
-    else wait_vm<8>();
-    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind waves 0-3
     PH_STAMP(1);
@@ -430,88 +434,51 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     for (int kt = 0; kt < nt; kt += 2) {
         kstep(I0{}, kt);
         PH_STAMP(2 + (kt < 40 ? kt : 40));
-        if (kt + 1 < nt) { kstep(I1{}, kt + 1); PH_STAMP(3 + (kt < 40 ? kt : 40)); }
+        kstep(I1{}, kt + 1);
+        PH_STAMP(3 + (kt < 40 ? kt : 40));
     }
-    if (wr == 0) __builtin_amdgcn_s_barrier();   // re-join: every wave has finished reading its operands
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // re-join: every wave has finished reading this tile's operands
     PH_STAMP(50);
 #undef PH_SYNC
 #undef PH_END
 
-    // ---- epilogue ----------------------------------------------------------------------------------------------
+    // ---- epilogue: from the accumulators to memory, no LDS, no barrier ------------------------------------------
     int etid = tid;
     asm volatile("" : "+v"(etid));               // epilogue addresses are formed here, per tile, not hoisted out of the tile loop
     const int efr = etid & 15, ekq = (etid >> 4) & 3;
-    uint4 rres[RES == 1 ? 16 : 1];               // RES 1: this lane's residual chunks, [row group][column half]
-    if constexpr (RESPRE) {
-        const int b = (nt - 1) & 1;               // the last K-step's buffer: its A_m1 and B_n1 regions are still to come
-        stage_res(b * STEP + OFF_A1);
-        stage_res(b * STEP + OFF_B1);
-        PH_WAIT(0);
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int g = 0; g < 8; ++g)
-#pragma unroll
-            for (int nj = 0; nj < 2; ++nj) {
-                const int row = wr * 128 + g * 16 + efr;                        // g = mi * 4 + i; row & 15 == efr
-                const int cidx = wc * 8 + nj * 4 + ekq;                         // the lane's 8 columns as a chunk of the row
-                rres[g * 2 + nj] = *reinterpret_cast<const uint4 *>(lds + row * 512 + ((cidx ^ efr) * 16));
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();             // LDS belongs to the next tile from here on
-    }
-    PH_STAMP(51);
-    // this tile's coordinates and bias (the tile state is about to describe the next tile)
-    const long e_m0 = m0;
-    const int e_n0 = n0, e_vr = vr, e_z = z;
-    uint4 eb[2][BIASF32 ? 2 : 1];
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-        for (int q = 0; q < (BIASF32 ? 2 : 1); ++q) {
-            eb[nj][q] = bq[nj][q];
-            // a use HERE: the compiler's wait for these loads (issued before the K loop) lands ahead of the next prologue's
-            // LDS-DMA -- behind it, it would be a vmcnt(0) that drains the prefetch
-            asm volatile("" : "+v"(eb[nj][q].x), "+v"(eb[nj][q].y), "+v"(eb[nj][q].z), "+v"(eb[nj][q].w));
-        }
-    __builtin_amdgcn_sched_barrier(0);
-    const long tnext = t + gridDim.x;
-    if (tnext < total) {
-        setup(tnext);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_prologue();
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    PH_STAMP(52);
-
-    const int ncol = GLU ? p.N / 2 : p.N;
-    const int nrt = (e_vr + 15) >> 4;             // 16-row groups with a valid row
-    // descriptors start at the tile's first row: offsets stay small whatever the size of the tensors
-    const __amdgpu_buffer_rsrc_t Or = make_rsrc(reinterpret_cast<unsigned char *>(p.out) + (e_z * p.sO + e_m0 * p.ldo) * OSZ,
-                                                ((p.M - 1 - e_m0) * p.ldo + (OUT == 2 ? p.lo_off : 0) + ncol) * OSZ);
-    __amdgpu_buffer_rsrc_t Fr = Or;               // RES 2: the fp32 residual, same rows
-    if constexpr (RES == 2)
-        Fr = make_rsrc(reinterpret_cast<const unsigned char *>(p.res) + (e_z * p.sR + e_m0 * p.ldr) * 4,
-                       ((p.M - 1 - e_m0) * p.ldr + p.N) * 4);
-    auto unpack8 = [&](const uint4 &q, float (&f)[8]) {
+    auto unpack8 = [&](const u32x4p &q, float (&f)[8]) {
         f[0] = bf16_bits_to_f32(q.x & 0xffffu); f[1] = __uint_as_float(q.x & 0xffff0000u);
         f[2] = bf16_bits_to_f32(q.y & 0xffffu); f[3] = __uint_as_float(q.y & 0xffff0000u);
         f[4] = bf16_bits_to_f32(q.z & 0xffffu); f[5] = __uint_as_float(q.z & 0xffff0000u);
         f[6] = bf16_bits_to_f32(q.w & 0xffffu); f[7] = __uint_as_float(q.w & 0xffff0000u);
     };
-    auto bias8 = [&](int nj, float (&f)[8]) {
-        if constexpr (BIASF32) {
-            f[0] = __uint_as_float(eb[nj][0].x); f[1] = __uint_as_float(eb[nj][0].y);
-            f[2] = __uint_as_float(eb[nj][0].z); f[3] = __uint_as_float(eb[nj][0].w);
-            f[4] = __uint_as_float(eb[nj][BIASF32 ? 1 : 0].x); f[5] = __uint_as_float(eb[nj][BIASF32 ? 1 : 0].y);
-            f[6] = __uint_as_float(eb[nj][BIASF32 ? 1 : 0].z); f[7] = __uint_as_float(eb[nj][BIASF32 ? 1 : 0].w);
+    const int ncol = GLU ? p.N / 2 : p.N;
+    const int nrt = (cur.vr + 15) >> 4;           // 16-row groups with a valid row
+    // descriptors start at the tile's first row: offsets stay small whatever the size of the tensors
+    const __amdgpu_buffer_rsrc_t Or = make_rsrc(reinterpret_cast<unsigned char *>(p.out) + (cur.z * p.sO + cur.m0 * p.ldo) * OSZ,
+                                                ((p.M - 1 - cur.m0) * p.ldo + (OUT == 2 ? p.lo_off : 0) + ncol) * OSZ);
+    constexpr int RSZ = RES == 2 ? 4 : 2;         // bytes per residual element
+    __amdgpu_buffer_rsrc_t Rr = Or;
+    if constexpr (RES != 0)
+        Rr = make_rsrc(reinterpret_cast<const unsigned char *>(p.res) + (cur.z * p.sR + cur.m0 * p.ldr) * RSZ,
+                       ((p.M - 1 - cur.m0) * p.ldr + p.N) * RSZ);
+    const bool has_bias = p.bias != nullptr;
+    auto bias8 = [&](int nj, float (&f)[8]) {     // the lane's 8 columns of column half nj, from the wave's bias slot
+        const unsigned char *slot = lds + 2 * STEP + wave * 1024 + (wc * 64 + nj * 32 + ekq * 8) * (BIASF32 ? 4 : 2);
+        if (!has_bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = 0.f;
+        } else if constexpr (BIASF32) {
+            const u32x4p q0 = *reinterpret_cast<const u32x4p *>(slot), q1 = *reinterpret_cast<const u32x4p *>(slot + 16);
+            f[0] = __uint_as_float(q0.x); f[1] = __uint_as_float(q0.y); f[2] = __uint_as_float(q0.z); f[3] = __uint_as_float(q0.w);
+            f[4] = __uint_as_float(q1.x); f[5] = __uint_as_float(q1.y); f[6] = __uint_as_float(q1.z); f[7] = __uint_as_float(q1.w);
         } else {
-            unpack8(eb[nj][0], f);
+            unpack8(*reinterpret_cast<const u32x4p *>(slot), f);
         }
     };
     // store the lane's 8 consecutive values o[] of (row, col): bf16 one 16-byte store, fp32 two, hi | lo planes two
     auto store8 = [&](const float (&o)[8], bool live, int row, int col) {
-        const bool ok = row < e_vr && col < ncol;
+        const bool ok = row < cur.vr && col < ncol;
         const unsigned off = ok ? (unsigned)(((long)row * p.ldo + col) * OSZ) : PH_OOB;
         if constexpr (OUT == 0) {
             u32x4p w{0u, 0u, 0u, 0u};
@@ -528,10 +495,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         } else {
             u32x4p wh{0u, 0u, 0u, 0u}, wl{0u, 0u, 0u, 0u};
             if (live) {
-                float lo[8];
+                float lo[8], hf[8];
                 wh = u32x4p{pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
-                float hf[8];
-                unpack8(uint4{wh.x, wh.y, wh.z, wh.w}, hf);
+                unpack8(wh, hf);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) lo[e] = o[e] - hf[e];
                 wl = u32x4p{pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(lo[4], lo[5]), pack_bf16(lo[6], lo[7])};
@@ -540,8 +506,25 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
             __builtin_amdgcn_raw_buffer_store_b128(wl, Or, ok ? off + (unsigned)(p.lo_off * 2) : PH_OOB, 0, 0);
         }
     };
+    // The residual comes straight to registers, 64-row half by half: all loads of a half are issued, then consumed (one
+    // exposed round trip per half; rows / columns outside the matrix read zeros).  bf16: 8 loads, fp32: 16 per half.
+    constexpr int RLD = RES == 2 ? 2 : 1;         // 16-byte loads per (row group, column half)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 2; ++mi) {
+        u32x4p rr[RES != 0 ? 4 : 1][2][RLD];
+        if constexpr (RES != 0) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj) {
+                    const int row = wr * 128 + mi * 64 + i * 16 + efr, col = cur.n0 + wc * 64 + nj * 32 + ekq * 8;
+                    const bool ok = row < cur.vr && col < p.N;
+                    const unsigned off = ok ? (unsigned)(((long)row * p.ldr + col) * RSZ) : PH_OOB;
+#pragma unroll
+                    for (int q = 0; q < RLD; ++q) rr[i][nj][q] = __builtin_amdgcn_raw_buffer_load_b128(Rr, ok ? off + 16 * q : PH_OOB, 0, 0);
+                }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             __builtin_amdgcn_sched_barrier(0);    // one row group at a time: keeps the epilogue's registers few
@@ -563,19 +546,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
                             o[j * 4 + e] = a * __builtin_amdgcn_rcpf(1.f + __expf(-b));
                         }
                 }
-                store8(o, live, row, e_n0 / 2 + wc * 32 + ekq * 8);
+                store8(o, live, row, cur.n0 / 2 + wc * 32 + ekq * 8);
             } else {
 #pragma unroll
                 for (int nj = 0; nj < 2; ++nj) {
-                    const int col = e_n0 + wc * 64 + nj * 32 + ekq * 8;
+                    const int col = cur.n0 + wc * 64 + nj * 32 + ekq * 8;
                     float o[8];
-                    u32x4p r0{0u, 0u, 0u, 0u}, r1{0u, 0u, 0u, 0u};
-                    if constexpr (RES == 2) {     // out-of-range rows / columns read zeros
-                        const bool ok = row < e_vr && col < p.N;
-                        const unsigned off = ok ? (unsigned)(((long)row * p.ldr + col) * 4) : PH_OOB;
-                        r0 = __builtin_amdgcn_raw_buffer_load_b128(Fr, off, 0, 0);
-                        r1 = __builtin_amdgcn_raw_buffer_load_b128(Fr, ok ? off + 16 : PH_OOB, 0, 0);
-                    }
                     if (live) {
                         float bv[8];
                         bias8(nj, bv);
@@ -586,29 +562,33 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
                                 o[j * 4 + e] = act_apply<ACT>(fmaf(acc[mi][nj][i][j][e], p.alpha, bv[j * 4 + e]));
                         if constexpr (RES == 1) {
                             float rv[8];
-                            unpack8(rres[g * 2 + nj], rv);
+                            unpack8(rr[i][nj][0], rv);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) o[e] += rv[e];
                         } else if constexpr (RES == 2) {
-                            o[0] += __uint_as_float(r0.x); o[1] += __uint_as_float(r0.y);
-                            o[2] += __uint_as_float(r0.z); o[3] += __uint_as_float(r0.w);
-                            o[4] += __uint_as_float(r1.x); o[5] += __uint_as_float(r1.y);
-                            o[6] += __uint_as_float(r1.z); o[7] += __uint_as_float(r1.w);
+                            o[0] += __uint_as_float(rr[i][nj][0].x); o[1] += __uint_as_float(rr[i][nj][0].y);
+                            o[2] += __uint_as_float(rr[i][nj][0].z); o[3] += __uint_as_float(rr[i][nj][0].w);
+                            o[4] += __uint_as_float(rr[i][nj][RLD - 1].x); o[5] += __uint_as_float(rr[i][nj][RLD - 1].y);
+                            o[6] += __uint_as_float(rr[i][nj][RLD - 1].z); o[7] += __uint_as_float(rr[i][nj][RLD - 1].w);
                         }
                     }
                     store8(o, live, row, col);
                 }
             }
         }
+    }
     __builtin_amdgcn_sched_barrier(0);
-    st_pending = true;
+    first = false;
+    if constexpr (CONV) make_tile(t + gridDim.x, cur);    // (nxt is the empty tile here)
+    else cur = nxt;
     PH_STAMP(53);
     }   // tile loop
+    PH_WAIT(0);                                   // the (empty) prefetch of a tile that does not exist: nothing in flight at exit
 }
 
 template <bool GLU, int ACT, int RES, int OUT, bool CONV = false>
 int launch_ph(const PhParams &p, int batch, hipStream_t s) {
-    constexpr size_t lds = 2 * (2 * 128 * 128 + 2 * (PBN / 2) * 128);        // 128 KiB
+    constexpr size_t lds = 2 * (2 * 128 * 128 + 2 * (PBN / 2) * 128) + 8 * 1024;   // two K-steps (128 KiB) + a bias slot per wave
     auto kern = gemm_ph_kernel<GLU, ACT, RES, OUT, CONV>;
     static bool attr_set[64];                     // per device; a racing first call sets the same attribute twice
     int dev = 0;
@@ -646,7 +626,7 @@ extern "C" int pafc_gemm_ph_ex(long M, int N, int K, int batch, const void *A, l
     else if (res_kind == 0) return PAFC_ERR_BAD_DIMS;
     const bool glu = act == 4;
     if (tile_m < 64 || tile_m > 256 || tile_m % 64) return PAFC_ERR_UNSUPPORTED;
-    if (N % 8 || K % 64 || K < 128) return PAFC_ERR_UNSUPPORTED;
+    if (N % 8 || K % 128) return PAFC_ERR_UNSUPPORTED;          // an even number of 64-deep K-steps (see the kernel's tile loop)
     if (glu && (N % 256 || residual)) return PAFC_ERR_UNSUPPORTED;
     if (residual && act != 0) return PAFC_ERR_UNSUPPORTED;      // the layer never pairs a residual with an activation
     if (res_kind == 1 && out_kind != 0) return PAFC_ERR_UNSUPPORTED;   // a bf16 residual stream has a bf16 output
@@ -657,11 +637,10 @@ extern "C" int pafc_gemm_ph_ex(long M, int N, int K, int batch, const void *A, l
     if (out_kind == 2 ? (lo_off < No || ldo < lo_off + No) : ldo < No) return PAFC_ERR_BAD_DIMS;
     if ((lda | ldw | strideA | strideW) % 8 || (ldo | strideO | lo_off) % 8 || (residual && ((ldr | strideR) % 8))) return PAFC_ERR_ALIGNMENT;
     if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)bias) & 15) != 0) return PAFC_ERR_ALIGNMENT;
-    // 31-bit byte extents inside one batch entry of A / W / a bf16 residual (buffer descriptors that start at the tensor), and
-    // inside one 256-row tile of the output / fp32 residual (descriptors that start at the tile)
-    if ((double)M * lda * 2 >= 2.0e9 || (double)N * ldw * 2 >= 2.0e9 || (res_kind == 1 && (double)M * ldr * 2 >= 2.0e9))
-        return PAFC_ERR_UNSUPPORTED;
-    if ((double)256 * ldo * 4 >= 2.0e9 || (res_kind == 2 && (double)256 * ldr * 4 >= 2.0e9)) return PAFC_ERR_UNSUPPORTED;
+    // 31-bit byte extents inside one batch entry of A / W (buffer descriptors that start at the tensor), and inside one
+    // 256-row tile of the output / residual (descriptors that start at the tile)
+    if ((double)M * lda * 2 >= 2.0e9 || (double)N * ldw * 2 >= 2.0e9) return PAFC_ERR_UNSUPPORTED;
+    if ((double)256 * ldo * 4 >= 2.0e9 || (residual && (double)256 * ldr * 4 >= 2.0e9)) return PAFC_ERR_UNSUPPORTED;
     pafc::PhParams p{};
     p.A = (const pafc::bf16_t *)A; p.W = (const pafc::bf16_t *)W; p.bias = bias; p.res = residual; p.out = out;
     p.M = M; p.N = N; p.K = Kw;
@@ -714,7 +693,8 @@ extern "C" int pafc_conv3x3s2_nhwc_bf16_ph(int B, int T1, int F1, int Ci, int Co
                                            const void *bias, void *out, int relu, int tile_m, pafc_stream_t stream) {
     if (!in || !w_tap_co_ci || !out) return PAFC_ERR_NULL_POINTER;
     if (B <= 0 || T1 < 3 || F1 < 3 || Ci <= 0 || Co <= 0) return PAFC_ERR_BAD_DIMS;
-    if (Ci % 64 || (Ci / 64) & (Ci / 64 - 1) || Co % 8) return PAFC_ERR_UNSUPPORTED;       // 64-channel K-steps, a power of two per tap
+    // 64-channel K-steps, a power of two per tap and an even number of them in all (9 Ci / 64 even <=> Ci % 128 == 0)
+    if (Ci % 128 || (Ci / 64) & (Ci / 64 - 1) || Co % 8) return PAFC_ERR_UNSUPPORTED;
     if (tile_m != 256 && tile_m != 192 && tile_m != 128) return PAFC_ERR_UNSUPPORTED;
     if ((((uintptr_t)in | (uintptr_t)w_tap_co_ci | (uintptr_t)out | (uintptr_t)bias) & 15) != 0) return PAFC_ERR_ALIGNMENT;
     const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;

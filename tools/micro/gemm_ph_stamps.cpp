@@ -1,8 +1,11 @@
 // Diagnostic build of csrc/gemm_ph.hip with in-kernel shader-clock stamps (PH_STAMPS): where a tile's cycles go --
 // prologue fill, each K-step, re-join, residual DMA, accumulator -> LDS, LDS -> global.  Stamps go to a buffer no other
 // code reads; in the shipped library no stamp executes.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -I paper_accurate_fast_cheap_amd/csrc tools/micro/gemm_ph_stamps.cpp -o build_exp/gemm_ph_stamps
-//   build_exp/gemm_ph_stamps M N K residual(0/1) tile_n tile_m
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -I paper_accurate_fast_cheap_amd/csrc tools/micro/gemm_ph_stamps.cpp -o tools/micro/bin/gemm_ph_stamps
+//   tools/micro/bin/gemm_ph_stamps M N K mode(0 SiLU / 1 bf16 residual / 2 plain / 3 GLU) tile_m
+// Round 3 stamps: 0 tile start (its prologue units are already in flight, issued ahead of the previous tile's epilogue) |
+// 1 first operands landed | 2.. K-steps | 50 re-join | 51 residual folded into the accumulators (RES 1) | 52 next tile set up
+// and its prologue issued | 53 epilogue arithmetic + stores issued.
 #define PH_STAMPS 1
 #include "../../paper_accurate_fast_cheap_amd/csrc/gemm_ph.hip"
 
@@ -25,7 +28,8 @@ __global__ void fill_rand(unsigned short *p, size_t n, unsigned seed) {
 int main(int argc, char **argv) {
     const long M = argc > 1 ? atol(argv[1]) : 44998;
     const int N = argc > 2 ? atoi(argv[2]) : 2048, K = argc > 3 ? atoi(argv[3]) : 512, res = argc > 4 ? atoi(argv[4]) : 0;
-    const int tn = argc > 5 ? atoi(argv[5]) : 256, tm = argc > 6 ? atoi(argv[6]) : 256;
+    const int tn = 256, tm = argc > 5 ? atoi(argv[5]) : 256;
+    const int mode = res;
     unsigned short *A, *W, *O, *R, *B;
     hipMalloc(&A, M * K * 2); hipMalloc(&W, (size_t)N * K * 2); hipMalloc(&O, M * N * 2); hipMalloc(&R, M * N * 2); hipMalloc(&B, N * 2);
     fill_rand<<<2048, 256>>>(A, M * K, 1); fill_rand<<<512, 256>>>(W, (size_t)N * K, 2); fill_rand<<<2048, 256>>>(R, M * N, 3);
@@ -35,7 +39,7 @@ int main(int argc, char **argv) {
     hipMalloc(&st, nblk * 2 * 64 * 8);
     hipMemset(st, 0, nblk * 2 * 64 * 8);
     pafc::PhParams p{};
-    p.A = A; p.W = W; p.bias = B; p.res = res ? R : nullptr; p.out = O;
+    p.A = A; p.W = W; p.bias = B; p.res = mode == 1 ? R : nullptr; p.out = O; p.a_wrap = INT_MAX;
     p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldo = N; p.ldr = N; p.alpha = 1.f;
     p.mtiles = (int)mt; p.ntiles = (int)nt; p.tm = tm; p.stamps = st; p.batch = 1;
     hipEvent_t e0, e1;
@@ -44,8 +48,8 @@ int main(int argc, char **argv) {
     for (int rep = 0; rep < 5; ++rep) {
         hipEventRecord(e0, 0);
         int rc;
-        if (tn == 256) rc = res ? pafc::launch_ph<256, 1, 0>(p, 1, 0) : pafc::launch_ph<256, 0, 1>(p, 1, 0);
-        else rc = res ? pafc::launch_ph<128, 1, 0>(p, 1, 0) : pafc::launch_ph<128, 0, 1>(p, 1, 0);
+        rc = mode == 1 ? pafc::launch_ph<false, 0, 1, 0>(p, 1, 0) : mode == 2 ? pafc::launch_ph<false, 0, 0, 0>(p, 1, 0)
+             : mode == 3 ? pafc::launch_ph<true, 0, 0, 0>(p, 1, 0) : pafc::launch_ph<false, 1, 0, 0>(p, 1, 0);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
@@ -54,7 +58,7 @@ int main(int argc, char **argv) {
     std::vector<unsigned long long> h(nblk * 2 * 64);
     hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
     const int nk = K / 64;
-    printf("M %ld N %d K %d residual %d tile %d x %d: %ld tiles, %.1f us with stamps (%.0f TF/s)\n", M, N, K, res, tm, tn, nblk, ms * 1e3,
+    printf("M %ld N %d K %d mode %d tile %d x %d: %ld tiles, %.1f us with stamps (%.0f TF/s)\n", M, N, K, mode, tm, tn, nblk, ms * 1e3,
            2.0 * M * N * K / ms / 1e9);
     for (int g = 0; g < 2; ++g) {
         // medians over the blocks of: prologue, mean K-step, first / last K-step, re-join, residual DMA, acc -> LDS, store, total
@@ -73,25 +77,9 @@ int main(int argc, char **argv) {
             tot.push_back((double)(s[53] - s[0]));
         }
         auto med = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
-        printf("  wave %d (median cycles over %zu tiles): prologue %.0f | K-step mean %.0f (first %.0f, last %.0f; ideal %d) x %d | re-join %.0f | "
-               "residual DMA %.0f | acc->LDS %.0f | LDS->global %.0f | tile total %.0f\n",
+        printf("  wave %d (median cycles over %zu tiles): wait for first operands %.0f | K-step mean %.0f (first %.0f, last %.0f; ideal %d) x %d | re-join %.0f | "
+               "residual -> acc %.0f | next setup + prologue issue %.0f | epilogue %.0f | tile total %.0f\n",
                g * 4, tot.size(), med(pro), med(ks), med(k0), med(kl), tn == 256 ? 2048 : 1024, nk, med(rj), med(rd), med(wr), med(so), med(tot));
     }
-    // inside K-step 4: per phase, median cycles of [reads + DMA issue] [counted wait + barrier] [16 MFMAs] [closing barrier]
-    if (nk > 4)
-        for (int g = 0; g < 2; ++g) {
-            printf("  wave %d, K-step 4:", g * 4);
-            for (int ph = 0; ph < 4; ++ph) {
-                std::vector<double> d[4];
-                for (long b = 0; b < nblk; ++b) {
-                    const unsigned long long *s = &h[(b * 2 + g) * 64] + 20 + 4 * ph;
-                    if (!s[0] || !s[4]) continue;
-                    for (int i = 0; i < 4; ++i) d[i].push_back((double)(s[i + 1] - s[i]));
-                }
-                auto med = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
-                printf("  p%d: issue %.0f | wait+barrier %.0f | mfma %.0f | barrier %.0f", ph + 1, med(d[0]), med(d[1]), med(d[2]), med(d[3]));
-            }
-            printf("\n");
-        }
     return 0;
 }
