@@ -59,11 +59,26 @@ int pafc_dwconv1d_cl_wgrad(int dtype, int B, int T_in, int C, int K, int left_pa
  * (src/model.py:323) and norm_final + the next layer's first pre-norm.  rows = B*T, row index = b*T + t.
  * dtype: x, y, x_out, gamma*, beta*; dtype_out: out1/out2 (bf16 out of an fp32 stream = the slot's input cast,
  * rwkv_wrapper_bidirectional.py:40-41).  ld1/ld2: row strides of out1/out2 in elements (a (rows, 2C) buffer can
- * receive two LayerNorms side by side).  C % 8 == 0, C <= 1024.  eps as nn.LayerNorm (1e-5). */
+ * receive two LayerNorms side by side).  C % 8 == 0, C <= 1024.  eps as nn.LayerNorm (1e-5).
+ * dtype_out PAFC_SPLIT_BF16 (fp32 streams only): out1 / out2 rows are [hi (C) | lo (C)] bf16 planes of the fp32 result
+ * (ld >= 2C) -- the A operand of pafc_gemm_ph_ex(a_split = 1); nothing is rounded to bf16 on the way. */
 int pafc_add_layernorm(int dtype, int dtype_out, int rows, int C, const void *x, const void *y, float alpha,
                        const int32_t *lens, int T, int mask_y, void *x_out, const void *gamma1, const void *beta1,
                        void *out1, long ld1, int silu1, int zero1, const void *gamma2, const void *beta2, void *out2,
                        long ld2, float eps, pafc_stream_t stream);
+
+/* The same with a second output form: dtype_out2 = dtype_out, or PAFC_SPLIT_BF16 beside dtype_out = PAFC_F32 (norm_final
+ * in fp32 for the caller + the next layer's first pre-norm as the planes its GEMM reads). */
+int pafc_add_layernorm_ex(int dtype, int dtype_out, int dtype_out2, int rows, int C, const void *x, const void *y, float alpha,
+                          const int32_t *lens, int T, int mask_y, void *x_out, const void *gamma1, const void *beta1,
+                          void *out1, long ld1, int silu1, int zero1, const void *gamma2, const void *beta2, void *out2,
+                          long ld2, float eps, pafc_stream_t stream);
+
+/* fp32 (rows, cols), rows ldx apart -> bf16 planes: out row = [hi | lo] with lo at column lo_off (triple = 0: an
+ * activation for pafc_gemm_ph_ex(a_split = 1)) or [hi | hi | lo] at columns 0, cols, 2 cols (triple = 1: its weight).
+ * cols % 8 == 0. */
+int pafc_split_planes(long rows, int cols, const float *x, long ldx, void *out, long ldo, long lo_off, int triple,
+                      pafc_stream_t stream);
 
 /* LayerNorm backward for the training step (config c4): the seven nn.LayerNorm of the layer under autograd
  * (encoder_layer.py:201-259, convolution.py:136, src/model.py:323; train_utils.py:646-660).  mean / rstd are recomputed

@@ -50,7 +50,8 @@ enum {
     PAFC_ERR_ALIGNMENT = -8      /* r, k, v, w, y must be 16-byte aligned (torch allocations and (B,T,C) views are) */
 };
 
-enum { PAFC_F32 = 0, PAFC_BF16 = 1 };
+enum { PAFC_F32 = 0, PAFC_BF16 = 1,
+       PAFC_SPLIT_BF16 = 2 /* OUTPUT form only: an fp32 value as two bf16 planes, hi = bf16(x) | lo = bf16(x - hi) */ };
 
 /* Library/ABI version, bumped when a signature changes. */
 int pafc_abi_version(void);

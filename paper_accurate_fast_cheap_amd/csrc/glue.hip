@@ -5,10 +5,18 @@
 // rounded to bf16 in registers), so the fused result tracks the reference's numerics, not a re-association.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pafc_common.h"
 #include "../../include/pafc_encoder_ops.h"
 
 namespace pafc {
+
+struct SplitBf16 {};          // output form PAFC_SPLIT_BF16 (see store8_split below)
+template <> struct Elem<SplitBf16> {
+    __device__ static __forceinline__ float round(float v) { return v; }
+};
+
 namespace {
 
 constexpr int VEC = 8;       // channels per lane per iteration
@@ -36,6 +44,22 @@ template <> __device__ __forceinline__ void store8<float>(float *p, const float 
     reinterpret_cast<float4 *>(p)[1] = make_float4(f[4], f[5], f[6], f[7]);
 }
 
+// An fp32 value as two bf16 planes, hi = bf16(x), lo = bf16(x - hi): 16 significant bits, the form the phase-pipelined GEMM
+// takes as the A operand of an fp32 model (csrc/gemm_ph.hip).  Output "dtype" PAFC_SPLIT_BF16: a row is [hi (C) | lo (C)].
+__device__ __forceinline__ void store8_split(bf16_t *hi_p, bf16_t *lo_p, const float *f) {
+    float lo[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) lo[e] = f[e] - round_bf16(f[e]);
+    store8<bf16_t>(hi_p, f);
+    store8<bf16_t>(lo_p, lo);
+}
+// row `row` of an LN output: ld elements apart, 8 values from column c
+template <typename EO>
+__device__ __forceinline__ void store_out(void *base, size_t row, long ld, int c, int C, const float *f) {
+    if constexpr (std::is_same<EO, SplitBf16>::value) store8_split((bf16_t *)base + row * ld + c, (bf16_t *)base + row * ld + C + c, f);
+    else store8<EO>((EO *)base + row * ld + c, f);
+}
+
 __device__ __forceinline__ float silu_(float x) { return x / (1.f + __expf(-x)); }
 
 struct LnArgs {
@@ -56,6 +80,7 @@ struct LnArgs {
     long ld2;
     int rows, C;
     float eps;
+    int split2;           // EO = float only: o2 is written as bf16 planes [hi | lo] (o1 stays fp32)
 };
 
 // One wave per row.  EX: residual / parameter dtype; EO: dtype of the LayerNorm outputs.
@@ -120,7 +145,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const LnArgs a) {
                 v[it][e] = o;
                 sum2 += o;
             }
-            store8<EO>((EO *)a.o1 + (size_t)row * a.ld1 + c, v[it]);
+            store_out<EO>(a.o1, (size_t)row, a.ld1, c, C, v[it]);
         }
     }
     if (!a.o2) return;
@@ -144,7 +169,8 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const LnArgs a) {
             load8<EX>((const EX *)a.b2 + c, b);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] = fmaf((v[it][e] - mean) * rstd, g[e], b[e]);
-            store8<EO>((EO *)a.o2 + (size_t)row * a.ld2 + c, o);
+            if (std::is_same<EO, float>::value && a.split2) store_out<SplitBf16>(a.o2, (size_t)row, a.ld2, c, C, o);
+            else store_out<EO>(a.o2, (size_t)row, a.ld2, c, C, o);
         }
     }
 }
@@ -593,11 +619,32 @@ __global__ __launch_bounds__(NW * 64) void tmix_lora_down_kernel(int T, long row
     }
 }
 
+// x (rows, cols) fp32, rows ldx apart -> out (rows, ldo) bf16 = [hi | lo] (lo at column lo_off), optionally scaled.
+// `triple`: out = [hi | hi | lo] at columns 0, cols, 2 cols -- the weight of a split-operand GEMM (gemm_ph.hip).
+__global__ __launch_bounds__(256) void split_planes_kernel(long rows, int cols, const float *__restrict__ x, long ldx,
+                                                           bf16_t *__restrict__ out, long ldo, long lo_off, int triple) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cpr = cols / VEC;
+    const long row = gid / cpr;
+    if (row >= rows) return;
+    const int c = (int)(gid % cpr) * VEC;
+    float f[VEC];
+    load8<float>(x + row * ldx + c, f);
+    if (triple) {
+        store8<bf16_t>(out + row * ldo + c, f);
+        store8_split(out + row * ldo + cols + c, out + row * ldo + 2 * cols + c, f);
+    } else {
+        store8_split(out + row * ldo + c, out + row * ldo + lo_off + c, f);
+    }
+}
+
 template <typename EX>
 int launch_ln(int dtype_out, const LnArgs &a, hipStream_t s) {
     dim3 grid((a.rows + 3) / 4), block(256);
     if (dtype_out == PAFC_BF16)
         hipLaunchKernelGGL((add_layernorm_kernel<EX, bf16_t>), grid, block, 0, s, a);
+    else if (dtype_out == PAFC_SPLIT_BF16)
+        hipLaunchKernelGGL((add_layernorm_kernel<EX, SplitBf16>), grid, block, 0, s, a);
     else
         hipLaunchKernelGGL((add_layernorm_kernel<EX, float>), grid, block, 0, s, a);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
@@ -612,19 +659,42 @@ int pafc_add_layernorm(int dtype, int dtype_out, int rows, int C, const void *x,
                        const int32_t *lens, int T, int mask_y, void *x_out, const void *gamma1, const void *beta1,
                        void *out1, long ld1, int silu1, int zero1, const void *gamma2, const void *beta2, void *out2,
                        long ld2, float eps, pafc_stream_t stream) {
+    return pafc_add_layernorm_ex(dtype, dtype_out, dtype_out, rows, C, x, y, alpha, lens, T, mask_y, x_out, gamma1, beta1, out1, ld1,
+                                 silu1, zero1, gamma2, beta2, out2, ld2, eps, stream);
+}
+
+int pafc_add_layernorm_ex(int dtype, int dtype_out, int dtype_out2, int rows, int C, const void *x, const void *y, float alpha,
+                          const int32_t *lens, int T, int mask_y, void *x_out, const void *gamma1, const void *beta1,
+                          void *out1, long ld1, int silu1, int zero1, const void *gamma2, const void *beta2, void *out2,
+                          long ld2, float eps, pafc_stream_t stream) {
     if (!x) return PAFC_ERR_NULL_POINTER;
+    if (dtype_out2 != dtype_out && !(dtype_out == PAFC_F32 && dtype_out2 == PAFC_SPLIT_BF16)) return PAFC_ERR_DTYPE;
     if (out1 && (!gamma1 || !beta1)) return PAFC_ERR_NULL_POINTER;
     if (out2 && (!gamma2 || !beta2 || !out1)) return PAFC_ERR_NULL_POINTER;
     if (rows <= 0 || C <= 0 || C % pafc::VEC || C > 64 * pafc::VEC * pafc::MAXIT || (lens && T <= 0))
         return PAFC_ERR_BAD_DIMS;
     if (ld1 % pafc::VEC || ld2 % pafc::VEC) return PAFC_ERR_BAD_DIMS;
-    if (dtype == PAFC_BF16 && dtype_out == PAFC_F32) return PAFC_ERR_DTYPE;
+    if (dtype == PAFC_BF16 && dtype_out != PAFC_BF16) return PAFC_ERR_DTYPE;
+    if ((dtype_out == PAFC_SPLIT_BF16 && out1 && ld1 < 2 * C) || (dtype_out2 == PAFC_SPLIT_BF16 && out2 && ld2 < 2 * C))
+        return PAFC_ERR_BAD_DIMS;
     pafc::LnArgs a{x, y, alpha, lens, T, mask_y, x_out, gamma1, beta1, out1, ld1, silu1, zero1,
-                   gamma2, beta2, out2, ld2, rows, C, eps};
+                   gamma2, beta2, out2, ld2, rows, C, eps, dtype_out2 != dtype_out};
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PAFC_BF16) return pafc::launch_ln<pafc::bf16_t>(dtype_out, a, s);
     if (dtype == PAFC_F32) return pafc::launch_ln<float>(dtype_out, a, s);
     return PAFC_ERR_DTYPE;
+}
+
+int pafc_split_planes(long rows, int cols, const float *x, long ldx, void *out, long ldo, long lo_off, int triple,
+                      pafc_stream_t stream) {
+    if (!x || !out) return PAFC_ERR_NULL_POINTER;
+    if (rows <= 0 || cols <= 0 || cols % pafc::VEC || ldx < cols || ldx % 4) return PAFC_ERR_BAD_DIMS;
+    if (triple ? ldo < 3L * cols : (lo_off < cols || ldo < lo_off + cols)) return PAFC_ERR_BAD_DIMS;
+    if (ldo % pafc::VEC || lo_off % pafc::VEC || (((uintptr_t)x | (uintptr_t)out) & 15)) return PAFC_ERR_ALIGNMENT;
+    const long threads = rows * (cols / pafc::VEC);
+    hipLaunchKernelGGL(pafc::split_planes_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows,
+                       cols, x, ldx, (pafc::bf16_t *)out, ldo, lo_off, triple);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 
 int pafc_tmix_shift_mix(int dtype, int B, int T, int C, int ndir, int reverse0, const void *x, const void *maa_x0,

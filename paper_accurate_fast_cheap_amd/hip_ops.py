@@ -379,35 +379,138 @@ def _bind2():
     return L
 
 
+PAFC_SPLIT_BF16 = 2      # output form: an fp32 value as bf16 planes [hi | lo] (include/pafc_wkv6.h)
+
+
 def add_layernorm(x: torch.Tensor, y: Optional[torch.Tensor], alpha: float, gamma1, beta1, *, out1: torch.Tensor = None,
                   out_dtype: Optional[torch.dtype] = None, silu: bool = False, zero_rows: bool = False,
                   lens: Optional[torch.Tensor] = None, T: int = 0, mask_y: bool = False, gamma2=None, beta2=None,
-                  want_ln: bool = True, want_x: bool = True, eps: float = 1e-5):
+                  want_ln: bool = True, want_x: bool = True, eps: float = 1e-5, split1: bool = False, split2: bool = False):
     """x_new = x + alpha*y; out1 = LN1(x_new) [silu] [rows >= len zeroed]; out2 = LN2(out1).
     Returns (x_new or x, out1 or None, out2 or None).  `out1` may be a pre-allocated (rows, ld) view (last-dim
-    slice of a wider buffer) so that two LayerNorms can land side by side."""
+    slice of a wider buffer) so that two LayerNorms can land side by side.
+    split1 / split2 (fp32 x only): that output comes as bf16 planes (..., 2C) = [hi | lo] of the fp32 result, the A operand
+    of gemm_ph_ex(a_split=True); split1 implies split2."""
     _lib.require_gpu(x, y, gamma1, beta1, gamma2, beta2, lens)
     C = x.shape[-1]
     rows = x.numel() // C
     out_dtype = out_dtype or x.dtype
+    if (split1 or split2) and (x.dtype != torch.float32 or out_dtype != torch.float32 or out1 is not None):
+        raise _lib.PafcError("add_layernorm: plane outputs are a form of an fp32 result")
     x_out = torch.empty_like(x) if (y is not None and want_x) else None
     o1 = None
     ld1 = C
+    planes = lambda: torch.empty(x.shape[:-1] + (2 * C,), dtype=torch.bfloat16, device=x.device)
     if want_ln:
-        if out1 is None:
+        if split1:
+            o1, ld1 = planes(), 2 * C
+        elif out1 is None:
             o1 = torch.empty(x.shape, dtype=out_dtype, device=x.device)
         else:
             o1 = out1
             ld1 = out1.stride(-2)
             if out1.stride(-1) != 1 or out1.dtype != out_dtype:
                 raise _lib.PafcError("out1 must be a unit-stride view in the output dtype")
-    o2 = torch.empty(x.shape, dtype=out_dtype, device=x.device) if gamma2 is not None else None
-    rc = _bind2().pafc_add_layernorm(
-        _lib.dtype_code(x.dtype), _lib.dtype_code(out_dtype), rows, C, _lib.ptr(x), _lib.ptr(y), float(alpha),
-        _lib.ptr(lens), int(T), int(mask_y), _lib.ptr(x_out), _lib.ptr(gamma1), _lib.ptr(beta1), _lib.ptr(o1), ld1,
-        int(silu), int(zero_rows), _lib.ptr(gamma2), _lib.ptr(beta2), _lib.ptr(o2), C, float(eps), _lib.stream_of(x))
+    s2 = split1 or split2
+    o2 = None
+    if gamma2 is not None:
+        o2 = planes() if s2 else torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    L = _bind2()
+    if not getattr(L, "_pafc_lnex_bound", False):
+        from ctypes import c_float, c_long
+        P, I = c_void_p, c_int
+        _lib._sig(L.pafc_add_layernorm_ex, I, I, I, I, I, I, P, P, c_float, P, I, I, P, P, P, P, c_long, I, I, P, P, P, c_long,
+                  c_float, P)
+        L._pafc_lnex_bound = True
+    code = _lib.dtype_code(out_dtype)
+    rc = L.pafc_add_layernorm_ex(
+        _lib.dtype_code(x.dtype), PAFC_SPLIT_BF16 if split1 else code, PAFC_SPLIT_BF16 if s2 else code, rows, C, _lib.ptr(x),
+        _lib.ptr(y), float(alpha), _lib.ptr(lens), int(T), int(mask_y), _lib.ptr(x_out), _lib.ptr(gamma1), _lib.ptr(beta1),
+        _lib.ptr(o1), ld1, int(silu), int(zero_rows), _lib.ptr(gamma2), _lib.ptr(beta2), _lib.ptr(o2), 2 * C if s2 else C,
+        float(eps), _lib.stream_of(x))
     _lib.check(rc, "pafc_add_layernorm")
     return (x_out if y is not None else x), o1, o2  # first item is None when want_x=False
+
+
+def split_planes(x: torch.Tensor, triple: bool = False) -> torch.Tensor:
+    """fp32 (..., K) -> bf16 (..., 2K) = [hi | lo] with hi = bf16(x), lo = bf16(x - hi) (an activation for
+    gemm_ph_ex(a_split=True)), or, triple, (..., 3K) = [hi | hi | lo] (its weight)."""
+    _lib.require_gpu(x)
+    if x.dtype != torch.float32 or x.stride(-1) != 1:
+        raise _lib.PafcError("split_planes: contiguous fp32 input")
+    K = x.shape[-1]
+    rows = x.numel() // K
+    out = torch.empty(x.shape[:-1] + ((3 if triple else 2) * K,), dtype=torch.bfloat16, device=x.device)
+    L = _bind2()
+    if not getattr(L, "_pafc_split_planes_bound", False):
+        from ctypes import c_long
+        _lib._sig(L.pafc_split_planes, c_int, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_void_p)
+        L._pafc_split_planes_bound = True
+    _lib.check(L.pafc_split_planes(rows, K, _lib.ptr(x), K, _lib.ptr(out), out.shape[-1], K, int(triple), _lib.stream_of(x)),
+               "pafc_split_planes")
+    return out
+
+
+def _ph_tile_m(M: int, N: int, batch: int = 1) -> int:
+    """Rows per tile of the phase-pipelined GEMM for this problem (the count that needs the fewest rounds of one-tile-per-CU
+    work, a round weighted by its rows plus a fixed per-tile part worth ~64 rows), as csrc/gemm_bf16.hip:ph_tile_m."""
+    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    nt = (N + 255) // 256
+    best = None
+    for tm in (256, 192, 128):
+        tiles = ((M + tm - 1) // tm) * nt * batch
+        cost = ((tiles + cus - 1) // cus) * (tm + 64)
+        if best is None or cost < best[0]:
+            best = (cost, tm)
+    return best[1]
+
+
+def gemm_ph_ex(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none", alpha: float = 1.0,
+               residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, a_split: bool = False,
+               out_kind: str = "bf16", tile_m: int = 0) -> torch.Tensor:
+    """The phase-pipelined GEMM with every operand form (include/pafc_encoder_ops.h: pafc_gemm_ph_ex).
+    a: (M, K) bf16, or with a_split (M, 2K) planes [hi | lo] of an fp32 activation, then w: (N, 3K) = split_planes(W, triple=True);
+    out_kind "bf16" | "f32" | "planes" ((M, 2N) bf16 = [hi | lo] of the fp32 result); residual bf16 (out bf16) or fp32 (out f32),
+    may be `out`; bias bf16 for out_kind bf16, fp32 otherwise; act as gemm_bf16 (GLU: glu_interleave(w, 32) rows before splitting)."""
+    _lib.require_gpu(bias)
+    for t in (a, w, residual, out):
+        if t is not None and (not t.is_cuda or t.stride(-1) != 1):
+            raise _lib.PafcError("gemm_ph_ex: GPU tensors with unit stride in the last dimension")
+    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or a.dim() != 2 or w.dim() != 2:
+        raise _lib.PafcError("gemm_ph_ex: a and w are 2-d bf16 (planes of fp32 operands with a_split)")
+    M = a.shape[0]
+    N = w.shape[0]
+    K = w.shape[1] // 3 if a_split else w.shape[1]
+    if a.shape[1] != (2 * K if a_split else K) or (a_split and w.shape[1] != 3 * K):
+        raise _lib.PafcError("gemm_ph_ex: a (M, K) x w (N, K); split: a (M, 2K) x w (N, 3K)")
+    No = N // 2 if act == "glu" else N
+    kinds = {"bf16": (0, torch.bfloat16, No), "f32": (1, torch.float32, No), "planes": (2, torch.bfloat16, 2 * No)}
+    ok, odt, ocols = kinds[out_kind]
+    if out is None:
+        out = torch.empty((M, ocols), dtype=odt, device=a.device)
+    if out.dtype != odt or tuple(out.shape) != (M, ocols):
+        raise _lib.PafcError("gemm_ph_ex: out must be (M, N) in the output form's dtype ((M, 2N) bf16 for planes)")
+    rk = 0
+    if residual is not None:
+        rk = 1 if residual.dtype == torch.bfloat16 else 2
+        if tuple(residual.shape) != (M, N) or residual.dtype != (torch.bfloat16 if ok == 0 else torch.float32) or ok == 2:
+            raise _lib.PafcError("gemm_ph_ex: residual (M, N) in the output dtype (bf16 / fp32), not with planes")
+    if bias is not None and (bias.dtype != (torch.bfloat16 if ok == 0 else torch.float32) or bias.numel() != N):
+        raise _lib.PafcError("gemm_ph_ex: bias (N) bf16 for a bf16 output, fp32 otherwise")
+    L = _bind2()
+    if not getattr(L, "_pafc_gemmex_bound", False):
+        from ctypes import c_float, c_long
+        P, I, G = c_void_p, c_int, c_long
+        _lib._sig(L.pafc_gemm_ph_ex, I, G, I, I, I, P, G, G, I, P, G, G, P, G, P, I, G, G, P, I, G, G, G, c_float, I, I, P)
+        L._pafc_gemmex_bound = True
+    from .profiling import op_timer
+    with op_timer("gemm%s_%dx%d" % ("3" if a_split else "", K, N), sample=12, flops=2.0 * M * N * K * (3 if a_split else 1)):
+        rc = L.pafc_gemm_ph_ex(M, N, K, 1, _lib.ptr(a), a.stride(0), 0, int(a_split), _lib.ptr(w), w.stride(0), 0, _lib.ptr(bias), 0,
+                               _lib.ptr(residual), rk, residual.stride(0) if residual is not None else 0, 0, _lib.ptr(out), ok,
+                               out.stride(0), No if ok == 2 else 0, 0, float(alpha), _ACTS[act], int(tile_m or _ph_tile_m(M, N)),
+                               _lib.stream_of(a))
+    _lib.check(rc, "pafc_gemm_ph_ex")
+    return out
 
 
 def tmix_shift_mix(x: torch.Tensor, maa_x0: torch.Tensor, maa_x1: Optional[torch.Tensor], reverse0: bool = False):
@@ -646,12 +749,34 @@ def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
     return out
 
 
+# fp32 GEMMs of long inputs run on the bf16 matrix cores with split operands (csrc/gemm_ph.hip: three bf16 products per fp32
+# product, fp32 accumulation, ~2^-16 relative); shorter ones keep the library's exact fp32 kernels.
+_SPLIT_GEMM_MIN_ROWS = int(os.environ.get("PAFC_SPLIT_GEMM_MIN_ROWS", "16384"))
+_split_weights = {}      # id(weight) -> (stamp, [hi | hi | lo] planes); bounded, weights of inference modules are few
+
+
+def split_weight_cached(weight: torch.Tensor) -> torch.Tensor:
+    stamp = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    ent = _split_weights.get(id(weight))
+    if ent is None or ent[0] != stamp:
+        if len(_split_weights) > 64:
+            _split_weights.clear()
+        ent = _split_weights[id(weight)] = (stamp, split_planes(weight.detach().contiguous(), triple=True))
+    return ent[1]
+
+
 def linear_fused(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: str = "none") -> torch.Tensor:
     """act(x @ weight.T + bias) with the epilogue fused: bf16 operands on the hand-written GEMM (K % 64 == 0, N % 8 == 0),
-    anything else on the library GEMM."""
+    long fp32 inputs on the same kernel with split operands, anything else on the library GEMM."""
     N, K = weight.shape
     if x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and K % 64 == 0 and N % 8 == 0:
         return gemm_bf16(x.reshape(-1, K), weight, bias, act).view(x.shape[:-1] + (N,))
+    rows = x.numel() // K
+    if (x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_cuda and K % 128 == 0 and N % 8 == 0 and N >= 256
+            and rows >= _SPLIT_GEMM_MIN_ROWS and act == "none" and not torch.is_grad_enabled()
+            and (bias is None or bias.dtype == torch.float32)):
+        planes = split_planes(x.reshape(rows, K) if x.is_contiguous() else x.reshape(rows, K).contiguous())
+        return gemm_ph_ex(planes, split_weight_cached(weight), bias, a_split=True, out_kind="f32").view(x.shape[:-1] + (N,))
     return linear_bias_act(x, weight, bias, act)
 
 

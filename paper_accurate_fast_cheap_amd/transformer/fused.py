@@ -52,7 +52,10 @@ class LayerPlan:
         L = self.layer
         ps = [p for b in self.blocks for p in b.parameters()] + [L.feed_forward_macaron.w_2.bias, L.feed_forward.w_2.bias,
                                                                     L.conv_module.pointwise_conv1.weight,
-                                                                    L.conv_module.pointwise_conv1.bias]
+                                                                    L.conv_module.pointwise_conv1.bias,
+                                                                    L.feed_forward_macaron.w_1.weight, L.feed_forward_macaron.w_2.weight,
+                                                                    L.feed_forward.w_1.weight, L.feed_forward.w_2.weight,
+                                                                    L.conv_module.pointwise_conv2.weight]
         return tuple((p.data_ptr(), p._version, p.dtype) for p in ps if p is not None)
 
     def refresh(self):
@@ -77,7 +80,27 @@ class LayerPlan:
                 self.pw1_glu = {h: (hip_ops.glu_interleave(pw1.weight.squeeze(-1), h),
                                     hip_ops.glu_interleave(pw1.bias, h) if pw1.bias is not None else None)
                                 for h in ((64, 32) if rows2 % 256 == 0 else (64,))}
+            self._refresh_split()
         self._stamp = stamp
+
+    def _refresh_split(self):
+        """fp32 layer around a bf16 slot (the reference's default precision): every fp32 projection as the split-operand
+        weight [hi | hi | lo] of csrc/gemm_ph.hip (three bf16 products per fp32 product, ~2^-16 relative), biases fp32."""
+        L = self.layer
+        self.split = None
+        w1 = L.feed_forward.w_1.weight
+        cm = L.conv_module
+        if not (self.rwkv and self.slot_bf16 and w1.dtype == torch.float32 and w1.is_cuda and L.size % 128 == 0
+                and w1.shape[0] % 128 == 0 and cm is not None and cm.pointwise_conv1.weight.shape[0] % 256 == 0):
+            return
+        sp = hip_ops.split_planes
+        pw1 = cm.pointwise_conv1
+        self.split = dict(
+            ffm_w1=sp(L.feed_forward_macaron.w_1.weight.contiguous(), True), ffm_w2=sp(L.feed_forward_macaron.w_2.weight.contiguous(), True),
+            ff_w1=sp(L.feed_forward.w_1.weight.contiguous(), True), ff_w2=sp(L.feed_forward.w_2.weight.contiguous(), True),
+            pw1=sp(hip_ops.glu_interleave(pw1.weight.squeeze(-1), 32).contiguous(), True),
+            pw1_b=hip_ops.glu_interleave(pw1.bias, 32).contiguous() if pw1.bias is not None else None,
+            pw2=sp(cm.pointwise_conv2.weight.squeeze(-1).contiguous(), True))
 
     def _refresh_rwkv(self, bl):
         self.maa_x = [b.time_maa_x.reshape(-1).contiguous() for b in bl]
@@ -198,6 +221,11 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
     for d, y in enumerate(ys):
         ln = plan.blocks[d].ln_x
         hip_ops.add_layernorm(y.view(M, C), None, 1.0, ln.weight, ln.bias, out1=ycat[:, d * C:(d + 1) * C], eps=ln.eps)
+    if residual is not None and residual.dtype == torch.float32 and ycat.dtype == torch.bfloat16:
+        # bf16 slot inside an fp32 stream: the output projection adds straight into the fp32 residual (rwkv_wrapper_
+        # bidirectional.py:55-56 `.float()` + encoder_layer.py:232), one rounding less than cast + add
+        r2 = residual.view(M, C)
+        return hip_ops.gemm_ph_ex(ycat, plan.Wo, None, residual=r2, out=r2, out_kind="f32").view(B, T, C)
     if residual is not None:
         return proj(ycat, plan.Wo, None, "none", residual=residual.view(M, C), inplace=True).view(B, T, C)
     return proj(ycat, plan.Wo, None).view(B, T, C)
@@ -258,6 +286,67 @@ def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optio
     _, out, hn = hip_ops.add_layernorm(x, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False,
                                        gamma2=next_norm.weight if next_norm is not None else None,
                                        beta2=next_norm.bias if next_norm is not None else None, eps=L.norm_final.eps)
+    return out, hn
+
+
+# fp32 streams shorter than this keep the library's fp32 GEMMs (exact fp32 products; small problems do not fill 256-wide tiles)
+_SPLIT_GEMM_MIN_ROWS = int(os.environ.get("PAFC_SPLIT_GEMM_MIN_ROWS", "16384"))
+
+
+def split_eligible(plan: LayerPlan, x: torch.Tensor) -> bool:
+    return (plan.split is not None and x.dtype == torch.float32 and x.is_cuda
+            and x.numel() // x.shape[-1] >= _SPLIT_GEMM_MIN_ROWS)
+
+
+def layer_forward_split(plan: LayerPlan, x: torch.Tensor, hp: torch.Tensor, lens: Optional[torch.Tensor],
+                        next_norm: Optional[nn.LayerNorm], next_split: bool):
+    """layer_forward for an fp32 layer around the bf16 slot, on the bf16 matrix cores: every fp32 activation that feeds a
+    projection travels as bf16 planes [hi | lo] (written by the kernel that produces it: LayerNorm passes and the w_1 GEMM),
+    every projection is the split-operand GEMM with its bias / SiLU / GLU / residual epilogue, the residual stream stays fp32.
+    hp = planes of norm_ff_macaron(x).  Returns (layer output fp32, next_norm(output) as planes / fp32 / None)."""
+    L, S = plan.layer, plan.split
+    B, T, C = x.shape
+    M = B * T
+    masked = lens is not None
+    cm = L.conv_module
+    G = hip_ops.gemm_ph_ex
+
+    def ffn(ff, w1, w2, b2_scaled, hpl, xr, inplace):
+        hid = G(hpl.view(M, 2 * C), w1, ff.w_1.bias, "silu", a_split=True, out_kind="planes")
+        out = xr.view(M, C) if inplace else torch.empty((M, C), dtype=torch.float32, device=xr.device)
+        return G(hid, w2, b2_scaled, alpha=L.ff_scale, residual=xr.view(M, C), out=out, a_split=True, out_kind="f32").view(B, T, C)
+
+    x = ffn(L.feed_forward_macaron, S["ffm_w1"], S["ffm_w2"], plan.b2_macaron, hp, x, False)
+    _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_mha.weight, L.norm_mha.bias, out_dtype=torch.bfloat16, want_x=False,
+                                    eps=L.norm_mha.eps)
+    x = slot_forward(plan, h, residual=x)
+    _, hc, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_conv.weight, L.norm_conv.bias, zero_rows=masked, lens=lens, T=T,
+                                     want_x=False, eps=L.norm_conv.eps, split1=True)
+    left_pad, Tc = (cm.kernel_size - 1) // 2, T
+    if cm.lorder > 0:    # causal module: lorder zero frames in front of pointwise_conv1 (convolution.py:112-118)
+        hc = torch.cat([hc.new_zeros(B, cm.lorder, 2 * C), hc], dim=1)
+        left_pad, Tc = 0, T + cm.lorder
+    p = G(hc.view(B * Tc, 2 * C), S["pw1"], S["pw1_b"], "glu", a_split=True, out_kind="f32").view(B, Tc, C)
+    dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, left_pad, T)
+    _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps, split1=True)
+    if not masked:
+        x2 = x.view(M, C)
+        G(g.view(M, 2 * C), S["pw2"], cm.pointwise_conv2.bias, residual=x2, out=x2, a_split=True, out_kind="f32")
+        _, h2, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff.weight, L.norm_ff.bias, want_x=False, eps=L.norm_ff.eps, split1=True)
+    else:   # padded frames of the conv branch count as zero (convolution.py:140-141): the add stays in the norm pass
+        c = G(g.view(M, 2 * C), S["pw2"], cm.pointwise_conv2.bias, a_split=True, out_kind="f32").view(B, T, C)
+        x, h2, _ = hip_ops.add_layernorm(x, c, 1.0, L.norm_ff.weight, L.norm_ff.bias, lens=lens, T=T, mask_y=True,
+                                         eps=L.norm_ff.eps, split1=True)
+    x = ffn(L.feed_forward, S["ff_w1"], S["ff_w2"], plan.b2, h2, x, True)
+    if next_norm is not None and next_norm.eps != L.norm_final.eps:      # the one-pass pair shares one epsilon
+        _, out, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False, eps=L.norm_final.eps)
+        _, hn, _ = hip_ops.add_layernorm(out, None, 1.0, next_norm.weight, next_norm.bias, want_x=False, eps=next_norm.eps,
+                                         split1=next_split)
+        return out, hn
+    _, out, hn = hip_ops.add_layernorm(x, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False,
+                                       gamma2=next_norm.weight if next_norm is not None else None,
+                                       beta2=next_norm.bias if next_norm is not None else None, eps=L.norm_final.eps,
+                                       split2=next_split and next_norm is not None)
     return out, hn
 
 
@@ -345,12 +434,18 @@ def encoder_layers_forward(plan: EncoderPlan, xs: torch.Tensor, masks: torch.Ten
     lens = masks.squeeze(1).sum(1).to(torch.int32) if masks.numel() > 0 else None
     xs = xs.contiguous()
     first = plan.layers[0].layer.norm_ff_macaron
-    _, h, _ = hip_ops.add_layernorm(xs, None, 1.0, first.weight, first.bias, eps=first.eps)
+    split = [split_eligible(lp, xs) for lp in plan.layers] + [False]   # (after_norm's output goes to the caller: fp32)
+    _, h, _ = hip_ops.add_layernorm(xs, None, 1.0, first.weight, first.bias, eps=first.eps, split1=split[0])
     outs: List[torch.Tensor] = []
     n = len(plan.layers)
     for i, lp in enumerate(plan.layers):
         nxt = plan.layers[i + 1].layer.norm_ff_macaron if i + 1 < n else after_norm
-        xs, h = layer_forward(lp, xs, h, lens, nxt)
+        if split[i]:
+            xs, h = layer_forward_split(lp, xs, h, lens, nxt, split[i + 1])
+        else:
+            xs, h = layer_forward(lp, xs, h, lens, nxt)
+            if split[i + 1]:
+                h = hip_ops.split_planes(h.contiguous())
         if want_layers:
             outs.append(xs)
     if after_norm is not None:

@@ -67,7 +67,8 @@ class Conv2dSubsampling4(BaseSubsampling):
             from ..hip_ops import conv_sub_f32split
             y = conv_sub_f32split(x.contiguous(), c1.weight, c1.bias, self._w_c2_split[0], self._w_c2_split[1], c2.bias)
             b, t, f, c = y.shape
-            return F.linear(y.view(b, t, f * c), self._w_lin, lin.bias)
+            from ..hip_ops import linear_fused
+            return linear_fused(y.view(b, t, f * c), self._w_lin, lin.bias, "none")     # (long inputs: split operands too)
         p = x.unsqueeze(1).unfold(2, 3, 2).unfold(3, 3, 2).reshape(B, T1 * F1, 9)
         # relu(bias + p W^T) in one GEMM epilogue
         y = torch._addmm_activation(c1.bias, p.view(B * T1 * F1, 9), c1.weight.view(C, 9).t(), use_gelu=False)

@@ -376,6 +376,48 @@ def test_bf16slot_full_size_vs_oracle(hip):
     _token_parity(logp, ref_logp, valid, 0.08, "bf16slot full size")   # recorded 0.035
 
 
+def test_bf16slot_full_size_split_operand_path_vs_oracle(hip, monkeypatch):
+    """The same comparison with the long-form schedule of this precision forced onto the ragged batch (it starts at 16 384
+    rows by default): every fp32 projection of the layer, Linear(9728, 512) and the CTC head on the bf16 matrix cores with
+    split operands, fp32 residual stream, bf16 slot.  Same bounds as the library-GEMM path above, and the two agree with
+    each other to the noise of the bf16 slot."""
+    import bench
+    from paper_accurate_fast_cheap_amd import hip_ops
+    from paper_accurate_fast_cheap_amd.transformer import fused
+    from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    conf = bench.encoder_conf()
+    torch.manual_seed(777)
+    enc = ConformerEncoder(80, **conf).eval()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.02)
+    ctc = CTC(256, 512).eval()
+    lens = torch.tensor([600, 577, 431, 402, 300, 222, 133, 100])
+    xs = synth.randn((8, 600, 80), 903, 2.0)
+    sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    ref, ref_masks = EO.encoder_forward(xs, lens, sd, conf, env={})
+    ref_logp = EO.ctc_log_softmax(ref, {"ctc." + k: v for k, v in ctc.state_dict().items()})
+    enc, ctc = enc.cuda(), ctc.cuda()
+    with torch.no_grad():
+        lib_out, _ = enc(xs.cuda(), lens.cuda())
+        monkeypatch.setattr(fused, "_SPLIT_GEMM_MIN_ROWS", 0)
+        monkeypatch.setattr(hip_ops, "_SPLIT_GEMM_MIN_ROWS", 0)
+        assert all(fused.split_eligible(lp, lib_out) for lp in enc._fused(lib_out).layers)
+        out, masks = enc(xs.cuda(), lens.cuda())
+        logp = ctc.log_softmax(out)
+    assert out.dtype == torch.float32 and torch.equal(masks.cpu(), ref_masks)
+    valid = ref_masks.squeeze(1)
+    d = (out.cpu()[valid] - ref[valid]).abs()
+    dl = (out.cpu()[valid] - lib_out.cpu()[valid]).abs()
+    parity_log.record("bf16slot full size, split-operand GEMMs", max_abs_err=float(d.max()), mean_abs_err=float(d.mean()),
+                      vs_library_gemm_path_max=float(dl.max()), vs_library_gemm_path_mean=float(dl.mean()))
+    assert float(d.mean()) <= 1.6e-2 and float(d.max()) <= 0.12
+    assert float(dl.mean()) <= 1.6e-2 and float(dl.max()) <= 0.12
+    _token_parity(logp, ref_logp, valid, 0.08, "bf16slot full size, split-operand GEMMs")
+
+
 @pytest.mark.parametrize("variant", ["bf16slot", "f32", "uni_bf16slot"])
 def test_forward_chunk_by_chunk_golden(hip, variant):
     """BaseEncoder.forward_chunk_by_chunk vs the reference's own output (tests/golden/make_goldens_r2.py): the batched

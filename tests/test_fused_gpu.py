@@ -661,3 +661,64 @@ def test_gemm_at_the_production_shape(hip, K, N, Z, act, res, name):
             gemm_bf16(a, w, b, "none", alpha=alpha, residual=view, out=view)
             assert bool((buf[M:] == 7.0).all())
             torch.testing.assert_close(view, got)
+
+
+def _planes_value(p):
+    """(…, 2K) bf16 planes [hi | lo] -> the fp32 value hi + lo."""
+    K = p.shape[-1] // 2
+    return p[..., :K].float() + p[..., K:].float()
+
+
+def test_layernorm_and_split_plane_outputs(hip):
+    """PAFC_SPLIT_BF16 outputs: split_planes and the LayerNorm pass write an fp32 result as bf16 planes hi | lo whose sum is
+    the fp32 value to 2^-16 relative (the A operand of the split-operand GEMM); the triple form is the weight's."""
+    from paper_accurate_fast_cheap_amd.hip_ops import add_layernorm, split_planes
+    x = (synth.randn((3, 37, 512), 5) * 3).cuda()
+    p = split_planes(x)
+    assert p.shape == (3, 37, 1024) and p.dtype == torch.bfloat16
+    assert torch.equal(p[..., :512], x.bfloat16())
+    torch.testing.assert_close(_planes_value(p), x, rtol=2 ** -15, atol=1e-30)
+    w3 = split_planes(x[0], triple=True)
+    assert w3.shape == (37, 1536) and torch.equal(w3[:, :512], w3[:, 512:1024])
+    assert torch.equal(w3[:, :512], p[0][:, :512]) and torch.equal(w3[:, 1024:], p[0][:, 512:])
+    g, b = synth.randn((512,), 6).cuda() + 1, synth.randn((512,), 7).cuda()
+    g2, b2 = synth.randn((512,), 8).cuda() + 1, synth.randn((512,), 9).cuda()
+    _, o1, o2 = add_layernorm(x, None, 1.0, g, b, gamma2=g2, beta2=b2)
+    _, s1, s2 = add_layernorm(x, None, 1.0, g, b, gamma2=g2, beta2=b2, split1=True)
+    _, f1, t2 = add_layernorm(x, None, 1.0, g, b, gamma2=g2, beta2=b2, split2=True)
+    assert s1.shape == (3, 37, 1024) and s2.shape == (3, 37, 1024) and f1.dtype == torch.float32
+    torch.testing.assert_close(_planes_value(s1), o1, rtol=2 ** -15, atol=1e-7)
+    torch.testing.assert_close(_planes_value(s2), o2, rtol=2 ** -15, atol=1e-7)
+    assert torch.equal(f1, o1) and torch.equal(t2, s2)
+    _, sg, _ = add_layernorm(x, None, 1.0, g, b, silu=True, split1=True)
+    _, og, _ = add_layernorm(x, None, 1.0, g, b, silu=True)
+    torch.testing.assert_close(_planes_value(sg), og, rtol=2 ** -15, atol=1e-7)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 256), (2500, 2048, 512), (301, 1024, 128)])
+def test_gemm_split_operand_forms(hip, M, N, K):
+    """pafc_gemm_ph_ex: fp32 activations and weights as bf16 planes (three bf16 products per fp32 product), fp32 / plane
+    outputs, fp32 bias and residual, GLU -- against fp32 torch: the error is that of 16-bit significands, not of bf16."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_ph_ex, glu_interleave, split_planes
+    a = synth.randn((M, K), 31).cuda()
+    w = (synth.randn((N, K), 32) / K ** 0.5).cuda()
+    b = (synth.randn((N,), 33) * 0.3).cuda()
+    r = synth.randn((M, N), 34).cuda()
+    ap, w3 = split_planes(a), split_planes(w, triple=True)
+    lin = a.double() @ w.double().t()
+    tol = dict(rtol=1e-4, atol=1e-4)
+    got = gemm_ph_ex(ap, w3, b, a_split=True, out_kind="f32")
+    torch.testing.assert_close(got.double(), lin + b.double(), **tol)
+    buf = r.clone()
+    same = gemm_ph_ex(ap, w3, b, alpha=0.5, residual=buf, out=buf, a_split=True, out_kind="f32")
+    assert same.data_ptr() == buf.data_ptr()
+    torch.testing.assert_close(buf.double(), 0.5 * lin + b.double() + r.double(), **tol)
+    got = gemm_ph_ex(ap, w3, b, "silu", a_split=True, out_kind="planes")
+    assert got.shape == (M, 2 * N) and got.dtype == torch.bfloat16
+    torch.testing.assert_close(_planes_value(got).double(), F.silu(lin + b.double()), **tol)
+    got = gemm_ph_ex(ap, split_planes(glu_interleave(w, 32), triple=True), glu_interleave(b, 32), "glu", a_split=True, out_kind="f32")
+    torch.testing.assert_close(got.double(), F.glu(lin + b.double(), dim=-1), **tol)
+    # bf16 operands into an fp32 stream (the slot's output projection): exact products, fp32 residual and output
+    ab, wb = a.bfloat16(), w.bfloat16()
+    got = gemm_ph_ex(ab, wb, None, residual=r, out_kind="f32")
+    torch.testing.assert_close(got.double(), ab.double() @ wb.double().t() + r.double(), rtol=1e-5, atol=1e-5)
