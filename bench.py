@@ -420,7 +420,9 @@ def main():
             ms2 = (time.perf_counter() - t0) / 3 * 1e3
         out["extra"] = {"f32_model_bf16_slot_ms_per_step": round(ms2, 3),
                         "f32_model_bf16_slot_audio_sec_per_sec": round(frames_per_step / 100.0 / (ms2 * 1e-3), 1),
-                        "note": "rwkv_do_bfloat16 on an fp32 model (conf/rwkv/*.yaml as shipped): fp32 library GEMMs outside the slot"}
+                        "note": "rwkv_do_bfloat16 on an fp32 model (conf/rwkv/*.yaml as shipped): fp32 residual stream, every fp32 "
+                                "projection and both subsampling convolutions on the bf16 matrix cores with split operands "
+                                "(hi + lo planes, three bf16 products per fp32 product), bf16 slot"}
         del m2, fb2
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, feats32, conf, min(args.cpu_sample_frames, FRAMES))

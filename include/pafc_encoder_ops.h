@@ -170,6 +170,10 @@ int pafc_conv3x3s2_c1_wgrad_bf16(int B, int T, int F, int C, const void *x, cons
  * the same way by the caller -> out (B, T2, F2, Co) fp32 (+ bias, ReLU).  Shapes and limits as the bf16 entry points. */
 int pafc_conv3x3s2_c1_nhwc_f32split(int B, int T, int F, int C, const float *x, const float *w_c_9, const float *bias,
                                     void *out_hi, void *out_lo, int relu, pafc_stream_t stream);
+/* ... with pixel_stride elements between the pixels of each plane (out_lo = out_hi + C, pixel_stride = 2 C: one tensor
+ * (B, T1, F1, 2 C) = [hi C | lo C] per pixel, the input form of pafc_conv3x3s2_nhwc_split_ph). */
+int pafc_conv3x3s2_c1_nhwc_f32split_ps(int B, int T, int F, int C, const float *x, const float *w_c_9, const float *bias,
+                                       void *out_hi, void *out_lo, long pixel_stride, int relu, pafc_stream_t stream);
 int pafc_conv3x3s2_nhwc_f32split(int B, int T1, int F1, int Ci, int Co, const void *in_hi, const void *in_lo,
                                  const void *w_hi_tap_co_ci, const void *w_lo_tap_co_ci, const float *bias, float *out,
                                  int relu, pafc_stream_t stream);
@@ -298,6 +302,18 @@ int pafc_gemm_ph_ex(long M, int N, int K, int batch, const void *A, long lda, lo
                     long strideW, const void *bias, long strideBias, const void *residual, int res_kind, long ldr, long strideR,
                     void *out, int out_kind, long ldo, long lo_off, long strideO, float alpha, int act, int tile_m,
                     pafc_stream_t stream);
+/* ... with the planes of a split A alternating in blocks of a_plane_block columns, [hi PB | lo PB] [hi PB | lo PB] ...
+ * (PB = 64 << n, K % PB == 0; 0 = one block, the row is [hi K | lo K]): the form pafc_conv3x3s2_nhwc_split_ph writes. */
+int pafc_gemm_ph_ex2(long M, int N, int K, int batch, const void *A, long lda, long strideA, int a_split, int a_plane_block,
+                     const void *W, long ldw, long strideW, const void *bias, long strideBias, const void *residual, int res_kind,
+                     long ldr, long strideR, void *out, int out_kind, long ldo, long lo_off, long strideO, float alpha, int act,
+                     int tile_m, pafc_stream_t stream);
+/* Conv2d(Ci, Co, 3, stride 2) + bias (+ ReLU) of an fp32 model (subsampling.py:187-192) on the same kernel with split
+ * operands: in_planes (B, T1, F1, 2 Ci) bf16 = [hi Ci | lo Ci] per pixel of the fp32 image, w3 (9, Co, 3 Ci) = [hi | hi | lo]
+ * of the fp32 weight per tap (tap-major, then Co), fp32 bias, out_planes (B, T2, F2, 2 Co) = [hi Co | lo Co] per position.
+ * Ci % 128 == 0, Co % 8 == 0; tile_m 256 / 192 / 128. */
+int pafc_conv3x3s2_nhwc_split_ph(int B, int T1, int F1, int Ci, int Co, const void *in_planes, const void *w3_tap_co_3ci,
+                                 const float *bias, void *out_planes, int relu, int tile_m, pafc_stream_t stream);
 
 #ifdef __cplusplus
 }

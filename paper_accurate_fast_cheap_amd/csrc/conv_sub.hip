@@ -334,7 +334,8 @@ __global__ __launch_bounds__(1024) void conv_c1_wgrad_reduce_kernel(int n, int n
 // conv1 for fp32 inputs: fp32 arithmetic, output as hi / lo bf16 planes
 __global__ __launch_bounds__(256) void conv3x3s2_c1_split_kernel(int T, int F, int T1, int F1, int C, const float *x,
                                                                  const float *w /* (C, 9) */, const float *bias,
-                                                                 bf16_t *out_hi, bf16_t *out_lo, int relu) {
+                                                                 bf16_t *out_hi, bf16_t *out_lo, int relu,
+                                                                 long ps /* elements per output pixel in each plane */) {
     extern __shared__ float s_x[];   // [3][F]
     const int tid = threadIdx.x;
     const long bt = blockIdx.x;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void conv3x3s2_c1_split_kernel(int T, int F, i
         }
     }
     __syncthreads();
-    const long obase = bt * (long)F1 * C + cg * 8;
+    const long obase = bt * (long)F1 * ps + cg * 8;
     for (int f1 = pl; f1 < F1; f1 += ppi) {
         float xv[9];
 #pragma unroll
@@ -379,8 +380,8 @@ __global__ __launch_bounds__(256) void conv3x3s2_c1_split_kernel(int T, int F, i
         uint4 oh, ol;
         oh.x = hi[0] | (hi[1] << 16); oh.y = hi[2] | (hi[3] << 16); oh.z = hi[4] | (hi[5] << 16); oh.w = hi[6] | (hi[7] << 16);
         ol.x = lo[0] | (lo[1] << 16); ol.y = lo[2] | (lo[3] << 16); ol.z = lo[4] | (lo[5] << 16); ol.w = lo[6] | (lo[7] << 16);
-        *reinterpret_cast<uint4 *>(out_hi + obase + (long)f1 * C) = oh;
-        *reinterpret_cast<uint4 *>(out_lo + obase + (long)f1 * C) = ol;
+        *reinterpret_cast<uint4 *>(out_hi + obase + (long)f1 * ps) = oh;
+        *reinterpret_cast<uint4 *>(out_lo + obase + (long)f1 * ps) = ol;
     }
 }
 
@@ -578,13 +579,23 @@ extern "C" int pafc_conv3x3s2_c1_nhwc_bf16(int B, int T, int F, int C, const voi
 extern "C" int pafc_conv3x3s2_c1_nhwc_f32split(int B, int T, int F, int C, const float *x, const float *w_c_9,
                                                const float *bias, void *out_hi, void *out_lo, int relu,
                                                pafc_stream_t stream) {
+    return pafc_conv3x3s2_c1_nhwc_f32split_ps(B, T, F, C, x, w_c_9, bias, out_hi, out_lo, C, relu, stream);
+}
+
+// ... with `pixel_stride` elements between the pixels of each plane: out_lo = out_hi + C and pixel_stride = 2 C give one
+// tensor (B, T1, F1, 2 C) = [hi C | lo C] per pixel, the input of pafc_conv3x3s2_nhwc_split_ph.
+extern "C" int pafc_conv3x3s2_c1_nhwc_f32split_ps(int B, int T, int F, int C, const float *x, const float *w_c_9,
+                                                  const float *bias, void *out_hi, void *out_lo, long pixel_stride, int relu,
+                                                  pafc_stream_t stream) {
     if (!x || !w_c_9 || !out_hi || !out_lo) return PAFC_ERR_NULL_POINTER;
-    if (B <= 0 || T < 3 || F < 3 || C <= 0 || C % 8 || (256 % (C / 8)) || C > 2048) return PAFC_ERR_BAD_DIMS;
+    if (B <= 0 || T < 3 || F < 3 || C <= 0 || C % 8 || (256 % (C / 8)) || C > 2048 || pixel_stride < C || pixel_stride % 8)
+        return PAFC_ERR_BAD_DIMS;
     const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
     const long nblk = (long)B * T1;
     if (nblk > 0x7fffffffL) return PAFC_ERR_BAD_DIMS;
     hipLaunchKernelGGL(pafc::conv3x3s2_c1_split_kernel, dim3((unsigned)nblk), dim3(256), 3 * F * sizeof(float),
-                       (hipStream_t)stream, T, F, T1, F1, C, x, w_c_9, bias, (pafc::bf16_t *)out_hi, (pafc::bf16_t *)out_lo, relu);
+                       (hipStream_t)stream, T, F, T1, F1, C, x, w_c_9, bias, (pafc::bf16_t *)out_hi, (pafc::bf16_t *)out_lo, relu,
+                       pixel_stride);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 

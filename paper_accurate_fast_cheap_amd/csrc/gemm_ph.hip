@@ -38,8 +38,9 @@
 // fp32 activations on the bf16 matrix cores (fp32 models; the reference's default precision is an fp32 model around the bf16
 // slot, rwkv_wrapper_bidirectional.py:40-56): x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 significant bits), the
 // same for the weight, and x w = hi_x hi_w + lo_x hi_w + hi_x lo_w (+ 2^-16 relative).  As a GEMM: A stored as [hi | lo]
-// (M x 2K), W' = [hi_w | hi_w | lo_w] (N x 3K), and the K walk of A wraps back to column 0 after 2K (`a_wrap`): three
-// bf16 products on the fast path instead of one fp32 product at 1/16 of the rate.
+// (M x 2K), W' = [hi_w | hi_w | lo_w] (N x 3K), and the K walk of A visits hi, lo, hi (`a_soff`): three bf16 products on
+// the fast path instead of one fp32 product at 1/16 of the rate.  The planes may also alternate in blocks ([hi 512 | lo 512]
+// per pixel: what the split convolution writes and Linear(9728, 512) then reads).
 #include <climits>
 #include <type_traits>
 
@@ -66,11 +67,18 @@ struct PhParams {
     int mtiles, ntiles;
     int tm;                           // rows per tile actually used: 256, 192, 128 or 64 (balances the grid over the CUs)
     int batch;
-    int a_wrap;                       // K-step at which the walk over A's columns starts again at 0 (INT_MAX: never)
+    // split-operand A (planes hi | lo of an fp32 activation): the K walk visits hi, lo, hi -- nk1 64-deep K-steps each
+    // (nk1 = a huge number: a plain bf16 A).  The planes alternate in blocks of 64 << pb_shift columns: [hi PB | lo PB] ...
+    // (pb_shift = 31: one block, the row is [hi K | lo K]); pb_bytes = bytes of one plane block.
+    int nk1, pb_shift;
+    long pb_bytes;
     long lo_off;                      // OUT 2: column offset of the lo plane inside an output row
     // implicit-GEMM mode (CONV): A is an NHWC image (B, T1, F1, Ci), row m = output position (b, t2, f2) of a 3 x 3 stride-2
     // convolution, K = 9 taps x Ci; W is (9, N, Ci) tap-major.  K-step kt = (tap, 64-channel slice).
-    int T1, F1, T2, F2, Ci, kshift;   // kshift = log2(Ci / 64)
+    // CiA: elements per input pixel (Ci, or 2 Ci for planes [hi Ci | lo Ci]); CiW: elements per weight row and tap (Ci, or
+    // 3 Ci = [hi | hi | lo]); spt = CiW / 64 K-steps per tap, inv_spt = ceil(2^16 / spt) (tap = kt * inv_spt >> 16, checked on
+    // the host for every kt the kernel forms).
+    int T1, F1, T2, F2, Ci, CiA, CiW, spt, inv_spt;
     long in_bytes;                    // bytes of the whole image tensor
 #ifdef PH_STAMPS
     unsigned long long *stamps;       // diagnostic build only: [block][2 waves][64] shader-clock stamps (s_memtime)
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         const long tf = (long)p.T2 * p.F2;
         const long bb = m / tf, rem = m - bb * tf;
         const long t2 = rem / p.F2, f2 = rem - t2 * p.F2;
-        return (((bb * p.T1 + 2 * t2) * p.F1 + 2 * f2) * p.Ci) * 2;
+        return (((bb * p.T1 + 2 * t2) * p.F1 + 2 * f2) * p.CiA) * 2;
     };
 
     // ---- a tile = its coordinates + the buffer descriptors of its operands, all wave-uniform (SGPRs).  The descriptors START
@@ -184,10 +192,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         if constexpr (CONV) {
             const long a_base = pix_off(T.m0);
             T.Ar = make_rsrc(reinterpret_cast<const unsigned char *>(p.A) + a_base, real ? p.in_bytes - a_base : 0);
-            T.Wr = make_rsrc(p.W + (long)T.n0 * p.Ci, real ? ((long)8 * p.N + p.N - T.n0) * p.Ci * 2 : 0);
+            T.Wr = make_rsrc(p.W + (long)T.n0 * p.CiW, real ? ((long)8 * p.N + p.N - T.n0) * p.CiW * 2 : 0);
         } else {
-            const long acols = p.a_wrap == INT_MAX ? p.K : (long)p.a_wrap * PBK;
-            T.Ar = make_rsrc(p.A + T.z * p.sA + T.m0 * p.lda, real ? ((p.M - 1 - T.m0) * p.lda + acols) * 2 : 0);
+            T.Ar = make_rsrc(p.A + T.z * p.sA + T.m0 * p.lda, real ? (p.M - T.m0) * p.lda * 2 : 0);   // (whole rows)
             T.Wr = make_rsrc(p.W + T.z * p.sW + (long)T.n0 * p.ldw, real ? ((long)(p.N - 1 - T.n0) * p.ldw + p.K) * 2 : 0);
         }
     };
@@ -218,20 +225,27 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
                 const int u = (wave * DB + j) * 8 + sub;                         // 0..127: wave column group u >> 5, row u & 31
                 const int r = u & 31;                                            // MFMA tile r >> 4, its n index r & 15
                 const int pc = ((r & 15) >> 2) * 8 + (r >> 4) * 4 + (r & 3);     // -> column inside the half (see the head comment)
-                b_off[h][j] = (unsigned)((long)((u >> 5) * 64 + h * 32 + pc) * (CONV ? p.Ci : p.ldw) * 2 + 16 * (pch ^ sub));
+                b_off[h][j] = (unsigned)((long)((u >> 5) * 64 + h * 32 + pc) * (CONV ? p.CiW : p.ldw) * 2 + 16 * (pch ^ sub));
             }
     };
-    // wave-uniform byte offset of K-step kt inside a row of A / W
+    // wave-uniform byte offset of K-step kt inside a row of A / W (all scalar arithmetic)
     auto a_soff = [&](int kt) -> unsigned {
-        if constexpr (!CONV) return (unsigned)(kt >= p.a_wrap ? kt - p.a_wrap : kt) * 128;
-        const int tap = kt >> p.kshift, kc = kt - (tap << p.kshift);
-        const int dt = (tap * 11) >> 5, df = tap - 3 * dt;                  // tap / 3, tap % 3 for tap < 9
-        return (unsigned)(((dt * p.F1 + df) * p.Ci) * 2 + kc * 128);
+        if constexpr (!CONV) {
+            const int seg = (kt >= p.nk1) + (kt >= 2 * p.nk1);           // hi, lo, hi (plain bf16 A: always 0)
+            const int r = kt - seg * p.nk1;
+            const int blk = r >> p.pb_shift, c = r - (blk << p.pb_shift);
+            return (unsigned)(blk * 2 * p.pb_bytes + (seg == 1 ? p.pb_bytes : 0) + c * 128);
+        } else {
+            const int tap = (kt * p.inv_spt) >> 16, kc = kt - tap * p.spt;
+            const int seg = (kc >= p.nk1) + (kc >= 2 * p.nk1), cc = kc - seg * p.nk1;
+            const int dt = (tap * 11) >> 5, df = tap - 3 * dt;              // tap / 3, tap % 3 for tap < 9
+            return (unsigned)(((dt * p.F1 + df) * p.CiA + (seg == 1 ? p.Ci : 0)) * 2 + cc * 128);
+        }
     };
     auto w_soff = [&](int kt) -> unsigned {
         if constexpr (!CONV) return kt * 128;
-        const int tap = kt >> p.kshift, kc = kt - (tap << p.kshift);
-        return (unsigned)(tap * p.N * p.Ci * 2 + kc * 128);
+        const int tap = (kt * p.inv_spt) >> 16, kc = kt - tap * p.spt;
+        return (unsigned)(tap * p.N * p.CiW * 2 + kc * 128);
     };
     auto stage_a = [&](const Tile &T, int h, int buf, int kt) {
 #ifdef PH_ABL_NODMA
@@ -619,6 +633,16 @@ extern "C" int pafc_gemm_ph_ex(long M, int N, int K, int batch, const void *A, l
                                long ldw, long strideW, const void *bias, long strideBias, const void *residual, int res_kind,
                                long ldr, long strideR, void *out, int out_kind, long ldo, long lo_off, long strideO, float alpha,
                                int act, int tile_m, pafc_stream_t stream) {
+    return pafc_gemm_ph_ex2(M, N, K, batch, A, lda, strideA, a_split, 0, W, ldw, strideW, bias, strideBias, residual, res_kind, ldr,
+                            strideR, out, out_kind, ldo, lo_off, strideO, alpha, act, tile_m, stream);
+}
+
+//   a_plane_block (with a_split): 0 = the row is [hi K | lo K]; else the planes alternate in blocks of that many columns,
+//                 [hi PB | lo PB] [hi PB | lo PB] ... (PB = 64 << n, K % PB == 0).
+extern "C" int pafc_gemm_ph_ex2(long M, int N, int K, int batch, const void *A, long lda, long strideA, int a_split,
+                                int a_plane_block, const void *W, long ldw, long strideW, const void *bias, long strideBias,
+                                const void *residual, int res_kind, long ldr, long strideR, void *out, int out_kind, long ldo,
+                                long lo_off, long strideO, float alpha, int act, int tile_m, pafc_stream_t stream) {
     if (!A || !W || !out) return PAFC_ERR_NULL_POINTER;
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535) return PAFC_ERR_BAD_DIMS;
     if (act < 0 || act > 4 || out_kind < 0 || out_kind > 2 || res_kind < 0 || res_kind > 2) return PAFC_ERR_UNSUPPORTED;
@@ -647,7 +671,16 @@ extern "C" int pafc_gemm_ph_ex(long M, int N, int K, int batch, const void *A, l
     p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr;
     p.sA = strideA; p.sW = strideW; p.sO = strideO; p.sB = strideBias; p.sR = strideR;
     p.alpha = alpha;
-    p.a_wrap = a_split ? 2 * K / 64 : INT_MAX;
+    p.nk1 = a_split ? K / 64 : INT_MAX / 4;
+    p.pb_shift = 31;
+    p.pb_bytes = (long)K * 2;
+    if (a_split && a_plane_block) {
+        int sh = 0;
+        while ((64 << sh) < a_plane_block) ++sh;
+        if ((64 << sh) != a_plane_block || K % a_plane_block) return PAFC_ERR_UNSUPPORTED;
+        p.pb_shift = sh;
+        p.pb_bytes = (long)a_plane_block * 2;
+    }
     p.lo_off = lo_off;
     p.tm = tile_m;
     p.mtiles = (int)((M + tile_m - 1) / tile_m);
@@ -686,32 +719,51 @@ extern "C" int pafc_gemm_bf16_ph(long M, int N, int K, int batch, const void *A,
                            strideR, out, 0, ldo, 0, strideO, alpha, act, tile_m, stream);
 }
 
-// The second subsampling convolution, Conv2d(Ci, Co, 3, stride 2) + bias (+ ReLU) on NHWC bf16 (wenet/transformer/
-// subsampling.py:187-192), as an implicit GEMM on the phase-pipelined kernel: same contract as pafc_conv3x3s2_nhwc_bf16,
-// which dispatches here when the problem fills the chip with 256-wide tiles.  PAFC_ERR_UNSUPPORTED = take the other kernel.
-extern "C" int pafc_conv3x3s2_nhwc_bf16_ph(int B, int T1, int F1, int Ci, int Co, const void *in, const void *w_tap_co_ci,
-                                           const void *bias, void *out, int relu, int tile_m, pafc_stream_t stream) {
-    if (!in || !w_tap_co_ci || !out) return PAFC_ERR_NULL_POINTER;
+// The second subsampling convolution, Conv2d(Ci, Co, 3, stride 2) + bias (+ ReLU) on NHWC (wenet/transformer/
+// subsampling.py:187-192), as an implicit GEMM on the phase-pipelined kernel.  split = 0: bf16 in, bf16 weights (9, Co, Ci),
+// bf16 bias, bf16 out -- same contract as pafc_conv3x3s2_nhwc_bf16, which dispatches here when the problem fills the chip
+// with 256-wide tiles.  split = 1 (fp32 models): in = planes per pixel [hi Ci | lo Ci] of the fp32 image (what
+// pafc_conv3x3s2_c1_f32split writes with a pixel stride of 2 Ci), weights (9, Co, 3 Ci) = [hi | hi | lo] per tap, fp32 bias,
+// out = planes per output position [hi Co | lo Co] of the fp32 result -- read as it lies by pafc_gemm_ph_ex2(a_split = 1,
+// a_plane_block = Co) for Linear(F' Co, odim).  PAFC_ERR_UNSUPPORTED = take the other kernel.
+static int conv_ph_launch(int B, int T1, int F1, int Ci, int Co, const void *in, const void *w, const void *bias, void *out,
+                          int relu, int tile_m, int split, pafc_stream_t stream) {
+    if (!in || !w || !out) return PAFC_ERR_NULL_POINTER;
     if (B <= 0 || T1 < 3 || F1 < 3 || Ci <= 0 || Co <= 0) return PAFC_ERR_BAD_DIMS;
-    // 64-channel K-steps, a power of two per tap and an even number of them in all (9 Ci / 64 even <=> Ci % 128 == 0)
-    if (Ci % 128 || (Ci / 64) & (Ci / 64 - 1) || Co % 8) return PAFC_ERR_UNSUPPORTED;
+    // 64-channel K-steps and an even number of them in all (9 Ci / 64 even <=> Ci % 128 == 0)
+    if (Ci % 128 || Co % 8) return PAFC_ERR_UNSUPPORTED;
     if (tile_m != 256 && tile_m != 192 && tile_m != 128) return PAFC_ERR_UNSUPPORTED;
-    if ((((uintptr_t)in | (uintptr_t)w_tap_co_ci | (uintptr_t)out | (uintptr_t)bias) & 15) != 0) return PAFC_ERR_ALIGNMENT;
+    if ((((uintptr_t)in | (uintptr_t)w | (uintptr_t)out | (uintptr_t)bias) & 15) != 0) return PAFC_ERR_ALIGNMENT;
     const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
     const long M = (long)B * T2 * F2;
-    if ((double)9 * Co * Ci * 2 >= 2.0e9) return PAFC_ERR_UNSUPPORTED;
     pafc::PhParams p{};
-    p.A = (const pafc::bf16_t *)in; p.W = (const pafc::bf16_t *)w_tap_co_ci; p.bias = bias; p.out = out;
-    p.M = M; p.N = Co; p.K = 9 * Ci; p.lda = Ci; p.ldw = Ci; p.ldo = Co; p.alpha = 1.f;
-    p.a_wrap = INT_MAX;
-    p.T1 = T1; p.F1 = F1; p.T2 = T2; p.F2 = F2; p.Ci = Ci;
-    p.in_bytes = (long)B * T1 * F1 * Ci * 2;
-    int ks = 0;
-    while ((64 << ks) < Ci) ++ks;
-    p.kshift = ks;
+    p.A = (const pafc::bf16_t *)in; p.W = (const pafc::bf16_t *)w; p.bias = bias; p.out = out;
+    p.Ci = Ci; p.CiA = split ? 2 * Ci : Ci; p.CiW = split ? 3 * Ci : Ci;
+    if ((double)9 * Co * p.CiW * 2 >= 2.0e9 || (double)3 * F1 * p.CiA * 2 >= 2.0e9) return PAFC_ERR_UNSUPPORTED;
+    p.M = M; p.N = Co; p.K = 9 * p.CiW; p.lda = p.CiA; p.ldw = p.CiW; p.alpha = 1.f;
+    p.ldo = split ? 2 * Co : Co; p.lo_off = split ? Co : 0;
+    p.nk1 = Ci / 64;                   // per tap: hi (, lo, hi)
+    p.pb_shift = 31; p.pb_bytes = 0;
+    p.spt = p.CiW / 64;
+    p.inv_spt = (65536 + p.spt - 1) / p.spt;
+    for (int kt = 0; kt < p.K / 64 + 2; ++kt)
+        if (((kt * p.inv_spt) >> 16) != kt / p.spt) return PAFC_ERR_UNSUPPORTED;     // (never for the sizes above; checked, not assumed)
+    p.T1 = T1; p.F1 = F1; p.T2 = T2; p.F2 = F2;
+    p.in_bytes = (long)B * T1 * F1 * p.CiA * 2;
     p.tm = tile_m;
     p.mtiles = (int)((M + tile_m - 1) / tile_m);
     p.ntiles = (Co + 255) / 256;
     hipStream_t s = (hipStream_t)stream;
+    if (split) return relu ? pafc::launch_ph<false, 3, 0, 2, true>(p, 1, s) : pafc::launch_ph<false, 0, 0, 2, true>(p, 1, s);
     return relu ? pafc::launch_ph<false, 3, 0, 0, true>(p, 1, s) : pafc::launch_ph<false, 0, 0, 0, true>(p, 1, s);
+}
+
+extern "C" int pafc_conv3x3s2_nhwc_bf16_ph(int B, int T1, int F1, int Ci, int Co, const void *in, const void *w_tap_co_ci,
+                                           const void *bias, void *out, int relu, int tile_m, pafc_stream_t stream) {
+    return conv_ph_launch(B, T1, F1, Ci, Co, in, w_tap_co_ci, bias, out, relu, tile_m, 0, stream);
+}
+
+extern "C" int pafc_conv3x3s2_nhwc_split_ph(int B, int T1, int F1, int Ci, int Co, const void *in_planes, const void *w3_tap_co_3ci,
+                                            const float *bias, void *out_planes, int relu, int tile_m, pafc_stream_t stream) {
+    return conv_ph_launch(B, T1, F1, Ci, Co, in_planes, w3_tap_co_3ci, bias, out_planes, relu, tile_m, 1, stream);
 }

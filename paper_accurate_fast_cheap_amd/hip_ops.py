@@ -467,11 +467,12 @@ def _ph_tile_m(M: int, N: int, batch: int = 1) -> int:
 
 def gemm_ph_ex(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none", alpha: float = 1.0,
                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, a_split: bool = False,
-               out_kind: str = "bf16", tile_m: int = 0) -> torch.Tensor:
+               out_kind: str = "bf16", tile_m: int = 0, a_plane_block: int = 0) -> torch.Tensor:
     """The phase-pipelined GEMM with every operand form (include/pafc_encoder_ops.h: pafc_gemm_ph_ex).
     a: (M, K) bf16, or with a_split (M, 2K) planes [hi | lo] of an fp32 activation, then w: (N, 3K) = split_planes(W, triple=True);
     out_kind "bf16" | "f32" | "planes" ((M, 2N) bf16 = [hi | lo] of the fp32 result); residual bf16 (out bf16) or fp32 (out f32),
-    may be `out`; bias bf16 for out_kind bf16, fp32 otherwise; act as gemm_bf16 (GLU: glu_interleave(w, 32) rows before splitting)."""
+    may be `out`; bias bf16 for out_kind bf16, fp32 otherwise; act as gemm_bf16 (GLU: glu_interleave(w, 32) rows before splitting).
+    a_plane_block: the planes of a split `a` alternate in blocks of that many columns ([hi PB | lo PB] ...; 0: [hi K | lo K])."""
     _lib.require_gpu(bias)
     for t in (a, w, residual, out):
         if t is not None and (not t.is_cuda or t.stride(-1) != 1):
@@ -501,11 +502,12 @@ def gemm_ph_ex(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     if not getattr(L, "_pafc_gemmex_bound", False):
         from ctypes import c_float, c_long
         P, I, G = c_void_p, c_int, c_long
-        _lib._sig(L.pafc_gemm_ph_ex, I, G, I, I, I, P, G, G, I, P, G, G, P, G, P, I, G, G, P, I, G, G, G, c_float, I, I, P)
+        _lib._sig(L.pafc_gemm_ph_ex2, I, G, I, I, I, P, G, G, I, I, P, G, G, P, G, P, I, G, G, P, I, G, G, G, c_float, I, I, P)
         L._pafc_gemmex_bound = True
     from .profiling import op_timer
     with op_timer("gemm%s_%dx%d" % ("3" if a_split else "", K, N), sample=12, flops=2.0 * M * N * K * (3 if a_split else 1)):
-        rc = L.pafc_gemm_ph_ex(M, N, K, 1, _lib.ptr(a), a.stride(0), 0, int(a_split), _lib.ptr(w), w.stride(0), 0, _lib.ptr(bias), 0,
+        rc = L.pafc_gemm_ph_ex2(M, N, K, 1, _lib.ptr(a), a.stride(0), 0, int(a_split), int(a_plane_block), _lib.ptr(w), w.stride(0), 0,
+                                _lib.ptr(bias), 0,
                                _lib.ptr(residual), rk, residual.stride(0) if residual is not None else 0, 0, _lib.ptr(out), ok,
                                out.stride(0), No if ok == 2 else 0, 0, float(alpha), _ACTS[act], int(tile_m or _ph_tile_m(M, N)),
                                _lib.stream_of(a))
@@ -1234,6 +1236,40 @@ def conv_sub_f32split(x: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tens
     out = torch.empty((B, T2, F2, C), dtype=torch.float32, device=x.device)
     _lib.check(L.pafc_conv3x3s2_nhwc_f32split(B, T1, F1, C, C, _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(w2_hi), _lib.ptr(w2_lo),
                                               _lib.ptr(b2), _lib.ptr(out), 1, st), "pafc_conv3x3s2_nhwc_f32split")
+    return out
+
+
+def conv_sub_f32split_planes(x: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor], w2_3: torch.Tensor,
+                             b2: Optional[torch.Tensor]) -> torch.Tensor:
+    """Both subsampling convolutions (+ ReLU) of an fp32 model at long-form sizes: conv1 in fp32 arithmetic writing planes
+    [hi C | lo C] per pixel, conv2 as the split-operand implicit GEMM of csrc/gemm_ph.hip (include/pafc_encoder_ops.h:
+    pafc_conv3x3s2_nhwc_split_ph).  x (B, T, F) fp32; w1 (C, 1, 3, 3) fp32; w2_3 (9, C, 3 C) = split_planes(w2 taps, triple)
+    -> (B, T', F', 2 C) bf16 planes [hi C | lo C] of the fp32 result, the A operand of gemm_ph_ex(a_split, a_plane_block=C)."""
+    _lib.require_gpu(x, w1, b1, w2_3, b2)
+    B, T, Fd = x.shape
+    C = w1.shape[0]
+    if x.dtype != torch.float32 or w1.dtype != torch.float32 or w2_3.dtype != torch.bfloat16 or tuple(w2_3.shape) != (9, C, 3 * C):
+        raise _lib.PafcError("conv_sub_f32split_planes: fp32 x (B, T, F) / w1, w2 as (9, C, 3C) bf16 planes")
+    L = _bind()
+    if not getattr(L, "_pafc_splitph_bound", False):
+        from ctypes import c_long
+        P, I = c_void_p, c_int
+        _lib._sig(L.pafc_conv3x3s2_c1_nhwc_f32split_ps, I, I, I, I, I, P, P, P, P, P, c_long, I, P)
+        _lib._sig(L.pafc_conv3x3s2_nhwc_split_ph, I, I, I, I, I, I, P, P, P, P, I, I, P)
+        L._pafc_splitph_bound = True
+    T1, F1 = (T - 3) // 2 + 1, (Fd - 3) // 2 + 1
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    y1 = torch.empty((B, T1, F1, 2 * C), dtype=torch.bfloat16, device=x.device)
+    st = _lib.stream_of(x)
+    lo = c_void_p(y1.data_ptr() + 2 * C)
+    _lib.check(L.pafc_conv3x3s2_c1_nhwc_f32split_ps(B, T, Fd, C, _lib.ptr(x), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(y1), lo, 2 * C, 1, st),
+               "pafc_conv3x3s2_c1_nhwc_f32split_ps")
+    out = torch.empty((B, T2, F2, 2 * C), dtype=torch.bfloat16, device=x.device)
+    from .profiling import op_timer
+    with op_timer("conv3x3s2_split", flops=2.0 * B * T2 * F2 * C * 9 * C * 3):
+        rc = L.pafc_conv3x3s2_nhwc_split_ph(B, T1, F1, C, C, _lib.ptr(y1), _lib.ptr(w2_3), _lib.ptr(b2), _lib.ptr(out), 1,
+                                            _ph_tile_m(B * T2 * F2, C), st)
+    _lib.check(rc, "pafc_conv3x3s2_nhwc_split_ph")
     return out
 
 

@@ -47,10 +47,12 @@ class Conv2dSubsampling4(BaseSubsampling):
             self._w_lin = lin.weight.detach().view(-1, C, Fo).permute(0, 2, 1).reshape(-1, Fo * C).contiguous()
             self._w_c2 = c2.weight.detach().contiguous(memory_format=torch.channels_last)
             self._w_c2_taps = c2.weight.detach().permute(2, 3, 0, 1).reshape(9, C, C).contiguous()   # (tap, co, ci)
-            self._w_c2_split = None
+            self._w_c2_split = self._w_c2_3 = None
             if x.dtype == torch.float32 and c2.weight.dtype == torch.float32:
-                from ..hip_ops import split_bf16
+                from ..hip_ops import split_bf16, split_planes
                 self._w_c2_split = split_bf16(self._w_c2_taps)
+                if C % 128 == 0:
+                    self._w_c2_3 = split_planes(self._w_c2_taps, triple=True)          # (9, C, 3C) = [hi | hi | lo] per tap
             self._nhwc_stamp = stamp
         if x.dtype == torch.bfloat16 and C % 128 == 0 and 256 % (C // 8) == 0:
             # conv1 + ReLU: write-bound direct kernel (its output is the largest tensor of the whole pass);
@@ -61,6 +63,16 @@ class Conv2dSubsampling4(BaseSubsampling):
             b, t, f, c = y.shape
             from ..hip_ops import linear_fused
             return linear_fused(y.view(b, t, f * c), self._w_lin, lin.bias, "none")
+        if x.dtype == torch.float32 and self._w_c2_3 is not None and 256 % (C // 8) == 0 and lin.weight.dtype == torch.float32:
+            # long fp32 inputs: conv2 as the split-operand implicit GEMM of the phase-pipelined kernel, its output left as the
+            # bf16 planes Linear(F' C, odim) reads as they lie (hip_ops.conv_sub_f32split_planes)
+            from .. import hip_ops
+            T2 = ((T - 3) // 2 + 1 - 3) // 2 + 1
+            F2 = ((Fd - 3) // 2 + 1 - 3) // 2 + 1
+            if B * T2 >= hip_ops._SPLIT_GEMM_MIN_ROWS and lin.out_features >= 256 and lin.out_features % 8 == 0:
+                y = hip_ops.conv_sub_f32split_planes(x.contiguous(), c1.weight, c1.bias, self._w_c2_3, c2.bias)
+                return hip_ops.gemm_ph_ex(y.view(B * T2, F2 * 2 * C), hip_ops.split_weight_cached(self._w_lin), lin.bias, a_split=True,
+                                          out_kind="f32", a_plane_block=C).view(B, T2, lin.out_features)
         if x.dtype == torch.float32 and self._w_c2_split is not None and C % 128 == 0 and 256 % (C // 8) == 0:
             # fp32 model: both convolutions on the bf16 matrix cores with hi + lo split operands (fp32 accumulation,
             # ~1e-5 relative to the fp32 convolution) instead of the fp32 MFMA path (57 ms -> 13 ms per 30-minute file)

@@ -722,3 +722,29 @@ def test_gemm_split_operand_forms(hip, M, N, K):
     ab, wb = a.bfloat16(), w.bfloat16()
     got = gemm_ph_ex(ab, wb, None, residual=r, out_kind="f32")
     torch.testing.assert_close(got.double(), ab.double() @ wb.double().t() + r.double(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,T,C", [(2, 203, 256), (1, 1203, 512)])
+def test_conv_sub_split_operand_planes(hip, B, T, C):
+    """The subsampling front end of an fp32 model at long-form sizes: conv1 (fp32 arithmetic) writing planes, conv2 as the
+    split-operand implicit GEMM (planes in, planes out), Linear(F' C, odim) reading those planes in blocks of C columns --
+    against fp32 torch on the same operands (16-bit significands: ~1e-4, not bf16's 1e-2)."""
+    from paper_accurate_fast_cheap_amd.hip_ops import conv_sub_f32split_planes, gemm_ph_ex, split_planes
+    x = synth.randn((B, T, 80), 41, 2.0).cuda()
+    w1 = (synth.randn((C, 1, 3, 3), 42) / 3).cuda()
+    b1 = (synth.randn((C,), 43) * 0.1).cuda()
+    w2 = (synth.randn((C, C, 3, 3), 44) / (3 * C ** 0.5)).cuda()
+    b2 = (synth.randn((C,), 45) * 0.1).cuda()
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(x.unsqueeze(1), w1, b1, stride=2)), w2, b2, stride=2))      # (B, C, T', F')
+    ref = ref.permute(0, 2, 3, 1).contiguous()                                                          # (B, T', F', C)
+    taps3 = split_planes(w2.permute(2, 3, 0, 1).reshape(9, C, C).contiguous(), triple=True)
+    y = conv_sub_f32split_planes(x, w1, b1, taps3, b2)
+    assert y.shape == ref.shape[:-1] + (2 * C,) and y.dtype == torch.bfloat16
+    got = y[..., :C].float() + y[..., C:].float()
+    torch.testing.assert_close(got, ref, rtol=2e-4, atol=2e-4)
+    Bt, Tp, Fp = ref.shape[0], ref.shape[1], ref.shape[2]
+    wl = (synth.randn((256, Fp * C), 46) / (Fp * C) ** 0.5).cuda()
+    bl = (synth.randn((256,), 47) * 0.1).cuda()
+    out = gemm_ph_ex(y.view(Bt * Tp, Fp * 2 * C), split_planes(wl, triple=True), bl, a_split=True, out_kind="f32", a_plane_block=C)
+    want = F.linear(ref.reshape(Bt * Tp, Fp * C).double(), wl.double(), bl.double())
+    torch.testing.assert_close(out.double(), want, rtol=2e-4, atol=2e-4)

@@ -39,7 +39,7 @@ int main(int argc, char **argv) {
     hipMalloc(&st, nblk * 2 * 64 * 8);
     hipMemset(st, 0, nblk * 2 * 64 * 8);
     pafc::PhParams p{};
-    p.A = A; p.W = W; p.bias = B; p.res = mode == 1 ? R : nullptr; p.out = O; p.a_wrap = INT_MAX;
+    p.A = A; p.W = W; p.bias = B; p.res = mode == 1 ? R : nullptr; p.out = O; p.nk1 = INT_MAX / 4; p.pb_shift = 31;
     p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldo = N; p.ldr = N; p.alpha = 1.f;
     p.mtiles = (int)mt; p.ntiles = (int)nt; p.tm = tm; p.stamps = st; p.batch = 1;
     hipEvent_t e0, e1;
