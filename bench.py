@@ -18,6 +18,7 @@ Prints ONE JSON line on rank 0 (schema in the task contract) with two extra obje
                   of the same features, on this box's host cores (rank 0, N == 1 only).
 """
 import argparse
+import contextlib
 import json
 import math
 import os
@@ -185,6 +186,10 @@ def main():
     ap.add_argument("--chunk-size", type=int, default=0, help="frames per window; 0 = the whole file as one sequence")
     ap.add_argument("--batch-size", type=int, default=8)
     ap.add_argument("--cpu-sample-frames", type=int, default=20000)
+    ap.add_argument("--streams", type=int, default=0,
+                    help="c2: decode batches in flight at once, each on a HIP stream of its own (0 = 2).  A batch of 64 short "
+                         "utterances fills half the chip per kernel; independent batches side by side fill the rest -- same "
+                         "kernels, same batches, same results")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the fp32-model / bf16-slot timing reported under 'extra'")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
@@ -194,6 +199,13 @@ def main():
         # ~90 distinct (B, T) shapes: MIOpen's default exhaustive per-shape search costs seconds each; the
         # immediate-mode heuristic is the production setting for ragged batches
         os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+        if (args.streams or 2) > 1:
+            # several decode batches in flight: half-full grids of the big-tile GEMM run side by side, so it takes over from
+            # the 128 x 128 kernel earlier, and the hand-written kernels take over from the library at fewer rows (measured,
+            # profiles/r03c_bench_c2_knobs.txt)
+            os.environ.setdefault("PAFC_PH_MIN_FILL", "25")
+            os.environ.setdefault("PAFC_OWN_GEMM_MIN_ROWS", "2048")
+            os.environ.setdefault("PAFC_LDS_RESIDENT_MIN_ROWS", "2048")
     one_gpu = os.environ.get("PAFC_BENCH_ONE_GPU") == "1"   # rehearsal of the N > 1 code path on a single-GPU box
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         have = torch.cuda.device_count()           # counts devices without initialising the GPU
@@ -266,12 +278,26 @@ def main():
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         progress = open(os.path.join(ROOT, "gpurun_out", "bench_c2_progress.log"), "a")
 
+    nstreams = (args.streams or 2) if args.workload == "c2" else 1
+    side = [torch.cuda.Stream(device=device) for _ in range(nstreams)] if nstreams > 1 else []
+    last_tokens = []
+
     def step():
-        for fb, lens in batches:
-            enc, mask = model._forward_encoder(fb, lens)
-            logp = model.ctc_logprobs(enc)
-            if greedy is not None:            # c2 = encoder + CTC log-softmax + greedy tokens (search.py:106-121)
-                toks = greedy(logp, mask.squeeze(1).sum(1), 0)
+        main = torch.cuda.current_stream(device)
+        for s_ in side:
+            s_.wait_stream(main)
+        last_tokens.clear()
+        for i, (fb, lens) in enumerate(batches):
+            ctx = torch.cuda.stream(side[i % nstreams]) if side else contextlib.nullcontext()
+            with ctx:
+                enc, mask = model._forward_encoder(fb, lens)
+                logp = model.ctc_logprobs(enc)
+                if greedy is not None:            # c2 = encoder + CTC log-softmax + greedy tokens (search.py:106-121)
+                    last_tokens.append(greedy(logp, mask.squeeze(1).sum(1), 0, defer=bool(side)))
+        for s_ in side:
+            main.wait_stream(s_)
+        if side:                              # the token lists come back once per pass, not once per batch
+            last_tokens[:] = [f() for f in last_tokens]
         if progress is not None:
             progress.write(f"{time.strftime('%H:%M:%S')} pass over {len(batches)} batches queued\n")
             progress.flush()
@@ -396,6 +422,7 @@ def main():
                         "max_vram_GB": round(max_vram_mb / 1024.0, 3), "max_vram_MB": round(max_vram_mb, 2),
                         "max_cpu_ram_MB": round(rss_mb(), 2)},
         "rccl_ranks": rccl_ranks,
+        "streams": nstreams,
         "roofline": roofline, "mfma": mfma,
         "front_end": {"kernel": "fbank (HIP, fp32 MFMA DFT)", "ms_per_file": round(fbank_ms, 3),
                       "audio_sec_per_sec": round(frames_per_step / 100.0 / (fbank_ms * 1e-3), 1),

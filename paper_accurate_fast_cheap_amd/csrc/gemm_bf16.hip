@@ -17,6 +17,8 @@
 // bf16 otherwise -- and leave as whole 256-byte rows.
 // (Tried and measured, not kept: a persistent tile loop that prefetches the next tile's first K-step across the
 // epilogue -- 177 vs 165 us on the FFN shape: the wait for the prefetch also waits for the tile's output stores.)
+#include <stdlib.h>
+
 #include "pafc_common.h"
 #include "../../include/pafc_encoder_ops.h"
 
@@ -260,7 +262,11 @@ static int ph_tile_m(long M, int N, int K, int batch, int act, bool has_residual
     if (has_residual && act != 0) return 0;
     const int cus = pafc::device_cus();
     const long nt = (N + 255) / 256;
-    if (((M + 255) / 256) * nt * batch < (long)cus * 3 / 4) return 0;      // too few big tiles: the small-tile kernel fills the chip better
+    // too few big tiles: the small-tile kernel fills the chip better.  PAFC_PH_MIN_FILL (percent of the CUs, default 75)
+    // moves the line for A/B runs: with several independent batches in flight on streams of their own (bench.py --streams)
+    // half-full grids of the big-tile kernel run side by side
+    static const long min_fill = [] { const char *e = getenv("PAFC_PH_MIN_FILL"); const long v = e ? atol(e) : 75; return v > 0 ? v : 75; }();
+    if (((M + 255) / 256) * nt * batch * 100 < (long)cus * min_fill) return 0;
     long best_cost = -1;
     int best = 0;
     for (int tm = 256; tm >= 192; tm -= 64) {

@@ -43,13 +43,20 @@ def remove_duplicates_and_blank(hyp: List[int], blank_id: int = 0) -> List[int]:
     return new_hyp
 
 
-def ctc_greedy_search(ctc_probs: torch.Tensor, ctc_lens: torch.Tensor, blank_id: int = 0) -> List[DecodeResult]:
+def ctc_greedy_search(ctc_probs: torch.Tensor, ctc_lens: torch.Tensor, blank_id: int = 0, defer: bool = False):
     """search.py:106-121.  On the GPU the argmax, the padding rule and the collapse run in two kernels
     (``pafc_ctc_greedy``) and only the collapsed ids come back -- two small copies for the whole batch instead of a
-    (B, T) copy and a Python loop per frame.  Host tensors take the reference's own steps below."""
+    (B, T) copy and a Python loop per frame.  Host tensors take the reference's own steps below.
+    defer (GPU only): return a zero-argument function that fetches the List[DecodeResult] -- the device work is queued
+    now, the host waits for it only when the function is called, so several batches can be in flight."""
     if ctc_probs.is_cuda:
         from ..hip_ops import ctc_greedy
         tokens, ntok = ctc_greedy(ctc_probs.contiguous(), ctc_lens.to(ctc_probs.device), blank_id)
+        if defer:       # nothing here may wait for the device (a boolean-mask gather would): whole rows come back later
+            def fetch() -> List[DecodeResult]:
+                rows, counts = tokens.tolist(), ntok.tolist()
+                return [DecodeResult(r[:n]) for r, n in zip(rows, counts)]
+            return fetch
         keep = torch.arange(tokens.shape[1], device=tokens.device)[None, :] < ntok[:, None]
         flat = tokens[keep].tolist()          # all utterances back to back
         counts = ntok.tolist()
