@@ -191,3 +191,38 @@ def test_decode_windows_stitches_long_form(hip):
     assert singles == out["windows"]
     beam = decode_windows(model, feats, 600, 2, mode="ctc_prefix_beam_search", beam_size=4)
     assert len(beam["windows"]) == 5 and beam["token_start_ms"] is None
+
+
+def test_batches_in_flight_on_two_streams_decode_to_the_same_tokens(hip):
+    """bench.py --workload c2 keeps two decode batches in flight, each on a stream of its own, and fetches the greedy
+    tokens once per pass (ctc_greedy_search(defer=True)): batch for batch the same token lists as the one-stream,
+    fetch-per-batch loop -- the batches, the kernels and therefore the padded-frame semantics are untouched."""
+    import bench
+    from paper_accurate_fast_cheap_amd.transformer.search import ctc_greedy_search
+    dev = torch.device("cuda")
+    model, _ = bench.build_model("bf16", dev)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    batches = []
+    for B, T in ((5, 331), (7, 203), (4, 1203), (6, 97), (3, 611)):
+        lens = torch.randint(T // 2, T + 1, (B,), generator=torch.Generator().manual_seed(T))
+        lens[0] = T
+        fb = (torch.randn(B, T, 80, device=dev, generator=g) * 2 + 8).to(torch.bfloat16)
+        batches.append((fb, lens.to(dev)))
+
+    def one(fb, lens, defer):
+        enc, mask = model._forward_encoder(fb, lens)
+        return ctc_greedy_search(model.ctc_logprobs(enc), mask.squeeze(1).sum(1), 0, defer=defer)
+    with torch.no_grad():
+        want = [[list(r.tokens) for r in one(fb, lens, False)] for fb, lens in batches]
+        main = torch.cuda.current_stream(dev)
+        side = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        for s in side:
+            s.wait_stream(main)
+        pending = []
+        for i, (fb, lens) in enumerate(batches):
+            with torch.cuda.stream(side[i % 2]):
+                pending.append(one(fb, lens, True))
+        for s in side:
+            main.wait_stream(s)
+        got = [[list(r.tokens) for r in f()] for f in pending]
+    assert got == want and any(len(t) > 0 for b in want for t in b)

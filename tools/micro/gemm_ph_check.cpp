@@ -261,6 +261,29 @@ static void run_case(const Case &c, bool race) {
     if (Af) { CK(hipFree(Af)); CK(hipFree(Wf)); }
 }
 
+// `pmc <case>`: the new kernel alone, eight launches of one 30-minute shape on random operands -- the command profiled by
+// rocprofv3 --pmc for profiles/r03*_gemm_ph_pmc_*.txt (0 SiLU 512->2048, 1 w_2 + residual, 2 GLU, 3 pointwise_conv2 +
+// residual, 5 r,k,v stack, 6 CTC head)
+static int run_pmc(const Case &c) {
+    const long M = c.M; const int N = c.N, K = c.K, Z = c.Z;
+    const int No = c.act == 4 ? N / 2 : N;
+    u16 *A, *W, *bias, *res = nullptr, *out;
+    CK(hipMalloc(&A, (size_t)Z * M * K * 2)); CK(hipMalloc(&W, (size_t)Z * N * K * 2)); CK(hipMalloc(&bias, (size_t)Z * N * 2));
+    CK(hipMalloc(&out, (size_t)Z * M * No * 2));
+    fill_bf16<<<2048, 256>>>(A, (size_t)Z * M * K, 11, 1.7f);
+    fill_bf16<<<512, 256>>>(W, (size_t)Z * N * K, 12, 1.7f / sqrtf((float)K));
+    fill_bf16<<<8, 256>>>(bias, (size_t)Z * N, 13, 0.5f);
+    if (c.res_kind) { CK(hipMalloc(&res, (size_t)Z * M * N * 2)); fill_bf16<<<2048, 256>>>(res, (size_t)Z * M * N, 14, 1.3f); }
+    for (int i = 0; i < 8; ++i) {
+        const int rc = pafc_gemm_ph_ex(M, N, K, Z, A, K, M * K, 0, W, K, (long)N * K, bias, N, res, c.res_kind, N, M * (long)N, out, 0, No, 0,
+                                       M * (long)No, c.alpha, c.act, c.tile_m, 0);
+        if (rc != PAFC_OK) { printf("pafc_gemm_ph_ex returned %d\n", rc); return 1; }
+    }
+    CK(hipDeviceSynchronize());
+    printf("%s: 8 launches done\n", c.name);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     const std::string mode = argc > 1 ? argv[1] : "all";
     const bool race = mode != "check";
@@ -295,6 +318,7 @@ int main(int argc, char **argv) {
         {"small 300x512x128 no bias check", 300, 512, 128, 1, 0, 1, 0, 0, 256, 1.f},
         {"small f32 300x512x128 planes", 300, 512, 128, 2, 1, 0, 2, 1, 192, 1.f},
     };
+    if (mode == "pmc") return run_pmc(big[argc > 2 ? atoi(argv[2]) : 0]);
     if (mode != "race") for (const Case &c : small) run_case(c, false);
     for (const Case &c : big) run_case(c, race);
     printf(g_fail ? "FAILED: %d problem(s)\n" : "all checks passed\n", g_fail);
