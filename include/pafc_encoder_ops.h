@@ -68,11 +68,23 @@ int pafc_add_layernorm(int dtype, int dtype_out, int rows, int C, const void *x,
                        long ld2, float eps, pafc_stream_t stream);
 
 /* The same with a second output form: dtype_out2 = dtype_out, or PAFC_SPLIT_BF16 beside dtype_out = PAFC_F32 (norm_final
- * in fp32 for the caller + the next layer's first pre-norm as the planes its GEMM reads). */
+ * in fp32 for the caller + the next layer's first pre-norm as the planes its GEMM reads), and with row statistics for a
+ * LayerNorm folded into the projection that follows (pafc_gemm_bf16_ph_ln): stats_x / stats_out1 (either may be NULL) receive
+ * float2 [rows][8] -- pair 0 = (sum, sum of squares) of the row of x_new / of out1 as stored, pairs 1..7 zero. */
 int pafc_add_layernorm_ex(int dtype, int dtype_out, int dtype_out2, int rows, int C, const void *x, const void *y, float alpha,
                           const int32_t *lens, int T, int mask_y, void *x_out, const void *gamma1, const void *beta1,
                           void *out1, long ld1, int silu1, int zero1, const void *gamma2, const void *beta2, void *out2,
-                          long ld2, float eps, pafc_stream_t stream);
+                          long ld2, float eps, float *stats_x, float *stats_out1, pafc_stream_t stream);
+/* A pre-norm LayerNorm folded into the two bf16 GEMMs either side of it (csrc/gemm_ph.hip, LNF; encoder_layer.py:201-259:
+ * `x = residual + branch(...)` then `norm(x)` then the branch's first projection):
+ *   LN(x) W^T + b = rstd (x W'^T - mean csum) + b',   W' = gamma * W (rounded to bf16), csum[n] = sum_k W'[n][k], b' = b + W beta.
+ * ln_mode 2, the residual GEMM that produces x (N == ln_c == 512): as pafc_gemm_bf16_ph with a residual, and stats
+ *            (float2 [M][8]) receives (sum, sum of squares) of every row's eight 64-column slices (of the fp32 result).
+ * ln_mode 1, the projection that consumes LN(x) (act 1 SiLU or 4 GLU, no residual, alpha 1, K == ln_c): A = x itself,
+ *            W = W', bias = b' (bf16), csum fp32 (N); mean / rstd per row from stats.  The normalised tensor never exists. */
+int pafc_gemm_bf16_ph_ln(long M, int N, int K, const void *A, long lda, const void *W, long ldw, const void *bias,
+                         const void *residual, long ldr, void *out, long ldo, float alpha, int act, int ln_mode, float *stats,
+                         const float *csum, int ln_c, float ln_eps, int tile_m, pafc_stream_t stream);
 
 /* fp32 (rows, cols), rows ldx apart -> bf16 planes: out row = [hi | lo] with lo at column lo_off (triple = 0: an
  * activation for pafc_gemm_ph_ex(a_split = 1)) or [hi | hi | lo] at columns 0, cols, 2 cols (triple = 1: its weight).

@@ -73,6 +73,12 @@ struct PhParams {
     int nk1, pb_shift;
     long pb_bytes;
     long lo_off;                      // OUT 2: column offset of the lo plane inside an output row
+    // LayerNorm folded into the GEMMs either side of it (LNF): row statistics as 8 partial (sum, sum of squares) pairs per
+    // row, float2 [M][8] -- written by the GEMM that produces the row (LNF 2: one pair per 64-column wave slice of the
+    // 512-column output) and read by the GEMM that consumes it (LNF 1) together with ln_csum[n] = sum_k W'[n][k].
+    float *ln_stats;
+    const float *ln_csum;
+    float ln_eps, ln_inv_c;
     // implicit-GEMM mode (CONV): A is an NHWC image (B, T1, F1, Ci), row m = output position (b, t2, f2) of a 3 x 3 stride-2
     // convolution, K = 9 taps x Ci; W is (9, N, Ci) tap-major.  K-step kt = (tap, 64-channel slice).
     // CiA: elements per input pixel (Ci, or 2 Ci for planes [hi Ci | lo Ci]); CiW: elements per weight row and tap (Ci, or
@@ -132,7 +138,13 @@ constexpr unsigned PH_OOB = 0xC0000000u;       // a byte offset beyond every des
 // RES: 0 none, 1 bf16 residual, 2 fp32 residual (both loaded to registers in the epilogue).
 // OUT: 0 bf16, 1 fp32, 2 fp32 as bf16 planes hi | lo.  With OUT != 0 the bias is fp32.
 // CONV: the second subsampling convolution as an implicit GEMM.
-template <bool GLU, int ACT, int RES, int OUT, bool CONV = false>
+// LNF:  the pre-norm LayerNorm between a residual GEMM and the projection that follows it, folded into the two:
+//       LN(x) W^T + b = rstd (x W'^T - mean csum) + b'  with W' = gamma * W, csum[n] = sum_k W'[n][k], b' = b + W beta.
+//       2 = producer (RES 1): besides x_new the epilogue writes each row's partial (sum, sum of squares) of its 64 columns;
+//       1 = consumer (SiLU or GLU, alpha 1): A is the UN-normalised stream, W / bias are W' / b', the epilogue applies
+//       rstd (acc - mean csum) + b' per row.  The normalised tensor never exists in memory (encoder_layer.py:201-259 writes
+//       and re-reads it once per sub-block).
+template <bool GLU, int ACT, int RES, int OUT, bool CONV = false, int LNF = 0>
 __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     constexpr int BN = PBN;
     constexpr int UA = 128 * 128;                 // bytes of an A unit: 128 rows x 64 k
@@ -146,10 +158,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     constexpr bool BIASF32 = OUT != 0;
     // 16-byte stores per lane and tile, ALWAYS issued (rows / columns outside the matrix go to an out-of-range offset): the
     // counted waits of the next tile's first K-step rely on the exact number
-    constexpr int NST = 8 * (GLU ? 1 : 2) * (OUT == 0 ? 1 : 2);
+    constexpr int NST = 8 * (GLU ? 1 : 2) * (OUT == 0 ? 1 : 2) + (LNF == 2 ? 8 : 0);
+    static_assert(LNF == 0 || (OUT == 0 && !CONV), "LayerNorm folding: bf16 GEMMs");
+    static_assert(LNF != 1 || (RES == 0 && (GLU || ACT == 1)), "LNF 1: the w_1 (SiLU) / pointwise_conv1 (GLU) projections");
+    static_assert(LNF != 2 || RES == 1, "LNF 2: a residual GEMM");
     static_assert(!(GLU && (ACT != 0 || RES != 0)), "GLU excludes an activation and a residual");
     static_assert(!(RES != 0 && ACT != 0), "the layer never pairs a residual with an activation");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // 2 x STEP + 8 x 1 KiB (bias slots)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // 2 x STEP + 8 KiB (bias slots) [+ 8 KiB csum slots + 16 KiB row statistics]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -338,12 +353,16 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     // a slot of the wave's own behind the two K-step buffers: an LDS-DMA stays where it is written (a register load could be
     // moved to its use by the compiler, and the first K-step's counted waits rely on the exact sequence), it holds no
     // registers across the K loop, and the wave reads it back in its epilogue, long after the K loop's waits retired it.
-    constexpr int NBL = 1;
+    constexpr int NBL = LNF == 1 ? 4 : 1;     // bias; LNF 1: + csum + the tile's row statistics (2, below)
     {
         const long esz = BIASF32 ? 4 : 2;
         const __amdgpu_buffer_rsrc_t Br = make_rsrc(reinterpret_cast<const unsigned char *>(p.bias) + ((long)cur.z * p.sB + cur.n0) * esz,
                                                     p.bias ? (long)(p.N - cur.n0) * esz : 0);
         dma16(Br, lane * 16, 0, lds + 2 * STEP + wave * 1024);
+        if constexpr (LNF == 1) {             // csum of the tile's 256 columns, fp32: the second slot of the wave
+            const __amdgpu_buffer_rsrc_t Cr = make_rsrc(p.ln_csum + cur.n0, (long)(p.N - cur.n0) * 4);
+            dma16(Cr, lane * 16, 0, lds + 2 * STEP + 8 * 1024 + wave * 1024);
+        }
     }
 
     f32x4p acc[2][2][4][TN];
@@ -442,6 +461,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     using I1 = std::integral_constant<int, 1>;
 
     __builtin_amdgcn_s_barrier();
+    if constexpr (LNF == 1) {
+        // the tile's row statistics (256 rows x 8 pairs = 16 KiB) to LDS, two pieces per wave, behind the barrier every wave
+        // passes after its previous epilogue (which read this region); read back in the epilogue, many K-step barriers later
+        const __amdgpu_buffer_rsrc_t Sd = make_rsrc(p.ln_stats + (cur.z * p.M + cur.m0) * 16, (p.M - cur.m0) * 64);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            dma16(Sd, (wave * 2 + j) * 1024 + lane * 16, 0, lds + 2 * STEP + 16 * 1024 + (wave * 2 + j) * 1024);
+    }
     if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind waves 0-3
     PH_STAMP(1);
 
@@ -520,9 +547,49 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
             __builtin_amdgcn_raw_buffer_store_b128(wl, Or, ok ? off + (unsigned)(p.lo_off * 2) : PH_OOB, 0, 0);
         }
     };
+    // LNF: the rows' statistics.  8 partial (sum, sum of squares) pairs per row, [M][8] float2; the descriptor starts at the
+    // tile's first row.
+    __amdgpu_buffer_rsrc_t Sr = Or;
+    if constexpr (LNF == 2) Sr = make_rsrc(p.ln_stats + (cur.z * p.M + cur.m0) * 16, (p.M - cur.m0) * 64);
+    // consumer: a row's eight pairs from the LDS copy (no cross-lane traffic) -> rstd, -mean * rstd.  Software-pipelined over
+    // the row groups: a group's pairs are read while the previous group's values are computed (a group is one scheduling
+    // region: read and used inside it, every group would expose an LDS round trip and the rsqrt chain)
+    auto row_read = [&](int g, u32x4p (&v)[4]) {
+        const unsigned char *rp = lds + 2 * STEP + 16 * 1024 + (wr * 128 + g * 16 + efr) * 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const u32x4p *>(rp + q * 16);
+    };
+    auto row_norm = [&](const u32x4p (&v)[4], float &rstd, float &nm) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s1 += __uint_as_float(v[q].x) + __uint_as_float(v[q].z);
+            s2 += __uint_as_float(v[q].y) + __uint_as_float(v[q].w);
+        }
+        const float mean = s1 * p.ln_inv_c;
+        const float var = fmaxf(fmaf(-mean, mean, s2 * p.ln_inv_c), 0.f);
+        rstd = rsqrtf(var + p.ln_eps);
+        nm = -mean * rstd;
+    };
+    auto csum8 = [&](int nj, float (&f)[8]) {     // the lane's 8 columns of column half nj, from the wave's csum slot
+        const unsigned char *slot = lds + 2 * STEP + 8 * 1024 + wave * 1024 + (wc * 64 + nj * 32 + ekq * 8) * 4;
+        const u32x4p q0 = *reinterpret_cast<const u32x4p *>(slot), q1 = *reinterpret_cast<const u32x4p *>(slot + 16);
+        f[0] = __uint_as_float(q0.x); f[1] = __uint_as_float(q0.y); f[2] = __uint_as_float(q0.z); f[3] = __uint_as_float(q0.w);
+        f[4] = __uint_as_float(q1.x); f[5] = __uint_as_float(q1.y); f[6] = __uint_as_float(q1.z); f[7] = __uint_as_float(q1.w);
+    };
     // The residual comes straight to registers, 64-row half by half: all loads of a half are issued, then consumed (one
     // exposed round trip per half; rows / columns outside the matrix read zeros).  bf16: 8 loads, fp32: 16 per half.
     constexpr int RLD = RES == 2 ? 2 : 1;         // 16-byte loads per (row group, column half)
+    // LNF 1: the column sums and the bias of the lane's 16 columns are the same for every row group: held in registers
+    float lcs[LNF == 1 ? 2 : 1][8], lbv[LNF == 1 ? 2 : 1][8], nx_rstd = 1.f, nx_nm = 0.f;
+    if constexpr (LNF == 1) {
+        csum8(0, lcs[0]); csum8(LNF == 1 ? 1 : 0, lcs[LNF == 1 ? 1 : 0]);
+        bias8(0, lbv[0]); bias8(LNF == 1 ? 1 : 0, lbv[LNF == 1 ? 1 : 0]);
+        u32x4p v0[4];
+        row_read(0, v0);
+        row_norm(v0, nx_rstd, nx_nm);
+    }
+    float gst1[LNF == 2 ? 8 : 1], gst2[LNF == 2 ? 8 : 1];      // LNF 2: this lane's share of each row group's (sum, sum of squares)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         u32x4p rr[RES != 0 ? 4 : 1][2][RLD];
@@ -545,35 +612,54 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
             const int g = mi * 4 + i;
             const bool live = wr * 8 + g < nrt;   // wave-uniform: a row group beyond the tile's rows computes nothing
             const int row = wr * 128 + g * 16 + efr;
+            const float ln_rstd = nx_rstd, ln_nm = nx_nm;
+            u32x4p vn[4];
+            if constexpr (LNF == 1) row_read(g < 7 ? g + 1 : 7, vn);      // the next group's pairs: in flight under this group's values
             if constexpr (GLU) {
                 float o[8];
                 if (live) {
                     float bv[8], bg[8];
-                    bias8(0, bv);
-                    bias8(1, bg);
+                    if constexpr (LNF == 1) {     // b' - mean rstd csum, then rstd acc on top
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            bv[e] = fmaf(ln_nm, lcs[0][e], lbv[0][e]);
+                            bg[e] = fmaf(ln_nm, lcs[LNF == 1 ? 1 : 0][e], lbv[LNF == 1 ? 1 : 0][e]);
+                        }
+                    } else {
+                        bias8(0, bv);
+                        bias8(1, bg);
+                    }
+                    const float sc = LNF == 1 ? ln_rstd : p.alpha;
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float a = fmaf(acc[mi][0][i][j][e], p.alpha, bv[j * 4 + e]);
-                            const float b = fmaf(acc[mi][1][i][j][e], p.alpha, bg[j * 4 + e]);
+                            const float a = fmaf(acc[mi][0][i][j][e], sc, bv[j * 4 + e]);
+                            const float b = fmaf(acc[mi][1][i][j][e], sc, bg[j * 4 + e]);
                             o[j * 4 + e] = a * __builtin_amdgcn_rcpf(1.f + __expf(-b));
                         }
                 }
                 store8(o, live, row, cur.n0 / 2 + wc * 32 + ekq * 8);
             } else {
+                float st1 = 0.f, st2 = 0.f;   // LNF 2: this lane's share of the row's sum / sum of squares
 #pragma unroll
                 for (int nj = 0; nj < 2; ++nj) {
                     const int col = cur.n0 + wc * 64 + nj * 32 + ekq * 8;
                     float o[8];
                     if (live) {
                         float bv[8];
-                        bias8(nj, bv);
+                        if constexpr (LNF == 1) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) bv[e] = fmaf(ln_nm, lcs[LNF == 1 ? nj : 0][e], lbv[LNF == 1 ? nj : 0][e]);
+                        } else {
+                            bias8(nj, bv);
+                        }
+                        const float sc = LNF == 1 ? ln_rstd : p.alpha;
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                o[j * 4 + e] = act_apply<ACT>(fmaf(acc[mi][nj][i][j][e], p.alpha, bv[j * 4 + e]));
+                                o[j * 4 + e] = act_apply<ACT>(fmaf(acc[mi][nj][i][j][e], sc, bv[j * 4 + e]));
                         if constexpr (RES == 1) {
                             float rv[8];
                             unpack8(rr[i][nj][0], rv);
@@ -585,10 +671,33 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
                             o[4] += __uint_as_float(rr[i][nj][RLD - 1].x); o[5] += __uint_as_float(rr[i][nj][RLD - 1].y);
                             o[6] += __uint_as_float(rr[i][nj][RLD - 1].z); o[7] += __uint_as_float(rr[i][nj][RLD - 1].w);
                         }
+                        if constexpr (LNF == 2) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { st1 += o[e]; st2 = fmaf(o[e], o[e], st2); }
+                        }
                     }
                     store8(o, live, row, col);
                 }
+                if constexpr (LNF == 2) { gst1[LNF == 2 ? g : 0] = live ? st1 : 0.f; gst2[LNF == 2 ? g : 0] = live ? st2 : 0.f; }
             }
+            if constexpr (LNF == 1) row_norm(vn, nx_rstd, nx_nm);
+        }
+    }
+    if constexpr (LNF == 2) {
+        // the wave's 64 columns of each row: the four lanes of a row add up (all groups' exchanges back to back: one exposed
+        // round trip, not one per group), lane kq = 0 writes the pair
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { gst1[g] += __shfl_xor(gst1[g], 16, 64); gst2[g] += __shfl_xor(gst2[g], 16, 64); }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { gst1[g] += __shfl_xor(gst1[g], 32, 64); gst2[g] += __shfl_xor(gst2[g], 32, 64); }
+        typedef unsigned u32x2p __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int row = wr * 128 + g * 16 + efr;
+            const bool ok = ekq == 0 && row < cur.vr;
+            const unsigned off = ok ? (unsigned)(row * 64 + ((cur.n0 >> 8) * 4 + wc) * 8) : PH_OOB;
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2p{__float_as_uint(gst1[g]), __float_as_uint(gst2[g])}, Sr, off, 0, 0);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -600,10 +709,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     PH_WAIT(0);                                   // the (empty) prefetch of a tile that does not exist: nothing in flight at exit
 }
 
-template <bool GLU, int ACT, int RES, int OUT, bool CONV = false>
+template <bool GLU, int ACT, int RES, int OUT, bool CONV = false, int LNF = 0>
 int launch_ph(const PhParams &p, int batch, hipStream_t s) {
-    constexpr size_t lds = 2 * (2 * 128 * 128 + 2 * (PBN / 2) * 128) + 8 * 1024;   // two K-steps (128 KiB) + a bias slot per wave
-    auto kern = gemm_ph_kernel<GLU, ACT, RES, OUT, CONV>;
+    // two K-steps (128 KiB) + a bias slot per wave
+    // (LNF 1: + a csum slot per wave + the tile's row statistics = all 160 KiB)
+    constexpr size_t lds = 2 * (2 * 128 * 128 + 2 * (PBN / 2) * 128) + 8 * 1024 + (LNF == 1 ? 8 * 1024 + 16 * 1024 : 0);
+    auto kern = gemm_ph_kernel<GLU, ACT, RES, OUT, CONV, LNF>;
     static bool attr_set[64];                     // per device; a racing first call sets the same attribute twice
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return PAFC_ERR_LAUNCH;
@@ -707,6 +818,52 @@ extern "C" int pafc_gemm_ph_ex2(long M, int N, int K, int batch, const void *A, 
     if (act == 1) return pafc::launch_ph<false, 1, 0, 2>(p, batch, s);
     if (act == 0) return pafc::launch_ph<false, 0, 0, 2>(p, batch, s);
     return PAFC_ERR_UNSUPPORTED;
+}
+
+// The bf16 projections either side of a pre-norm LayerNorm with the norm folded in (include/pafc_encoder_ops.h).
+//   ln_mode 2 (producer): out = alpha A W^T + bias + residual as pafc_gemm_bf16_ph, N == 512, and stats[m][8] (float2) receives
+//                         each row's (sum, sum of squares) per 64-column slice of the fp32 result.
+//   ln_mode 1 (consumer): out = act(rstd_m (A W'^T)[m][n] - rstd_m mean_m csum[n] + bias[n]), act SiLU (1) or GLU (4), with
+//                         mean / rstd of row m from stats (C = `ln_c` channels, eps `ln_eps`); A is the un-normalised stream.
+extern "C" int pafc_gemm_bf16_ph_ln(long M, int N, int K, const void *A, long lda, const void *W, long ldw, const void *bias,
+                                    const void *residual, long ldr, void *out, long ldo, float alpha, int act, int ln_mode,
+                                    float *stats, const float *csum, int ln_c, float ln_eps, int tile_m, pafc_stream_t stream) {
+    if (!A || !W || !out || !stats) return PAFC_ERR_NULL_POINTER;
+    if (M <= 0 || N <= 0 || K <= 0 || ln_c <= 0) return PAFC_ERR_BAD_DIMS;
+    if (tile_m < 64 || tile_m > 256 || tile_m % 64) return PAFC_ERR_UNSUPPORTED;
+    if (N % 8 || K % 128) return PAFC_ERR_UNSUPPORTED;
+    const bool glu = act == 4;
+    if (ln_mode == 1) {
+        if (!csum || residual || (act != 1 && act != 4) || alpha != 1.f || K != ln_c) return PAFC_ERR_UNSUPPORTED;
+        if (glu && N % 256) return PAFC_ERR_UNSUPPORTED;
+    } else if (ln_mode == 2) {
+        if (!residual || act != 0 || N != 512 || ln_c != N) return PAFC_ERR_UNSUPPORTED;
+    } else {
+        return PAFC_ERR_UNSUPPORTED;
+    }
+    const int No = glu ? N / 2 : N;
+    if (lda < K || ldw < K || ldo < No || (residual && ldr < N)) return PAFC_ERR_BAD_DIMS;
+    if ((lda | ldw | ldo) % 8 || (residual && ldr % 8)) return PAFC_ERR_ALIGNMENT;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)bias | (uintptr_t)stats | (uintptr_t)csum) & 15) != 0)
+        return PAFC_ERR_ALIGNMENT;
+    if ((double)M * lda * 2 >= 2.0e9 || (double)N * ldw * 2 >= 2.0e9 || (double)256 * ldo * 4 >= 2.0e9 ||
+        (residual && (double)256 * ldr * 4 >= 2.0e9))
+        return PAFC_ERR_UNSUPPORTED;
+    pafc::PhParams p{};
+    p.A = (const pafc::bf16_t *)A; p.W = (const pafc::bf16_t *)W; p.bias = bias; p.res = residual; p.out = out;
+    p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr;
+    p.alpha = alpha;
+    p.nk1 = INT_MAX / 4; p.pb_shift = 31; p.pb_bytes = (long)K * 2;
+    p.ln_stats = stats; p.ln_csum = csum; p.ln_eps = ln_eps; p.ln_inv_c = 1.f / (float)ln_c;
+    p.tm = tile_m;
+    p.mtiles = (int)((M + tile_m - 1) / tile_m);
+    p.ntiles = (N + 255) / 256;
+    if ((long)p.mtiles * p.ntiles > 0x7fffffffL) return PAFC_ERR_BAD_DIMS;
+    hipStream_t s = (hipStream_t)stream;
+    if (ln_mode == 2) return pafc::launch_ph<false, 0, 1, 0, false, 2>(p, 1, s);
+    if (glu) return pafc::launch_ph<true, 0, 0, 0, false, 1>(p, 1, s);
+    return pafc::launch_ph<false, 1, 0, 0, false, 1>(p, 1, s);
 }
 
 // Same contract as pafc_gemm_bf16 (which calls this for the shapes it suits); exported for A/B measurements.

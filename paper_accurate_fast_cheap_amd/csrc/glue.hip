@@ -81,7 +81,14 @@ struct LnArgs {
     int rows, C;
     float eps;
     int split2;           // EO = float only: o2 is written as bf16 planes [hi | lo] (o1 stays fp32)
+    // row statistics for a LayerNorm folded into the GEMM that follows (csrc/gemm_ph.hip, LNF): float2 [rows][8], pair 0 =
+    // (sum, sum of squares) of the row, pairs 1..7 zero -- of x_new (stats_x) and / or of the LN1 output as stored (stats_o1)
+    float *stats_x, *stats_o1;
 };
+
+__device__ __forceinline__ void write_row_stats(float *stats, size_t row, int lane, float s1, float s2) {
+    if (lane < 8) reinterpret_cast<float2 *>(stats)[row * 8 + lane] = lane == 0 ? make_float2(s1, s2) : make_float2(0.f, 0.f);
+}
 
 // One wave per row.  EX: residual / parameter dtype; EO: dtype of the LayerNorm outputs.
 template <typename EX, typename EO>
@@ -116,6 +123,16 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const LnArgs a) {
             for (int e = 0; e < VEC; ++e) sum += v[it][e];
         }
     }
+    if (a.stats_x) {
+        float sq0 = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it)
+            if ((it * 64 + lane) * VEC < C) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sq0 = fmaf(v[it][e], v[it][e], sq0);
+            }
+        write_row_stats(a.stats_x, (size_t)row, lane, wave_sum(sum), wave_sum(sq0));
+    }
     if (!a.o1) return;
     const float inv_c = 1.f / (float)C;
     float mean = wave_sum(sum) * inv_c;
@@ -129,7 +146,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const LnArgs a) {
         }
     }
     float rstd = rsqrtf(wave_sum(sq) * inv_c + a.eps);
-    float sum2 = 0.f;
+    float sum2 = 0.f, sq2 = 0.f;
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
         const int c = (it * 64 + lane) * VEC;
@@ -144,10 +161,12 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const LnArgs a) {
                 if (a.zero1 && beyond) o = 0.f;
                 v[it][e] = o;
                 sum2 += o;
+                sq2 = fmaf(o, o, sq2);
             }
             store_out<EO>(a.o1, (size_t)row, a.ld1, c, C, v[it]);
         }
     }
+    if (a.stats_o1) write_row_stats(a.stats_o1, (size_t)row, lane, wave_sum(sum2), wave_sum(sq2));
     if (!a.o2) return;
     mean = wave_sum(sum2) * inv_c;
     sq = 0.f;
@@ -660,14 +679,15 @@ int pafc_add_layernorm(int dtype, int dtype_out, int rows, int C, const void *x,
                        void *out1, long ld1, int silu1, int zero1, const void *gamma2, const void *beta2, void *out2,
                        long ld2, float eps, pafc_stream_t stream) {
     return pafc_add_layernorm_ex(dtype, dtype_out, dtype_out, rows, C, x, y, alpha, lens, T, mask_y, x_out, gamma1, beta1, out1, ld1,
-                                 silu1, zero1, gamma2, beta2, out2, ld2, eps, stream);
+                                 silu1, zero1, gamma2, beta2, out2, ld2, eps, nullptr, nullptr, stream);
 }
 
 int pafc_add_layernorm_ex(int dtype, int dtype_out, int dtype_out2, int rows, int C, const void *x, const void *y, float alpha,
                           const int32_t *lens, int T, int mask_y, void *x_out, const void *gamma1, const void *beta1,
                           void *out1, long ld1, int silu1, int zero1, const void *gamma2, const void *beta2, void *out2,
-                          long ld2, float eps, pafc_stream_t stream) {
+                          long ld2, float eps, float *stats_x, float *stats_out1, pafc_stream_t stream) {
     if (!x) return PAFC_ERR_NULL_POINTER;
+    if (stats_out1 && !out1) return PAFC_ERR_NULL_POINTER;
     if (dtype_out2 != dtype_out && !(dtype_out == PAFC_F32 && dtype_out2 == PAFC_SPLIT_BF16)) return PAFC_ERR_DTYPE;
     if (out1 && (!gamma1 || !beta1)) return PAFC_ERR_NULL_POINTER;
     if (out2 && (!gamma2 || !beta2 || !out1)) return PAFC_ERR_NULL_POINTER;
@@ -678,7 +698,7 @@ int pafc_add_layernorm_ex(int dtype, int dtype_out, int dtype_out2, int rows, in
     if ((dtype_out == PAFC_SPLIT_BF16 && out1 && ld1 < 2 * C) || (dtype_out2 == PAFC_SPLIT_BF16 && out2 && ld2 < 2 * C))
         return PAFC_ERR_BAD_DIMS;
     pafc::LnArgs a{x, y, alpha, lens, T, mask_y, x_out, gamma1, beta1, out1, ld1, silu1, zero1,
-                   gamma2, beta2, out2, ld2, rows, C, eps, dtype_out2 != dtype_out};
+                   gamma2, beta2, out2, ld2, rows, C, eps, dtype_out2 != dtype_out, stats_x, stats_out1};
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PAFC_BF16) return pafc::launch_ln<pafc::bf16_t>(dtype_out, a, s);
     if (dtype == PAFC_F32) return pafc::launch_ln<float>(dtype_out, a, s);

@@ -385,12 +385,14 @@ PAFC_SPLIT_BF16 = 2      # output form: an fp32 value as bf16 planes [hi | lo] (
 def add_layernorm(x: torch.Tensor, y: Optional[torch.Tensor], alpha: float, gamma1, beta1, *, out1: torch.Tensor = None,
                   out_dtype: Optional[torch.dtype] = None, silu: bool = False, zero_rows: bool = False,
                   lens: Optional[torch.Tensor] = None, T: int = 0, mask_y: bool = False, gamma2=None, beta2=None,
-                  want_ln: bool = True, want_x: bool = True, eps: float = 1e-5, split1: bool = False, split2: bool = False):
+                  want_ln: bool = True, want_x: bool = True, eps: float = 1e-5, split1: bool = False, split2: bool = False,
+                  stats_x: Optional[torch.Tensor] = None, stats_out1: Optional[torch.Tensor] = None):
     """x_new = x + alpha*y; out1 = LN1(x_new) [silu] [rows >= len zeroed]; out2 = LN2(out1).
     Returns (x_new or x, out1 or None, out2 or None).  `out1` may be a pre-allocated (rows, ld) view (last-dim
     slice of a wider buffer) so that two LayerNorms can land side by side.
     split1 / split2 (fp32 x only): that output comes as bf16 planes (..., 2C) = [hi | lo] of the fp32 result, the A operand
-    of gemm_ph_ex(a_split=True); split1 implies split2."""
+    of gemm_ph_ex(a_split=True); split1 implies split2.
+    stats_x / stats_out1: float32 (rows, 8, 2) buffers that receive the row statistics of x_new / of out1 (gemm_bf16_ln)."""
     _lib.require_gpu(x, y, gamma1, beta1, gamma2, beta2, lens)
     C = x.shape[-1]
     rows = x.numel() // C
@@ -420,16 +422,51 @@ def add_layernorm(x: torch.Tensor, y: Optional[torch.Tensor], alpha: float, gamm
         from ctypes import c_float, c_long
         P, I = c_void_p, c_int
         _lib._sig(L.pafc_add_layernorm_ex, I, I, I, I, I, I, P, P, c_float, P, I, I, P, P, P, P, c_long, I, I, P, P, P, c_long,
-                  c_float, P)
+                  c_float, P, P, P)
         L._pafc_lnex_bound = True
     code = _lib.dtype_code(out_dtype)
     rc = L.pafc_add_layernorm_ex(
         _lib.dtype_code(x.dtype), PAFC_SPLIT_BF16 if split1 else code, PAFC_SPLIT_BF16 if s2 else code, rows, C, _lib.ptr(x),
         _lib.ptr(y), float(alpha), _lib.ptr(lens), int(T), int(mask_y), _lib.ptr(x_out), _lib.ptr(gamma1), _lib.ptr(beta1),
         _lib.ptr(o1), ld1, int(silu), int(zero_rows), _lib.ptr(gamma2), _lib.ptr(beta2), _lib.ptr(o2), 2 * C if s2 else C,
-        float(eps), _lib.stream_of(x))
+        float(eps), _lib.ptr(stats_x), _lib.ptr(stats_out1), _lib.stream_of(x))
     _lib.check(rc, "pafc_add_layernorm")
     return (x_out if y is not None else x), o1, o2  # first item is None when want_x=False
+
+
+def gemm_bf16_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stats: torch.Tensor, *, act: str = "none",
+                 alpha: float = 1.0, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                 csum: Optional[torch.Tensor] = None, ln_c: int = 0, eps: float = 1e-5) -> torch.Tensor:
+    """The bf16 GEMMs either side of a folded pre-norm LayerNorm (include/pafc_encoder_ops.h: pafc_gemm_bf16_ph_ln).
+    csum given: the CONSUMER -- act(rstd (a w^T) - rstd mean csum + bias), a = the un-normalised rows, w = gamma * W, act
+    "silu" | "glu", row statistics READ from stats (rows, 8, 2) fp32.  csum None: the PRODUCER -- alpha a w^T + bias + residual
+    (N = 512) with the rows' statistics WRITTEN to stats."""
+    _lib.require_gpu(bias, stats, csum)
+    for t in (a, w, residual, out):
+        if t is not None and (not t.is_cuda or t.dtype != torch.bfloat16 or t.stride(-1) != 1 or t.dim() != 2):
+            raise _lib.PafcError("gemm_bf16_ln: 2-d bf16 GPU tensors with unit stride in the last dimension")
+    M, K = a.shape
+    N = w.shape[0]
+    No = N // 2 if act == "glu" else N
+    if stats.dtype != torch.float32 or stats.numel() != M * 16 or not stats.is_contiguous():
+        raise _lib.PafcError("gemm_bf16_ln: stats is a contiguous float32 (M, 8, 2) buffer")
+    if out is None:
+        out = torch.empty((M, No), dtype=a.dtype, device=a.device)
+    L = _bind2()
+    if not getattr(L, "_pafc_gemmln_bound", False):
+        from ctypes import c_float, c_long
+        P, I, G = c_void_p, c_int, c_long
+        _lib._sig(L.pafc_gemm_bf16_ph_ln, I, G, I, I, P, G, P, G, P, P, G, P, G, c_float, I, I, P, P, I, c_float, I, P)
+        L._pafc_gemmln_bound = True
+    from .profiling import op_timer
+    with op_timer("gemm_%dx%d" % (K, N), sample=12, flops=2.0 * M * N * K):
+        rc = L.pafc_gemm_bf16_ph_ln(M, N, K, _lib.ptr(a), a.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(bias), _lib.ptr(residual),
+                                    residual.stride(0) if residual is not None else 0, _lib.ptr(out), out.stride(0), float(alpha),
+                                    _ACTS[act], 1 if csum is not None else 2, _lib.ptr(stats), _lib.ptr(csum),
+                                    int(ln_c or (K if csum is not None else N)),
+                                    float(eps), _ph_tile_m(M, N), _lib.stream_of(a))
+    _lib.check(rc, "pafc_gemm_bf16_ph_ln")
+    return out
 
 
 def split_planes(x: torch.Tensor, triple: bool = False) -> torch.Tensor:

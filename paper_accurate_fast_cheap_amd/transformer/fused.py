@@ -55,7 +55,10 @@ class LayerPlan:
                                                                     L.conv_module.pointwise_conv1.bias,
                                                                     L.feed_forward_macaron.w_1.weight, L.feed_forward_macaron.w_2.weight,
                                                                     L.feed_forward.w_1.weight, L.feed_forward.w_2.weight,
-                                                                    L.conv_module.pointwise_conv2.weight]
+                                                                    L.conv_module.pointwise_conv2.weight,
+                                                                    L.norm_ff_macaron.weight, L.norm_ff_macaron.bias, L.norm_ff.weight,
+                                                                    L.norm_ff.bias, L.norm_conv.weight, L.norm_conv.bias,
+                                                                    L.feed_forward_macaron.w_1.bias, L.feed_forward.w_1.bias]
         return tuple((p.data_ptr(), p._version, p.dtype) for p in ps if p is not None)
 
     def refresh(self):
@@ -81,7 +84,34 @@ class LayerPlan:
                                     hip_ops.glu_interleave(pw1.bias, h) if pw1.bias is not None else None)
                                 for h in ((64, 32) if rows2 % 256 == 0 else (64,))}
             self._refresh_split()
+            self._refresh_lnfold()
         self._stamp = stamp
+
+    def _refresh_lnfold(self):
+        """bf16 layer, C = 512: the three pre-norm LayerNorms whose consumer is a projection (norm_ff_macaron -> w_1,
+        norm_conv -> pointwise_conv1, norm_ff -> w_1) folded into that projection (csrc/gemm_ph.hip, LNF):
+        W' = bf16(gamma * W), b' = b + W beta, csum[n] = sum_k W'[n][k] (fp32, of the ROUNDED W': what the MFMA multiplies)."""
+        L = self.layer
+        self.lnf = None
+        w1 = L.feed_forward.w_1.weight
+        cm = L.conv_module
+        if not (self.rwkv and w1.dtype == torch.bfloat16 and w1.is_cuda and L.size == 512 and L.feed_forward_macaron is not None
+                and cm is not None and cm.pointwise_conv1.weight.shape[0] % 256 == 0 and cm.lorder == 0
+                and os.environ.get("PAFC_LN_FOLD", "1") != "0"):
+            return
+
+        def fold(w, b, norm, interleave=False):
+            wf, g, be = w.float(), norm.weight.float(), norm.bias.float()
+            bf = (b.float() if b is not None else 0) + wf @ be
+            wp = (wf * g).to(torch.bfloat16)
+            if interleave:
+                wp, bf = hip_ops.glu_interleave(wp, 32), hip_ops.glu_interleave(bf, 32)
+            return wp.contiguous(), bf.to(torch.bfloat16).contiguous(), wp.float().sum(-1).contiguous()
+
+        pw1 = cm.pointwise_conv1
+        self.lnf = dict(ffm=fold(L.feed_forward_macaron.w_1.weight, L.feed_forward_macaron.w_1.bias, L.norm_ff_macaron),
+                        ff=fold(L.feed_forward.w_1.weight, L.feed_forward.w_1.bias, L.norm_ff),
+                        pw1=fold(pw1.weight.squeeze(-1), pw1.bias, L.norm_conv, interleave=True))
 
     def _refresh_split(self):
         """fp32 layer around a bf16 slot (the reference's default precision): every fp32 projection as the split-operand
@@ -180,9 +210,11 @@ def _pw1_glu(plan: "LayerPlan", h2: torch.Tensor) -> torch.Tensor:
     return hip_ops.gemm_bf16(h2, w, b, act="glu")
 
 
-def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                 stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """h: (B, T, C) in the slot dtype -> slot output (B, T, C) in the slot dtype (both directions averaged).
-    With ``residual`` (same dtype) the result is residual + slot output, written over ``residual``."""
+    With ``residual`` (same dtype) the result is residual + slot output, written over ``residual``; ``stats`` (rows, 8, 2)
+    then also receives the new rows' statistics (the LayerNorm that follows is folded into its consumer)."""
     B, T, C = h.shape
     M, nd = B * T, plan.ndir
     own_gemm = h.dtype == torch.bfloat16 and C % 64 == 0
@@ -226,6 +258,9 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
         # bidirectional.py:55-56 `.float()` + encoder_layer.py:232), one rounding less than cast + add
         r2 = residual.view(M, C)
         return hip_ops.gemm_ph_ex(ycat, plan.Wo, None, residual=r2, out=r2, out_kind="f32").view(B, T, C)
+    if residual is not None and stats is not None:
+        r2 = residual.view(M, C)
+        return hip_ops.gemm_bf16_ln(ycat, plan.Wo, None, stats, residual=r2, out=r2).view(B, T, C)
     if residual is not None:
         return proj(ycat, plan.Wo, None, "none", residual=residual.view(M, C), inplace=True).view(B, T, C)
     return proj(ycat, plan.Wo, None).view(B, T, C)
@@ -284,6 +319,57 @@ def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optio
         _, hn, _ = hip_ops.add_layernorm(out, None, 1.0, next_norm.weight, next_norm.bias, want_x=False, eps=next_norm.eps)
         return out, hn
     _, out, hn = hip_ops.add_layernorm(x, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False,
+                                       gamma2=next_norm.weight if next_norm is not None else None,
+                                       beta2=next_norm.bias if next_norm is not None else None, eps=L.norm_final.eps)
+    return out, hn
+
+
+def lnfold_eligible(plan: LayerPlan, x: torch.Tensor, lens: Optional[torch.Tensor]) -> bool:
+    """Long unmasked bf16 inputs (the 30-minute file, equal-length windows): enough rows for the 256-wide tiles to fill
+    the chip; a ragged batch keeps the LayerNorm passes (they also apply the padding masks)."""
+    return (plan.lnf is not None and lens is None and x.dtype == torch.bfloat16 and x.is_cuda
+            and x.numel() // x.shape[-1] >= 3 * _OWN_GEMM_MIN_ROWS)
+
+
+def layer_forward_lnfold(plan: LayerPlan, x: torch.Tensor, st: torch.Tensor, next_norm: Optional[nn.LayerNorm], next_fold: bool):
+    """layer_forward for the long unmasked bf16 case with the three projection-feeding pre-norms folded into their GEMMs:
+    the residual GEMM that produces a row also writes its (sum, sum of squares), the projection that follows reads the
+    UN-normalised row and normalises in its epilogue -- norm_ff_macaron(x), norm_conv(x), norm_ff(x) never exist in memory
+    (two of the layer's seven LayerNorm passes, and norm_final's second output, are gone).
+    x: residual stream, st: its row statistics (rows, 8, 2).  Returns (layer output, its statistics or next_norm(output))."""
+    L, F = plan.layer, plan.lnf
+    B, T, C = x.shape
+    M = B * T
+    cm = L.conv_module
+    G = hip_ops.gemm_bf16_ln
+    new_stats = lambda: torch.empty((M, 8, 2), dtype=torch.float32, device=x.device)
+    x2 = x.view(M, C)
+    w, b, cs = F["ffm"]
+    hid = G(x2, w, b, st, act="silu", csum=cs, eps=L.norm_ff_macaron.eps)
+    x2 = hip_ops.gemm_bf16(hid, L.feed_forward_macaron.w_2.weight, plan.b2_macaron, "none", alpha=L.ff_scale, residual=x2)
+    _, h, _ = hip_ops.add_layernorm(x2.view(B, T, C), None, 1.0, L.norm_mha.weight, L.norm_mha.bias, want_x=False, eps=L.norm_mha.eps)
+    st2 = new_stats()
+    slot_forward(plan, h, residual=x2.view(B, T, C), stats=st2)
+    w, b, cs = F["pw1"]
+    p = G(x2, w, b, st2, act="glu", csum=cs, eps=L.norm_conv.eps).view(B, T, C)
+    dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, (cm.kernel_size - 1) // 2, T)
+    _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
+    st3 = new_stats()
+    G(g.view(M, C), cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, st3, residual=x2, out=x2)
+    w, b, cs = F["ff"]
+    hid = G(x2, w, b, st3, act="silu", csum=cs, eps=L.norm_ff.eps)
+    hip_ops.gemm_bf16(hid, L.feed_forward.w_2.weight, plan.b2, "none", alpha=L.ff_scale, residual=x2, out=x2)
+    xo = x2.view(B, T, C)
+    if next_fold:       # the next layer's first pre-norm is folded too: it wants this layer's output and its statistics
+        stn = new_stats()
+        _, out, _ = hip_ops.add_layernorm(xo, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False, eps=L.norm_final.eps,
+                                          stats_out1=stn)
+        return out, stn
+    if next_norm is not None and next_norm.eps != L.norm_final.eps:
+        _, out, _ = hip_ops.add_layernorm(xo, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False, eps=L.norm_final.eps)
+        _, hn, _ = hip_ops.add_layernorm(out, None, 1.0, next_norm.weight, next_norm.bias, want_x=False, eps=next_norm.eps)
+        return out, hn
+    _, out, hn = hip_ops.add_layernorm(xo, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False,
                                        gamma2=next_norm.weight if next_norm is not None else None,
                                        beta2=next_norm.bias if next_norm is not None else None, eps=L.norm_final.eps)
     return out, hn
@@ -434,10 +520,27 @@ def encoder_layers_forward(plan: EncoderPlan, xs: torch.Tensor, masks: torch.Ten
     lens = masks.squeeze(1).sum(1).to(torch.int32) if masks.numel() > 0 else None
     xs = xs.contiguous()
     first = plan.layers[0].layer.norm_ff_macaron
-    split = [split_eligible(lp, xs) for lp in plan.layers] + [False]   # (after_norm's output goes to the caller: fp32)
-    _, h, _ = hip_ops.add_layernorm(xs, None, 1.0, first.weight, first.bias, eps=first.eps, split1=split[0])
     outs: List[torch.Tensor] = []
     n = len(plan.layers)
+    if (lens is not None and all(lnfold_eligible(lp, xs, None) for lp in plan.layers)
+            and not torch.cuda.is_current_stream_capturing() and int(lens.min()) == xs.shape[1]):
+        # a long input whose rows are all full length (the 30-minute file, B = 1): the padding masks are no-ops -- worth one
+        # host read of the lengths per pass to take the unmasked schedule
+        lens = None
+    if all(lnfold_eligible(lp, xs, lens) for lp in plan.layers):
+        st = torch.empty((xs.numel() // xs.shape[-1], 8, 2), dtype=torch.float32, device=xs.device)
+        hip_ops.add_layernorm(xs, None, 1.0, first.weight, first.bias, want_ln=False, stats_x=st)    # statistics only
+        h = st
+        for i, lp in enumerate(plan.layers):
+            nxt = plan.layers[i + 1].layer.norm_ff_macaron if i + 1 < n else after_norm
+            xs, h = layer_forward_lnfold(lp, xs, h, nxt, i + 1 < n)
+            if want_layers:
+                outs.append(xs)
+        if after_norm is not None:
+            xs = h
+        return xs, outs
+    split = [split_eligible(lp, xs) for lp in plan.layers] + [False]   # (after_norm's output goes to the caller: fp32)
+    _, h, _ = hip_ops.add_layernorm(xs, None, 1.0, first.weight, first.bias, eps=first.eps, split1=split[0])
     for i, lp in enumerate(plan.layers):
         nxt = plan.layers[i + 1].layer.norm_ff_macaron if i + 1 < n else after_norm
         if split[i]:

@@ -344,6 +344,37 @@ def test_headline_bf16_full_size_five_minute_file_vs_oracle(hip):
     _bf16_headline(xs, torch.tensor([30000]), enc, ctc, conf, "full-size 12-layer, 5-minute file as one sequence")
 
 
+def test_headline_bf16_layernorm_folded_schedule_vs_oracle(hip, monkeypatch):
+    """The same 5-minute comparison through the schedule the 30-minute bench takes (it starts at 24 576 unmasked rows):
+    norm_ff_macaron / norm_conv / norm_ff folded into the GEMMs either side of them (fused.layer_forward_lnfold), the
+    normalised tensors never written.  Same bounds; the fold skips one bf16 rounding per folded norm, so it may only sit
+    closer to the exact model."""
+    import bench
+    from paper_accurate_fast_cheap_amd import hip_ops
+    from paper_accurate_fast_cheap_amd.transformer import fused
+    from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    conf = bench.encoder_conf()
+    torch.manual_seed(777)
+    enc = ConformerEncoder(80, **conf).eval()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.02)
+            if ".norm_" in n and n.endswith("weight"):
+                p.uniform_(0.7, 1.3)           # non-trivial gamma / beta: the fold multiplies them into the weights
+            if ".norm_" in n and n.endswith("bias"):
+                p.normal_(0, 0.1)
+    ctc = CTC(200, 512).eval()
+    xs = synth.randn((1, 30000, 80), 905, 2.0)
+    monkeypatch.setattr(fused, "_OWN_GEMM_MIN_ROWS", 2048)          # 3 x 2048 < 7 499 rows: the folded schedule is taken
+    calls = []
+    real = hip_ops.gemm_bf16_ln
+    monkeypatch.setattr(hip_ops, "gemm_bf16_ln", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    _bf16_headline(xs, torch.tensor([30000]), enc, ctc, conf, "full-size 12-layer, 5-minute file, LayerNorms folded into the GEMMs")
+    assert len(calls) == 12 * 5                                      # 3 consumers + 2 producers per layer
+
+
 def test_bf16slot_full_size_vs_oracle(hip):
     """The YAML-default precision (fp32 model, bf16 slot returning fp32 -- what the reference CAN run) at full size on
     the same ragged batch: HIP fused path vs the oracle, bf16-inside tolerance, token rule as above."""

@@ -748,3 +748,43 @@ def test_conv_sub_split_operand_planes(hip, B, T, C):
     out = gemm_ph_ex(y.view(Bt * Tp, Fp * 2 * C), split_planes(wl, triple=True), bl, a_split=True, out_kind="f32", a_plane_block=C)
     want = F.linear(ref.reshape(Bt * Tp, Fp * C).double(), wl.double(), bl.double())
     torch.testing.assert_close(out.double(), want, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("M", [700, 5000])
+def test_layernorm_folded_into_the_gemms_either_side(hip, M):
+    """pafc_gemm_bf16_ph_ln: the residual GEMM writes each row's (sum, sum of squares) in eight 64-column slices; the SiLU / GLU
+    projection that follows reads the UN-normalised rows and applies rstd (acc - mean csum) + b' in its epilogue -- against
+    LayerNorm + Linear in fp32 torch on the same bf16 operands."""
+    from paper_accurate_fast_cheap_amd.hip_ops import add_layernorm, gemm_bf16_ln, glu_interleave
+    bf, C = torch.bfloat16, 512
+    a = synth.randn((M, 1024), 51).to(bf).cuda()
+    wo = (synth.randn((C, 1024), 52) / 32).to(bf).cuda()
+    r = (synth.randn((M, C), 53) * 2 + 0.7).to(bf).cuda()
+    st = torch.full((M, 8, 2), float("nan"), device="cuda")
+    x = gemm_bf16_ln(a, wo, None, st, residual=r)                      # producer: x = r + a wo^T, stats of x
+    xf = r.float() + a.float() @ wo.float().t()
+    torch.testing.assert_close(x.float(), xf, rtol=2 ** -7, atol=2e-2)
+    s = st.sum(1)                                                       # (M, 2): sum, sum of squares of the fp32 rows
+    torch.testing.assert_close(s[:, 0], xf.sum(-1), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(s[:, 1], (xf * xf).sum(-1), rtol=1e-4, atol=1e-2)
+    # statistics from the LayerNorm pass instead (of its input and of its output): same layout
+    g0, b0 = (synth.randn((C,), 54) * 0.2 + 1).to(bf).cuda(), (synth.randn((C,), 55) * 0.2).to(bf).cuda()
+    sx, so = torch.empty((M, 8, 2), device="cuda"), torch.empty((M, 8, 2), device="cuda")
+    _, o1, _ = add_layernorm(x, None, 1.0, g0, b0, stats_x=sx, stats_out1=so)
+    torch.testing.assert_close(sx.sum(1)[:, 0], x.float().sum(-1), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(so.sum(1)[:, 1], (o1.float() ** 2).sum(-1), rtol=1e-5, atol=1e-3)
+    assert float(sx[:, 1:].abs().max()) == 0.0
+    # consumers: LN(x; g, be) w^T + b with SiLU, and with GLU
+    g, be = (synth.randn((C,), 56) * 0.3 + 1).to(bf).cuda(), (synth.randn((C,), 57) * 0.3).to(bf).cuda()
+    for N, act in ((2048, "silu"), (1024, "glu")):
+        w = (synth.randn((N, C), 58) / C ** 0.5).to(bf).cuda()
+        b = (synth.randn((N,), 59) * 0.3).to(bf).cuda()
+        wp = (w.float() * g.float()).to(bf)
+        bp = (b.float() + w.float() @ be.float()).to(bf)
+        if act == "glu":
+            wp, bp = glu_interleave(wp, 32), glu_interleave(bp, 32)
+        got = gemm_bf16_ln(x, wp.contiguous(), bp.contiguous(), st, act=act, csum=wp.float().sum(-1).contiguous(), eps=1e-5)
+        lin = F.linear(F.layer_norm(x.float(), (C,), g.float(), be.float(), 1e-5), w.float(), b.float())
+        want = F.silu(lin) if act == "silu" else F.glu(lin, dim=-1)
+        torch.testing.assert_close(got.float(), want, rtol=2 ** -6, atol=3e-2)
+        assert float((got.float() - want).abs().mean()) < 4e-3

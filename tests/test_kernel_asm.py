@@ -29,15 +29,18 @@ def _kernels(asm):
 
 def test_gemm_ph_vector_memory_instructions_are_only_the_ones_written(asm):
     ks = _kernels(asm)
-    assert len(ks) >= 13                                     # every instantiation the library dispatches to
+    assert len(ks) >= 18                                     # every instantiation the library dispatches to
     for name, body in ks.items():
         ops = re.findall(r"^\s+((?:buffer|global|flat|scratch)_\w+)[^\n]*?(\blds\b)?\s*$", body, flags=re.M)
         kinds = {(op, bool(l)) for op, l in ops}
         assert all(op.startswith("buffer_") for op, _ in kinds), (name, sorted(kinds))       # descriptors only, no spills
         assert ("buffer_load_dwordx4", True) in kinds and ("buffer_store_dwordx4", False) in kinds
         plain_loads = sum(1 for op, l in ops if op == "buffer_load_dwordx4" and not l)
-        res = int(re.search(r"gemm_ph_kernelILb[01]ELi\d+ELi(\d)", name).group(1))
-        assert plain_loads == {0: 0, 1: 16, 2: 32}[res], (name, plain_loads)                # the residual, and nothing else
+        m = re.search(r"gemm_ph_kernelILb[01]ELi\d+ELi(\d)ELi\d+ELb[01]ELi(\d)E", name)
+        res, lnf = int(m.group(1)), int(m.group(2))
+        # the residual (16 / 32 loads) and nothing else (bias, csum and row statistics arrive by LDS-DMA)
+        assert plain_loads == {0: 0, 1: 16, 2: 32}[res], (name, plain_loads)
+        assert (("buffer_store_dwordx2", False) in kinds) == (lnf == 2), name
 
 
 def test_gemm_ph_has_no_register_spills(asm):

@@ -2,7 +2,7 @@
 // prologue fill, each K-step, re-join, residual DMA, accumulator -> LDS, LDS -> global.  Stamps go to a buffer no other
 // code reads; in the shipped library no stamp executes.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -I paper_accurate_fast_cheap_amd/csrc tools/micro/gemm_ph_stamps.cpp -o tools/micro/bin/gemm_ph_stamps
-//   tools/micro/bin/gemm_ph_stamps M N K mode(0 SiLU / 1 bf16 residual / 2 plain / 3 GLU) tile_m
+//   tools/micro/bin/gemm_ph_stamps M N K mode(0 SiLU / 1 bf16 residual / 2 plain / 3 GLU / 4 SiLU with folded LayerNorm / 5 residual + row statistics) tile_m
 // Round 3 stamps: 0 tile start (its prologue units are already in flight, issued ahead of the previous tile's epilogue) |
 // 1 first operands landed | 2.. K-steps | 50 re-join | 51 residual folded into the accumulators (RES 1) | 52 next tile set up
 // and its prologue issued | 53 epilogue arithmetic + stores issued.
@@ -39,7 +39,11 @@ int main(int argc, char **argv) {
     hipMalloc(&st, nblk * 2 * 64 * 8);
     hipMemset(st, 0, nblk * 2 * 64 * 8);
     pafc::PhParams p{};
-    p.A = A; p.W = W; p.bias = B; p.res = mode == 1 ? R : nullptr; p.out = O; p.nk1 = INT_MAX / 4; p.pb_shift = 31;
+    p.A = A; p.W = W; p.bias = B; p.res = (mode == 1 || mode == 5) ? R : nullptr; p.out = O; p.nk1 = INT_MAX / 4; p.pb_shift = 31;
+    float *stats, *csum;
+    hipMalloc(&stats, M * 64); hipMalloc(&csum, (size_t)N * 4);
+    hipMemset(stats, 0, M * 64); hipMemset(csum, 0, (size_t)N * 4);
+    p.ln_stats = stats; p.ln_csum = csum; p.ln_eps = 1e-5f; p.ln_inv_c = 1.f / 512;
     p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.ldo = N; p.ldr = N; p.alpha = 1.f;
     p.mtiles = (int)mt; p.ntiles = (int)nt; p.tm = tm; p.stamps = st; p.batch = 1;
     hipEvent_t e0, e1;
@@ -49,7 +53,8 @@ int main(int argc, char **argv) {
         hipEventRecord(e0, 0);
         int rc;
         rc = mode == 1 ? pafc::launch_ph<false, 0, 1, 0>(p, 1, 0) : mode == 2 ? pafc::launch_ph<false, 0, 0, 0>(p, 1, 0)
-             : mode == 3 ? pafc::launch_ph<true, 0, 0, 0>(p, 1, 0) : pafc::launch_ph<false, 1, 0, 0>(p, 1, 0);
+             : mode == 3 ? pafc::launch_ph<true, 0, 0, 0>(p, 1, 0) : mode == 4 ? pafc::launch_ph<false, 1, 0, 0, false, 1>(p, 1, 0)
+             : mode == 5 ? pafc::launch_ph<false, 0, 1, 0, false, 2>(p, 1, 0) : pafc::launch_ph<false, 1, 0, 0>(p, 1, 0);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
@@ -71,14 +76,14 @@ int main(int argc, char **argv) {
             k0.push_back((double)(s[2] - s[1]));
             kl.push_back((double)(s[1 + nk] - s[nk]));
             rj.push_back((double)(s[50] - s[1 + nk]));
-            rd.push_back((double)(s[51] - s[50]));
-            wr.push_back((double)(s[52] - s[51]));
-            so.push_back((double)(s[53] - s[52]));
+            rd.push_back(0.0);
+            wr.push_back(0.0);
+            so.push_back((double)(s[53] - s[50]));
             tot.push_back((double)(s[53] - s[0]));
         }
         auto med = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
-        printf("  wave %d (median cycles over %zu tiles): wait for first operands %.0f | K-step mean %.0f (first %.0f, last %.0f; ideal %d) x %d | re-join %.0f | "
-               "residual -> acc %.0f | next setup + prologue issue %.0f | epilogue %.0f | tile total %.0f\n",
+        printf("  wave %d (median cycles over %zu tiles): tile-top barrier wait %.0f | K-step mean %.0f (first %.0f, last %.0f; ideal %d) x %d | re-join %.0f | "
+               "(%.0f %.0f) epilogue %.0f | tile total %.0f\n",
                g * 4, tot.size(), med(pro), med(ks), med(k0), med(kl), tn == 256 ? 2048 : 1024, nk, med(rj), med(rd), med(wr), med(so), med(tot));
     }
     return 0;
