@@ -129,6 +129,18 @@ int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const 
 int pafc_tmix_lora_down_bf16(int B, int T, int C, int N, int ndir, int reverse0, const void *x, const void *maa_x,
                              const void *w1n, void *t, pafc_stream_t stream);
 
+/* The three passes above for a STREAMING chunk (recurrent-state carry between chunks, BASELINE configs[2]; the reference's
+ * time-mix has no streaming form -- `self.time_shift = nn.ZeroPad2d((0, 0, 1, -1))`, src/model.py:262,274 -- so the carried
+ * quantity is defined by what makes chunked == whole-sequence: the last frame of the previous chunk):
+ * prev (B, C) = the frame before each sequence's first one, used by the backward-looking direction instead of the zero the
+ * offline form pads with; null = the offline form.  Everything else as in the functions without `_prev`. */
+int pafc_tmix_shift_mix_prev(int dtype, int B, int T, int C, int ndir, int reverse0, const void *x, const void *maa_x0,
+                             const void *maa_x1, const void *prev, void *out, pafc_stream_t stream);
+int pafc_tmix_lora_mix4_bf16_prev(int B, int T, int C, int ndir, int reverse0, const void *x, const void *t, const void *w2t,
+                                  const void *maa, const void *prev, void *z, pafc_stream_t stream);
+int pafc_tmix_lora_down_bf16_prev(int B, int T, int C, int N, int ndir, int reverse0, const void *x, const void *maa_x,
+                                  const void *w1n, const void *prev, void *t, pafc_stream_t stream);
+
 /* The decay LoRA of the time-mix in one pass (bf16): w = bf16( bf16(tanh(zw @ time_decay_w1)) @ time_decay_w2 ) [+ bias]
  * (src/model.py:286-287: ww = tanh(xw @ time_decay_w1) @ time_decay_w2; w = time_decay + ww).  zw: (ndir, rows, C) the
  * fourth lerp; d1n: (ndir, H, C) = time_decay_w1^T, d2n: (ndir, C, H) = time_decay_w2^T (K innermost); bias: (ndir, C)

@@ -200,7 +200,9 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const LnArgs a) {
 template <typename ET>
 __global__ __launch_bounds__(256) void tmix_shift_mix_kernel(int T, int C, long rows, int ndir, int rev0,
                                                              const ET *__restrict__ x, const ET *__restrict__ maa0,
-                                                             const ET *__restrict__ maa1, ET *__restrict__ out) {
+                                                             const ET *__restrict__ maa1, ET *__restrict__ out,
+                                                             const ET *__restrict__ prev) {
+    // prev: (B, C) or null -- the frame before each sequence's first one (streaming: the previous chunk's last frame)
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int cpr = C / VEC;  // lanes per row
     const long row = gid / cpr;
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(256) void tmix_shift_mix_kernel(int T, int C, long 
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { xp[e] = 0.f; xn[e] = 0.f; }
     if (t > 0) load8<ET>(x + (row - 1) * C + c, xp);
+    else if (prev) load8<ET>(prev + (row / T) * C + c, xp);
     if (t < T - 1) load8<ET>(x + (row + 1) * C + c, xn);
     for (int d = 0; d < ndir; ++d) {
         const bool rev = (d == 0) ? (rev0 != 0) : true;
@@ -278,7 +281,8 @@ template <bool LDSW, bool FULLROW = false>
 __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long rows, int ndir, int rev0,
                                                              const bf16_t *__restrict__ x, const bf16_t *__restrict__ t,
                                                              const bf16_t *__restrict__ w2t,
-                                                             const bf16_t *__restrict__ maa, bf16_t *__restrict__ z) {
+                                                             const bf16_t *__restrict__ maa, bf16_t *__restrict__ z,
+                                                             const bf16_t *__restrict__ prev) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, qq = lane >> 4;
     const long row = ((long)blockIdx.x * 4 + wave) * 16 + r16;
@@ -303,8 +307,9 @@ __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long 
     }
     for (int d = 0; d < ndir; ++d) {
         const bool rev = (d == 0) ? (rev0 != 0) : true;
-        const bool has_nb = rev ? (tt < T - 1) : (tt > 0);
-        const long nb = rev ? rowc + 1 : rowc - 1;
+        const bool in_seq = rev ? (tt < T - 1) : (tt > 0);
+        const bool has_nb = in_seq || (prev != nullptr && !rev);       // prev: (B, C) the frame before each sequence, or null
+        const bf16_t *nbrow = in_seq ? x + (rev ? rowc + 1 : rowc - 1) * C : (has_nb ? prev + (rowc / T) * C : x + rowc * C);
         uint4 tb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(256) void tmix_lora_mix4_kernel(int T, int C, long 
             const int col = (blockIdx.y * 2 + cbi) * 32 + 8 * qq;            // this lane's 8 output columns
             float xn[VEC];
             load8<bf16_t>(x + rowc * C + col, xc[cbi]);
-            load8<bf16_t>(x + (has_nb ? nb : rowc) * C + col, xn);          // branch-free: select after the load
+            load8<bf16_t>(nbrow + col, xn);                                 // branch-free: select after the load
 #pragma unroll
             for (int e = 0; e < VEC; ++e) xx[cbi][e] = round_bf16((has_nb ? xn[e] : 0.f) - xc[cbi][e]);
         }
@@ -378,7 +383,8 @@ template <int NW, int WCOLS>   // waves per block; how many of them sit side by 
 __global__ __launch_bounds__(NW * 64) void tmix_lora_mix4_ws_kernel(int T, int C, long rows, int ndir, int rev0,
                                                                 const bf16_t *__restrict__ x, const bf16_t *__restrict__ t,
                                                                 const bf16_t *__restrict__ w2t,
-                                                                const bf16_t *__restrict__ maa, bf16_t *__restrict__ z) {
+                                                                const bf16_t *__restrict__ maa, bf16_t *__restrict__ z,
+                                                                const bf16_t *__restrict__ prev) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, qq = lane >> 4;
     constexpr int WROWS = NW / WCOLS;
@@ -405,8 +411,9 @@ __global__ __launch_bounds__(NW * 64) void tmix_lora_mix4_ws_kernel(int T, int C
         const long row = tile * 16 + r16;
         const long rowc = row < rows ? row : rows - 1;     // clamp (every lane takes part in the MFMAs), skip the store
         const int tt = (int)(rowc % T);
-        const bool has_nb = rev ? (tt < T - 1) : (tt > 0);
-        const long nb = has_nb ? (rev ? rowc + 1 : rowc - 1) : rowc;
+        const bool in_seq = rev ? (tt < T - 1) : (tt > 0);
+        const bool has_nb = in_seq || (prev != nullptr && !rev);       // prev: (B, C) the frame before each sequence, or null
+        const bf16_t *nbrow = in_seq ? x + (rev ? rowc + 1 : rowc - 1) * C : (has_nb ? prev + (rowc / T) * C : x + rowc * C);
         uint4 tb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(NW * 64) void tmix_lora_mix4_ws_kernel(int T, int C
             const int col = (cy * 2 + cbi) * 32 + 8 * qq;
             float xn[VEC];
             load8<bf16_t>(x + rowc * C + col, xc[cbi]);
-            load8<bf16_t>(x + nb * C + col, xn);
+            load8<bf16_t>(nbrow + col, xn);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) xx[cbi][e] = round_bf16((has_nb ? xn[e] : 0.f) - xc[cbi][e]);
         }
@@ -576,7 +583,8 @@ constexpr int LD_C = 512, LD_N = 128;
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void tmix_lora_down_kernel(int T, long rows, int rev0, const bf16_t *__restrict__ x,
                                                                        const bf16_t *__restrict__ maa_x,
-                                                                       const bf16_t *__restrict__ w1n, bf16_t *__restrict__ tout) {
+                                                                       const bf16_t *__restrict__ w1n, bf16_t *__restrict__ tout,
+                                                                       const bf16_t *__restrict__ prev) {
     constexpr int C = LD_C;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, qq = lane >> 4;
@@ -596,9 +604,10 @@ __global__ __launch_bounds__(NW * 64) void tmix_lora_down_kernel(int T, long row
         const long row = tile * 16 + r16;
         const long rowc = row < rows ? row : rows - 1;     // clamp (every lane takes part in the MFMAs), skip the store
         const int tt = (int)(rowc % T);
-        const bool has_nb = rev ? (tt < T - 1) : (tt > 0);
-        const long nb = has_nb ? (rev ? rowc + 1 : rowc - 1) : rowc;
-        const bf16_t *xr = x + rowc * C + 8 * qq, *xnr = x + nb * C + 8 * qq, *mr = maa_x + (size_t)d * C + 8 * qq;
+        const bool in_seq = rev ? (tt < T - 1) : (tt > 0);
+        const bool has_nb = in_seq || (prev != nullptr && !rev);       // prev: (B, C) the frame before each sequence, or null
+        const bf16_t *nbrow = in_seq ? x + (rev ? rowc + 1 : rowc - 1) * C : (has_nb ? prev + (rowc / T) * C : x + rowc * C);
+        const bf16_t *xr = x + rowc * C + 8 * qq, *xnr = nbrow + 8 * qq, *mr = maa_x + (size_t)d * C + 8 * qq;
         f32x4g acc[4][2];
 #pragma unroll
         for (int np = 0; np < 4; ++np) { acc[np][0] = zero; acc[np][1] = zero; }
@@ -719,6 +728,11 @@ int pafc_split_planes(long rows, int cols, const float *x, long ldx, void *out, 
 
 int pafc_tmix_shift_mix(int dtype, int B, int T, int C, int ndir, int reverse0, const void *x, const void *maa_x0,
                         const void *maa_x1, void *out, pafc_stream_t stream) {
+    return pafc_tmix_shift_mix_prev(dtype, B, T, C, ndir, reverse0, x, maa_x0, maa_x1, nullptr, out, stream);
+}
+
+int pafc_tmix_shift_mix_prev(int dtype, int B, int T, int C, int ndir, int reverse0, const void *x, const void *maa_x0,
+                             const void *maa_x1, const void *prev, void *out, pafc_stream_t stream) {
     if (!x || !maa_x0 || !out || (ndir == 2 && !maa_x1)) return PAFC_ERR_NULL_POINTER;
     if (B <= 0 || T <= 0 || C <= 0 || C % pafc::VEC || ndir < 1 || ndir > 2) return PAFC_ERR_BAD_DIMS;
     const long rows = (long)B * T;
@@ -728,10 +742,10 @@ int pafc_tmix_shift_mix(int dtype, int B, int T, int C, int ndir, int reverse0, 
     if (dtype == PAFC_BF16)
         hipLaunchKernelGGL(pafc::tmix_shift_mix_kernel<pafc::bf16_t>, grid, block, 0, s, T, C, rows, ndir, reverse0,
                            (const pafc::bf16_t *)x, (const pafc::bf16_t *)maa_x0, (const pafc::bf16_t *)maa_x1,
-                           (pafc::bf16_t *)out);
+                           (pafc::bf16_t *)out, (const pafc::bf16_t *)prev);
     else if (dtype == PAFC_F32)
         hipLaunchKernelGGL(pafc::tmix_shift_mix_kernel<float>, grid, block, 0, s, T, C, rows, ndir, reverse0,
-                           (const float *)x, (const float *)maa_x0, (const float *)maa_x1, (float *)out);
+                           (const float *)x, (const float *)maa_x0, (const float *)maa_x1, (float *)out, (const float *)prev);
     else
         return PAFC_ERR_DTYPE;
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
@@ -760,6 +774,11 @@ int pafc_tmix_mix4(int dtype, int B, int T, int C, int ndir, int reverse0, const
 
 int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const void *x, const void *t, const void *w2t,
                              const void *maa, void *z, pafc_stream_t stream) {
+    return pafc_tmix_lora_mix4_bf16_prev(B, T, C, ndir, reverse0, x, t, w2t, maa, nullptr, z, stream);
+}
+
+int pafc_tmix_lora_mix4_bf16_prev(int B, int T, int C, int ndir, int reverse0, const void *x, const void *t, const void *w2t,
+                                  const void *maa, const void *prev, void *z, pafc_stream_t stream) {
     if (!x || !t || !w2t || !maa || !z) return PAFC_ERR_NULL_POINTER;
     if (B <= 0 || T <= 0 || C <= 0 || C % 64 || ndir < 1 || ndir > 2) return PAFC_ERR_BAD_DIMS;
     const long rows = (long)B * T;
@@ -775,7 +794,7 @@ int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const 
 #define PAFC_WS(NW, WCOLS)                                                                                               \
     hipLaunchKernelGGL((pafc::tmix_lora_mix4_ws_kernel<NW, WCOLS>), dim3((unsigned)G, (C / 64) / WCOLS, ndir), dim3(NW * 64), 0, \
                        (hipStream_t)stream, T, C, rows, ndir, reverse0, (const pafc::bf16_t *)x, (const pafc::bf16_t *)t,  \
-                       (const pafc::bf16_t *)w2t, (const pafc::bf16_t *)maa, (pafc::bf16_t *)z)
+                       (const pafc::bf16_t *)w2t, (const pafc::bf16_t *)maa, (pafc::bf16_t *)z, (const pafc::bf16_t *)prev)
         if (wcols == 8 && (C / 64) % 8 == 0) PAFC_WS(8, 8);
         else if (wcols == 4 && (C / 64) % 4 == 0) PAFC_WS(4, 4);
         else PAFC_WS(4, 1);
@@ -785,11 +804,11 @@ int pafc_tmix_lora_mix4_bf16(int B, int T, int C, int ndir, int reverse0, const 
     if (e && e[0] == '1')
         hipLaunchKernelGGL(pafc::tmix_lora_mix4_kernel<true>, grid, block, 0, (hipStream_t)stream, T, C, rows, ndir, reverse0,
                            (const pafc::bf16_t *)x, (const pafc::bf16_t *)t, (const pafc::bf16_t *)w2t,
-                           (const pafc::bf16_t *)maa, (pafc::bf16_t *)z);
+                           (const pafc::bf16_t *)maa, (pafc::bf16_t *)z, (const pafc::bf16_t *)prev);
     else
         hipLaunchKernelGGL(pafc::tmix_lora_mix4_kernel<false>, grid, block, 0, (hipStream_t)stream, T, C, rows, ndir, reverse0,
                            (const pafc::bf16_t *)x, (const pafc::bf16_t *)t, (const pafc::bf16_t *)w2t,
-                           (const pafc::bf16_t *)maa, (pafc::bf16_t *)z);
+                           (const pafc::bf16_t *)maa, (pafc::bf16_t *)z, (const pafc::bf16_t *)prev);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 
@@ -817,6 +836,11 @@ int pafc_decay_lora_bf16(long rows, int C, int H, int ndir, const void *zw, cons
 
 int pafc_tmix_lora_down_bf16(int B, int T, int C, int N, int ndir, int reverse0, const void *x, const void *maa_x,
                              const void *w1n, void *t, pafc_stream_t stream) {
+    return pafc_tmix_lora_down_bf16_prev(B, T, C, N, ndir, reverse0, x, maa_x, w1n, nullptr, t, stream);
+}
+
+int pafc_tmix_lora_down_bf16_prev(int B, int T, int C, int N, int ndir, int reverse0, const void *x, const void *maa_x,
+                                  const void *w1n, const void *prev, void *t, pafc_stream_t stream) {
     if (!x || !maa_x || !w1n || !t) return PAFC_ERR_NULL_POINTER;
     if (B <= 0 || T <= 0 || ndir < 1 || ndir > 2) return PAFC_ERR_BAD_DIMS;
     if (C != pafc::LD_C || N != pafc::LD_N) return PAFC_ERR_UNSUPPORTED;
@@ -837,7 +861,7 @@ int pafc_tmix_lora_down_bf16(int B, int T, int C, int N, int ndir, int reverse0,
             return PAFC_ERR_LAUNCH;                                                                                        \
         hipLaunchKernelGGL(pafc::tmix_lora_down_kernel<NW>, dim3((unsigned)grid, ndir), dim3(NW * 64), lds, (hipStream_t)stream, T, \
                            rows, reverse0, (const pafc::bf16_t *)x, (const pafc::bf16_t *)maa_x, (const pafc::bf16_t *)w1n, \
-                           (pafc::bf16_t *)t);                                                                             \
+                           (pafc::bf16_t *)t, (const pafc::bf16_t *)prev);                                                 \
     } while (0)
     if (nw == 8) PAFC_DOWN(8);
     else PAFC_DOWN(16);

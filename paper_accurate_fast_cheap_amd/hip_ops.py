@@ -375,6 +375,9 @@ def _bind2():
     _lib._sig(L.pafc_tmix_shift_mix, I, I, I, I, I, I, P, P, P, P, P)
     _lib._sig(L.pafc_tmix_mix4, I, I, I, I, I, I, P, P, P, P, P)
     _lib._sig(L.pafc_tmix_lora_mix4_bf16, I, I, I, I, I, I, P, P, P, P, P, P)
+    _lib._sig(L.pafc_tmix_shift_mix_prev, I, I, I, I, I, I, P, P, P, P, P, P)
+    _lib._sig(L.pafc_tmix_lora_mix4_bf16_prev, I, I, I, I, I, I, P, P, P, P, P, P, P)
+    _lib._sig(L.pafc_tmix_lora_down_bf16_prev, I, I, I, I, I, I, P, P, P, P, P, P)
     L._pafc_glue_bound = True
     return L
 
@@ -552,14 +555,28 @@ def gemm_ph_ex(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     return out
 
 
-def tmix_shift_mix(x: torch.Tensor, maa_x0: torch.Tensor, maa_x1: Optional[torch.Tensor], reverse0: bool = False):
-    """(B, T, C) -> (ndir, B, T, C): x + (shift_d(x) - x) * maa_x_d."""
-    _lib.require_gpu(x, maa_x0, maa_x1)
+def wkv6_single_chunk(B: int, T: int, C: int, H: int) -> bool:
+    """Does the library walk a (B, T, C) one-direction scan as ONE chunk (then the carried state may be updated in place)?"""
+    return _lib.lib().pafc_wkv6_pick_chunk_len(B, T, C, H, 1) >= T
+
+
+def _check_prev(prev: Optional[torch.Tensor], x: torch.Tensor):
+    """prev: (B, 1, C) / (B, C) = the frame before each sequence's first one (streaming), same dtype as x, contiguous."""
+    if prev is not None and (prev.dtype != x.dtype or prev.numel() != x.shape[0] * x.shape[2] or not prev.is_contiguous()
+                             or prev.device != x.device):
+        raise _lib.PafcError("tmix: prev must be a contiguous (B, C) tensor of x's dtype on x's device")
+
+
+def tmix_shift_mix(x: torch.Tensor, maa_x0: torch.Tensor, maa_x1: Optional[torch.Tensor], reverse0: bool = False,
+                   prev: Optional[torch.Tensor] = None):
+    """(B, T, C) -> (ndir, B, T, C): x + (shift_d(x) - x) * maa_x_d.  prev: the frame before the chunk (streaming), or None."""
+    _lib.require_gpu(x, maa_x0, maa_x1, prev)
+    _check_prev(prev, x)
     B, T, C = x.shape
     ndir = 2 if maa_x1 is not None else 1
     out = torch.empty((ndir, B, T, C), dtype=x.dtype, device=x.device)
-    rc = _bind2().pafc_tmix_shift_mix(_lib.dtype_code(x.dtype), B, T, C, ndir, int(reverse0), _lib.ptr(x),
-                                      _lib.ptr(maa_x0), _lib.ptr(maa_x1), _lib.ptr(out), _lib.stream_of(x))
+    rc = _bind2().pafc_tmix_shift_mix_prev(_lib.dtype_code(x.dtype), B, T, C, ndir, int(reverse0), _lib.ptr(x),
+                                           _lib.ptr(maa_x0), _lib.ptr(maa_x1), _lib.ptr(prev), _lib.ptr(out), _lib.stream_of(x))
     _lib.check(rc, "pafc_tmix_shift_mix")
     return out
 
@@ -819,36 +836,37 @@ def linear_fused(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return linear_bias_act(x, weight, bias, act)
 
 
-def tmix_lora_mix4(x: torch.Tensor, t: torch.Tensor, w2t: torch.Tensor, maa: torch.Tensor, reverse0: bool = False):
-    """bf16: x (B,T,C), t (ndir,B*T,128) = tanh(xxx W1), w2t (ndir,4,C,32), maa (ndir,4,C) -> z (4,ndir,B*T,C)."""
-    _lib.require_gpu(x, t, w2t, maa)
+def tmix_lora_mix4(x: torch.Tensor, t: torch.Tensor, w2t: torch.Tensor, maa: torch.Tensor, reverse0: bool = False,
+                   prev: Optional[torch.Tensor] = None):
+    """bf16: x (B,T,C), t (ndir,B*T,128) = tanh(xxx W1), w2t (ndir,4,C,32), maa (ndir,4,C) -> z (4,ndir,B*T,C).
+    prev: the frame before the chunk (streaming), or None."""
+    _lib.require_gpu(x, t, w2t, maa, prev)
+    _check_prev(prev, x)
     B, T, C = x.shape
     ndir = t.shape[0]
     if x.dtype != torch.bfloat16 or t.shape != (ndir, B * T, 128) or w2t.shape != (ndir, 4, C, 32):
         raise _lib.PafcError("tmix_lora_mix4: bf16 only, t (ndir, B*T, 128), w2t (ndir, 4, C, 32)")
     z = torch.empty((4, ndir, B * T, C), dtype=x.dtype, device=x.device)
-    rc = _bind2().pafc_tmix_lora_mix4_bf16(B, T, C, ndir, int(reverse0), _lib.ptr(x), _lib.ptr(t), _lib.ptr(w2t),
-                                           _lib.ptr(maa), _lib.ptr(z), _lib.stream_of(x))
+    rc = _bind2().pafc_tmix_lora_mix4_bf16_prev(B, T, C, ndir, int(reverse0), _lib.ptr(x), _lib.ptr(t), _lib.ptr(w2t),
+                                                _lib.ptr(maa), _lib.ptr(prev), _lib.ptr(z), _lib.stream_of(x))
     _lib.check(rc, "pafc_tmix_lora_mix4_bf16")
     return z
 
 
 # The one-pass LoRA kernels stage 128 KiB of weights into LDS per block: worth it from a few thousand rows on (30-minute
-# file: 45 k rows, a c2 batch: ~16 k); a streaming chunk (65 rows x streams) keeps the small-GEMM path (measured: 2.1 vs 2.8 ms
-# per 12-layer chunk step with one stream, 4.2 vs 4.8 ms with 64).  PAFC_LDS_RESIDENT_MIN_ROWS overrides (tests, A/B).
+# file: 45 k rows, a c2 batch: ~16 k) and, as ONE launch instead of two or three, in the launch-bound streaming chunk step
+# (`one_pass=True`, fused.layer_forward_carry); in between the small-GEMM path.  PAFC_LDS_RESIDENT_MIN_ROWS overrides (tests, A/B).
 _LDS_RESIDENT_MIN_ROWS = int(os.environ.get("PAFC_LDS_RESIDENT_MIN_ROWS", "8192"))
 
 
-def tmix_lora_down(x: torch.Tensor, maa_x: torch.Tensor, w1n: torch.Tensor, reverse0: bool = False):
+def tmix_lora_down(x: torch.Tensor, maa_x: torch.Tensor, w1n: torch.Tensor, reverse0: bool = False,
+                   prev: Optional[torch.Tensor] = None, one_pass: Optional[bool] = None):
     """bf16: t = tanh((x + (x_nb - x) * maa_x) w1n^T) in one pass.  x (B, T, C), maa_x (ndir, C), w1n (ndir, N, C) ->
     (ndir, B*T, N).  C = 512, N = 128 run the fused kernel (weights resident in LDS); other sizes take the shift/lerp pass and
     a GEMM with the same roundings."""
-    _lib.require_gpu(x, maa_x, w1n)
+    _lib.require_gpu(x, maa_x, w1n, prev)
+    _check_prev(prev, x)
     L = _bind2()
-    if not getattr(L, "_pafc_down_bound", False):
-        _lib._sig(L.pafc_tmix_lora_down_bf16, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                  c_void_p, c_void_p)
-        L._pafc_down_bound = True
     B, T, C = x.shape
     ndir, N = w1n.shape[0], w1n.shape[1]
     if x.dtype != torch.bfloat16 or w1n.shape != (ndir, N, C) or maa_x.shape != (ndir, C):
@@ -856,19 +874,20 @@ def tmix_lora_down(x: torch.Tensor, maa_x: torch.Tensor, w1n: torch.Tensor, reve
     for a in (x, maa_x, w1n):
         if not a.is_contiguous() or a.dtype != torch.bfloat16:
             raise _lib.PafcError("tmix_lora_down: contiguous bf16 tensors")
-    if C == 512 and N == 128 and B * T >= _LDS_RESIDENT_MIN_ROWS:
+    if C == 512 and N == 128 and (B * T >= _LDS_RESIDENT_MIN_ROWS if one_pass is None else one_pass):
         t = torch.empty((ndir, B * T, N), dtype=x.dtype, device=x.device)
         from .profiling import op_timer
         with op_timer("tmix_lora_down"):
-            rc = L.pafc_tmix_lora_down_bf16(B, T, C, N, ndir, int(reverse0), _lib.ptr(x), _lib.ptr(maa_x), _lib.ptr(w1n),
-                                            _lib.ptr(t), _lib.stream_of(x))
+            rc = L.pafc_tmix_lora_down_bf16_prev(B, T, C, N, ndir, int(reverse0), _lib.ptr(x), _lib.ptr(maa_x), _lib.ptr(w1n),
+                                                 _lib.ptr(prev), _lib.ptr(t), _lib.stream_of(x))
         _lib.check(rc, "pafc_tmix_lora_down_bf16")
         return t
-    xxx = tmix_shift_mix(x, maa_x[0], maa_x[1] if ndir == 2 else None, reverse0=reverse0)
+    xxx = tmix_shift_mix(x, maa_x[0], maa_x[1] if ndir == 2 else None, reverse0=reverse0, prev=prev)
     return gemm_bf16(xxx.view(ndir, B * T, C), w1n, act="tanh")
 
 
-def decay_lora(zw: torch.Tensor, d1n: torch.Tensor, d2n: torch.Tensor, bias: Optional[torch.Tensor] = None):
+def decay_lora(zw: torch.Tensor, d1n: torch.Tensor, d2n: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               one_pass: Optional[bool] = None):
     """bf16: w = bf16(bf16(tanh(zw d1n^T)) d2n^T) [+ bias] in one pass.  zw (ndir, rows, C), d1n (ndir, H, C), d2n (ndir, C, H),
     bias (ndir, C) or None -> (ndir, rows, C).  C = 512, H = 64 run the fused kernel (weights resident in LDS); other sizes
     take two GEMMs with the same roundings."""
@@ -886,7 +905,7 @@ def decay_lora(zw: torch.Tensor, d1n: torch.Tensor, d2n: torch.Tensor, bias: Opt
     for a in (zw, d1n, d2n) + ((bias,) if bias is not None else ()):
         if not a.is_contiguous() or a.dtype != torch.bfloat16:
             raise _lib.PafcError("decay_lora: contiguous bf16 tensors")
-    if C == 512 and H == 64 and rows >= _LDS_RESIDENT_MIN_ROWS:
+    if C == 512 and H == 64 and (rows >= _LDS_RESIDENT_MIN_ROWS if one_pass is None else one_pass):
         w = torch.empty_like(zw)
         from .profiling import op_timer
         with op_timer("decay_lora"):

@@ -41,16 +41,28 @@ def _workspace(B, T, C, H, ndir, chunk_len, device):
 
 
 def wkv6_forward(r, k, v, w, u, *, reverse: bool = False, s_in: Optional[torch.Tensor] = None,
-                 want_state: bool = False, chunk_len: int = 0):
+                 want_state: bool = False, chunk_len: int = 0, s_out: Optional[torch.Tensor] = None):
     """y = WKV6(r, k, v, w, u); optionally from an initial state and returning the final one.
 
     chunk_len: 0 = library heuristic, T (or more) = serial schedule, else steps per chunk.
+    s_out: where the final state goes (float32 (B, H, 64, 64); allocated here when want_state and None).  It may BE s_in
+    -- a streaming step that updates its carried state in place -- when the sequence is walked as one chunk (each wave then
+    reads its head's state before the first step and writes it after the last); refused otherwise.
     """
-    _lib.require_gpu(r, k, v, w, u, s_in)
+    _lib.require_gpu(r, k, v, w, u, s_in, s_out)
     B, T, C, H = _shape(r, u)
     code = _same(r, k, v, w, u)
     y = torch.empty_like(r)
-    s_out = torch.empty(B, H, HEAD_SIZE, HEAD_SIZE, dtype=torch.float32, device=r.device) if want_state else None
+    if s_out is not None:
+        want_state = True
+        if s_out.dtype != torch.float32 or s_out.shape != (B, H, HEAD_SIZE, HEAD_SIZE):
+            raise _lib.PafcError("s_out must be float32 (B, H, 64, 64)")
+        if s_in is not None and s_out.data_ptr() == s_in.data_ptr():
+            picked = chunk_len if chunk_len > 0 else _lib.lib().pafc_wkv6_pick_chunk_len(B, T, C, H, 1)
+            if picked < T:
+                raise _lib.PafcError("wkv6_forward: s_out may alias s_in only when the sequence is one chunk")
+    elif want_state:
+        s_out = torch.empty(B, H, HEAD_SIZE, HEAD_SIZE, dtype=torch.float32, device=r.device)
     if s_in is not None and (s_in.dtype != torch.float32 or s_in.shape != (B, H, HEAD_SIZE, HEAD_SIZE)):
         raise _lib.PafcError("s_in must be float32 (B, H, 64, 64)")
     ws, nbytes = _workspace(B, T, C, H, 1, chunk_len, r.device)

@@ -173,14 +173,15 @@ class BaseEncoder(torch.nn.Module):
         return xs, torch.cat(r_att_cache, dim=0), torch.cat(r_cnn_cache, dim=0)
 
     @torch.no_grad()
-    def forward_chunk_carry(self, xs: torch.Tensor, offset: int = 0, state: Optional[list] = None
+    def forward_chunk_carry(self, xs: torch.Tensor, offset: int = 0, state: Optional[list] = None, in_place: bool = False
                             ) -> Tuple[torch.Tensor, list]:
         """Streaming step with recurrent-state carry (BASELINE config c3 "recurrent-state carry, no KV cache").
         xs: (B, time, F) input window -- windows overlap exactly as in forward_chunk_by_chunk (encoder.py:379-391,
         window (chunk-1)*4+7, stride 4*chunk) because the subsampling convolutions keep no cache.  state: list of
         per-layer carries from the previous call (None to start).  Uni-directional slot only; exact (chunked == full
         sequence) when the conv module is causal, otherwise the conv sees zeros past the chunk edge like the
-        reference's forward_chunk does."""
+        reference's forward_chunk does.  in_place (fused kernels only): the tensors in `state` are updated where they lie
+        and `state` itself is returned -- the form a captured hipGraph step needs (stream_chunks)."""
         masks = torch.ones(xs.size(0), 1, xs.size(1), device=xs.device, dtype=torch.bool)
         if self.global_cmvn is not None:
             xs = self.global_cmvn(xs)
@@ -194,12 +195,18 @@ class BaseEncoder(torch.nn.Module):
                 if getattr(self, "_carry_plans", None) is None:
                     self._carry_plans = [fused.LayerPlan(l) for l in self.encoders]
                 plans = self._carry_plans
-        for i, (layer, carry) in enumerate(zip(self.encoders, state)):
-            if plans is not None:
+        if plans is not None:
+            n = len(plans)
+            tail = self.after_norm if self.normalize_before else None
+            h = None
+            for i, carry in enumerate(state):
                 plans[i].refresh()
-                xs, c = fused.layer_forward_carry(plans[i], xs, carry)
-            else:
-                xs, c = layer.forward_carry(xs, carry)
+                nxt = plans[i + 1].layer.norm_ff_macaron if i + 1 < n else tail
+                xs, c, h = fused.layer_forward_carry(plans[i], xs, carry, h0=h, next_norm=nxt, in_place=in_place and carry is not None)
+                new_state.append(c)
+            return (h if tail is not None else xs), new_state
+        for layer, carry in zip(self.encoders, state):
+            xs, c = layer.forward_carry(xs, carry)
             new_state.append(c)
         if self.normalize_before:
             xs = self.after_norm(xs)
@@ -242,10 +249,11 @@ class BaseEncoder(torch.nn.Module):
                 static_state = [{k: v.clone() for k, v in st.items()} for st in state]
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    y_static, new_state = self.forward_chunk_carry(static_in, 0, static_state)
+                    y_static, new_state = self.forward_chunk_carry(static_in, 0, static_state, in_place=True)
                     for st, nw in zip(static_state, new_state):
-                        for k in st:
-                            st[k].copy_(nw[k])
+                        if nw is not st:            # (the fused step updates its carries where they lie)
+                            for k in st:
+                                st[k].copy_(nw[k])
                 for c in full[warm:]:
                     static_in.copy_(xs[:, c:c + window])
                     graph.replay()

@@ -448,59 +448,85 @@ def carry_eligible(layer: nn.Module, x: torch.Tensor) -> bool:
             and bool(layer.self_attn.do_bfloat16))
 
 
-def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict]) -> Tuple[torch.Tensor, dict]:
+def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict], h0: Optional[torch.Tensor] = None,
+                        next_norm: Optional[nn.LayerNorm] = None, in_place: bool = False):
     """ConformerEncoderLayer.forward_carry (one chunk with recurrent-state carry) on the fused kernels, bf16, B streams:
     the same carries -- "shift" (B, 1, C) last normalised frame, "wkv" float32 (B, H, N, N), "cnn" (B, C, lorder) --
-    and the same arithmetic as the module path; ~25 launches instead of ~50.  The previous frame is prepended to the
-    slot input so that the token shift of the chunk's first frame sees it; that extra frame's own outputs are dropped
-    before the scan, which starts from the carried state."""
+    and the same arithmetic as the module path.  A chunk step is launch-bound (a 64-frame chunk is ~5 us of work per kernel),
+    so the step is built to be FEW launches: the frame before the chunk reaches the token-shift kernels through their `prev`
+    pointer (no concatenation, no extra row to drop again), the scan starts from the carried state and -- `in_place`, the
+    captured step of `stream_chunks`, whose carries are fixed buffers -- writes the new state over it, "shift" and "cnn" are
+    refreshed by one small copy each, and `norm_final` + the next layer's first pre-norm are one pass (h0 = that pre-norm of x
+    when the previous layer already produced it; next_norm = the norm to apply to this layer's output for the next one).
+    Returns (layer output, carries, next_norm(output) or None)."""
     L = plan.layer
-    carry = carry or {}
+    carry = carry if carry is not None else {}
     B, T, C = x.shape
     M = B * T
     x = x.contiguous()
-    _, h0, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff_macaron.weight, L.norm_ff_macaron.bias, want_x=False, eps=L.norm_ff_macaron.eps)
+    if h0 is None:
+        _, h0, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff_macaron.weight, L.norm_ff_macaron.bias, want_x=False, eps=L.norm_ff_macaron.eps)
     x = _ffn_residual(L.feed_forward_macaron, h0, x, L.ff_scale, plan.b2_macaron, inplace=False)
     _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_mha.weight, L.norm_mha.bias, want_x=False, eps=L.norm_mha.eps)
     shift = carry.get("shift")
     if shift is None:
         shift = h.new_zeros(B, 1, C)
-    hx = torch.cat([shift.to(h.dtype), h], dim=1)                                            # (B, T + 1, C)
-    M1 = B * (T + 1)
-    t = hip_ops.tmix_lora_down(hx, plan.maa_x_n, plan.W1n)
-    z = hip_ops.tmix_lora_mix4(hx, t, plan.W2t, plan.maa4)                                    # (4, 1, B, T + 1, C)
-    if M1 >= _OWN_GEMM_MIN_ROWS:
-        rkv = hip_ops.gemm_bf16(z[:3].view(3, M1, C), plan.Wrkv_n).view(3, B, T + 1, C)
+    elif shift.dtype != h.dtype or not shift.is_contiguous():
+        shift = shift.to(h.dtype).contiguous()
+    few = True if M < _OWN_GEMM_MIN_ROWS else None       # launch-bound: one kernel each for the two LoRA chains
+    t = hip_ops.tmix_lora_down(h, plan.maa_x_n, plan.W1n, prev=shift, one_pass=few)
+    z = hip_ops.tmix_lora_mix4(h, t, plan.W2t, plan.maa4, prev=shift)                         # (4, 1, M, C)
+    if M >= _OWN_GEMM_MIN_ROWS:
+        rkv = hip_ops.gemm_bf16(z[:3].view(3, M, C), plan.Wrkv_n).view(3, B, T, C)
     else:
-        rkv = torch.bmm(z[:3].view(3, M1, C), plan.Wrkv).view(3, B, T + 1, C)
-    w = hip_ops.decay_lora(z[3].view(1, M1, C), plan.D1n, plan.D2n, plan.time_decay.view(1, C)).view(B, T + 1, C)
-    if B == 1:
-        r_, k_, v_, w_ = rkv[0, :, 1:], rkv[1, :, 1:], rkv[2, :, 1:], w[:, 1:]                # contiguous views
+        rkv = torch.bmm(z[:3].view(3, M, C), plan.Wrkv).view(3, B, T, C)
+    w = hip_ops.decay_lora(z[3].view(1, M, C), plan.D1n, plan.D2n, plan.time_decay.view(1, C), one_pass=few).view(B, T, C)
+    s_in = carry.get("wkv")
+    new = carry if in_place else {}
+    if in_place and s_in is not None and hip_ops.wkv6_single_chunk(B, T, C, plan.u[0].shape[0]):
+        y, _ = wkv6_forward(rkv[0], rkv[1], rkv[2], w, plan.u[0], s_in=s_in, s_out=s_in)      # the state is updated where it lies
     else:
-        r_, k_, v_, w_ = (a[:, 1:].contiguous() for a in (rkv[0], rkv[1], rkv[2], w))
-    y, s_out = wkv6_forward(r_, k_, v_, w_, plan.u[0], s_in=carry.get("wkv"), want_state=True)
+        y, s_out = wkv6_forward(rkv[0], rkv[1], rkv[2], w, plan.u[0], s_in=s_in, want_state=True)
+        if in_place and s_in is not None:
+            s_in.copy_(s_out)
+        else:
+            new["wkv"] = s_out
+    if in_place and carry.get("shift") is not None and carry["shift"].dtype == h.dtype:
+        carry["shift"].copy_(h[:, -1:])               # (after the two passes that read the old one)
+    else:
+        new["shift"] = h[:, -1:].contiguous()
     ln = plan.blocks[0].ln_x
     _, yn, _ = hip_ops.add_layernorm(y.view(M, C), None, 1.0, ln.weight, ln.bias, eps=ln.eps, want_x=False)
     x = proj(yn, plan.Wo, None, "none", residual=x.view(M, C), inplace=True).view(B, T, C)
-    new = {"shift": h[:, -1:].clone(), "wkv": s_out}
     cm = L.conv_module
     _, hc, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_conv.weight, L.norm_conv.bias, want_x=False, eps=L.norm_conv.eps)
     cnn = carry.get("cnn")
     left = cnn.transpose(1, 2).to(hc.dtype) if cnn is not None and cnn.numel() > 0 else hc.new_zeros(B, cm.lorder, C)
     cx = torch.cat([left, hc], dim=1)                                                         # (B, lorder + T, C)
-    new["cnn"] = cx[:, -cm.lorder:, :].transpose(1, 2)
     if plan.pw1_glu is not None:
         p = _pw1_glu(plan, cx.view(-1, C)).view(B, -1, C)
         dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, 0, T)
     else:
         p = F.linear(cx, cm.pointwise_conv1.weight.squeeze(-1), cm.pointwise_conv1.bias)
         dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, 0, T, glu=True)
+    new_cnn = cx[:, -cm.lorder:, :].transpose(1, 2)
+    if in_place and cnn is not None and cnn.shape == new_cnn.shape and cnn.dtype == new_cnn.dtype:
+        cnn.copy_(new_cnn)
+    else:
+        new["cnn"] = new_cnn
     _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
     x = proj(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none", residual=x, inplace=True)
     _, h2, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff.weight, L.norm_ff.bias, want_x=False, eps=L.norm_ff.eps)
     x = _ffn_residual(L.feed_forward, h2, x, L.ff_scale, plan.b2, inplace=True)
+    if next_norm is not None and next_norm.eps == L.norm_final.eps:        # the one-pass pair shares one epsilon
+        _, out, hn = hip_ops.add_layernorm(x, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False, gamma2=next_norm.weight,
+                                           beta2=next_norm.bias, eps=L.norm_final.eps)
+        return out, new, hn
     _, out, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False, eps=L.norm_final.eps)
-    return out, new
+    hn = None
+    if next_norm is not None:
+        _, hn, _ = hip_ops.add_layernorm(out, None, 1.0, next_norm.weight, next_norm.bias, want_x=False, eps=next_norm.eps)
+    return out, new, hn
 
 
 class EncoderPlan:

@@ -12,7 +12,7 @@
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int PAT>
+template <int PAT, int AUX = 0>
 __global__ __launch_bounds__(512) void k(unsigned char *out, long M, int N, int mtiles, int ntiles, int reps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 2, wc = wave & 3;
     const __amdgpu_buffer_rsrc_t R = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0x7fffffff, 0x00020000);
@@ -29,20 +29,20 @@ __global__ __launch_bounds__(512) void k(unsigned char *out, long M, int N, int 
             else if (PAT == 1) { off = (long)(i * 8 + (lane & 7)) * N * 2 + (lane >> 3) * 16; }
             else if (PAT == 2) { off = (long)(i * 8 + (wc & 1) * 4 + (lane & 3)) * N * 2 + (lane >> 2) * 16 - (wc & 1) * 128; }
             else { off = (long)(i * 8 + wc * 2 + (lane >> 5)) * N * 2 + (lane & 31) * 16 - wc * 128; }
-            __builtin_amdgcn_raw_buffer_store_b128(v, R, (unsigned)(base + off), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v, R, (unsigned)(base + off), 0, AUX);
         }
     }
 }
 
-template <int PAT>
+template <int PAT, int AUX = 0>
 void run(const char *name, unsigned char *out, long M, int N, int reps = 1) {
     const int mt = (int)(M / 256), nt = N / 256;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<PAT>, dim3(256), dim3(512), 0, 0, out, M, N, mt, nt, reps);
+    hipLaunchKernelGGL((k<PAT, AUX>), dim3(256), dim3(512), 0, 0, out, M, N, mt, nt, reps);
     float best = 1e9f;
     for (int r = 0; r < 5; ++r) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k<PAT>, dim3(256), dim3(512), 0, 0, out, M, N, mt, nt, reps);
+        hipLaunchKernelGGL((k<PAT, AUX>), dim3(256), dim3(512), 0, 0, out, M, N, mt, nt, reps);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
@@ -68,6 +68,14 @@ int main() {
         run<1>("L2-resident 8 rows x 128 B", out, 4096, N, 64);
         run<3>("L2-resident 2 rows x 512 B", out, 4096, N, 64);
     }
+    // cache-policy bits of the store (aux: 1 = sc0, 2 = nt, 16 = sc1), L2-resident and HBM-bound
+    run<0, 1>("L2-resident 16x64 aux sc0", out, 4096, 512, 64);
+    run<0, 2>("L2-resident 16x64 aux nt", out, 4096, 512, 64);
+    run<0, 3>("L2-resident 16x64 aux sc0 nt", out, 4096, 512, 64);
+    run<0, 16>("L2-resident 16x64 aux sc1", out, 4096, 512, 64);
+    run<0, 17>("L2-resident 16x64 aux sc0 sc1", out, 4096, 512, 64);
+    run<0, 2>("16x64 aux nt", out, M, 2048);
+    run<0, 17>("16x64 aux sc0 sc1", out, M, 2048);
     hipFree(out);
     return 0;
 }
