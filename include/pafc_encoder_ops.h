@@ -104,6 +104,35 @@ int pafc_layernorm_bwd(int dtype_x, int dtype_dy, long rows, int C, const void *
                        float eps, void *dx, float *dgamma_dbeta, void *workspace, size_t workspace_bytes,
                        pafc_stream_t stream);
 
+/* Skinny bf16 GEMM for the streaming chunk step (csrc/gemm_skinny.hip): out = act(alpha * A W^T + bias [+ residual]) for FEW
+ * rows -- the projections of a layer while it serves 64-frame chunks with state carry (the same nn.Linear / 1x1 Conv1d call
+ * sites as pafc_gemm_bf16: positionwise_feed_forward.py:47-55, convolution.py:118-141, src/model.py:286-324,
+ * encoder_layer.py:201-259).  One block per 16 output columns walks all rows and all of K; ~4 us per launch at 64 rows.
+ * A: (M, K) row stride lda; W: (N, K) row stride ldw (nn.Linear layout); batch entries strideX elements apart (0 = shared).
+ * act: 0 none, 1 SiLU, 2 tanh, 3 ReLU, 4 GLU (F.glu over the N rows of W: value rows [0, N/2), gate rows [N/2, N); out has N/2
+ * columns; no residual).  K % 32 == 0, N % 16 == 0 (GLU: 32), 16-byte aligned rows.
+ * LayerNorm in front of the projection, folded (as pafc_gemm_bf16_ph_ln): ln_stats_in = float2 [M][ln_parts_in] partial
+ * (sum, sum of squares) of the UN-normalised A rows, ln_csum[N] = column sums of W' = bf16(gamma * W), bias = b + W beta;
+ * out = act(rstd (A W'^T - mean csum) + bias).  ln_stats_out (or null) receives float2 [batch][M][N_out / 16] partial
+ * statistics of the rows written (as stored, after rounding) for the next folded LayerNorm. */
+int pafc_gemm_skinny_bf16(long M, int N, int K, int batch, const void *A, long lda, long strideA, const void *W, long ldw,
+                          long strideW, const void *bias, long strideBias, const void *residual, long ldr, long strideR,
+                          void *out, long ldo, long strideO, float alpha, int act, const float *ln_stats_in, int ln_parts_in,
+                          const float *ln_csum, float ln_eps, float *ln_stats_out, pafc_stream_t stream);
+/* The same with the other things a chunk step wants inside the launch:
+ *   round_first: out = bf16(alpha * A W^T) + bias, rounded again -- where `ww = t @ time_decay_w2; w = time_decay + ww`
+ *                rounds (src/model.py:287-289);
+ *   ln_self:     the folded LayerNorm's row statistics are formed from the operand itself (ln_stats_in null, ln_csum given);
+ *   mix_maa:     the operand is the token shift + first lerp of the time-mix, xxx = x + (x_prev - x) * maa_x
+ *                (src/model.py:274-276), formed in registers from A = x (M = B * mix_T rows), its predecessor row and maa_x (K);
+ *                mix_prev (B, K) or null = the frame before each sequence (the streaming carry; null: zero as ZeroPad2d);
+ *                with act = 2 and W = time_maa_rkvw_w1^T this is pafc_tmix_lora_down_bf16_prev for a handful of rows. */
+int pafc_gemm_skinny_bf16_ex(long M, int N, int K, int batch, const void *A, long lda, long strideA, const void *W, long ldw,
+                             long strideW, const void *bias, long strideBias, const void *residual, long ldr, long strideR,
+                             void *out, long ldo, long strideO, float alpha, int act, int round_first,
+                             const float *ln_stats_in, int ln_parts_in, int ln_self, const float *ln_csum, float ln_eps,
+                             float *ln_stats_out, const void *mix_maa, const void *mix_prev, int mix_T, pafc_stream_t stream);
+
 /* Token shift + first lerp of the time-mix for ndir directions from one read of x (src/model.py:274-276):
  *   xx_d = shift_d(x) - x,  out[d] = x + xx_d * maa_x_d;   shift_0 = x_{t-1} (or x_{t+1} when reverse0), shift_1 = x_{t+1}
  * x: (B, T, C); maa_x0/1: (C); out: (ndir, B, T, C).  Zero beyond the sequence ends, like ZeroPad2d((0,0,1,-1)). */

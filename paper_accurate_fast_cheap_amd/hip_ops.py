@@ -2,6 +2,7 @@
 import contextlib
 import ctypes
 import os
+import threading
 import weakref
 from typing import Optional
 
@@ -825,9 +826,12 @@ def linear_fused(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     """act(x @ weight.T + bias) with the epilogue fused: bf16 operands on the hand-written GEMM (K % 64 == 0, N % 8 == 0),
     long fp32 inputs on the same kernel with split operands, anything else on the library GEMM."""
     N, K = weight.shape
+    rows = x.numel() // K
+    if (x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_cuda and weight.is_contiguous()
+            and skinny_ok(rows, N, K) and act != "glu"):         # a streaming chunk: the few-rows kernel
+        return gemm_skinny(x.reshape(-1, K), weight, bias, act).view(x.shape[:-1] + (N,))
     if x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and K % 64 == 0 and N % 8 == 0:
         return gemm_bf16(x.reshape(-1, K), weight, bias, act).view(x.shape[:-1] + (N,))
-    rows = x.numel() // K
     if (x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_cuda and K % 128 == 0 and N % 8 == 0 and N >= 256
             and rows >= _SPLIT_GEMM_MIN_ROWS and act == "none" and not torch.is_grad_enabled()
             and (bias is None or bias.dtype == torch.float32)):
@@ -1020,6 +1024,98 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
                               bs(residual) if residual is not None else 0, _lib.ptr(out), out.stride(-2), bs(out),
                               float(alpha), _ACTS[act], _lib.stream_of(a))
     _lib.check(rc, "pafc_gemm_bf16")
+    return out
+
+
+SKINNY_MAX_ROWS = int(os.environ.get("PAFC_SKINNY_MAX_ROWS", "160"))     # above: the library's small-problem kernels
+
+
+_chunk_step = threading.local()
+
+
+@contextlib.contextmanager
+def chunk_step():
+    """Inside: the caller is a streaming chunk step (encoder.forward_chunk_carry) -- its few-row projections run on
+    csrc/gemm_skinny.hip.  Outside (offline inputs that merely happen to be short) they keep the kernels the goldens of the
+    offline path were recorded with."""
+    prev = getattr(_chunk_step, "on", False)
+    _chunk_step.on = True
+    try:
+        yield
+    finally:
+        _chunk_step.on = prev
+
+
+def skinny_ok(rows: int, N: int, K: int, glu: bool = False) -> bool:
+    """Shapes csrc/gemm_skinny.hip takes, asked from inside a streaming chunk step."""
+    return (getattr(_chunk_step, "on", False) and 0 < rows <= SKINNY_MAX_ROWS and K % 32 == 0
+            and N % (32 if glu else 16) == 0)
+
+
+def gemm_skinny(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none", alpha: float = 1.0,
+                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None,
+                ln_csum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5, stats_out: Optional[torch.Tensor] = None,
+                ln_self: bool = False, round_first: bool = False, mix_maa: Optional[torch.Tensor] = None,
+                mix_prev: Optional[torch.Tensor] = None, mix_T: int = 0):
+    """The few-rows bf16 GEMM of the streaming chunk step (include/pafc_encoder_ops.h: pafc_gemm_skinny_bf16[_ex]), arguments as
+    gemm_bf16 except act "glu": w is the module's own (2C, K) weight (value rows, then gate rows), out (M, C).
+    ln_csum (N) fp32 with ln_stats (M, P, 2) fp32 or ln_self: the LayerNorm in front of the projection folded in (a = the
+    UN-normalised rows, w / bias = the folded ones; statistics from a producer's partials or formed in the launch);
+    stats_out (M, N_out / 16, 2) fp32 receives the partial row statistics of the result; round_first: bf16(alpha a w^T) + bias;
+    mix_maa (K) [+ mix_prev (B, K)], mix_T: a = x of B sequences of mix_T rows, the operand is x + (x_prev - x) * maa."""
+    _lib.require_gpu(bias, ln_stats, ln_csum, stats_out, mix_maa, mix_prev)
+    for t in (a, w, residual, out):
+        if t is not None and (not t.is_cuda or t.dtype != torch.bfloat16 or t.stride(-1) != 1):
+            raise _lib.PafcError("gemm_skinny: bf16 GPU tensors with unit stride in the last dimension")
+    L = _bind2()
+    if not getattr(L, "_pafc_skinny_bound", False):
+        from ctypes import c_float, c_long
+        P, I, G = c_void_p, c_int, c_long
+        _lib._sig(L.pafc_gemm_skinny_bf16_ex, I, G, I, I, I, P, G, G, P, G, G, P, G, P, G, G, P, G, G, c_float, I, I, P, I, I, P,
+                  c_float, P, P, P, I, P)
+        L._pafc_skinny_bound = True
+    batched = a.dim() == 3
+    Z = a.shape[0] if batched else 1
+    M, K = a.shape[-2], a.shape[-1]
+    N = w.shape[-2]
+    if w.shape[-1] != K or (batched and (w.dim() != 3 or w.shape[0] != Z)) or (not batched and (a.dim() != 2 or w.dim() != 2)):
+        raise _lib.PafcError("gemm_skinny: a (M, K) x w (N, K), or both with a leading batch")
+    No = N // 2 if act == "glu" else N
+    shape = (Z, M, No) if batched else (M, No)
+    if out is None:
+        out = torch.empty(shape, dtype=a.dtype, device=a.device)
+    for t in (residual, out):
+        if t is not None and tuple(t.shape) != shape:
+            raise _lib.PafcError("gemm_skinny: residual / out must be (M, N) per batch entry")
+    if bias is not None and (bias.dtype != a.dtype or bias.shape[-1] != N):
+        raise _lib.PafcError("gemm_skinny: bias must be (N) or (Z, N) bf16")
+    parts = 0
+    if ln_stats is not None or ln_self:
+        if ln_csum is None or batched or ln_csum.dtype != torch.float32 or ln_csum.numel() != N or (ln_stats is not None and ln_self):
+            raise _lib.PafcError("gemm_skinny: a folded LayerNorm wants ln_csum (N) fp32 and ln_stats or ln_self, unbatched")
+        if ln_stats is not None:
+            if ln_stats.dtype != torch.float32 or ln_stats.dim() != 3 or ln_stats.shape[0] != M or ln_stats.shape[2] != 2:
+                raise _lib.PafcError("gemm_skinny: ln_stats (M, P, 2) fp32")
+            parts = ln_stats.shape[1]
+    elif ln_csum is not None:
+        raise _lib.PafcError("gemm_skinny: ln_csum without ln_stats / ln_self")
+    if stats_out is not None and (stats_out.dtype != torch.float32 or stats_out.numel() != Z * M * (No // 16) * 2):
+        raise _lib.PafcError("gemm_skinny: stats_out must be fp32 (M, N_out / 16, 2) per batch entry")
+    if mix_maa is not None:
+        if (batched or mix_T <= 0 or M % mix_T or mix_maa.dtype != a.dtype or mix_maa.numel() != K or not a.is_contiguous()
+                or (mix_prev is not None and (mix_prev.dtype != a.dtype or mix_prev.numel() != (M // mix_T) * K))):
+            raise _lib.PafcError("gemm_skinny: mix wants contiguous a = (B * T, K), maa (K) and prev (B, K) of a's dtype")
+    elif mix_prev is not None:
+        raise _lib.PafcError("gemm_skinny: mix_prev without mix_maa")
+    sb = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
+    bs = lambda t: t.stride(0) if batched else 0
+    rc = L.pafc_gemm_skinny_bf16_ex(M, N, K, Z, _lib.ptr(a), a.stride(-2), bs(a), _lib.ptr(w), w.stride(-2), bs(w), _lib.ptr(bias),
+                                    sb, _lib.ptr(residual), residual.stride(-2) if residual is not None else 0,
+                                    bs(residual) if residual is not None else 0, _lib.ptr(out), out.stride(-2), bs(out),
+                                    float(alpha), _ACTS[act], int(round_first), _lib.ptr(ln_stats), parts, int(ln_self),
+                                    _lib.ptr(ln_csum), float(ln_eps), _lib.ptr(stats_out), _lib.ptr(mix_maa), _lib.ptr(mix_prev),
+                                    int(mix_T), _lib.stream_of(a))
+    _lib.check(rc, "pafc_gemm_skinny_bf16")
     return out
 
 

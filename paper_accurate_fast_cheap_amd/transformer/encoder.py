@@ -185,26 +185,31 @@ class BaseEncoder(torch.nn.Module):
         masks = torch.ones(xs.size(0), 1, xs.size(1), device=xs.device, dtype=torch.bool)
         if self.global_cmvn is not None:
             xs = self.global_cmvn(xs)
-        xs, _, _ = self.embed(xs, masks, offset)
         state = state or [None] * len(self.encoders)
         new_state = []
-        plans = None
-        if self.fused_inference and not torch.is_grad_enabled() and not self.training and xs.is_cuda:
+        fused_step = (self.fused_inference and not torch.is_grad_enabled() and not self.training and xs.is_cuda
+                      and xs.dtype == torch.bfloat16)
+        if fused_step:
             from . import fused
-            if all(fused.carry_eligible(l, xs) for l in self.encoders):     # one bf16 stream, causal conv: fused kernels
-                if getattr(self, "_carry_plans", None) is None:
-                    self._carry_plans = [fused.LayerPlan(l) for l in self.encoders]
-                plans = self._carry_plans
-        if plans is not None:
-            n = len(plans)
-            tail = self.after_norm if self.normalize_before else None
-            h = None
-            for i, carry in enumerate(state):
-                plans[i].refresh()
-                nxt = plans[i + 1].layer.norm_ff_macaron if i + 1 < n else tail
-                xs, c, h = fused.layer_forward_carry(plans[i], xs, carry, h0=h, next_norm=nxt, in_place=in_place and carry is not None)
-                new_state.append(c)
-            return (h if tail is not None else xs), new_state
+            from .. import hip_ops
+            with hip_ops.chunk_step():      # few rows: the launch-bound regime (csrc/gemm_skinny.hip)
+                xs, _, _ = self.embed(xs, masks, offset)
+                if all(fused.carry_eligible(l, xs) for l in self.encoders):     # bf16 streams, causal conv: fused kernels
+                    if getattr(self, "_carry_plans", None) is None:
+                        self._carry_plans = [fused.LayerPlan(l) for l in self.encoders]
+                    plans = self._carry_plans
+                    n = len(plans)
+                    tail = self.after_norm if self.normalize_before else None
+                    h = None
+                    for i, carry in enumerate(state):
+                        plans[i].refresh()
+                        nxt = plans[i + 1].layer.norm_ff_macaron if i + 1 < n else tail
+                        xs, c, h = fused.layer_forward_carry(plans[i], xs, carry, h0=h, next_norm=nxt,
+                                                             in_place=in_place and carry is not None)
+                        new_state.append(c)
+                    return (h if tail is not None else xs), new_state
+        else:
+            xs, _, _ = self.embed(xs, masks, offset)
         for layer, carry in zip(self.encoders, state):
             xs, c = layer.forward_carry(xs, carry)
             new_state.append(c)

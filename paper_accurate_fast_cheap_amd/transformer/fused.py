@@ -113,6 +113,24 @@ class LayerPlan:
                         ff=fold(L.feed_forward.w_1.weight, L.feed_forward.w_1.bias, L.norm_ff),
                         pw1=fold(pw1.weight.squeeze(-1), pw1.bias, L.norm_conv, interleave=True))
 
+    def carry_folds(self):
+        """The chunk step's two LayerNorms whose consumer is a few-rows projection -- ln_x -> output, norm_ff -> w_1 -- folded
+        into that projection (csrc/gemm_skinny.hip, statistics formed in the launch): W' = bf16(gamma * W), b' = b + W beta,
+        csum = row sums of the ROUNDED W'.  Built on first use, rebuilt when the parameters change (refresh)."""
+        if getattr(self, "_carry_folds", None) is not None and self._carry_folds[0] == self._stamp:
+            return self._carry_folds[1]
+        L = self.layer
+
+        def fold(w, b, norm):
+            wf, g, be = w.float(), norm.weight.float(), norm.bias.float()
+            bf = (b.float() if b is not None else 0) + wf @ be
+            wp = (wf * g).to(torch.bfloat16).contiguous()
+            return wp, bf.to(torch.bfloat16).contiguous(), wp.float().sum(-1).contiguous(), norm.eps
+
+        folds = dict(out=fold(self.Wo, None, self.blocks[0].ln_x), ff=fold(L.feed_forward.w_1.weight, L.feed_forward.w_1.bias, L.norm_ff))
+        self._carry_folds = (self._stamp, folds)
+        return folds
+
     def _refresh_split(self):
         """fp32 layer around a bf16 slot (the reference's default precision): every fp32 projection as the split-operand
         weight [hi | hi | lo] of csrc/gemm_ph.hip (three bf16 products per fp32 product, ~2^-16 relative), biases fp32."""
@@ -182,6 +200,12 @@ def _own_gemm(x: torch.Tensor, w: torch.Tensor) -> bool:
             and x.numel() // w.shape[-1] >= _OWN_GEMM_MIN_ROWS)
 
 
+def _skinny(x: torch.Tensor, w: torch.Tensor, glu: bool = False) -> bool:
+    """bf16 projections of a handful of rows (a streaming chunk of one or two streams): csrc/gemm_skinny.hip."""
+    return (x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_cuda and w.dim() == 2 and w.is_contiguous()
+            and hip_ops.skinny_ok(x.numel() // w.shape[-1], w.shape[0], w.shape[1], glu))
+
+
 def proj(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: str = "none", alpha: float = 1.0,
          residual: Optional[torch.Tensor] = None, inplace: bool = False) -> torch.Tensor:
     """act(alpha * x w^T + bias + residual) as ONE GEMM with a fused epilogue; w in nn.Linear layout (N, K)."""
@@ -190,6 +214,12 @@ def proj(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: st
         x2 = x.reshape(-1, K)
         r2 = residual.reshape(-1, N) if residual is not None else None
         out = hip_ops.gemm_bf16(x2, w, bias, act, alpha=alpha, residual=r2, out=r2 if (inplace and r2 is not None) else None)
+        return out.view(x.shape[:-1] + (N,))
+    if _skinny(x, w):      # a streaming chunk: few rows, launch-bound
+        N, K = w.shape
+        x2 = x.reshape(-1, K)
+        r2 = residual.reshape(-1, N) if residual is not None else None
+        out = hip_ops.gemm_skinny(x2, w, bias, act, alpha=alpha, residual=r2, out=r2 if (inplace and r2 is not None) else None)
         return out.view(x.shape[:-1] + (N,))
     return hip_ops.linear_bias_act(x, w, bias, act, alpha=alpha, residual=residual, inplace=inplace)
 
@@ -474,13 +504,23 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict],
     elif shift.dtype != h.dtype or not shift.is_contiguous():
         shift = shift.to(h.dtype).contiguous()
     few = True if M < _OWN_GEMM_MIN_ROWS else None       # launch-bound: one kernel each for the two LoRA chains
-    t = hip_ops.tmix_lora_down(h, plan.maa_x_n, plan.W1n, prev=shift, one_pass=few)
+    sk = h.dtype == torch.bfloat16 and hip_ops.skinny_ok(M, C, C)     # a handful of rows: the few-rows GEMM and its fusions
+    if sk:   # token shift + lerp as the operand producer of the down-projection (one ~5 us launch)
+        t = hip_ops.gemm_skinny(h.view(M, C), plan.W1n[0], None, "tanh", mix_maa=plan.maa_x_n[0], mix_prev=shift, mix_T=T).view(1, M, -1)
+    else:
+        t = hip_ops.tmix_lora_down(h, plan.maa_x_n, plan.W1n, prev=shift, one_pass=few)
     z = hip_ops.tmix_lora_mix4(h, t, plan.W2t, plan.maa4, prev=shift)                         # (4, 1, M, C)
     if M >= _OWN_GEMM_MIN_ROWS:
         rkv = hip_ops.gemm_bf16(z[:3].view(3, M, C), plan.Wrkv_n).view(3, B, T, C)
+    elif hip_ops.skinny_ok(M, C, C):
+        rkv = hip_ops.gemm_skinny(z[:3].view(3, M, C), plan.Wrkv_n).view(3, B, T, C)
     else:
         rkv = torch.bmm(z[:3].view(3, M, C), plan.Wrkv).view(3, B, T, C)
-    w = hip_ops.decay_lora(z[3].view(1, M, C), plan.D1n, plan.D2n, plan.time_decay.view(1, C), one_pass=few).view(B, T, C)
+    if sk:   # two short launches: tanh(z_w D1), then bf16(. D2) + time_decay rounded where the reference's op chain rounds
+        td = hip_ops.gemm_skinny(z[3].view(M, C), plan.D1n[0], None, "tanh")
+        w = hip_ops.gemm_skinny(td, plan.D2n[0], plan.time_decay.view(C), round_first=True).view(B, T, C)
+    else:
+        w = hip_ops.decay_lora(z[3].view(1, M, C), plan.D1n, plan.D2n, plan.time_decay.view(1, C), one_pass=few).view(B, T, C)
     s_in = carry.get("wkv")
     new = carry if in_place else {}
     if in_place and s_in is not None and hip_ops.wkv6_single_chunk(B, T, C, plan.u[0].shape[0]):
@@ -496,14 +536,23 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict],
     else:
         new["shift"] = h[:, -1:].contiguous()
     ln = plan.blocks[0].ln_x
-    _, yn, _ = hip_ops.add_layernorm(y.view(M, C), None, 1.0, ln.weight, ln.bias, eps=ln.eps, want_x=False)
-    x = proj(yn, plan.Wo, None, "none", residual=x.view(M, C), inplace=True).view(B, T, C)
+    if sk:   # ln_x folded into the output projection
+        wo, bo, cso, epo = plan.carry_folds()["out"]
+        x2 = x.view(M, C)
+        x = hip_ops.gemm_skinny(y.view(M, C), wo, bo, residual=x2, out=x2, ln_self=True, ln_csum=cso, ln_eps=epo).view(B, T, C)
+    else:
+        _, yn, _ = hip_ops.add_layernorm(y.view(M, C), None, 1.0, ln.weight, ln.bias, eps=ln.eps, want_x=False)
+        x = proj(yn, plan.Wo, None, "none", residual=x.view(M, C), inplace=True).view(B, T, C)
     cm = L.conv_module
     _, hc, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_conv.weight, L.norm_conv.bias, want_x=False, eps=L.norm_conv.eps)
     cnn = carry.get("cnn")
     left = cnn.transpose(1, 2).to(hc.dtype) if cnn is not None and cnn.numel() > 0 else hc.new_zeros(B, cm.lorder, C)
     cx = torch.cat([left, hc], dim=1)                                                         # (B, lorder + T, C)
-    if plan.pw1_glu is not None:
+    pw1 = cm.pointwise_conv1
+    if _skinny(cx, pw1.weight.view(2 * C, C), glu=True):
+        p = hip_ops.gemm_skinny(cx.view(-1, C), pw1.weight.view(2 * C, C), pw1.bias, "glu").view(B, -1, C)
+        dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, 0, T)
+    elif plan.pw1_glu is not None:
         p = _pw1_glu(plan, cx.view(-1, C)).view(B, -1, C)
         dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, 0, T)
     else:
@@ -516,8 +565,13 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict],
         new["cnn"] = new_cnn
     _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
     x = proj(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none", residual=x, inplace=True)
-    _, h2, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff.weight, L.norm_ff.bias, want_x=False, eps=L.norm_ff.eps)
-    x = _ffn_residual(L.feed_forward, h2, x, L.ff_scale, plan.b2, inplace=True)
+    if sk and hip_ops.skinny_ok(M, L.feed_forward.w_1.weight.shape[0], C):     # norm_ff folded into w_1
+        w1, b1, cs1, ep1 = plan.carry_folds()["ff"]
+        hid = hip_ops.gemm_skinny(x.view(M, C), w1, b1, "silu", ln_self=True, ln_csum=cs1, ln_eps=ep1)
+        x = proj(hid, L.feed_forward.w_2.weight, plan.b2, "none", alpha=L.ff_scale, residual=x.view(M, C), inplace=True).view(B, T, C)
+    else:
+        _, h2, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff.weight, L.norm_ff.bias, want_x=False, eps=L.norm_ff.eps)
+        x = _ffn_residual(L.feed_forward, h2, x, L.ff_scale, plan.b2, inplace=True)
     if next_norm is not None and next_norm.eps == L.norm_final.eps:        # the one-pass pair shares one epsilon
         _, out, hn = hip_ops.add_layernorm(x, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False, gamma2=next_norm.weight,
                                            beta2=next_norm.bias, eps=L.norm_final.eps)

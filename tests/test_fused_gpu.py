@@ -307,6 +307,139 @@ def test_gemm_bf16_strided_rows_and_errors(hip):
         gemm_bf16(a.float(), w.float())
 
 
+@pytest.mark.parametrize("M,N,K,Z", [(64, 2048, 512, 1), (65, 512, 2048, 1), (78, 512, 512, 3), (1, 512, 512, 1), (17, 64, 1024, 2),
+                                     (130, 512, 512, 1), (160, 2048, 512, 1)])
+@pytest.mark.parametrize("act", ["none", "silu", "tanh", "relu"])
+def test_gemm_skinny_streaming_chunk_shapes(hip, M, N, K, Z, act):
+    """pafc_gemm_skinny_bf16 (the few-rows GEMM of the streaming chunk step) vs fp32 torch: row tails, more rows than one
+    row group, batching, every epilogue, in-place residual."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_skinny
+    bf = torch.bfloat16
+    shp = (lambda *s: (Z,) + s) if Z > 1 else (lambda *s: s)
+    a = synth.randn(shp(M, K), 1).to(bf)
+    w = synth.randn(shp(N, K), 2, 0.05).to(bf)
+    b = synth.randn(shp(N), 3, 0.2).to(bf)
+    r = synth.randn(shp(M, N), 4).to(bf)
+    f = {"none": lambda t: t, "silu": F.silu, "tanh": torch.tanh, "relu": F.relu}[act]
+    lin = torch.matmul(a.float(), w.float().transpose(-1, -2))
+    bb = b.float().unsqueeze(-2) if Z > 1 else b.float()
+    tol = dict(rtol=2 ** -7, atol=2e-2)
+    got = gemm_skinny(a.cuda(), w.cuda(), b.cuda(), act)
+    torch.testing.assert_close(got.cpu().float(), f(lin + bb), **tol)
+    got = gemm_skinny(a.cuda(), w.cuda(), None, act, alpha=0.5, residual=r.cuda())
+    torch.testing.assert_close(got.cpu().float(), f(0.5 * lin + r.float()), **tol)
+    buf = r.cuda().clone()
+    assert gemm_skinny(a.cuda(), w.cuda(), b.cuda(), "none", residual=buf, out=buf).data_ptr() == buf.data_ptr()
+    torch.testing.assert_close(buf.cpu().float(), lin + bb + r.float(), **tol)
+
+
+@pytest.mark.parametrize("M", [64, 78, 3, 150])
+def test_gemm_skinny_glu_strided_rows_and_errors(hip, M):
+    """act "glu" on the module's own (2C, K) weight (value rows then gate rows); strided operands; refused shapes."""
+    from paper_accurate_fast_cheap_amd._lib import PafcError
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_skinny
+    bf = torch.bfloat16
+    K, N = 512, 1024
+    wide = synth.randn((M, K + 128), 1).to(bf).cuda()
+    a = wide[:, 64:64 + K]                                          # row stride K + 128, 16-byte aligned rows
+    w = synth.randn((N, K), 2, 0.08).to(bf).cuda()
+    b = synth.randn((N,), 3, 0.3).to(bf).cuda()
+    want = F.glu(F.linear(a.cpu().float(), w.cpu().float(), b.cpu().float()), dim=-1)
+    outw = torch.zeros(M, N, dtype=bf, device="cuda")
+    got = gemm_skinny(a, w, b, act="glu", out=outw[:, N // 4:N // 4 + N // 2])
+    assert got.shape == (M, N // 2)
+    torch.testing.assert_close(got.cpu().float(), want, rtol=2 ** -7, atol=1e-2)
+    assert float(outw[:, :N // 4].abs().max()) == 0 and float(outw[:, N // 4 + N // 2:].abs().max()) == 0
+    with pytest.raises(PafcError):
+        gemm_skinny(a[:, :48], w[:, :48].contiguous())             # K % 32
+    with pytest.raises(PafcError):
+        gemm_skinny(a, w[:1000].contiguous(), act="glu")           # GLU: N % 32
+    with pytest.raises(PafcError):
+        gemm_skinny(a, w, act="glu", residual=outw[:, :N // 2])    # GLU takes no residual
+    with pytest.raises(PafcError):
+        gemm_skinny(a.float(), w.float())
+
+
+@pytest.mark.parametrize("M,N,act", [(64, 2048, "silu"), (78, 1024, "glu"), (130, 512, "none")])
+def test_gemm_skinny_folded_layernorm_and_row_statistics(hip, M, N, act):
+    """The LayerNorm in front of the projection folded into the launch (statistics from the partials a producer left), and
+    the producer side: a residual GEMM that also writes the partial statistics of the rows it stores."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_skinny
+    bf = torch.bfloat16
+    C = 512
+    x0 = synth.randn((M, C), 1, 1.5).to(bf).cuda()
+    # producer: x = x0 + g W2^T, with statistics
+    g_ = synth.randn((M, 512), 5).to(bf).cuda()
+    w2 = synth.randn((C, 512), 6, 0.05).to(bf).cuda()
+    st = torch.empty(M, C // 16, 2, dtype=torch.float32, device="cuda")
+    x = gemm_skinny(g_, w2, None, residual=x0, stats_out=st)
+    xf = x.float()
+    torch.testing.assert_close(st[:, :, 0].sum(1), xf.sum(1), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(st[:, :, 1].sum(1), (xf * xf).sum(1), rtol=1e-4, atol=1e-2)
+    # consumer: act(LN(x) W^T + b) with the LayerNorm folded in
+    gamma = (1 + 0.2 * synth.randn((C,), 7)).float().cuda()
+    beta = (0.1 * synth.randn((C,), 8)).float().cuda()
+    w = synth.randn((N, C), 2, 0.05).to(bf).cuda()
+    b = synth.randn((N,), 3, 0.2).to(bf).cuda()
+    wp = (w.float() * gamma).to(bf)
+    bp = (b.float() + w.float() @ beta).to(bf)
+    cs = wp.float().sum(-1).contiguous()
+    got = gemm_skinny(x, wp, bp, act, ln_stats=st, ln_csum=cs, ln_eps=1e-5)
+    ln = F.layer_norm(xf, (C,), gamma, beta, 1e-5)
+    lin = F.linear(ln, w.float(), b.float())
+    want = {"silu": F.silu, "none": lambda t: t, "glu": lambda t: F.glu(t, dim=-1)}[act](lin)
+    torch.testing.assert_close(got.float(), want, rtol=2 ** -6, atol=4e-2)
+
+
+@pytest.mark.parametrize("B,T", [(1, 64), (2, 37), (3, 5)])
+@pytest.mark.parametrize("with_prev", [False, True])
+def test_gemm_skinny_token_shift_operand_equals_shift_mix_plus_gemm(hip, B, T, with_prev):
+    """mix mode: the LoRA down-projection of a chunk in one launch = tmix_shift_mix (with the carried frame) + tanh GEMM."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_bf16, gemm_skinny, tmix_shift_mix
+    bf = torch.bfloat16
+    C, N = 512, 128
+    x = synth.randn((B, T, C), 1).to(bf).cuda()
+    maa = synth.randn((C,), 2, 0.5).to(bf).cuda()
+    w1n = synth.randn((N, C), 3, 0.05).to(bf).cuda()
+    prev = synth.randn((B, 1, C), 4).to(bf).cuda() if with_prev else None
+    xxx = tmix_shift_mix(x, maa, None, prev=prev)[0]
+    if with_prev:      # the definition: the carried frame stands in front of each sequence
+        xc = torch.cat([prev, x], 1).float()
+        xx = (xc[:, :-1] - xc[:, 1:]).to(bf).float()
+        want_xxx = (x.float() + (xx * maa.float()).to(bf).float()).to(bf)
+        assert torch.equal(xxx, want_xxx)
+    want = gemm_bf16(xxx.view(B * T, C), w1n, None, "tanh")
+    got = gemm_skinny(x.view(B * T, C), w1n, None, "tanh", mix_maa=maa, mix_prev=prev, mix_T=T)
+    torch.testing.assert_close(got.float(), want.float(), rtol=2 ** -7, atol=1e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 512, 512), (70, 2048, 512), (33, 512, 2048)])
+def test_gemm_skinny_layernorm_from_its_own_operand_and_short_k(hip, M, N, K):
+    """ln_self: the folded LayerNorm's statistics come from the operand fragments of the launch itself; round_first and a
+    K of two steps (the decay LoRA's second product)."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_skinny
+    bf = torch.bfloat16
+    x = synth.randn((M, K), 1, 1.5).to(bf).cuda()
+    r = synth.randn((M, N), 9).to(bf).cuda()
+    gamma = (1 + 0.2 * synth.randn((K,), 7)).float().cuda()
+    beta = (0.1 * synth.randn((K,), 8)).float().cuda()
+    w = synth.randn((N, K), 2, 0.05).to(bf).cuda()
+    wp = (w.float() * gamma).to(bf)
+    bp = (w.float() @ beta).to(bf)
+    got = gemm_skinny(x, wp, bp, residual=r, ln_self=True, ln_csum=wp.float().sum(-1).contiguous(), ln_eps=1e-5)
+    want = F.linear(F.layer_norm(x.float(), (K,), gamma, beta, 1e-5), w.float()) + r.float()
+    torch.testing.assert_close(got.float(), want, rtol=2 ** -6, atol=4e-2)
+    # round_first with K = 64
+    t = synth.randn((M, 64), 3).to(bf).cuda()
+    d2 = synth.randn((N, 64), 4, 0.1).to(bf).cuda()
+    b = synth.randn((N,), 5).to(bf).cuda()
+    got = gemm_skinny(t, d2, b, round_first=True)
+    want = (b.float() + (t.float() @ d2.float().t()).to(bf).float()).to(bf)
+    diff = (got.float() - want.float()).abs()
+    assert float(diff.max()) <= 2 ** -6 * float(want.float().abs().max())       # one ulp where the fp32 sums differ in the last bit
+    assert float((diff > 0).float().mean()) < 0.02
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 128, 64), (129, 1024, 512), (64, 256, 128)])
 def test_gemm_bf16_glu_epilogue(hip, M, N, K):
     """act "glu": Linear -> F.glu as one GEMM, with the caller interleaving value / gate rows (glu_interleave)."""
