@@ -1027,7 +1027,7 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
     return out
 
 
-SKINNY_MAX_ROWS = int(os.environ.get("PAFC_SKINNY_MAX_ROWS", "160"))     # above: the library's small-problem kernels
+SKINNY_MAX_ROWS = int(os.environ.get("PAFC_SKINNY_MAX_ROWS", "640"))     # above (measured: 8 streams of 64-frame chunks still win, 16 lose): the library
 
 
 _chunk_step = threading.local()

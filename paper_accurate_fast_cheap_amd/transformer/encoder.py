@@ -201,12 +201,15 @@ class BaseEncoder(torch.nn.Module):
                     n = len(plans)
                     tail = self.after_norm if self.normalize_before else None
                     h = None
+                    pending = [] if in_place else None     # the carries' small refreshes: one multi-tensor copy at the end
                     for i, carry in enumerate(state):
                         plans[i].refresh()
                         nxt = plans[i + 1].layer.norm_ff_macaron if i + 1 < n else tail
                         xs, c, h = fused.layer_forward_carry(plans[i], xs, carry, h0=h, next_norm=nxt,
-                                                             in_place=in_place and carry is not None)
+                                                             in_place=in_place and carry is not None, pending=pending)
                         new_state.append(c)
+                    if pending:
+                        torch._foreach_copy_([d for d, _ in pending], [s_ for _, s_ in pending])
                     return (h if tail is not None else xs), new_state
         else:
             xs, _, _ = self.embed(xs, masks, offset)
@@ -252,6 +255,14 @@ class BaseEncoder(torch.nn.Module):
                 done = warm
                 static_in = xs[:, full[warm]:full[warm] + window].clone()
                 static_state = [{k: v.clone() for k, v in st.items()} for st in state]
+                if xs.size(0) == 1 and getattr(self, "_carry_plans", None) is not None:
+                    # one stream, fused step: the conv module's input buffer lives across steps (cache rows in front)
+                    for st in static_state:
+                        cnn = st.get("cnn")
+                        if cnn is not None and cnn.dim() == 3 and decoding_chunk_size >= cnn.size(2) > 0:
+                            cx = cnn.new_zeros(1, cnn.size(2) + decoding_chunk_size, cnn.size(1))
+                            cx[:, :cnn.size(2)] = cnn.transpose(1, 2)
+                            st["cx"] = cx
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     y_static, new_state = self.forward_chunk_carry(static_in, 0, static_state, in_place=True)
@@ -264,6 +275,10 @@ class BaseEncoder(torch.nn.Module):
                     graph.replay()
                     outs.append(y_static.clone())
                     done += 1
+                for st in static_state:            # back to the public carries
+                    cx = st.pop("cx", None)
+                    if cx is not None:
+                        st["cnn"] = cx[:, :st["cnn"].size(2)].transpose(1, 2).contiguous()
                 state = static_state
             except Exception:   # capture unsupported here: the remaining windows run eagerly from the current state
                 torch.cuda.synchronize(xs.device)

@@ -479,7 +479,7 @@ def carry_eligible(layer: nn.Module, x: torch.Tensor) -> bool:
 
 
 def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict], h0: Optional[torch.Tensor] = None,
-                        next_norm: Optional[nn.LayerNorm] = None, in_place: bool = False):
+                        next_norm: Optional[nn.LayerNorm] = None, in_place: bool = False, pending: Optional[list] = None):
     """ConformerEncoderLayer.forward_carry (one chunk with recurrent-state carry) on the fused kernels, bf16, B streams:
     the same carries -- "shift" (B, 1, C) last normalised frame, "wkv" float32 (B, H, N, N), "cnn" (B, C, lorder) --
     and the same arithmetic as the module path.  A chunk step is launch-bound (a 64-frame chunk is ~5 us of work per kernel),
@@ -488,6 +488,10 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict],
     captured step of `stream_chunks`, whose carries are fixed buffers -- writes the new state over it, "shift" and "cnn" are
     refreshed by one small copy each, and `norm_final` + the next layer's first pre-norm are one pass (h0 = that pre-norm of x
     when the previous layer already produced it; next_norm = the norm to apply to this layer's output for the next one).
+    `pending` (with in_place): instead of copying, the (destination, source) pairs of the small carry refreshes are appended
+    to it and the caller performs them all in ONE multi-tensor copy after the last layer.  A carry "cx" (B, lorder + T, C) --
+    set up by stream_chunks for one stream -- is the conv module's input buffer kept across steps: norm_conv writes the chunk
+    behind the cached rows (no concatenation) and the refresh moves the tail to the front.
     Returns (layer output, carries, next_norm(output) or None)."""
     L = plan.layer
     carry = carry if carry is not None else {}
@@ -532,7 +536,10 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict],
         else:
             new["wkv"] = s_out
     if in_place and carry.get("shift") is not None and carry["shift"].dtype == h.dtype:
-        carry["shift"].copy_(h[:, -1:])               # (after the two passes that read the old one)
+        if pending is not None:
+            pending.append((carry["shift"], h[:, -1:]))
+        else:
+            carry["shift"].copy_(h[:, -1:])           # (after the two passes that read the old one)
     else:
         new["shift"] = h[:, -1:].contiguous()
     ln = plan.blocks[0].ln_x
@@ -544,10 +551,17 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict],
         _, yn, _ = hip_ops.add_layernorm(y.view(M, C), None, 1.0, ln.weight, ln.bias, eps=ln.eps, want_x=False)
         x = proj(yn, plan.Wo, None, "none", residual=x.view(M, C), inplace=True).view(B, T, C)
     cm = L.conv_module
-    _, hc, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_conv.weight, L.norm_conv.bias, want_x=False, eps=L.norm_conv.eps)
     cnn = carry.get("cnn")
-    left = cnn.transpose(1, 2).to(hc.dtype) if cnn is not None and cnn.numel() > 0 else hc.new_zeros(B, cm.lorder, C)
-    cx = torch.cat([left, hc], dim=1)                                                         # (B, lorder + T, C)
+    cxb = carry.get("cx") if in_place else None
+    if cxb is not None and B == 1 and cxb.shape == (1, cm.lorder + T, C) and cxb.dtype == x.dtype and T >= cm.lorder:
+        cx = cxb                                      # rows [0, lorder) = the cache, the chunk's rows go behind them
+        hip_ops.add_layernorm(x, None, 1.0, L.norm_conv.weight, L.norm_conv.bias, want_x=False, eps=L.norm_conv.eps,
+                              out1=cx[0, cm.lorder:])
+        cnn = None                                    # ("cnn" is rebuilt from cx by stream_chunks when the captured steps end)
+    else:
+        _, hc, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_conv.weight, L.norm_conv.bias, want_x=False, eps=L.norm_conv.eps)
+        left = cnn.transpose(1, 2).to(hc.dtype) if cnn is not None and cnn.numel() > 0 else hc.new_zeros(B, cm.lorder, C)
+        cx = torch.cat([left, hc], dim=1)                                                     # (B, lorder + T, C)
     pw1 = cm.pointwise_conv1
     if _skinny(cx, pw1.weight.view(2 * C, C), glu=True):
         p = hip_ops.gemm_skinny(cx.view(-1, C), pw1.weight.view(2 * C, C), pw1.bias, "glu").view(B, -1, C)
@@ -558,11 +572,17 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict],
     else:
         p = F.linear(cx, cm.pointwise_conv1.weight.squeeze(-1), cm.pointwise_conv1.bias)
         dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, 0, T, glu=True)
-    new_cnn = cx[:, -cm.lorder:, :].transpose(1, 2)
-    if in_place and cnn is not None and cnn.shape == new_cnn.shape and cnn.dtype == new_cnn.dtype:
-        cnn.copy_(new_cnn)
+    if cx is cxb:                                     # (after pointwise_conv1 has read the old cache rows)
+        if pending is not None:
+            pending.append((cx[:, :cm.lorder], cx[:, T:]))
+        else:
+            cx[:, :cm.lorder].copy_(cx[:, T:])
     else:
-        new["cnn"] = new_cnn
+        new_cnn = cx[:, -cm.lorder:, :].transpose(1, 2)
+        if in_place and cnn is not None and cnn.shape == new_cnn.shape and cnn.dtype == new_cnn.dtype:
+            cnn.copy_(new_cnn)
+        else:
+            new["cnn"] = new_cnn
     _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
     x = proj(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none", residual=x, inplace=True)
     if sk and hip_ops.skinny_ok(M, L.feed_forward.w_1.weight.shape[0], C):     # norm_ff folded into w_1
