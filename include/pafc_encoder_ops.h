@@ -121,7 +121,7 @@ int pafc_gemm_skinny_bf16(long M, int N, int K, int batch, const void *A, long l
                           const float *ln_csum, float ln_eps, float *ln_stats_out, pafc_stream_t stream);
 /* The same with the other things a chunk step wants inside the launch:
  *   round_first: out = bf16(alpha * A W^T) + bias, rounded again -- where `ww = t @ time_decay_w2; w = time_decay + ww`
- *                rounds (src/model.py:287-289);
+ *                rounds (src/model.py:289);
  *   ln_self:     the folded LayerNorm's row statistics are formed from the operand itself (ln_stats_in null, ln_csum given);
  *   mix_maa:     the operand is the token shift + first lerp of the time-mix, xxx = x + (x_prev - x) * maa_x
  *                (src/model.py:274-276), formed in registers from A = x (M = B * mix_T rows), its predecessor row and maa_x (K);

@@ -42,7 +42,7 @@ struct SkParams {
     int N, K;              // N = rows of W (GLU: value rows [0, N/2), gate rows [N/2, N)); K % 32 == 0
     float alpha;
     int act;               // 0 none, 1 SiLU, 2 tanh, 3 ReLU, 4 GLU (the codes of pafc_gemm_bf16)
-    int round_first;       // out = bf16(alpha * acc) + bias rounded again: where an op chain `x @ W` then `+ b` rounds (model.py:287-289)
+    int round_first;       // out = bf16(alpha * acc) + bias rounded again: where an op chain `x @ W` then `+ b` rounds (model.py:289)
     const float *st_in;    // LayerNorm folded in front: float2 [M][parts_in] partial (sum, sum of squares) of the A rows, or null
     int parts_in;
     int ln_self;           // ... or: the statistics are formed here from the A fragments
