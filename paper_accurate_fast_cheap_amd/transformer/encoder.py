@@ -156,7 +156,9 @@ class BaseEncoder(torch.nn.Module):
         plan = self._fused(xs)
         if plan is not None and elayers == 0 and cnn_cache.size(0) == 0:
             from . import fused
-            xs, _ = fused.encoder_layers_forward(plan, xs, att_mask[:0], self.after_norm)
+            from .. import hip_ops
+            with hip_ops.chunk_step():      # a chunk's few rows: the launch-bound regime (csrc/gemm_skinny.hip)
+                xs, _ = fused.encoder_layers_forward(plan, xs, att_mask[:0], self.after_norm)
             n = len(self.encoders)
             return (xs, torch.zeros((0, 0, 0, 0), device=xs.device),
                     torch.zeros((n, 0, 0, 0), dtype=xs.dtype, device=xs.device))

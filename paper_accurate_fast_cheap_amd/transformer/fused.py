@@ -262,6 +262,8 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
         z = hip_ops.tmix_mix4(h, m, plan.maa4)                                              # (4, nd, M, C)
     if own_gemm and M >= _OWN_GEMM_MIN_ROWS:     # short inputs: the library's small-problem kernels, as in proj()
         rkv = hip_ops.gemm_bf16(z[:3].view(3 * nd, M, C), plan.Wrkv_n)                      # (3nd, M, C), one launch
+    elif own_gemm and hip_ops.skinny_ok(M, C, C):  # a chunk step: the few-rows kernel
+        rkv = hip_ops.gemm_skinny(z[:3].view(3 * nd, M, C), plan.Wrkv_n)
     else:
         rkv = torch.bmm(z[:3].view(3 * nd, M, C), plan.Wrkv)
     if own_gemm:
