@@ -822,6 +822,9 @@ def split_weight_cached(weight: torch.Tensor) -> torch.Tensor:
     return ent[1]
 
 
+_LONG_K_OWN_MIN_ROWS = int(os.environ.get("PAFC_LONG_K_OWN_MIN_ROWS", "8192"))
+
+
 def linear_fused(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: str = "none") -> torch.Tensor:
     """act(x @ weight.T + bias) with the epilogue fused: bf16 operands on the hand-written GEMM (K % 64 == 0, N % 8 == 0),
     long fp32 inputs on the same kernel with split operands, anything else on the library GEMM."""
@@ -830,6 +833,11 @@ def linear_fused(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     if (x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_cuda and weight.is_contiguous()
             and skinny_ok(rows, N, K) and act != "glu"):         # a streaming chunk: the few-rows kernel
         return gemm_skinny(x.reshape(-1, K), weight, bias, act).view(x.shape[:-1] + (N,))
+    if (x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_cuda and K >= 4096 and N <= 1024
+            and SKINNY_MAX_ROWS < rows < _LONG_K_OWN_MIN_ROWS and act in ("none", "silu")):
+        # a long K over a few thousand rows (Linear(9728, 512) behind the subsampling of 16-64 streams or of a batch of
+        # 2 000-frame windows): too few 128 x 128 tiles to fill the chip and 152 K-steps each -- the library splits K
+        return linear_bias_act(x, weight, bias, act)
     if x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and K % 64 == 0 and N % 8 == 0:
         return gemm_bf16(x.reshape(-1, K), weight, bias, act).view(x.shape[:-1] + (N,))
     if (x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_cuda and K % 128 == 0 and N % 8 == 0 and N >= 256
