@@ -614,6 +614,46 @@ def test_fused_state_carry_step_matches_module_path(hip):
     torch.testing.assert_close(st_f[0]["cnn"].float(), st_m[0]["cnn"].float(), rtol=5e-2, atol=5e-2)
 
 
+def test_fused_state_carry_captured_step_keeps_its_carries_in_place(hip, monkeypatch):
+    """One stream, chunks at least as long as the causal conv's left context: the captured step keeps the conv module's input
+    buffer across steps (no concatenation), updates the scan state where it lies and refreshes all carries in one
+    multi-tensor copy -- replayed == eager == (to bf16 round-off) the whole sequence, and the public carries come back."""
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_reduced_uni_bf16model")
+    conf = dict(g["conf"], causal=True, cnn_module_kernel=15)
+    torch.manual_seed(6)
+    enc = ConformerEncoder(80, **conf)
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.05)
+    enc = enc.to(torch.bfloat16).cuda().eval()
+    chunk = 16                                                       # >= lorder = 14
+    xs = synth.randn((1, 4 * chunk * 12 + 3, 80), 81, 2.0).to(torch.bfloat16).cuda()
+    with torch.no_grad():
+        enc.fused_inference = True
+        eager = enc.stream_chunks(xs, chunk, use_graph=False)
+        refreshed = []
+        real = torch._foreach_copy_
+        monkeypatch.setattr(torch, "_foreach_copy_", lambda d, s_: (refreshed.append(len(d)), real(d, s_))[1])
+        replayed = enc.stream_chunks(xs, chunk, use_graph=True)
+        monkeypatch.undo()
+        assert refreshed == [2 * len(enc.encoders)]      # captured once: shift + conv-input refresh of every layer, one launch
+        whole, _ = enc(xs, torch.tensor([xs.size(1)], device="cuda"))
+        # the carries after a captured run are the public ones again
+        sub, ctx = enc.embed.subsampling_rate, enc.embed.right_context + 1
+        win = (chunk - 1) * sub + ctx
+        _, st = enc.forward_chunk_carry(xs[:, :win], 0, None)
+        _, st2 = enc.forward_chunk_carry(xs[:, sub * chunk:sub * chunk + win], 0, st)
+    assert replayed.shape == eager.shape
+    d = (replayed.float() - eager.float()).abs()
+    assert float(d.mean()) < 2e-2 and float(d.max()) < 0.4, (float(d.mean()), float(d.max()))
+    n = min(whole.shape[1], replayed.shape[1])
+    d = (replayed[:, :n].float() - whole[:, :n].float()).abs()
+    assert float(d.mean()) < 3e-2 and float(d.max()) < 0.6, (float(d.mean()), float(d.max()))
+    assert set(st2[0]) == {"shift", "wkv", "cnn"} and st2[0]["cnn"].shape == st[0]["cnn"].shape
+
+
 def test_fused_state_carry_step_serves_concurrent_streams(hip):
     """B independent streams per chunk step (the serving shape): stream b of a batched run equals the same stream run
     alone -- the carries are per stream, nothing leaks across the batch -- eagerly and from the replayed hipGraph."""
