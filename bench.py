@@ -92,6 +92,38 @@ def windows(feats: torch.Tensor, chunk_size: int, batch_size: int):
         yield fb.reshape(nb, chunk_size, 80), lens.to(feats.device)
 
 
+def streaming_leg(feats32: torch.Tensor, device, seconds: float = 600.0, chunk: int = 64):
+    """BASELINE configs[2] beside the headline: the first `seconds` of the same features streamed through the UNI-directional
+    12-layer encoder (causal conv, k = 15) in 64-frame chunks (2.56 s) with recurrent-state carry, one stream, the step
+    replayed from a hipGraph (encoder.stream_chunks) -- ms per chunk over the second of two passes, graph capture included."""
+    from paper_accurate_fast_cheap_amd.utils.init_model import init_model
+    conf = encoder_conf()
+    conf.update(selfattention_layer_type="rwkv_tmix60", rnn_att_direction="uni", causal=True, cnn_module_kernel=15)
+    configs = dict(encoder="conformer", encoder_conf=conf, input_dim=80, output_dim=VOCAB, ctc="ctc",
+                   ctc_conf={"ctc_blank_id": 0}, model_conf={}, dataset_conf={})
+
+    class A:
+        checkpoint = None
+
+    torch.manual_seed(777)
+    model, _ = init_model(A(), configs)
+    enc = model.eval().to(torch.bfloat16).to(device).encoder
+    x = feats32[:, :int(seconds * 100)].to(device=device, dtype=torch.bfloat16)
+    sub, ctx = enc.embed.subsampling_rate, enc.embed.right_context + 1
+    nchunks = len(range(0, x.shape[1] - ctx + 1, sub * chunk))
+    with torch.no_grad():
+        enc.stream_chunks(x, chunk)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        y = enc.stream_chunks(x, chunk)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"workload": f"streaming with state carry: uni-directional 12-layer encoder, {x.shape[1] / 100.0:.0f} s of the same audio in "
+                        f"{chunk}-frame chunks ({chunk * 0.04:.2f} s), one stream, bf16",
+            "chunks": nchunks, "ms_per_chunk": round(dt * 1e3 / nchunks, 3),
+            "audio_sec_per_sec": round(x.shape[1] / 100.0 / dt, 1), "finite": bool(torch.isfinite(y.float()).all())}
+
+
 def build_model(dtype: str, device):
     from paper_accurate_fast_cheap_amd.utils.init_model import init_model
     torch.manual_seed(777)  # the trainer's seed, wenet/bin/train.py:71
@@ -451,6 +483,7 @@ def main():
                                 "projection and both subsampling convolutions on the bf16 matrix cores with split operands "
                                 "(hi + lo planes, three bf16 products per fp32 product), bf16 slot"}
         del m2, fb2
+        out["extra"]["streaming"] = streaming_leg(feats32, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, feats32, conf, min(args.cpu_sample_frames, FRAMES))
     else:
