@@ -126,12 +126,15 @@ int pafc_gemm_skinny_bf16(long M, int N, int K, int batch, const void *A, long l
  *   mix_maa:     the operand is the token shift + first lerp of the time-mix, xxx = x + (x_prev - x) * maa_x
  *                (src/model.py:274-276), formed in registers from A = x (M = B * mix_T rows), its predecessor row and maa_x (K);
  *                mix_prev (B, K) or null = the frame before each sequence (the streaming carry; null: zero as ZeroPad2d);
- *                with act = 2 and W = time_maa_rkvw_w1^T this is pafc_tmix_lora_down_bf16_prev for a handful of rows. */
+ *                with act = 2 and W = time_maa_rkvw_w1^T this is pafc_tmix_lora_down_bf16_prev for a handful of rows;
+ *   norm_gamma, norm_beta (K) + norm_eps: the operand is silu(LayerNorm(A)) -- the conv module's norm and activation in front
+ *                of pointwise_conv2 (convolution.py:136-139) -- each rounded to bf16 as the two separate passes round. */
 int pafc_gemm_skinny_bf16_ex(long M, int N, int K, int batch, const void *A, long lda, long strideA, const void *W, long ldw,
                              long strideW, const void *bias, long strideBias, const void *residual, long ldr, long strideR,
                              void *out, long ldo, long strideO, float alpha, int act, int round_first,
                              const float *ln_stats_in, int ln_parts_in, int ln_self, const float *ln_csum, float ln_eps,
-                             float *ln_stats_out, const void *mix_maa, const void *mix_prev, int mix_T, pafc_stream_t stream);
+                             float *ln_stats_out, const void *mix_maa, const void *mix_prev, int mix_T, const void *norm_gamma,
+                             const void *norm_beta, float norm_eps, pafc_stream_t stream);
 
 /* Token shift + first lerp of the time-mix for ndir directions from one read of x (src/model.py:274-276):
  *   xx_d = shift_d(x) - x,  out[d] = x + xx_d * maa_x_d;   shift_0 = x_{t-1} (or x_{t+1} when reverse0), shift_1 = x_{t+1}

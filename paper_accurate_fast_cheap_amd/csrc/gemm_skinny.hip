@@ -19,6 +19,8 @@
 //       - the token shift + first lerp of the time-mix as the operand's producer (src/model.py:274-276: the fragment of
 //         x + (x_prev - x) * maa_x is formed in registers from the row, its predecessor -- or the frame carried over from the
 //         previous chunk -- and maa_x), which makes the LoRA down-projection of a chunk one launch;
+//       - LayerNorm + SiLU as the operand's producer (the conv module's norm + activation in front of pointwise_conv2,
+//         convolution.py:136-139): row statistics in a first pass over the block's rows, the fragments normalised in registers;
 //       - the partial statistics of the rows it writes (for a folded LayerNorm downstream).
 // Same arithmetic forms as gemm_ph.hip (fp32 accumulation, one rounding; SiLU / tanh / sigmoid through exp + rcp).
 #include <hip/hip_runtime.h>
@@ -49,6 +51,8 @@ struct SkParams {
     const float *csum;     // [N] column sums of the folded weight
     float eps, inv_c;
     float *st_out;         // float2 [M][N_out / 16]: partial statistics of the rows written, or null
+    const bf16_t *nrm_g, *nrm_b;   // the operand is silu(LayerNorm(a)) (convolution.py:136-137 before pointwise_conv2): gamma, beta [K], or null
+    float nrm_eps;
     const bf16_t *mix_maa; // token shift + lerp as the operand's producer: maa_x [K], or null
     const bf16_t *mix_prev;// [M / T][K] the frame before each sequence (streaming carry), or null = zero
     int T;                 // rows per sequence (mix)
@@ -72,10 +76,11 @@ __device__ __forceinline__ unsigned sk_pack(float lo, float hi) {   // both alre
 
 // MT: 16-row tiles per block (rows beyond M are clamped on load and skipped on store); GLU doubles the weight fragments and
 // accumulators; NWV waves split K; MIX: the A fragments are formed from x, its predecessor row and maa_x.
-template <int MT, bool GLU, int NWV, bool MIX>
+template <int MT, bool GLU, int NWV, int PROD>
 __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const SkParams p) {
     constexpr int NB = GLU ? 2 : 1;
-    constexpr int KB = MIX ? 2 : (MT <= 2 ? 8 : (MT <= 5 ? 4 : 2));   // K-steps (of 32) whose operands are in flight together
+    constexpr bool MIX = PROD == 1, NRM = PROD == 2;
+    constexpr int KB = (MIX || NRM) ? 2 : (MT <= 2 ? 8 : (MT <= 5 ? 4 : 2));   // K-steps (of 32) whose operands are in flight together
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, qq = lane >> 4;
     const int z = blockIdx.z;
@@ -105,6 +110,41 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const SkParams p)
             nrow[i] = t > 0 ? arow[i] - p.lda : (p.mix_prev != nullptr ? p.mix_prev + b * p.K + 8 * qq : arow[i]);
         }
     }
+    // NRM: LayerNorm + SiLU as the operand's producer.  First pass: each wave sums its K-share of the block's rows (the
+    // fragments it will multiply later: they come back from L1 / L2), the shares meet in LDS -> rstd, -mean * rstd per row
+    float n_rstd[NRM ? MT : 1], n_nm[NRM ? MT : 1];
+    if constexpr (NRM) {
+        float q1[MT], q2[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) { q1[i] = 0.f; q2[i] = 0.f; }
+        for (int ks = ks0; ks < ks1; ++ks)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                float f[8];
+                sk_unpack(*reinterpret_cast<const uint4 *>(arow[i] + ks * 32), f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { q1[i] += f[e]; q2[i] = fmaf(f[e], f[e], q2[i]); }
+            }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float s1 = q1[i], s2 = q2[i];
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (qq == 0) { s_red[wave][i * 16 + r16][0] = s1; s_red[wave][i * 16 + r16][1] = s2; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) { s1 += s_red[w][i * 16 + r16][0]; s2 += s_red[w][i * 16 + r16][1]; }
+            const float mean = s1 * p.inv_c;
+            const float var = fmaxf(fmaf(-mean, mean, s2 * p.inv_c), 0.f);
+            n_rstd[i] = rsqrtf(var + p.nrm_eps);
+            n_nm[i] = -mean * n_rstd[i];
+        }
+        __syncthreads();                                  // (s_red is used again below when ln_self is on)
+    }
     f32x4s acc[MT][NB];
     float ls1[MT], ls2[MT];
 #pragma unroll
@@ -117,7 +157,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const SkParams p)
 
     auto step_batch = [&](int ks, auto nsteps) {
         constexpr int NS = decltype(nsteps)::value;
-        uint4 wf[NS][NB], af[NS][MT], nf[MIX ? NS : 1][MIX ? MT : 1], mf[MIX ? NS : 1];
+        uint4 wf[NS][NB], af[NS][MT], nf[MIX ? NS : 1][MIX ? MT : 1], mf[(MIX || NRM) ? NS : 1], bfq[NRM ? NS : 1];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int k = (ks + s) * 32;
@@ -129,6 +169,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const SkParams p)
                 mf[s] = *reinterpret_cast<const uint4 *>(p.mix_maa + k + 8 * qq);
 #pragma unroll
                 for (int i = 0; i < MT; ++i) nf[s][i] = *reinterpret_cast<const uint4 *>(nrow[i] + k);
+            }
+            if constexpr (NRM) {
+                mf[s] = *reinterpret_cast<const uint4 *>(p.nrm_g + k + 8 * qq);
+                bfq[s] = *reinterpret_cast<const uint4 *>(p.nrm_b + k + 8 * qq);
             }
         }
 #pragma unroll
@@ -143,6 +187,16 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const SkParams p)
                     for (int e = 0; e < 8; ++e) {
                         const float xx = round_bf16((has_nb[i] ? xn[e] : 0.f) - xc[e]);
                         o[e] = round_bf16(xc[e] + round_bf16(xx * mm[e]));
+                    }
+                    a = uint4{sk_pack(o[0], o[1]), sk_pack(o[2], o[3]), sk_pack(o[4], o[5]), sk_pack(o[6], o[7])};
+                }
+                if constexpr (NRM) {             // silu(bf16(LN(a))), rounded again: the two kernels' roundings
+                    float xc[8], gg[8], bb[8], o[8];
+                    sk_unpack(a, xc); sk_unpack(mf[s], gg); sk_unpack(bfq[s], bb);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float y = round_bf16(fmaf(fmaf(xc[e], n_rstd[i], n_nm[i]), gg[e], bb[e]));
+                        o[e] = round_bf16(y * __builtin_amdgcn_rcpf(1.f + __expf(-y)));
                     }
                     a = uint4{sk_pack(o[0], o[1]), sk_pack(o[2], o[3]), sk_pack(o[4], o[5]), sk_pack(o[6], o[7])};
                 }
@@ -262,11 +316,11 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const SkParams p)
     }
 }
 
-template <int MT, bool GLU, int NWV, bool MIX>
+template <int MT, bool GLU, int NWV, int PROD>
 void launch_sk(const SkParams &p, int batch, hipStream_t s) {
     const int n_out = GLU ? p.N / 2 : p.N;
     const long groups = (p.M + MT * 16 - 1) / (MT * 16);
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, GLU, NWV, MIX>), dim3((unsigned)(n_out / 16), (unsigned)groups, (unsigned)batch),
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, GLU, NWV, PROD>), dim3((unsigned)(n_out / 16), (unsigned)groups, (unsigned)batch),
                        dim3(NWV * 64), 0, s, p);
 }
 
@@ -278,7 +332,7 @@ extern "C" int pafc_gemm_skinny_bf16_ex(long M, int N, int K, int batch, const v
                                         long strideR, void *out, long ldo, long strideO, float alpha, int act, int round_first,
                                         const float *ln_stats_in, int ln_parts_in, int ln_self, const float *ln_csum, float ln_eps,
                                         float *ln_stats_out, const void *mix_maa, const void *mix_prev, int mix_T,
-                                        pafc_stream_t stream) {
+                                        const void *norm_gamma, const void *norm_beta, float norm_eps, pafc_stream_t stream) {
     if (!A || !W || !out) return PAFC_ERR_NULL_POINTER;
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return PAFC_ERR_BAD_DIMS;
     if (act < 0 || act > 4) return PAFC_ERR_UNSUPPORTED;
@@ -293,7 +347,9 @@ extern "C" int pafc_gemm_skinny_bf16_ex(long M, int N, int K, int batch, const v
     if (folded != (ln_csum != nullptr) || (ln_stats_in && (ln_parts_in <= 0 || ln_self))) return PAFC_ERR_BAD_DIMS;
     if (mix_maa && (mix_T <= 0 || M % mix_T != 0 || batch != 1 || glu)) return PAFC_ERR_BAD_DIMS;
     if (!mix_maa && mix_prev) return PAFC_ERR_BAD_DIMS;
-    if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)mix_maa | (uintptr_t)mix_prev) & 15 || ((uintptr_t)out & 7) || ((uintptr_t)bias & 7) ||
+    if ((norm_gamma != nullptr) != (norm_beta != nullptr) || (norm_gamma && (mix_maa || folded || glu || batch != 1)))
+        return PAFC_ERR_BAD_DIMS;
+    if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)mix_maa | (uintptr_t)mix_prev | (uintptr_t)norm_gamma | (uintptr_t)norm_beta) & 15 || ((uintptr_t)out & 7) || ((uintptr_t)bias & 7) ||
         ((uintptr_t)residual & 7) || ((uintptr_t)ln_csum & 15) || ((uintptr_t)ln_stats_in & 7) || ((uintptr_t)ln_stats_out & 7))
         return PAFC_ERR_UNSUPPORTED;
     pafc::SkParams p{};
@@ -304,24 +360,28 @@ extern "C" int pafc_gemm_skinny_bf16_ex(long M, int N, int K, int batch, const v
     p.st_in = ln_stats_in; p.parts_in = ln_parts_in; p.ln_self = ln_self; p.csum = ln_csum; p.eps = ln_eps; p.inv_c = 1.f / (float)K;
     p.st_out = ln_stats_out;
     p.mix_maa = (const pafc::bf16_t *)mix_maa; p.mix_prev = (const pafc::bf16_t *)mix_prev; p.T = mix_T;
+    p.nrm_g = (const pafc::bf16_t *)norm_gamma; p.nrm_b = (const pafc::bf16_t *)norm_beta; p.nrm_eps = norm_eps;
     hipStream_t s = (hipStream_t)stream;
     const long mt = (M + 15) / 16;
     const long cols = (long)(n_out / 16) * batch;
     const bool k8 = K >= 2048;                     // eight waves split a long K
     // Row tiles per block: all of them (<= 8: one group, the weights are read once) when the column blocks alone occupy a good
     // part of the chip; else one tile per block, so that ~100+ blocks share the work (the weight slices are re-read from L2)
-    if (mix_maa) {
-        if (k8) pafc::launch_sk<1, false, 8, true>(p, batch, s);
-        else pafc::launch_sk<1, false, 4, true>(p, batch, s);
+    if (norm_gamma) {
+        if (k8) pafc::launch_sk<1, false, 8, 2>(p, batch, s);
+        else pafc::launch_sk<1, false, 4, 2>(p, batch, s);
+    } else if (mix_maa) {
+        if (k8) pafc::launch_sk<1, false, 8, 1>(p, batch, s);
+        else pafc::launch_sk<1, false, 4, 1>(p, batch, s);
     } else if (glu) {
-        if (cols < 96) { if (k8) pafc::launch_sk<1, true, 8, false>(p, batch, s); else pafc::launch_sk<1, true, 4, false>(p, batch, s); }
-        else if (mt <= 4) pafc::launch_sk<4, true, 4, false>(p, batch, s);
-        else pafc::launch_sk<5, true, 4, false>(p, batch, s);
+        if (cols < 96) { if (k8) pafc::launch_sk<1, true, 8, 0>(p, batch, s); else pafc::launch_sk<1, true, 4, 0>(p, batch, s); }
+        else if (mt <= 4) pafc::launch_sk<4, true, 4, 0>(p, batch, s);
+        else pafc::launch_sk<5, true, 4, 0>(p, batch, s);
     } else {
-        if (cols < 96) { if (k8) pafc::launch_sk<1, false, 8, false>(p, batch, s); else pafc::launch_sk<1, false, 4, false>(p, batch, s); }
-        else if (mt <= 4) { if (k8) pafc::launch_sk<4, false, 8, false>(p, batch, s); else pafc::launch_sk<4, false, 4, false>(p, batch, s); }
-        else if (mt <= 5) pafc::launch_sk<5, false, 4, false>(p, batch, s);
-        else pafc::launch_sk<8, false, 4, false>(p, batch, s);
+        if (cols < 96) { if (k8) pafc::launch_sk<1, false, 8, 0>(p, batch, s); else pafc::launch_sk<1, false, 4, 0>(p, batch, s); }
+        else if (mt <= 4) { if (k8) pafc::launch_sk<4, false, 8, 0>(p, batch, s); else pafc::launch_sk<4, false, 4, 0>(p, batch, s); }
+        else if (mt <= 5) pafc::launch_sk<5, false, 4, 0>(p, batch, s);
+        else pafc::launch_sk<8, false, 4, 0>(p, batch, s);
     }
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
@@ -333,5 +393,5 @@ extern "C" int pafc_gemm_skinny_bf16(long M, int N, int K, int batch, const void
                                      pafc_stream_t stream) {
     return pafc_gemm_skinny_bf16_ex(M, N, K, batch, A, lda, strideA, W, ldw, strideW, bias, strideBias, residual, ldr, strideR, out,
                                     ldo, strideO, alpha, act, 0, ln_stats_in, ln_parts_in, 0, ln_csum, ln_eps, ln_stats_out, nullptr,
-                                    nullptr, 0, stream);
+                                    nullptr, 0, nullptr, nullptr, 0.f, stream);
 }

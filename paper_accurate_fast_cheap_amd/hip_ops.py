@@ -1064,14 +1064,16 @@ def gemm_skinny(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
                 residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None,
                 ln_csum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5, stats_out: Optional[torch.Tensor] = None,
                 ln_self: bool = False, round_first: bool = False, mix_maa: Optional[torch.Tensor] = None,
-                mix_prev: Optional[torch.Tensor] = None, mix_T: int = 0):
+                mix_prev: Optional[torch.Tensor] = None, mix_T: int = 0, norm_silu: Optional[tuple] = None):
     """The few-rows bf16 GEMM of the streaming chunk step (include/pafc_encoder_ops.h: pafc_gemm_skinny_bf16[_ex]), arguments as
     gemm_bf16 except act "glu": w is the module's own (2C, K) weight (value rows, then gate rows), out (M, C).
     ln_csum (N) fp32 with ln_stats (M, P, 2) fp32 or ln_self: the LayerNorm in front of the projection folded in (a = the
     UN-normalised rows, w / bias = the folded ones; statistics from a producer's partials or formed in the launch);
     stats_out (M, N_out / 16, 2) fp32 receives the partial row statistics of the result; round_first: bf16(alpha a w^T) + bias;
-    mix_maa (K) [+ mix_prev (B, K)], mix_T: a = x of B sequences of mix_T rows, the operand is x + (x_prev - x) * maa."""
-    _lib.require_gpu(bias, ln_stats, ln_csum, stats_out, mix_maa, mix_prev)
+    mix_maa (K) [+ mix_prev (B, K)], mix_T: a = x of B sequences of mix_T rows, the operand is x + (x_prev - x) * maa;
+    norm_silu = (gamma (K), beta (K), eps): the operand is silu(LayerNorm(a)), each rounded to bf16."""
+    ng, nb, neps = norm_silu if norm_silu is not None else (None, None, 0.0)
+    _lib.require_gpu(bias, ln_stats, ln_csum, stats_out, mix_maa, mix_prev, ng, nb)
     for t in (a, w, residual, out):
         if t is not None and (not t.is_cuda or t.dtype != torch.bfloat16 or t.stride(-1) != 1):
             raise _lib.PafcError("gemm_skinny: bf16 GPU tensors with unit stride in the last dimension")
@@ -1080,7 +1082,7 @@ def gemm_skinny(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         from ctypes import c_float, c_long
         P, I, G = c_void_p, c_int, c_long
         _lib._sig(L.pafc_gemm_skinny_bf16_ex, I, G, I, I, I, P, G, G, P, G, G, P, G, P, G, G, P, G, G, c_float, I, I, P, I, I, P,
-                  c_float, P, P, P, I, P)
+                  c_float, P, P, P, I, P, P, c_float, P)
         L._pafc_skinny_bound = True
     batched = a.dim() == 3
     Z = a.shape[0] if batched else 1
@@ -1115,6 +1117,8 @@ def gemm_skinny(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
             raise _lib.PafcError("gemm_skinny: mix wants contiguous a = (B * T, K), maa (K) and prev (B, K) of a's dtype")
     elif mix_prev is not None:
         raise _lib.PafcError("gemm_skinny: mix_prev without mix_maa")
+    if ng is not None and (batched or ng.dtype != a.dtype or nb.dtype != a.dtype or ng.numel() != K or nb.numel() != K):
+        raise _lib.PafcError("gemm_skinny: norm_silu wants gamma, beta (K) of a's dtype, unbatched")
     sb = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
     bs = lambda t: t.stride(0) if batched else 0
     rc = L.pafc_gemm_skinny_bf16_ex(M, N, K, Z, _lib.ptr(a), a.stride(-2), bs(a), _lib.ptr(w), w.stride(-2), bs(w), _lib.ptr(bias),
@@ -1122,7 +1126,7 @@ def gemm_skinny(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
                                     bs(residual) if residual is not None else 0, _lib.ptr(out), out.stride(-2), bs(out),
                                     float(alpha), _ACTS[act], int(round_first), _lib.ptr(ln_stats), parts, int(ln_self),
                                     _lib.ptr(ln_csum), float(ln_eps), _lib.ptr(stats_out), _lib.ptr(mix_maa), _lib.ptr(mix_prev),
-                                    int(mix_T), _lib.stream_of(a))
+                                    int(mix_T), _lib.ptr(ng), _lib.ptr(nb), float(neps), _lib.stream_of(a))
     _lib.check(rc, "pafc_gemm_skinny_bf16")
     return out
 

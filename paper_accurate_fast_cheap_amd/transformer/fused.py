@@ -522,6 +522,9 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict],
         rkv = hip_ops.gemm_skinny(z[:3].view(3, M, C), plan.Wrkv_n).view(3, B, T, C)
     else:
         rkv = torch.bmm(z[:3].view(3, M, C), plan.Wrkv).view(3, B, T, C)
+    # (the decay chain and the r / k / v projections are independent, but as two branches of the captured graph -- a second HIP
+    # stream forked and joined by events -- the step got 25 % SLOWER, 1.33 -> 1.66 ms: cross-queue dependencies cost more than
+    # the 5 us they hide; one stream)
     if sk:   # two short launches: tanh(z_w D1), then bf16(. D2) + time_decay rounded where the reference's op chain rounds
         td = hip_ops.gemm_skinny(z[3].view(M, C), plan.D1n[0], None, "tanh")
         w = hip_ops.gemm_skinny(td, plan.D2n[0], plan.time_decay.view(C), round_first=True).view(B, T, C)
@@ -585,8 +588,15 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict],
             cnn.copy_(new_cnn)
         else:
             new["cnn"] = new_cnn
-    _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
-    x = proj(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none", residual=x, inplace=True)
+    pw2 = cm.pointwise_conv2
+    if sk and dw.dtype == torch.bfloat16 and cm.norm.weight.dtype == torch.bfloat16 and pw2.weight.is_contiguous():
+        # the conv module's LayerNorm + SiLU as the operand producer of pointwise_conv2 (one launch instead of two)
+        x2 = x.view(M, C)
+        x = hip_ops.gemm_skinny(dw.view(M, C), pw2.weight.view(C, C), pw2.bias, residual=x2, out=x2,
+                                norm_silu=(cm.norm.weight, cm.norm.bias, cm.norm.eps)).view(B, T, C)
+    else:
+        _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
+        x = proj(g, pw2.weight.squeeze(-1), pw2.bias, "none", residual=x, inplace=True)
     if sk and hip_ops.skinny_ok(M, L.feed_forward.w_1.weight.shape[0], C):     # norm_ff folded into w_1
         w1, b1, cs1, ep1 = plan.carry_folds()["ff"]
         hid = hip_ops.gemm_skinny(x.view(M, C), w1, b1, "silu", ln_self=True, ln_csum=cs1, ln_eps=ep1)

@@ -413,6 +413,26 @@ def test_gemm_skinny_token_shift_operand_equals_shift_mix_plus_gemm(hip, B, T, w
     torch.testing.assert_close(got.float(), want.float(), rtol=2 ** -7, atol=1e-2)
 
 
+@pytest.mark.parametrize("M", [64, 37, 200])
+def test_gemm_skinny_layernorm_silu_operand_equals_the_two_passes(hip, M):
+    """norm_silu: silu(LayerNorm(a)) formed in registers as the operand == add_layernorm(silu=True) followed by the GEMM."""
+    from paper_accurate_fast_cheap_amd.hip_ops import add_layernorm, gemm_skinny
+    bf = torch.bfloat16
+    C = 512
+    a = synth.randn((M, C), 1, 1.7).to(bf).cuda()
+    gamma = (1 + 0.2 * synth.randn((C,), 7)).to(bf).cuda()
+    beta = (0.1 * synth.randn((C,), 8)).to(bf).cuda()
+    w = synth.randn((C, C), 2, 0.05).to(bf).cuda()
+    b = synth.randn((C,), 3, 0.2).to(bf).cuda()
+    r = synth.randn((M, C), 9).to(bf).cuda()
+    _, g, _ = add_layernorm(a, None, 1.0, gamma, beta, silu=True, eps=1e-5)
+    want = gemm_skinny(g, w, b, residual=r)
+    got = gemm_skinny(a, w, b, residual=r, norm_silu=(gamma, beta, 1e-5))
+    torch.testing.assert_close(got.float(), want.float(), rtol=2 ** -7, atol=2e-2)
+    exact = F.linear(F.silu(F.layer_norm(a.float(), (C,), gamma.float(), beta.float(), 1e-5)), w.float(), b.float()) + r.float()
+    torch.testing.assert_close(got.float(), exact, rtol=2 ** -6, atol=4e-2)
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 512, 512), (70, 2048, 512), (33, 512, 2048)])
 def test_gemm_skinny_layernorm_from_its_own_operand_and_short_k(hip, M, N, K):
     """ln_self: the folded LayerNorm's statistics come from the operand fragments of the launch itself; round_first and a
