@@ -182,3 +182,19 @@ def test_feats_batcher_windows_like_the_reference():
     assert [l.tolist() for _, l in feats_batcher(x[:, :800], 100, 4)] == [[100] * 4, [100] * 4]
     assert [l.tolist() for _, l in feats_batcher(x[:, :42], 100, 4)] == [[42]]
     assert window_offsets_ms(3, 2000) == [0.0, 20000.0, 40000.0]
+
+
+def test_few_rows_gemm_is_scoped_to_a_chunk_step():
+    """hip_ops.skinny_ok: the few-rows kernel (csrc/gemm_skinny.hip) is offered only inside hip_ops.chunk_step() -- offline
+    inputs that merely happen to be short keep the kernels their goldens were recorded with -- and only for shapes it takes."""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    assert not hip_ops.skinny_ok(64, 512, 512)
+    with hip_ops.chunk_step():
+        assert hip_ops.skinny_ok(64, 512, 512) and hip_ops.skinny_ok(78, 1024, 512, glu=True)
+        assert hip_ops.skinny_ok(hip_ops.SKINNY_MAX_ROWS, 512, 2048) and not hip_ops.skinny_ok(hip_ops.SKINNY_MAX_ROWS + 1, 512, 2048)
+        assert not hip_ops.skinny_ok(64, 512, 48)            # K in whole 32-deep steps
+        assert not hip_ops.skinny_ok(64, 1000, 512, glu=True) and not hip_ops.skinny_ok(0, 512, 512)
+        with hip_ops.chunk_step():                           # re-entrant
+            pass
+        assert hip_ops.skinny_ok(64, 512, 512)
+    assert not hip_ops.skinny_ok(64, 512, 512)
