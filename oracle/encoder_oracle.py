@@ -202,39 +202,68 @@ def positionwise_ff(x, sd: SD, p: str):
     return F.linear(F.silu(F.linear(x, sd[p + "w_1.weight"], sd[p + "w_1.bias"])), sd[p + "w_2.weight"], sd[p + "w_2.bias"])
 
 
-def conv_module(x, mask_pad, sd: SD, p: str, kernel_size: int):
-    """ConvolutionModule.forward, wenet/transformer/convolution.py:89-144; non-causal (lorder = 0),
-    cnn_module_norm = layer_norm, activation SiLU.  x: (B, T, C); mask_pad: (B, 1, T) bool or (0,0,0)."""
+def conv_module(x, mask_pad, sd: SD, p: str, kernel_size: int, causal: bool = False, cache=None):
+    """ConvolutionModule.forward, wenet/transformer/convolution.py:89-144; cnn_module_norm = layer_norm, activation SiLU.
+    x: (B, T, C); mask_pad: (B, 1, T) bool or (0,0,0).
+
+    Non-causal (`causal: false`, every shipped conf/rwkv YAML): lorder = 0 (:56-60), the depthwise convolution pads
+    (k - 1) / 2 frames either side, nothing is cached -- returns y.
+    Causal (:49-55,113-126): lorder = k - 1, the depthwise convolution has no padding of its own; the INPUT of the module
+    (after the pad mask, before pointwise_conv1) is extended on the left by `lorder` zero frames when `cache` is None or
+    has no frames (:114-115), otherwise by `cache` (B, C, cache_t) (:117-119); the new cache is the last `lorder` frames
+    of that extended input (:121) -- returns (y, new_cache (B, C, lorder))."""
     x = x.transpose(1, 2)
     if mask_pad.size(2) > 0:
         x = x.masked_fill(~mask_pad, 0.0)
+    new_cache = None
+    if causal:
+        lorder = kernel_size - 1
+        if cache is None or cache.size(2) == 0:
+            x = F.pad(x, (lorder, 0), "constant", 0.0)
+        else:
+            assert cache.size(0) == x.size(0) and cache.size(1) == x.size(1)
+            x = torch.cat((cache, x), dim=2)
+        assert x.size(2) > lorder
+        new_cache = x[:, :, -lorder:]
     x = F.conv1d(x, sd[p + "pointwise_conv1.weight"], sd[p + "pointwise_conv1.bias"])
     x = F.glu(x, dim=1)
     C = x.shape[1]
-    x = F.conv1d(x, sd[p + "depthwise_conv.weight"], sd[p + "depthwise_conv.bias"], padding=(kernel_size - 1) // 2, groups=C)
+    x = F.conv1d(x, sd[p + "depthwise_conv.weight"], sd[p + "depthwise_conv.bias"],
+                 padding=0 if causal else (kernel_size - 1) // 2, groups=C)
     x = x.transpose(1, 2)
     x = F.silu(F.layer_norm(x, (C,), sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-5))
     x = x.transpose(1, 2)
     x = F.conv1d(x, sd[p + "pointwise_conv2.weight"], sd[p + "pointwise_conv2.bias"])
     if mask_pad.size(2) > 0:
         x = x.masked_fill(~mask_pad, 0.0)
-    return x.transpose(1, 2)
+    return (x.transpose(1, 2), new_cache) if causal else x.transpose(1, 2)
 
 
-def conformer_layer(x, mask_pad, sd: SD, p: str, conf: dict, layer_id: int, env=None):
+def conformer_layer(x, mask_pad, sd: SD, p: str, conf: dict, layer_id: int, env=None, cnn_cache=None,
+                    return_cnn_cache: bool = False):
     """ConformerEncoderLayer.forward, wenet/transformer/encoder_layer.py:165-261: macaron FFN (ff_scale 0.5,
     :149-151), conv module, eval-mode dropout; normalize_before (the paper's configs) puts each LayerNorm in front of its
-    branch, otherwise behind the residual add (:203-208, :212-213/:233-234, :241-247, :251-256)."""
+    branch, otherwise behind the residual add (:203-208, :212-213/:233-234, :241-247, :251-256).  With `causal: true`
+    (encoder.py:572-573 -> convolution.py:49-55) the conv module takes `cnn_cache` (B, C, cache_t) and hands back its new
+    left context (encoder_layer.py:243), returned as the second value when `return_cnn_cache`."""
     head_size = conf["output_size"] // conf["attention_heads"]
     pre = bool(conf.get("normalize_before", True))
+    causal = bool(conf.get("causal", False))
+    side = {}
 
     def slot(h):
         return self_attn(h, sd, p + "self_attn.", conf["selfattention_layer_type"], head_size,
                          conf.get("rwkv_do_bfloat16", True), layer_id, env=env,
                          out_as_query=bool(conf.get("oracle_slot_out_as_query", False)))[0]
+
+    def conv(h):
+        y = conv_module(h, mask_pad, sd, p + "conv_module.", conf["cnn_module_kernel"], causal, cnn_cache)
+        if causal:
+            y, side["cnn"] = y
+        return y
     for norm, scale, fn in (("norm_ff_macaron.", 0.5, lambda h: positionwise_ff(h, sd, p + "feed_forward_macaron.")),
                             ("norm_mha.", None, slot),
-                            ("norm_conv.", None, lambda h: conv_module(h, mask_pad, sd, p + "conv_module.", conf["cnn_module_kernel"])),
+                            ("norm_conv.", None, conv),
                             ("norm_ff.", 0.5, lambda h: positionwise_ff(h, sd, p + "feed_forward."))):
         if not pre and norm == "norm_conv." and mask_pad.size(2) > 0:
             # post-norm hands the residual stream itself to the conv module, whose masked_fill_ is IN PLACE on a view of
@@ -245,7 +274,10 @@ def conformer_layer(x, mask_pad, sd: SD, p: str, conf: dict, layer_id: int, env=
         x = r + (y if scale is None else scale * y)
         if not pre:
             x = layer_norm(x, sd, p + norm)
-    return layer_norm(x, sd, p + "norm_final.")
+    x = layer_norm(x, sd, p + "norm_final.")
+    if return_cnn_cache:
+        return x, side.get("cnn", torch.zeros((0, 0, 0), dtype=x.dtype))
+    return x
 
 
 # ----------------------------------------------------------------------------
@@ -307,20 +339,26 @@ def encoder_forward(xs, xs_lens, sd: SD, conf: dict, env=None, return_layers: bo
     return (xs, masks, layers) if return_layers else (xs, masks)
 
 
-def encoder_forward_chunk(xs, sd: SD, conf: dict, env=None, offset: int = 0):
-    """BaseEncoder.forward_chunk, encoder.py:231-339, as it behaves with an RWKV slot and a non-causal
-    conv module: B == 1, all-ones masks, att_cache comes back (0,0,0,0) and cnn_cache (num_blocks,0,0,0)
-     -- i.e. an independent full-context pass over the chunk."""
+def encoder_forward_chunk(xs, sd: SD, conf: dict, env=None, offset: int = 0, cnn_cache=None):
+    """BaseEncoder.forward_chunk, encoder.py:231-339, as it behaves with an RWKV slot: B == 1, all-ones masks, the slot
+    hands `att_cache` back untouched so it comes back (0,0,0,0) (rwkv_wrapper.py:81): the
+    recurrence restarts from S = 0 and the token shift from a zero frame in every chunk.
+    Non-causal conv module: cnn_cache comes back (num_blocks,0,0,0) -- an independent full-context pass over the chunk.
+    Causal (`causal: true`): layer i takes cnn_cache[i] (B=1, C, cache_t) when cnn_cache has layers, else the empty
+    cache (encoder.py:311-318), and the new left contexts come back stacked (num_blocks, 1, C, lorder) (:322,335)."""
     assert xs.size(0) == 1
     masks = torch.ones(1, 1, xs.size(1), dtype=torch.bool)
     xs = global_cmvn(xs, sd)
     xs, _ = conv2d_subsampling4(xs, masks, sd, pos_enc=conf.get("pos_enc_layer_type", "rel_pos"), offset=offset)
     empty_mask = torch.ones((0, 0, 0), dtype=torch.bool)
+    new_cnn = []
     for i in range(conf["num_blocks"]):
-        xs = conformer_layer(xs, empty_mask, sd, f"encoders.{i}.", conf, i, env)
+        cc = cnn_cache[i] if (cnn_cache is not None and cnn_cache.size(0) > 0) else None
+        xs, nc = conformer_layer(xs, empty_mask, sd, f"encoders.{i}.", conf, i, env, cnn_cache=cc, return_cnn_cache=True)
+        new_cnn.append(nc.unsqueeze(0))
     if conf.get("normalize_before", True):       # encoder.py:328-329
         xs = layer_norm(xs, sd, "after_norm.")
-    return xs, torch.zeros((0, 0, 0, 0)), torch.zeros((conf["num_blocks"], 0, 0, 0))
+    return xs, torch.zeros((0, 0, 0, 0)), torch.cat(new_cnn, dim=0)
 
 
 def encoder_forward_chunk_by_chunk(xs, decoding_chunk_size: int, sd: SD, conf: dict, env=None):
@@ -328,15 +366,17 @@ def encoder_forward_chunk_by_chunk(xs, decoding_chunk_size: int, sd: SD, conf: d
     (chunk - 1) * subsampling + right_context + 1 frames every subsampling * chunk frames (subsampling_rate 4,
     right_context 6: subsampling.py:197-199), each through forward_chunk, outputs concatenated, all-ones mask.
     With the recurrent slot and the non-causal conv module the caches stay empty, so every window is an independent
-    full-context pass."""
+    full-context pass; a causal conv module's cnn_cache is threaded from window to window
+    (encoder.py:392-397)."""
     assert decoding_chunk_size > 0 and xs.size(0) == 1
     subsampling, context = 4, 6 + 1
     stride = subsampling * decoding_chunk_size
     window = (decoding_chunk_size - 1) * subsampling + context
     outs = []
     offset = 0          # encoder.py:377,399: the running count of output frames is the next window's positional offset
+    cnn_cache = None
     for cur in range(0, xs.size(1) - context + 1, stride):
-        y, _, _ = encoder_forward_chunk(xs[:, cur:min(cur + window, xs.size(1))], sd, conf, env, offset)
+        y, _, cnn_cache = encoder_forward_chunk(xs[:, cur:min(cur + window, xs.size(1))], sd, conf, env, offset, cnn_cache)
         outs.append(y)
         offset += y.size(1)
     ys = torch.cat(outs, 1)

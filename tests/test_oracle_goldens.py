@@ -314,3 +314,73 @@ def test_postnorm_and_abspos_goldens(case):
                                                   c["conf"], env={})[0]
                          for cur in range(0, g["long"].size(1) - 6, 4 * chunk)], 1)
         assert not torch.allclose(ys0.float(), want["ys"].float(), atol=1e-2)
+
+
+# ---------------------------------------------------------------- round 4: the causal conv module + cnn_cache (streaming leg)
+@pytest.mark.parametrize("case", ["k15_f32", "k15_bf16", "k31_f32", "k31_bf16"])
+def test_conv_module_causal_golden(case):
+    """ConvolutionModule(causal=True) (convolution.py:49-60,113-126) captured from the reference (make_goldens_r4.py):
+    a ragged masked batch without cache, and one stream cut in three with the cache handed on -- outputs and caches."""
+    c = load_golden("conv_module_causal")["cases"][case]
+    sd = _sd(c)
+    bf = case.endswith("bf16")
+    if bf:
+        sd = {k: v.bfloat16() for k, v in sd.items()}
+    k = c["kernel"]
+    mask = (torch.arange(c["xb"].size(1))[None, :] < c["lens"][:, None]).unsqueeze(1)
+    yb, cb = EO.conv_module(c["xb"], mask, sd, "", k, causal=True)
+    assert yb.dtype == c["yb"].dtype and _close(yb, c["yb"], bf) and cb.shape == c["cb"].shape == (3, 128, k - 1)
+    assert torch.equal(cb, c["cb"])                  # the cache is the (masked) input itself: exact
+    empty = torch.ones((0, 0, 0), dtype=torch.bool)
+    cache = None
+    for (a, b), want in zip(zip(c["cuts"][:-1], c["cuts"][1:]), c["pieces"]):
+        y, cache = EO.conv_module(c["xs"][:, a:b], empty, sd, "", k, causal=True, cache=cache)
+        assert _close(y, want["y"], bf) and torch.equal(cache, want["new_cache"]), (case, a, b)
+    whole, cw = EO.conv_module(c["xs"], empty, sd, "", k, causal=True)
+    assert _close(whole, c["whole"], bf) and torch.equal(cw, c["whole_cache"])
+    # causality: frame t of the output does not see inputs after t
+    x2 = c["xs"].clone()
+    x2[:, 50:] = 0
+    y2, _ = EO.conv_module(x2, empty, sd, "", k, causal=True)
+    assert torch.equal(y2[:, :50], whole[:, :50])
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16slot", "bf16model"])
+def test_encoder_causal_uni_golden(prec):
+    """Reduced ConformerEncoder, rwkv_tmix60 + causal: true, captured from the reference (make_goldens_r4.py): forward of
+    a ragged batch, of one long utterance, forward_chunk with the cnn_cache handed on (encoder.py:311-337), and
+    forward_chunk_by_chunk -- which in the reference carries the conv cache but restarts the recurrence per window."""
+    g = load_golden("encoder_causal_uni")
+    c = g["cases"][prec]
+    sd = _sd(c)
+    csd = synth.synth_state_dict(c["ctc_spec"], c["ctc_seed"])
+    xs, long = g["xs"], g["long"]
+    if prec == "bf16model":
+        sd = {k: v.bfloat16() for k, v in sd.items()}
+        csd = {k: v.bfloat16() for k, v in csd.items()}
+        xs, long = xs.bfloat16(), long.bfloat16()
+    bf = prec != "f32"
+    assert c["conf"]["causal"] is True and c["conf"]["selfattention_layer_type"] == "rwkv_tmix60"
+    out, masks, layers = EO.encoder_forward(xs, g["lens"], sd, c["conf"], env={}, return_layers=True)
+    assert torch.equal(masks, c["masks"]) and out.dtype == c["out"].dtype
+    assert _close(layers[0], c["layer0"], bf) and _close(layers[1], c["layer1"], bf) and _close(out, c["out"], bf)
+    enc_lens = masks.squeeze(1).sum(1)
+    assert EO.ctc_greedy_search(c["logp_full"].float(), enc_lens, 0) == c["greedy"]
+    logp = EO.ctc_log_softmax(out, {"ctc." + k: v for k, v in csd.items()})
+    if torch.equal(out, c["out"]):
+        assert EO.ctc_greedy_search(logp.float(), enc_lens, 0) == c["greedy"]
+    whole, _ = EO.encoder_forward(long, torch.tensor([long.size(1)]), sd, c["conf"], env={})
+    assert _close(whole, c["whole"], bf)
+    y0, a0, c0 = EO.encoder_forward_chunk(long[:, 0:35], sd, c["conf"], env={}, offset=0)
+    y1, a1, c1 = EO.encoder_forward_chunk(long[:, 32:67], sd, c["conf"], env={}, offset=8, cnn_cache=c0)
+    for (y, a, cc), want in (((y0, a0, c0), c["chunk0"]), ((y1, a1, c1), c["chunk1"])):
+        assert tuple(a.shape) == want["att_shape"] == (0, 0, 0, 0)
+        assert cc.shape == want["cnn"].shape == (2, 1, 128, 14)
+        assert _close(y, want["y"], bf) and _close(cc, want["cnn"], bf)
+    for chunk, want in c["chunks"].items():
+        ys, m = EO.encoder_forward_chunk_by_chunk(long, chunk, sd, c["conf"], env={})
+        assert torch.equal(m, want["masks"]) and _close(ys, want["ys"], bf), (prec, chunk)
+    # the first window has no history in either form: it equals the head of the whole-sequence pass (causal conv, uni slot)
+    assert _close(y0, c["whole"][:, :8], bf)
+    # ... the later ones do not: the reference restarts the recurrence per window (rwkv_wrapper.py:81)
+    assert not torch.allclose(c["chunks"][8]["ys"].float(), c["whole"].float(), atol=1e-2)
