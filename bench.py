@@ -118,10 +118,17 @@ def streaming_leg(feats32: torch.Tensor, device, seconds: float = 600.0, chunk: 
         y = enc.stream_chunks(x, chunk)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # the same audio as ONE sequence through the same model: a stream with carried state must reproduce it (the
+        # whole-sequence pass itself is pinned against the reference / oracle in tests/test_streaming_gpu.py)
+        whole, _ = enc(x, torch.tensor([x.shape[1]], dtype=torch.int32, device=device))
+        n = min(whole.shape[1], y.shape[1])
+        diff = (y[:, :n].float() - whole[:, :n].float()).abs()
     return {"workload": f"streaming with state carry: uni-directional 12-layer encoder, {x.shape[1] / 100.0:.0f} s of the same audio in "
                         f"{chunk}-frame chunks ({chunk * 0.04:.2f} s), one stream, bf16",
             "chunks": nchunks, "ms_per_chunk": round(dt * 1e3 / nchunks, 3),
-            "audio_sec_per_sec": round(x.shape[1] / 100.0 / dt, 1), "finite": bool(torch.isfinite(y.float()).all())}
+            "audio_sec_per_sec": round(x.shape[1] / 100.0 / dt, 1),
+            "max_abs_vs_whole_sequence": round(float(diff.max()), 4), "mean_abs_vs_whole_sequence": round(float(diff.mean()), 5),
+            "frames_compared": int(n), "finite": bool(torch.isfinite(y.float()).all())}
 
 
 def build_model(dtype: str, device):

@@ -809,16 +809,37 @@ def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
 # fp32 GEMMs of long inputs run on the bf16 matrix cores with split operands (csrc/gemm_ph.hip: three bf16 products per fp32
 # product, fp32 accumulation, ~2^-16 relative); shorter ones keep the library's exact fp32 kernels.
 _SPLIT_GEMM_MIN_ROWS = int(os.environ.get("PAFC_SPLIT_GEMM_MIN_ROWS", "16384"))
-_split_weights = {}      # id(weight) -> (stamp, [hi | hi | lo] planes); bounded, weights of inference modules are few
+_split_weights = {}      # id(weight) -> (stamp, [hi | hi | lo] planes, weakref to the weight); bounded
+
+# Derived copies of parameters (stacked / transposed / split / LayerNorm-folded weights of the inference plans) are keyed on
+# (storage, Tensor._version).  Fused optimizers (`torch.optim.Adam(fused=True)`, `p.data` writes) update parameters WITHOUT
+# touching `_version`, so the keys carry this process-wide epoch as well: it is bumped after every optimizer step of
+# utils.train_utils.train_step and whenever an encoder switches between train() and eval() -- a CV pass between training
+# steps therefore never multiplies stale weights.  Code that updates parameters behind torch's back calls it itself.
+_param_epoch = 0
+
+
+def param_epoch() -> int:
+    return _param_epoch
+
+
+def bump_param_epoch() -> None:
+    global _param_epoch
+    _param_epoch += 1
+
 
 
 def split_weight_cached(weight: torch.Tensor) -> torch.Tensor:
-    stamp = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    """[hi | hi | lo] planes of a weight, cached per weight OBJECT: an entry is valid only for the very tensor it was made
+    from (a weak reference is compared by identity -- a freed tensor's id and allocator block can both come back for a new
+    tensor of the same shape, whose `_version` is 0 again) and for its stamp (storage, in-place version, shape)."""
+    import weakref
+    stamp = (weight.data_ptr(), weight._version, tuple(weight.shape), _param_epoch)
     ent = _split_weights.get(id(weight))
-    if ent is None or ent[0] != stamp:
+    if ent is None or ent[0] != stamp or ent[2]() is not weight:
         if len(_split_weights) > 64:
             _split_weights.clear()
-        ent = _split_weights[id(weight)] = (stamp, split_planes(weight.detach().contiguous(), triple=True))
+        ent = _split_weights[id(weight)] = (stamp, split_planes(weight.detach().contiguous(), triple=True), weakref.ref(weight))
     return ent[1]
 
 

@@ -42,6 +42,7 @@ class BaseEncoder(torch.nn.Module):
         # inference executor (transformer/fused.py); PAFC_DISABLE_FUSED=1 keeps the op-by-op module path
         self.fused_inference = os.environ.get("PAFC_DISABLE_FUSED", "0") != "1"
         self._fused_plan = None
+        self._carry_last_fused = False
         # opt-in hipGraph cache for inference batches of a recurring (B, T) shape (windowed long-form decoding runs dozens
         # of identical batches whose ~300 short kernels are launch-bound): the N most recent shapes keep a captured
         # graph of the whole forward; 0 = off.  Each graph pins its activations, hence opt-in and bounded.
@@ -62,6 +63,14 @@ class BaseEncoder(torch.nn.Module):
 
     def output_size(self) -> int:
         return self._output_size
+
+    def train(self, mode: bool = True):
+        """train() / eval(): the inference plans' derived weight copies are keyed on Tensor._version, which fused optimizers
+        do not touch -- switching mode invalidates them (hip_ops.bump_param_epoch), so a CV pass after training steps
+        rebuilds them from the current parameters."""
+        from .. import hip_ops
+        hip_ops.bump_param_epoch()
+        return super().train(mode)
 
     def forward(self, xs: torch.Tensor, xs_lens: torch.Tensor, decoding_chunk_size: int = 0,
                 num_decoding_left_chunks: int = -1, cat_embs: Optional[torch.Tensor] = None
@@ -145,7 +154,9 @@ class BaseEncoder(torch.nn.Module):
                       cat_embs: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """One chunk, reference semantics (encoder.py:231-339): B == 1; with the recurrent slot the wrappers hand
         `cache` back untouched, so r_att_cache is (0,0,0,0) and, conv being non-causal in the paper's configs,
-        r_cnn_cache is (num_blocks,0,0,0): every chunk is an independent full-context pass over its own frames.
+        r_cnn_cache is (num_blocks,0,0,0): every chunk is an independent full-context pass over its own frames.  With
+        `causal: true` r_cnn_cache is (num_blocks, 1, C, lorder), to be handed to the next call (the recurrence still
+        restarts per chunk, as in the reference).
         State-carrying streaming (what the reference lacks) is forward_chunk_carry()."""
         assert xs.size(0) == 1
         tmp_masks = torch.ones(1, 1, xs.size(1), device=xs.device, dtype=torch.bool)
@@ -154,7 +165,10 @@ class BaseEncoder(torch.nn.Module):
         xs, pos_emb, _ = self.embed(xs, tmp_masks, offset)
         elayers = att_cache.size(0)
         plan = self._fused(xs)
-        if plan is not None and elayers == 0 and cnn_cache.size(0) == 0:
+        # a causal conv module threads its left context from call to call (encoder.py:311-337, convolution.py:113-126): the
+        # layer-by-layer path below hands the caches on; the fused executor serves the cache-free (non-causal) chunk
+        causal = any(l.conv_module is not None and l.conv_module.lorder > 0 for l in self.encoders)
+        if plan is not None and elayers == 0 and cnn_cache.size(0) == 0 and not causal:
             from . import fused
             from .. import hip_ops
             with hip_ops.chunk_step():      # a chunk's few rows: the launch-bound regime (csrc/gemm_skinny.hip)
@@ -174,6 +188,17 @@ class BaseEncoder(torch.nn.Module):
             xs = self.after_norm(xs)
         return xs, torch.cat(r_att_cache, dim=0), torch.cat(r_cnn_cache, dim=0)
 
+    def _carry_step_is_fused(self, xs: torch.Tensor) -> bool:
+        """Whether forward_chunk_carry serves THIS call on the fused chunk-step kernels (decided once per call, from the
+        call's own input: inference, bf16 streams on the GPU, every layer carry-eligible).  The outcome is kept in
+        `_carry_last_fused`: stream_chunks hands the step the in-place "cx" carry, which only that path understands,
+        only when the stream's own warm-up windows took it."""
+        if not (self.fused_inference and not torch.is_grad_enabled() and not self.training and xs.is_cuda
+                and xs.dtype == torch.bfloat16):
+            return False
+        from . import fused
+        return all(fused.carry_eligible(l, xs) for l in self.encoders)
+
     @torch.no_grad()
     def forward_chunk_carry(self, xs: torch.Tensor, offset: int = 0, state: Optional[list] = None, in_place: bool = False
                             ) -> Tuple[torch.Tensor, list]:
@@ -189,30 +214,28 @@ class BaseEncoder(torch.nn.Module):
             xs = self.global_cmvn(xs)
         state = state or [None] * len(self.encoders)
         new_state = []
-        fused_step = (self.fused_inference and not torch.is_grad_enabled() and not self.training and xs.is_cuda
-                      and xs.dtype == torch.bfloat16)
-        if fused_step:
+        self._carry_last_fused = self._carry_step_is_fused(xs)      # (after the CMVN: its output dtype is what the layers see)
+        if self._carry_last_fused:                  # bf16 streams, causal conv: fused kernels
             from . import fused
             from .. import hip_ops
             with hip_ops.chunk_step():      # few rows: the launch-bound regime (csrc/gemm_skinny.hip)
                 xs, _, _ = self.embed(xs, masks, offset)
-                if all(fused.carry_eligible(l, xs) for l in self.encoders):     # bf16 streams, causal conv: fused kernels
-                    if getattr(self, "_carry_plans", None) is None:
-                        self._carry_plans = [fused.LayerPlan(l) for l in self.encoders]
-                    plans = self._carry_plans
-                    n = len(plans)
-                    tail = self.after_norm if self.normalize_before else None
-                    h = None
-                    pending = [] if in_place else None     # the carries' small refreshes: one multi-tensor copy at the end
-                    for i, carry in enumerate(state):
-                        plans[i].refresh()
-                        nxt = plans[i + 1].layer.norm_ff_macaron if i + 1 < n else tail
-                        xs, c, h = fused.layer_forward_carry(plans[i], xs, carry, h0=h, next_norm=nxt,
-                                                             in_place=in_place and carry is not None, pending=pending)
-                        new_state.append(c)
-                    if pending:
-                        torch._foreach_copy_([d for d, _ in pending], [s_ for _, s_ in pending])
-                    return (h if tail is not None else xs), new_state
+                if getattr(self, "_carry_plans", None) is None:
+                    self._carry_plans = [fused.LayerPlan(l) for l in self.encoders]
+                plans = self._carry_plans
+                n = len(plans)
+                tail = self.after_norm if self.normalize_before else None
+                h = None
+                pending = [] if in_place else None     # the carries' small refreshes: one multi-tensor copy at the end
+                for i, carry in enumerate(state):
+                    plans[i].refresh()
+                    nxt = plans[i + 1].layer.norm_ff_macaron if i + 1 < n else tail
+                    xs, c, h = fused.layer_forward_carry(plans[i], xs, carry, h0=h, next_norm=nxt,
+                                                         in_place=in_place and carry is not None, pending=pending)
+                    new_state.append(c)
+                if pending:
+                    torch._foreach_copy_([d for d, _ in pending], [s_ for _, s_ in pending])
+                return (h if tail is not None else xs), new_state
         else:
             xs, _, _ = self.embed(xs, masks, offset)
         for layer, carry in zip(self.encoders, state):
@@ -247,31 +270,41 @@ class BaseEncoder(torch.nn.Module):
         warm = max(2, -(-lorder // decoding_chunk_size) + 1)
         done = 0
         if use_graph and xs.is_cuda and len(full) >= warm + 4:
+            side = torch.cuda.Stream(device=xs.device)
+            side.wait_stream(torch.cuda.current_stream(xs.device))
+            with torch.cuda.stream(side):
+                for c in full[:warm]:
+                    eager(c)
+            torch.cuda.current_stream(xs.device).wait_stream(side)
+            done = warm
+            static_in = xs[:, full[warm]:full[warm] + window].clone()
+            static_state = [{k: v.clone() for k, v in st.items()} for st in state]
+            if xs.size(0) == 1 and self._carry_last_fused:
+                # one stream and THIS stream's steps ran on the fused kernels (the decision forward_chunk_carry just made
+                # for the warm-up windows, same shapes and dtypes): the conv module's input buffer lives across steps
+                for st in static_state:
+                    cnn = st.get("cnn")
+                    if cnn is not None and cnn.dim() == 3 and decoding_chunk_size >= cnn.size(2) > 0:
+                        cx = cnn.new_zeros(1, cnn.size(2) + decoding_chunk_size, cnn.size(1))
+                        cx[:, :cnn.size(2)] = cnn.transpose(1, 2)
+                        st["cx"] = cx
+            graph = torch.cuda.CUDAGraph()
             try:
-                side = torch.cuda.Stream(device=xs.device)
-                side.wait_stream(torch.cuda.current_stream(xs.device))
-                with torch.cuda.stream(side):
-                    for c in full[:warm]:
-                        eager(c)
-                torch.cuda.current_stream(xs.device).wait_stream(side)
-                done = warm
-                static_in = xs[:, full[warm]:full[warm] + window].clone()
-                static_state = [{k: v.clone() for k, v in st.items()} for st in state]
-                if xs.size(0) == 1 and getattr(self, "_carry_plans", None) is not None:
-                    # one stream, fused step: the conv module's input buffer lives across steps (cache rows in front)
-                    for st in static_state:
-                        cnn = st.get("cnn")
-                        if cnn is not None and cnn.dim() == 3 and decoding_chunk_size >= cnn.size(2) > 0:
-                            cx = cnn.new_zeros(1, cnn.size(2) + decoding_chunk_size, cnn.size(1))
-                            cx[:, :cnn.size(2)] = cnn.transpose(1, 2)
-                            st["cx"] = cx
-                graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     y_static, new_state = self.forward_chunk_carry(static_in, 0, static_state, in_place=True)
                     for st, nw in zip(static_state, new_state):
                         if nw is not st:            # (the fused step updates its carries where they lie)
                             for k in st:
                                 st[k].copy_(nw[k])
+            except RuntimeError as e:
+                # only "this step cannot be captured here" (an operation the stream capture refuses) falls back to the eager
+                # loop -- nothing ran during the failed capture, so `state` is still the state after the warm-up windows;
+                # any other error is a real one and is raised
+                torch.cuda.synchronize(xs.device)
+                if "captur" not in str(e).lower():
+                    raise
+                graph = None
+            if graph is not None:                   # errors from here on are genuine kernel / launch errors: not swallowed
                 for c in full[warm:]:
                     static_in.copy_(xs[:, c:c + window])
                     graph.replay()
@@ -282,8 +315,6 @@ class BaseEncoder(torch.nn.Module):
                     if cx is not None:
                         st["cnn"] = cx[:, :st["cnn"].size(2)].transpose(1, 2).contiguous()
                 state = static_state
-            except Exception:   # capture unsupported here: the remaining windows run eagerly from the current state
-                torch.cuda.synchronize(xs.device)
         for c in starts[done:]:
             eager(c)
         return torch.cat(outs, 1)

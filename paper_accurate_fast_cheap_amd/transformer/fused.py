@@ -59,7 +59,7 @@ class LayerPlan:
                                                                     L.norm_ff_macaron.weight, L.norm_ff_macaron.bias, L.norm_ff.weight,
                                                                     L.norm_ff.bias, L.norm_conv.weight, L.norm_conv.bias,
                                                                     L.feed_forward_macaron.w_1.bias, L.feed_forward.w_1.bias]
-        return tuple((p.data_ptr(), p._version, p.dtype) for p in ps if p is not None)
+        return (hip_ops.param_epoch(),) + tuple((p.data_ptr(), p._version, p.dtype) for p in ps if p is not None)
 
     def refresh(self):
         stamp = self._current_stamp()

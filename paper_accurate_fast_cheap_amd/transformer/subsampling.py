@@ -41,18 +41,23 @@ class Conv2dSubsampling4(BaseSubsampling):
         B, T, Fd = x.shape
         C = c1.out_channels
         T1, F1 = (T - 3) // 2 + 1, (Fd - 3) // 2 + 1
-        stamp = (lin.weight.data_ptr(), lin.weight._version, c2.weight.data_ptr(), c2.weight._version, x.dtype)
+        from ..hip_ops import param_epoch
+        stamp = (lin.weight.data_ptr(), lin.weight._version, c2.weight.data_ptr(), c2.weight._version, x.dtype, param_epoch())
         if getattr(self, "_nhwc_stamp", None) != stamp:
             Fo = lin.in_features // C
             self._w_lin = lin.weight.detach().view(-1, C, Fo).permute(0, 2, 1).reshape(-1, Fo * C).contiguous()
             self._w_c2 = c2.weight.detach().contiguous(memory_format=torch.channels_last)
             self._w_c2_taps = c2.weight.detach().permute(2, 3, 0, 1).reshape(9, C, C).contiguous()   # (tap, co, ci)
-            self._w_c2_split = self._w_c2_3 = None
+            self._w_c2_split = self._w_c2_3 = self._w_lin_3 = None
             if x.dtype == torch.float32 and c2.weight.dtype == torch.float32:
                 from ..hip_ops import split_bf16, split_planes
                 self._w_c2_split = split_bf16(self._w_c2_taps)
                 if C % 128 == 0:
                     self._w_c2_3 = split_planes(self._w_c2_taps, triple=True)          # (9, C, 3C) = [hi | hi | lo] per tap
+                    if lin.weight.dtype == torch.float32 and self._w_lin.shape[1] % 128 == 0:
+                        # the planes of the DERIVED tensor live and die with it, here, under the same stamp (a cache keyed on
+                        # the object would see a new `_w_lin` with `_version` 0 after every weight update)
+                        self._w_lin_3 = split_planes(self._w_lin, triple=True)
             self._nhwc_stamp = stamp
         if x.dtype == torch.bfloat16 and C % 128 == 0 and 256 % (C // 8) == 0:
             # conv1 + ReLU: write-bound direct kernel (its output is the largest tensor of the whole pass);
@@ -69,9 +74,10 @@ class Conv2dSubsampling4(BaseSubsampling):
             from .. import hip_ops
             T2 = ((T - 3) // 2 + 1 - 3) // 2 + 1
             F2 = ((Fd - 3) // 2 + 1 - 3) // 2 + 1
-            if B * T2 >= hip_ops._SPLIT_GEMM_MIN_ROWS and lin.out_features >= 256 and lin.out_features % 8 == 0:
+            if (B * T2 >= hip_ops._SPLIT_GEMM_MIN_ROWS and lin.out_features >= 256 and lin.out_features % 8 == 0
+                    and self._w_lin_3 is not None):
                 y = hip_ops.conv_sub_f32split_planes(x.contiguous(), c1.weight, c1.bias, self._w_c2_3, c2.bias)
-                return hip_ops.gemm_ph_ex(y.view(B * T2, F2 * 2 * C), hip_ops.split_weight_cached(self._w_lin), lin.bias, a_split=True,
+                return hip_ops.gemm_ph_ex(y.view(B * T2, F2 * 2 * C), self._w_lin_3, lin.bias, a_split=True,
                                           out_kind="f32", a_plane_block=C).view(B, T2, lin.out_features)
         if x.dtype == torch.float32 and self._w_c2_split is not None and C % 128 == 0 and 256 % (C // 8) == 0:
             # fp32 model: both convolutions on the bf16 matrix cores with hi + lo split operands (fp32 accumulation,

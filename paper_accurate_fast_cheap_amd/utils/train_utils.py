@@ -143,6 +143,7 @@ def train_step(model: torch.nn.Module, batch: dict, optimizer: torch.optim.Optim
                     optimizer.step()
                     info["updated"] = True
         info["grad_norm"] = grad_norm.detach()
+        hip_ops.bump_param_epoch()              # the parameters may have moved (fused optimizers leave Tensor._version alone)
         optimizer.zero_grad(set_to_none=True)
         if scheduler is not None:
             scheduler.step()

@@ -333,6 +333,66 @@ def test_gemm_skinny_streaming_chunk_shapes(hip, M, N, K, Z, act):
     torch.testing.assert_close(buf.cpu().float(), lin + bb + r.float(), **tol)
 
 
+@pytest.mark.parametrize("M", [64, 78, 16, 1])
+def test_gemm_skinny_embedding_linear_k9728_vs_fp32(hip, M):
+    """The chunk step's Linear(9728, 512) behind the subsampling (K split over eight waves, 304 K-steps) on the few-rows
+    kernel, element-wise against the fp32 product of the same bf16 operands -- the largest K the kernel serves."""
+    from paper_accurate_fast_cheap_amd.hip_ops import chunk_step, gemm_skinny, skinny_ok
+    from tests import parity_log
+    bf, K, N = torch.bfloat16, 9728, 512
+    with chunk_step():
+        assert skinny_ok(M, N, K)                  # the chunk step's dispatch sends this shape to the few-rows kernel
+    a = F.relu(synth.randn((M, K), 11)).to(bf).cuda()                  # conv2's ReLU output: half zeros, non-negative
+    w = (synth.randn((N, K), 12) / K ** 0.5).to(bf).cuda()
+    b = (synth.randn((N,), 13) * 0.2).to(bf).cuda()
+    got = gemm_skinny(a, w, b, "none")
+    want = F.linear(a.float(), w.float(), b.float())
+    d = (got.float() - want).abs()
+    tol = 2 ** -7 * want.abs() + 1e-2
+    parity_log.record(f"gemm_skinny K=9728 M={M}", max_abs_err=float(d.max()), mean_abs_err=float(d.mean()),
+                      worst_err_over_tol=float((d / tol).max()), want_abs_max=float(want.abs().max()))
+    assert got.shape == (M, N) and bool((d <= tol).all()), float(d.max())
+    assert float(d.mean()) <= 2 ** -9 * float(want.abs().mean()) + 1e-4     # rounding of the output only: no K-split loss
+
+
+@pytest.mark.parametrize("B,T", [(1, 64), (8, 64), (2, 37)])
+def test_gemm_skinny_mix_and_norm_producers_at_c512_vs_fp32(hip, B, T):
+    """The two operand PRODUCERS of the chunk step at the model's width (C = 512) against fp32 torch, not against other
+    kernels: MIX -- token shift (carried frame in front) + first lerp + tanh(. W1), src/model.py:274-277 -- and NRM --
+    silu(LayerNorm(.)) as pointwise_conv2's operand, convolution.py:136-141.  Reference rounding points (every op rounds to
+    bf16) restated here in torch."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_skinny
+    from tests import parity_log
+    bf, C = torch.bfloat16, 512
+    r16 = lambda t: t.to(bf).float()
+    x = synth.randn((B, T, C), 21, 1.3).to(bf)
+    prev = synth.randn((B, 1, C), 22, 1.3).to(bf)
+    maa = torch.rand(C, generator=torch.Generator().manual_seed(23)).to(bf)
+    w1 = (synth.randn((128, C), 24) * 0.08).to(bf)                      # time_maa_rkvw_w1^T
+    xc = torch.cat([prev, x], 1).float()
+    xx = r16(xc[:, :-1] - xc[:, 1:])                                     # model.py:274  xx = shift(x) - x
+    xxx = r16(x.float() + r16(xx * maa.float()))                         # model.py:276
+    want = torch.tanh(F.linear(xxx, w1.float())).view(B * T, 128)        # model.py:277 (fp32 product of the bf16 operand)
+    got = gemm_skinny(x.view(B * T, C).cuda(), w1.cuda(), None, "tanh", mix_maa=maa.cuda(), mix_prev=prev.cuda(), mix_T=T)
+    d = (got.float().cpu() - want).abs()
+    parity_log.record(f"gemm_skinny MIX producer C=512 B={B} T={T}", max_abs_err=float(d.max()), mean_abs_err=float(d.mean()))
+    assert float(d.max()) <= 2 ** -7 + 4e-3 and float(d.mean()) <= 1.5e-3, (float(d.max()), float(d.mean()))
+    # NRM
+    M = B * T
+    a = (synth.randn((M, C), 25, 1.7) + 0.4).to(bf)
+    gamma = (1 + 0.2 * synth.randn((C,), 26)).to(bf)
+    beta = (0.1 * synth.randn((C,), 27)).to(bf)
+    w = (synth.randn((C, C), 28) / C ** 0.5).to(bf)
+    b = (synth.randn((C,), 29) * 0.2).to(bf)
+    res = synth.randn((M, C), 30).to(bf)
+    exact = F.linear(F.silu(F.layer_norm(a.float(), (C,), gamma.float(), beta.float(), 1e-5)), w.float(), b.float()) + res.float()
+    got = gemm_skinny(a.cuda(), w.cuda(), b.cuda(), residual=res.cuda(), norm_silu=(gamma.cuda(), beta.cuda(), 1e-5))
+    d = (got.float().cpu() - exact).abs()
+    parity_log.record(f"gemm_skinny NRM producer C=512 M={M}", max_abs_err=float(d.max()), mean_abs_err=float(d.mean()))
+    torch.testing.assert_close(got.float().cpu(), exact, rtol=2 ** -6, atol=4e-2)
+    assert float(d.mean()) <= 6e-3
+
+
 @pytest.mark.parametrize("M", [64, 78, 3, 150])
 def test_gemm_skinny_glu_strided_rows_and_errors(hip, M):
     """act "glu" on the module's own (2C, K) weight (value rows then gate rows); strided operands; refused shapes."""
@@ -901,6 +961,48 @@ def test_conv_sub_split_operand_planes(hip, B, T, C):
     out = gemm_ph_ex(y.view(Bt * Tp, Fp * 2 * C), split_planes(wl, triple=True), bl, a_split=True, out_kind="f32", a_plane_block=C)
     want = F.linear(ref.reshape(Bt * Tp, Fp * C).double(), wl.double(), bl.double())
     torch.testing.assert_close(out.double(), want, rtol=2e-4, atol=2e-4)
+
+
+def test_subsampling_f32_long_form_follows_weight_updates(hip, monkeypatch):
+    """The fp32 long-form front end keeps derived copies of its weights (NHWC taps, permuted Linear weight and their split
+    planes).  Updating the module's weights -- through load_state_dict / copy_ (visible to Tensor._version) AND behind the
+    version counter's back the way a fused optimizer does, followed by eval() -- must be followed by the next call; twice in
+    a row, so that a freed derived tensor's id / storage coming back cannot resurrect an old entry."""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    from paper_accurate_fast_cheap_amd.transformer.embedding import RelPositionalEncoding
+    from paper_accurate_fast_cheap_amd.transformer.subsampling import Conv2dSubsampling4
+    monkeypatch.setattr(hip_ops, "_SPLIT_GEMM_MIN_ROWS", 256)
+    C = 256
+    torch.manual_seed(3)
+    m = Conv2dSubsampling4(80, C, 0.0, RelPositionalEncoding(C, 0.0)).cuda().eval()
+    x = synth.randn((1, 4 * 300 + 7, 80), 48, 2.0).cuda()
+    mask = torch.ones(1, 1, x.size(1), dtype=torch.bool, device="cuda")
+    seen = []
+    real = hip_ops.gemm_ph_ex
+    monkeypatch.setattr(hip_ops, "gemm_ph_ex", lambda *a, **k: (seen.append(1), real(*a, **k))[1])
+
+    def ref():
+        y = F.relu(F.conv2d(F.relu(F.conv2d(x.unsqueeze(1), m.conv[0].weight, m.conv[0].bias, stride=2)), m.conv[2].weight,
+                            m.conv[2].bias, stride=2))
+        b, c, t, f = y.shape
+        return F.linear(y.transpose(1, 2).reshape(b, t, c * f), m.out[0].weight, m.out[0].bias) * C ** 0.5
+    with torch.no_grad():
+        for update in ("none", "copy_", "data", "copy_", "data"):
+            if update == "copy_":
+                m.out[0].weight.copy_(torch.randn_like(m.out[0].weight) / 70)
+                m.conv[2].weight.copy_(torch.randn_like(m.conv[2].weight) / 48)
+            elif update == "data":       # what a fused optimizer does: no version bump ...
+                v = m.out[0].weight._version
+                m.out[0].weight.data.mul_(-0.5)
+                m.conv[2].weight.data.mul_(1.5)
+                assert m.out[0].weight._version == v
+                m.train()
+                m.eval()
+                hip_ops.bump_param_epoch()   # ... the encoder's train() / eval() or train_step does this
+            got, _, _ = m(x, mask)
+            want = ref()
+            torch.testing.assert_close(got, want, rtol=3e-4, atol=3e-4 * float(want.abs().max()))
+    assert len(seen) == 5                 # the split-operand long-form path served every call
 
 
 @pytest.mark.parametrize("M", [700, 5000])

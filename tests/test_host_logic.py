@@ -198,3 +198,33 @@ def test_few_rows_gemm_is_scoped_to_a_chunk_step():
             pass
         assert hip_ops.skinny_ok(64, 512, 512)
     assert not hip_ops.skinny_ok(64, 512, 512)
+
+
+def test_inference_plans_follow_fused_optimizer_updates():
+    """Derived weight copies of the inference plans are keyed on (storage, Tensor._version) AND the parameter epoch: a fused
+    optimizer moves parameters without touching `_version` (checked here), so without the epoch a CV pass after a training
+    step would multiply the old weights.  train() / eval() and train_step's optimizer step bump it."""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    from paper_accurate_fast_cheap_amd.transformer.fused import LayerPlan
+    g = load_golden("encoder_reduced_f32")
+    enc = ConformerEncoder(80, **g["conf"]).eval()
+    layer = enc.encoders[0]
+    plan = LayerPlan(layer)
+    wo = layer.self_attn.rwkv_wrapper_forward.tmix_block.output.weight
+    b2 = layer.feed_forward.w_2.bias
+    assert torch.equal(plan.Wo[:, :128], wo * 0.5) and torch.equal(plan.b2, b2 * layer.ff_scale)
+    enc.train()
+    opt = torch.optim.Adam(enc.parameters(), lr=0.05, fused=True)
+    v0 = wo._version
+    for p in enc.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    assert wo._version == v0                         # the hazard: the update is invisible to the version counter
+    assert not torch.equal(plan.Wo[:, :128], wo.detach() * 0.5)
+    enc.eval()                                       # mode switch = new parameter epoch
+    plan.refresh()
+    assert torch.equal(plan.Wo[:, :128], wo.detach() * 0.5) and torch.equal(plan.b2, b2.detach() * layer.ff_scale)
+    e0 = hip_ops.param_epoch()
+    hip_ops.bump_param_epoch()
+    assert hip_ops.param_epoch() == e0 + 1

@@ -1,0 +1,194 @@
+"""The streaming leg (BASELINE configs[2]: forward_chunk, recurrent-state carry) against the REFERENCE, not against itself.
+
+`causal: true` + the uni-directional slot is the configuration the state-carrying stream runs.  Everything here compares the
+HIP path with (a) goldens captured from the reference's own classes for that configuration (tests/golden/make_goldens_r4.py:
+ConvolutionModule(causal=True) with and without cache; ConformerEncoder forward / forward_chunk with cnn_cache /
+forward_chunk_by_chunk) and (b) the CPU oracle's WHOLE-SEQUENCE forward, which a stream with carried (token shift, WKV
+state, conv cache) must reproduce: the reference has no state carry (rwkv_wrapper.py:81), so "chunked == whole sequence of
+the reference" is the definition (wkv6state_cuda.cu:6-65 is the specification of the carried state).  GPU only."""
+import pytest
+import torch
+
+from oracle import encoder_oracle as EO
+from tests import parity_log, synth
+from tests.conftest import load_golden
+from tests.test_encoder_gpu import _assert_close, _sd, _token_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", ["k15_f32", "k15_bf16", "k31_f32", "k31_bf16"])
+def test_conv_module_causal_vs_reference_golden(hip, case):
+    """ConvolutionModule(causal=True), convolution.py:49-60,113-126: masked ragged batch without cache; one stream in three
+    pieces with the cache handed on; the whole stream -- outputs to tolerance, caches exact (they are the input itself)."""
+    from paper_accurate_fast_cheap_amd.transformer.convolution import ConvolutionModule
+    c = load_golden("conv_module_causal")["cases"][case]
+    bf = case.endswith("bf16")
+    k = c["kernel"]
+    m = ConvolutionModule(128, k, torch.nn.SiLU(), "layer_norm", True)
+    m.load_state_dict(_sd(c))
+    m = m.to(torch.bfloat16 if bf else torch.float32).cuda().eval()
+    assert m.lorder == k - 1
+    mask = (torch.arange(c["xb"].size(1))[None, :] < c["lens"][:, None]).unsqueeze(1).cuda()
+    with torch.no_grad():
+        yb, cb = m(c["xb"].cuda(), mask)
+        _assert_close(yb, c["yb"], bf, f"conv_module_causal/{case}/batch")
+        assert torch.equal(cb.cpu(), c["cb"])
+        cache = torch.zeros((0, 0, 0), device="cuda")
+        empty = torch.ones((0, 0, 0), dtype=torch.bool, device="cuda")
+        for (a, b), want in zip(zip(c["cuts"][:-1], c["cuts"][1:]), c["pieces"]):
+            y, cache = m(c["xs"][:, a:b].cuda(), empty, cache)
+            _assert_close(y, want["y"], bf, f"conv_module_causal/{case}/piece{a}")
+            assert torch.equal(cache.cpu(), want["new_cache"])
+        whole, cw = m(c["xs"].cuda())
+        _assert_close(whole, c["whole"], bf, f"conv_module_causal/{case}/whole")
+        assert torch.equal(cw.cpu(), c["whole_cache"])
+
+
+def _causal_encoder(c, prec):
+    from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    enc = ConformerEncoder(80, **c["conf"])
+    enc.load_state_dict(_sd(c))                       # strict: the reference's keys, nothing extra
+    ctc = CTC(50, 128)
+    ctc.load_state_dict(synth.synth_state_dict(c["ctc_spec"], c["ctc_seed"]))
+    if prec == "bf16model":
+        enc, ctc = enc.to(torch.bfloat16), ctc.to(torch.bfloat16)
+    return enc.cuda().eval(), ctc.cuda().eval()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("prec", ["f32", "bf16slot", "bf16model"])
+def test_encoder_causal_uni_vs_reference_golden(hip, prec, fused):
+    """The reduced encoder with rwkv_tmix60 + causal: true against the reference: forward() (ragged batch, per layer, CTC
+    tokens), forward_chunk() with the cnn_cache of one call handed to the next (encoder.py:311-337), forward_chunk_by_chunk()
+    -- fused executor and module path."""
+    from paper_accurate_fast_cheap_amd.transformer.search import ctc_greedy_search
+    g = load_golden("encoder_causal_uni")
+    c = g["cases"][prec]
+    enc, ctc = _causal_encoder(c, prec)
+    enc.fused_inference = fused
+    bf, wm = prec != "f32", prec == "bf16model"
+    dt = torch.bfloat16 if wm else torch.float32
+    xs, long = g["xs"].to(dt).cuda(), g["long"].to(dt).cuda()
+    tag = f"encoder_causal_uni/{prec}/{'fused' if fused else 'module'}"
+
+    def close(a, b, what):
+        _assert_close(a, b, bf, f"{tag}/{what}", whole_model_bf16=wm)
+    with torch.no_grad():
+        out, masks, layers = enc.forward_return_layers(xs, g["lens"].cuda(), want_layers=True)
+        assert torch.equal(masks.cpu(), c["masks"]) and out.dtype == c["out"].dtype
+        close(layers[0], c["layer0"], "layer0")
+        close(layers[1], c["layer1"], "layer1")
+        close(out, c["out"], "out")
+        logp = ctc.log_softmax(out)
+        ours = [r.tokens for r in ctc_greedy_search(logp.float(), masks.squeeze(1).sum(1), 0)]
+        if not bf:
+            assert ours == c["greedy"]
+        else:
+            flips = _token_parity(logp, c["logp_full"], masks.squeeze(1), 0.07, tag)
+            if flips == 0:
+                assert ours == c["greedy"]
+        whole, _ = enc(long, torch.tensor([long.size(1)], device="cuda"))
+        close(whole, c["whole"], "whole")
+        y0, a0, c0 = enc.forward_chunk(long[:, 0:35], 0, -1)
+        y1, a1, c1 = enc.forward_chunk(long[:, 32:67], 8, -1, a0, c0)
+        for (y, a, cc), want, n in (((y0, a0, c0), c["chunk0"], 0), ((y1, a1, c1), c["chunk1"], 1)):
+            assert tuple(a.shape) == want["att_shape"] and cc.shape == want["cnn"].shape == (2, 1, 128, 14)
+            close(y, want["y"], f"forward_chunk{n}")
+            close(cc, want["cnn"], f"cnn_cache{n}")
+        for chunk, want in c["chunks"].items():
+            ys, m = enc.forward_chunk_by_chunk(long, chunk, -1)
+            assert torch.equal(m.cpu(), want["masks"])
+            close(ys, want["ys"], f"chunk_by_chunk{chunk}")
+
+
+@pytest.mark.parametrize("chunk", [8, 16])
+@pytest.mark.parametrize("prec", ["f32", "bf16slot", "bf16model"])
+def test_state_carry_stream_vs_reference_whole_sequence(hip, prec, chunk):
+    """stream_chunks (eager and replayed from the captured hipGraph; chunk 16 >= lorder takes the in-place conv-input buffer)
+    against the REFERENCE's whole-sequence forward of the same utterance (golden `whole`, and the oracle recomputed here):
+    fp32 to the 1e-3 bar, the bf16 modes to the bounds of the reduced headline test (max 0.18 / mean 1.4e-2)."""
+    g = load_golden("encoder_causal_uni")
+    c = g["cases"][prec]
+    enc, _ = _causal_encoder(c, prec)
+    wm = prec == "bf16model"
+    dt = torch.bfloat16 if wm else torch.float32
+    long = g["long"].to(dt).cuda()
+    sd = _sd(c)
+    if wm:
+        sd = {k: v.bfloat16() for k, v in sd.items()}
+    ref, _ = EO.encoder_forward(g["long"].to(dt), torch.tensor([long.size(1)]), sd, c["conf"], env={})
+    with torch.no_grad():
+        enc.fused_inference = True
+        eager = enc.stream_chunks(long, chunk, use_graph=False)
+        replayed = enc.stream_chunks(long, chunk, use_graph=True)
+        if wm:
+            assert getattr(enc, "_carry_plans", None) is not None        # the fused chunk step (gemm_skinny & co) really ran
+    assert eager.shape == replayed.shape == ref.shape == c["whole"].shape
+    for name, got in (("eager", eager), ("graph", replayed)):
+        for rname, want in (("golden", c["whole"]), ("oracle", ref)):
+            d = (got.float().cpu() - want.float()).abs()
+            parity_log.record(f"streaming/reduced {prec} chunk {chunk} {name} vs whole-sequence {rname}",
+                              max_abs_err=float(d.max()), mean_abs_err=float(d.mean()))
+            if prec == "f32":
+                tol = 1e-3 * want.float().abs().clamp_min(5e-2)
+                assert bool((d <= tol).all()), (name, rname, float(d.max()))
+            else:
+                assert float(d.max()) <= 0.18 and float(d.mean()) <= 1.4e-2, (name, rname, float(d.max()), float(d.mean()))
+
+
+def test_state_carry_stream_full_size_sixty_seconds_vs_oracle(hip):
+    """The bench's streaming leg at FULL size: the 12 x 512 uni-directional encoder (causal conv, k = 15), whole-model bf16,
+    60 s of audio streamed in 64-frame chunks with state carry from the captured hipGraph -- against the matched-precision
+    oracle's whole-sequence forward (every op rounds to bf16) and the exact model (same bf16-valued parameters, fp32
+    arithmetic), element-wise and by CTC token."""
+    import bench
+    from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    conf = bench.encoder_conf()
+    conf.update(selfattention_layer_type="rwkv_tmix60", rnn_att_direction="uni", causal=True, cnn_module_kernel=15)
+    torch.manual_seed(777)
+    enc = ConformerEncoder(80, **conf).eval()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.02)
+            if ".norm_" in n and n.endswith("weight"):
+                p.uniform_(0.7, 1.3)           # the chunk step folds gamma / beta into its projections: make them matter
+            if ".norm_" in n and n.endswith("bias"):
+                p.normal_(0, 0.1)
+    ctc = CTC(200, 512).eval()
+    xs = synth.randn((1, 6000, 80), 906, 2.0).to(torch.bfloat16)
+    lens = torch.tensor([6000])
+    sd_b = {k: v.detach().to(torch.bfloat16) for k, v in enc.state_dict().items()}
+    csd_b = {"ctc." + k: v.detach().to(torch.bfloat16) for k, v in ctc.state_dict().items()}
+    ref, _ = EO.encoder_forward(xs, lens, sd_b, conf, env={})
+    assert ref.dtype == torch.bfloat16
+    ref_logp = EO.ctc_log_softmax(ref, csd_b)
+    exact, _ = EO.encoder_forward(xs.float(), lens, {k: v.float() for k, v in sd_b.items()},
+                                  dict(conf, rwkv_do_bfloat16=False), env={})
+    encb, ctcb = enc.to(torch.bfloat16).cuda().eval(), ctc.to(torch.bfloat16).cuda().eval()
+    with torch.no_grad():
+        encb.fused_inference = True
+        out = encb.stream_chunks(xs.cuda(), 64, use_graph=True)
+        assert getattr(encb, "_carry_plans", None) is not None
+        eager = encb.stream_chunks(xs.cuda(), 64, use_graph=False)
+        logp = ctcb.log_softmax(out)
+    assert out.shape == ref.shape == (1, 1499, 512)
+    o, r, x = out.float().cpu()[0], ref.float()[0], exact[0]
+    d_ref, e_hip, e_ref = (o - r).abs(), (o - x).abs(), (r - x).abs()
+    d_eg = (out.float() - eager.float()).abs()
+    parity_log.record("streaming/full-size 12-layer uni bf16, 60 s in 64-frame chunks (graph) vs whole-sequence oracle",
+                      vs_matched_oracle_max=float(d_ref.max()), vs_matched_oracle_mean=float(d_ref.mean()),
+                      hip_vs_exact_max=float(e_hip.max()), hip_vs_exact_mean=float(e_hip.mean()),
+                      oracle_bf16_vs_exact_max=float(e_ref.max()), oracle_bf16_vs_exact_mean=float(e_ref.mean()),
+                      graph_vs_eager_max=float(d_eg.max()), graph_vs_eager_mean=float(d_eg.mean()))
+    print(f"[streaming full size] vs matched oracle max {float(d_ref.max()):.4g} mean {float(d_ref.mean()):.4g}; vs exact: HIP "
+          f"{float(e_hip.max()):.4g} / {float(e_hip.mean()):.4g}, oracle-bf16 {float(e_ref.max()):.4g} / {float(e_ref.mean()):.4g}")
+    # the 12-layer bounds of the headline comparison (tests/test_encoder_gpu.py:_bf16_headline)
+    assert float(d_ref.mean()) <= 3.6e-2 and float(d_ref.max()) <= 0.4
+    assert float(e_hip.mean()) <= 1.1 * float(e_ref.mean()) + 1e-3
+    assert float(e_hip.max()) <= 1.5 * float(e_ref.max()) + 1e-2
+    valid = torch.ones(1, 1499, dtype=torch.bool)
+    _token_parity(logp, ref_logp, valid, 0.25, "streaming full-size 60 s vs matched-precision whole-sequence oracle")
