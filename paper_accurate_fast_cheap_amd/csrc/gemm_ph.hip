@@ -672,8 +672,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
                             o[6] += __uint_as_float(rr[i][nj][RLD - 1].z); o[7] += __uint_as_float(rr[i][nj][RLD - 1].w);
                         }
                         if constexpr (LNF == 2) {
+                            // statistics of the row AS STORED (rounded to bf16, the very conversion store8 performs): the
+                            // consumer multiplies the stored rows, and mean / rstd must be those of what it multiplies
+                            float q[8];
+                            unpack8(u32x4p{pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])}, q);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) { st1 += o[e]; st2 = fmaf(o[e], o[e], st2); }
+                            for (int e = 0; e < 8; ++e) { st1 += q[e]; st2 = fmaf(q[e], q[e], st2); }
                         }
                     }
                     store8(o, live, row, col);
