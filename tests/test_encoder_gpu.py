@@ -336,8 +336,9 @@ def _decisive_head_token_checks(out, ref, exact, valid, what):
         tok_x, tok_h, tok_r = lp_x.argmax(-1), lp_hip.argmax(-1), lp_ref.argmax(-1)
         fer_h = float(((tok_h != tok_x) & valid).sum()) / n
         fer_r = float(((tok_r != tok_x) & valid).sum()) / n
-        e_h = ((lp_hip - lp_x).abs().max(-1).values * valid)
-        e_r = ((lp_ref - lp_x).abs().max(-1).values * valid)
+        nv = len(rows)                                           # (the padding rows sit at -60: never candidates, and a bf16
+        e_h = ((lp_hip - lp_x)[..., :nv].abs().max(-1).values * valid)    # log-prob of that size is quantised to 0.25)
+        e_r = ((lp_ref - lp_x)[..., :nv].abs().max(-1).values * valid)
         und = lambda e: float(((margin <= 2 * e) & valid).sum()) / n
         changes = int(((tok_x[:, 1:] != tok_x[:, :-1]) & valid[:, 1:]).sum())
         parity_log.record(f"decisive head n={npc}/{what}", vocab=len(rows), frames=int(n), exact_token_changes=changes,
