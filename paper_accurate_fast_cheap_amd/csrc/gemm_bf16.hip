@@ -17,6 +17,7 @@
 // bf16 otherwise -- and leave as whole 256-byte rows.
 // (Tried and measured, not kept: a persistent tile loop that prefetches the next tile's first K-step across the
 // epilogue -- 177 vs 165 us on the FFN shape: the wait for the prefetch also waits for the tile's output stores.)
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "pafc_common.h"
@@ -57,10 +58,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // EPI: 0 = plain (bf16 staging), 1 = residual (fp32 staging), 2 = GLU (the tile's columns [0, 64) are values, [64, 128)
 // the gates of the same 64 output channels; the output has N / 2 columns)
-template <int EPI>
+// BM x BN = the block's tile: 128 x 128 (two blocks per CU), or -- for the few-thousand-row problems whose 128 x 128 tiles
+// would leave half the CUs idle (a batch of 2 000-frame windows, 16-64 concurrent streams, a c2 decode batch) -- 128 x 64 or
+// 64 x 64: same loop, the wave's share of the tile shrinks (MI x NI MFMA tiles of 16 x 16), more tiles fill the chip.
+template <int EPI, int BM = GBM, int BN = GBN>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     constexpr bool HAS_RES = EPI == 1;
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];   // [2 stages][A 128x64 | W 128x64] (64 KiB)
+    constexpr int MI = BM / 32, NI = BN / 32;      // 16 x 16 MFMA tiles per wave along m / n (2 x 2 waves)
+    static_assert(EPI != 2 || (BM == 128 && BN == 128), "GLU: value | gate blocks of 64 columns need the 128 x 128 tile");
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];   // [2 stages][A BM x 64 | W BN x 64] (64 KiB at 128 x 128)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int z = blockIdx.y;
@@ -70,42 +76,46 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     const long per = nblk / 8;
     if (bid < per * 8) bid = (bid % 8) * per + bid / 8;   // XCD-aware order; the tail keeps its id
     const int mt0 = (int)(bid / p.ntiles), nt0 = (int)(bid % p.ntiles);
-    const long m0 = (long)mt0 * GBM;
-    const int n0 = nt0 * GBN;
+    const long m0 = (long)mt0 * BM;
+    const int n0 = nt0 * BN;
 
     const bf16_t *Az = p.A + z * p.sA, *Wz = p.W + z * p.sW;
     const int sub = lane >> 3, pch = lane & 7;
-    const bf16_t *a_src[4];
-    const bf16_t *w_src[4];
+    const bf16_t *a_src[MI];                               // a wave stages BM / 4 rows of A and BN / 4 rows of W, 8 per instruction
+    const bf16_t *w_src[NI];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wave * 32 + j * 8 + sub;
+    for (int j = 0; j < MI; ++j) {
+        const int row = wave * (BM / 4) + j * 8 + sub;
         const int c = pch ^ (row & 7);
         long m = m0 + row;
         if (m >= p.M) m = p.M - 1;                          // clamp: the row is computed but never stored
         a_src[j] = Az + m * p.lda + 8 * c;
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int row = wave * (BN / 4) + j * 8 + sub;
+        const int c = pch ^ (row & 7);
         const int n = min(n0 + row, p.N - 1);               // N tail: clamped rows feed columns that are never stored
         w_src[j] = Wz + (long)n * p.ldw + 8 * c;
     }
     const int iters = p.K / GBK;
+    constexpr int STAGE = (BM + BN) * GBK;                  // elements per stage
 
     auto issue = [&](int it, int buf) {
-        bf16_t *A = lds + buf * (2 * GBM * GBK);
-        bf16_t *Wt = A + GBM * GBK;
+        bf16_t *A = lds + buf * STAGE;
+        bf16_t *Wt = A + BM * GBK;
         const int koff = it * GBK;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rowbase = (wave * 32 + j * 8) * GBK;
-            gdma16(a_src[j] + koff, A + rowbase);
-            gdma16(w_src[j] + koff, Wt + rowbase);
-        }
+        for (int j = 0; j < MI; ++j) gdma16(a_src[j] + koff, A + (wave * (BM / 4) + j * 8) * GBK);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) gdma16(w_src[j] + koff, Wt + (wave * (BN / 4) + j * 8) * GBK);
     };
 
-    f32x4g acc[4][4];
+    f32x4g acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4g{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4g{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, kq = lane >> 4;
     issue(0, 0);
@@ -113,25 +123,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (it + 1 < iters) issue(it + 1, (it + 1) & 1);
-        const bf16_t *A = lds + (it & 1) * (2 * GBM * GBK);
-        const bf16_t *Wt = A + GBM * GBK;
+        const bf16_t *A = lds + (it & 1) * STAGE;
+        const bf16_t *Wt = A + BM * GBK;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8g af[4], wf[4];
+            bf16x8g af[MI], wf[NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wm * 64 + i * 16 + fr;
+            for (int i = 0; i < MI; ++i) {
+                const int row = wm * (BM / 2) + i * 16 + fr;
                 af[i] = *reinterpret_cast<const bf16x8g *>(A + row * GBK + (((ks * 4 + kq) ^ (row & 7)) * 8));
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wn * 64 + j * 16 + fr;
+            for (int j = 0; j < NI; ++j) {
+                const int row = wn * (BN / 2) + j * 16 + fr;
                 wf[j] = *reinterpret_cast<const bf16x8g *>(Wt + row * GBK + (((ks * 4 + kq) ^ (row & 7)) * 8));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -141,23 +151,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     const bf16_t *bz = p.bias ? p.bias + z * p.sB : nullptr;
     bf16_t *Oz = p.out + z * p.sO;
     if constexpr (HAS_RES) {
-        constexpr int LDF = GBN + 4;   // fp32 staging [128][132] = 66 KiB
+        constexpr int LDF = BN + 4;   // fp32 staging [BM][BN + 4] (66 KiB at 128 x 128)
         float *O = reinterpret_cast<float *>(lds);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = wn * 64 + j * 16 + fr;
+        for (int j = 0; j < NI; ++j) {
+            const int col = wn * (BN / 2) + j * 16 + fr;
             const float bv = bz ? bf16_bits_to_f32(bz[min(n0 + col, p.N - 1)]) : 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    O[(wm * 64 + i * 16 + 4 * kq + g) * LDF + col] = apply_act(fmaf(acc[i][j][g], p.alpha, bv), p.act);
+                    O[(wm * (BM / 2) + i * 16 + 4 * kq + g) * LDF + col] = apply_act(fmaf(acc[i][j][g], p.alpha, bv), p.act);
         }
         __syncthreads();
         const bf16_t *Rz = p.res + z * p.sR;
+        constexpr int CPR = BN / 8, RPP = 256 / CPR;       // 16-byte chunks per row, rows per pass of the 256 threads
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int row = q * 16 + (tid >> 4), c8 = (tid & 15) * 8;
+        for (int q = 0; q < BM / RPP; ++q) {
+            const int row = q * RPP + tid / CPR, c8 = (tid % CPR) * 8;
             const long m = m0 + row;
             if (m < p.M && n0 + c8 < p.N) {
                 const uint4 rq = *reinterpret_cast<const uint4 *>(Rz + m * p.ldr + n0 + c8);
@@ -220,23 +231,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
                 *reinterpret_cast<uint4 *>(Oz + m * p.ldo + oc0 + c8) = *reinterpret_cast<const uint4 *>(O + row * LDH + c8);
         }
     } else {
-        constexpr int LDO = GBN + 8;
-        bf16_t *O = lds;   // [128][136] bf16 = 34 KiB
+        constexpr int LDO = BN + 8;
+        bf16_t *O = lds;   // [BM][BN + 8] bf16 (34 KiB at 128 x 128)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = wn * 64 + j * 16 + fr;
+        for (int j = 0; j < NI; ++j) {
+            const int col = wn * (BN / 2) + j * 16 + fr;
             const float bv = bz ? bf16_bits_to_f32(bz[min(n0 + col, p.N - 1)]) : 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    O[(wm * 64 + i * 16 + 4 * kq + g) * LDO + col] =
+                    O[(wm * (BM / 2) + i * 16 + 4 * kq + g) * LDO + col] =
                         (bf16_t)f32_to_bf16_bits(apply_act(fmaf(acc[i][j][g], p.alpha, bv), p.act));
         }
         __syncthreads();
+        constexpr int CPR = BN / 8, RPP = 256 / CPR;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int row = q * 16 + (tid >> 4), c8 = (tid & 15) * 8;
+        for (int q = 0; q < BM / RPP; ++q) {
+            const int row = q * RPP + tid / CPR, c8 = (tid % CPR) * 8;
             const long m = m0 + row;
             if (m < p.M && n0 + c8 < p.N)
                 *reinterpret_cast<uint4 *>(Oz + m * p.ldo + n0 + c8) = *reinterpret_cast<const uint4 *>(O + row * LDO + c8);
@@ -309,24 +321,36 @@ extern "C" int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, lo
     p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr;
     p.sA = strideA; p.sW = strideW; p.sO = strideO; p.sB = strideBias; p.sR = strideR;
     p.alpha = alpha; p.act = act;
-    p.mtiles = (int)((M + pafc::GBM - 1) / pafc::GBM);
-    p.ntiles = (N + pafc::GBN - 1) / pafc::GBN;
+    // tile: 128 x 128 while its tiles give every CU one; below that 128 x 64, then 64 x 64 (a few thousand rows: a batch of
+    // 2 000-frame windows, 16-64 streams, a short c2 batch) -- more, smaller tiles instead of idle CUs.  GLU keeps 128 x 128.
+    const long cus = pafc::device_cus();
+    auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)batch; };
+    int bm = 128, bn = 128;
+    if (!glu && tiles(128, 128) < cus) {
+        if (tiles(128, 64) >= cus || N <= 64) bn = 64;
+        else { bm = 64; bn = 64; }
+    }
+    if (const char *e = getenv("PAFC_GEMM_TILE")) {          // A/B runs: "128x128", "128x64", "64x64"
+        if (!glu && sscanf(e, "%dx%d", &bm, &bn) == 2 && !((bm == 128 && (bn == 128 || bn == 64)) || (bm == 64 && bn == 64))) {
+            bm = 128; bn = 128;
+        }
+    }
+    p.mtiles = (int)((M + bm - 1) / bm);
+    p.ntiles = (N + bn - 1) / bn;
     const long nblk = (long)p.mtiles * p.ntiles;
     if (nblk > 0x7fffffffL) return PAFC_ERR_BAD_DIMS;
     const dim3 grid((unsigned)nblk, (unsigned)batch);
     hipStream_t s = (hipStream_t)stream;
-    if (residual) {
-        const size_t lds = (size_t)pafc::GBM * (pafc::GBN + 4) * sizeof(float);   // 66 KiB (>= the 64 KiB of the stages)
-        if (hipFuncSetAttribute((const void *)pafc::gemm_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return PAFC_ERR_LAUNCH;
-        hipLaunchKernelGGL(pafc::gemm_bf16_kernel<1>, grid, dim3(256), lds, s, p);
-    } else {
-        const size_t lds = 2 * 2 * pafc::GBM * pafc::GBK * sizeof(pafc::bf16_t);       // 64 KiB
-        auto kern = glu ? pafc::gemm_bf16_kernel<2> : pafc::gemm_bf16_kernel<0>;
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return PAFC_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
-    }
+    const size_t stage_bytes = 2 * (size_t)(bm + bn) * pafc::GBK * sizeof(pafc::bf16_t);          // 64 KiB at 128 x 128
+    const size_t res_bytes = (size_t)bm * (bn + 4) * sizeof(float);                                // fp32 staging of the epilogue
+    const size_t lds = residual ? (res_bytes > stage_bytes ? res_bytes : stage_bytes) : stage_bytes;
+    typedef void (*kern_t)(const pafc::GemmParams);
+    kern_t kern;
+    if (glu) kern = pafc::gemm_bf16_kernel<2>;
+    else if (residual) kern = bm == 64 ? pafc::gemm_bf16_kernel<1, 64, 64> : bn == 64 ? pafc::gemm_bf16_kernel<1, 128, 64> : pafc::gemm_bf16_kernel<1>;
+    else kern = bm == 64 ? pafc::gemm_bf16_kernel<0, 64, 64> : bn == 64 ? pafc::gemm_bf16_kernel<0, 128, 64> : pafc::gemm_bf16_kernel<0>;
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PAFC_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }

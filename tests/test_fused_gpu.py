@@ -288,6 +288,36 @@ def test_gemm_bf16_hand_written(hip, M, N, K, Z, act):
     torch.testing.assert_close(buf.cpu().float(), lin + bb + r.float(), **tol)
 
 
+@pytest.mark.parametrize("tile", ["128x128", "128x64", "64x64", "auto"])
+@pytest.mark.parametrize("M,N,K,Z,act", [(3992, 512, 2048, 1, "none"), (3992, 2048, 512, 1, "silu"), (2056, 512, 512, 6, "none"),
+                                         (1235, 512, 1024, 1, "tanh"), (4160, 64, 512, 2, "none"), (999, 520, 192, 1, "relu")])
+def test_gemm_bf16_tile_variants_mid_rows(hip, monkeypatch, tile, M, N, K, Z, act):
+    """The 128 x 128 kernel's tile variants (128 x 64, 64 x 64: a few thousand rows -- a batch of 2 000-frame windows, 16-64
+    streams -- would leave CUs idle on 128 x 128 tiles), each forced through PAFC_GEMM_TILE and as the dispatcher picks them,
+    plain and residual epilogues, against the fp32 product of the same bf16 operands."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_bf16
+    if tile != "auto":
+        monkeypatch.setenv("PAFC_GEMM_TILE", tile)
+    bf = torch.bfloat16
+    shp = (lambda *s: (Z,) + s) if Z > 1 else (lambda *s: s)
+    a = synth.randn(shp(M, K), 1).to(bf).cuda()
+    w = (synth.randn(shp(N, K), 2) / K ** 0.5).to(bf).cuda()
+    b = (synth.randn(shp(N), 3) * 0.2).to(bf).cuda()
+    r = synth.randn(shp(M, N), 4).to(bf).cuda()
+    f = {"none": lambda t: t, "silu": F.silu, "tanh": torch.tanh, "relu": F.relu}[act]
+    lin = torch.matmul(a.float(), w.float().transpose(-1, -2))
+    bb = b.float().unsqueeze(-2) if Z > 1 else b.float()
+    tol = dict(rtol=2 ** -7, atol=1e-2)
+    torch.testing.assert_close(gemm_bf16(a, w, b, act).float(), f(lin + bb), **tol)
+    torch.testing.assert_close(gemm_bf16(a, w, None, act, alpha=0.5, residual=r).float(), f(0.5 * lin) + r.float(), **tol)
+    # nothing is written past the matrix: rows beyond M of a larger buffer keep their sentinel
+    buf = torch.full(shp(M + 70, N), 7.0, dtype=bf, device="cuda")
+    view = buf[..., :M, :]
+    if Z == 1:
+        gemm_bf16(a, w, b, act, out=view)
+        assert bool((buf[M:] == 7.0).all())
+
+
 def test_gemm_bf16_strided_rows_and_errors(hip):
     from paper_accurate_fast_cheap_amd._lib import PafcError
     from paper_accurate_fast_cheap_amd.hip_ops import gemm_bf16
