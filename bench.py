@@ -234,17 +234,6 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     args = ap.parse_args()
 
-    if args.workload == "c2":
-        # ~90 distinct (B, T) shapes: MIOpen's default exhaustive per-shape search costs seconds each; the
-        # immediate-mode heuristic is the production setting for ragged batches
-        os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
-        if (args.streams or 2) > 1:
-            # several decode batches in flight: half-full grids of the big-tile GEMM run side by side, so it takes over from
-            # the 128 x 128 kernel earlier, and the hand-written kernels take over from the library at fewer rows (measured,
-            # profiles/r03c_bench_c2_knobs.txt)
-            os.environ.setdefault("PAFC_PH_MIN_FILL", "25")
-            os.environ.setdefault("PAFC_OWN_GEMM_MIN_ROWS", "2048")
-            os.environ.setdefault("PAFC_LDS_RESIDENT_MIN_ROWS", "2048")
     one_gpu = os.environ.get("PAFC_BENCH_ONE_GPU") == "1"   # rehearsal of the N > 1 code path on a single-GPU box
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         have = torch.cuda.device_count()           # counts devices without initialising the GPU

@@ -61,7 +61,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // BM x BN = the block's tile: 128 x 128 (two blocks per CU), or -- for the few-thousand-row problems whose 128 x 128 tiles
 // would leave half the CUs idle (a batch of 2 000-frame windows, 16-64 concurrent streams, a c2 decode batch) -- 128 x 64 or
 // 64 x 64: same loop, the wave's share of the tile shrinks (MI x NI MFMA tiles of 16 x 16), more tiles fill the chip.
-template <int EPI, int BM = GBM, int BN = GBN>
+// NST = LDS stages: 2 for 128 x 128 (two blocks of 64 KiB per CU), 3 for the smaller tiles -- a few-thousand-row problem
+// with a long K (w_2: 32 K-steps) is bound by the latency of each K-step's operands, one more step in flight hides it.
+template <int EPI, int BM = GBM, int BN = GBN, int NST = 2>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     constexpr bool HAS_RES = EPI == 1;
     constexpr int MI = BM / 32, NI = BN / 32;      // 16 x 16 MFMA tiles per wave along m / n (2 x 2 waves)
@@ -119,11 +121,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 
     const int fr = lane & 15, kq = lane >> 4;
     issue(0, 0);
+    if constexpr (NST == 3) { if (iters > 1) issue(1, 1); }
     for (int it = 0; it < iters; ++it) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (it + 1 < iters) issue(it + 1, (it + 1) & 1);
-        const bf16_t *A = lds + (it & 1) * STAGE;
+        if constexpr (NST == 3) {
+            // stage `it` has landed when at most the next stage's loads are outstanding (loads complete in order)
+            if (it + 1 < iters) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI + NI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                   // everyone is done reading stage it - 1 = the buffer of it + 2
+            if (it + 2 < iters) issue(it + 2, (it + 2) % 3);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (it + 1 < iters) issue(it + 1, (it + 1) & 1);
+        }
+        const bf16_t *A = lds + (NST == 3 ? it % 3 : (it & 1)) * STAGE;
         const bf16_t *Wt = A + BM * GBK;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -274,10 +285,10 @@ static int ph_tile_m(long M, int N, int K, int batch, int act, bool has_residual
     if (has_residual && act != 0) return 0;
     const int cus = pafc::device_cus();
     const long nt = (N + 255) / 256;
-    // too few big tiles: the small-tile kernel fills the chip better.  PAFC_PH_MIN_FILL (percent of the CUs, default 75)
-    // moves the line for A/B runs: with several independent batches in flight on streams of their own (bench.py --streams)
-    // half-full grids of the big-tile kernel run side by side
-    static const long min_fill = [] { const char *e = getenv("PAFC_PH_MIN_FILL"); const long v = e ? atol(e) : 75; return v > 0 ? v : 75; }();
+    // too few big tiles: the small-tile kernel fills the chip better.  PAFC_PH_MIN_FILL (percent of the CUs the 256-wide tiles
+    // must cover, default 45) moves the line for A/B runs: a c2 pass (ragged decode batches, two in flight on streams of their
+    // own) measured 75 / 45 / 25 / 15 within 1.5 % of each other (profiles/r03c_bench_c2_knobs.txt)
+    static const long min_fill = [] { const char *e = getenv("PAFC_PH_MIN_FILL"); const long v = e ? atol(e) : 45; return v > 0 ? v : 45; }();
     if (((M + 255) / 256) * nt * batch * 100 < (long)cus * min_fill) return 0;
     long best_cost = -1;
     int best = 0;
@@ -325,9 +336,11 @@ extern "C" int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, lo
     // 2 000-frame windows, 16-64 streams, a short c2 batch) -- more, smaller tiles instead of idle CUs.  GLU keeps 128 x 128.
     const long cus = pafc::device_cus();
     auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)batch; };
+    // the largest tile that still gives two tiles per CU (two blocks are co-resident and cover each other's barriers); measured
+    // at 1 024 - 8 192 rows on every layer shape: profiles/r04d_gemm_mid_rows_own_tiles_vs_library.txt
     int bm = 128, bn = 128;
-    if (!glu && tiles(128, 128) < cus) {
-        if (tiles(128, 64) >= cus || N <= 64) bn = 64;
+    if (!glu && tiles(128, 128) < 2 * cus) {
+        if (tiles(128, 64) >= 2 * cus) bn = 64;
         else { bm = 64; bn = 64; }
     }
     if (const char *e = getenv("PAFC_GEMM_TILE")) {          // A/B runs: "128x128", "128x64", "64x64"
@@ -341,14 +354,15 @@ extern "C" int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, lo
     if (nblk > 0x7fffffffL) return PAFC_ERR_BAD_DIMS;
     const dim3 grid((unsigned)nblk, (unsigned)batch);
     hipStream_t s = (hipStream_t)stream;
-    const size_t stage_bytes = 2 * (size_t)(bm + bn) * pafc::GBK * sizeof(pafc::bf16_t);          // 64 KiB at 128 x 128
+    const int nst = (bm == 128 && bn == 128) ? 2 : 3;
+    const size_t stage_bytes = (size_t)nst * (bm + bn) * pafc::GBK * sizeof(pafc::bf16_t);        // 64 KiB at 128 x 128
     const size_t res_bytes = (size_t)bm * (bn + 4) * sizeof(float);                                // fp32 staging of the epilogue
     const size_t lds = residual ? (res_bytes > stage_bytes ? res_bytes : stage_bytes) : stage_bytes;
     typedef void (*kern_t)(const pafc::GemmParams);
     kern_t kern;
     if (glu) kern = pafc::gemm_bf16_kernel<2>;
-    else if (residual) kern = bm == 64 ? pafc::gemm_bf16_kernel<1, 64, 64> : bn == 64 ? pafc::gemm_bf16_kernel<1, 128, 64> : pafc::gemm_bf16_kernel<1>;
-    else kern = bm == 64 ? pafc::gemm_bf16_kernel<0, 64, 64> : bn == 64 ? pafc::gemm_bf16_kernel<0, 128, 64> : pafc::gemm_bf16_kernel<0>;
+    else if (residual) kern = bm == 64 ? pafc::gemm_bf16_kernel<1, 64, 64, 3> : bn == 64 ? pafc::gemm_bf16_kernel<1, 128, 64, 3> : pafc::gemm_bf16_kernel<1>;
+    else kern = bm == 64 ? pafc::gemm_bf16_kernel<0, 64, 64, 3> : bn == 64 ? pafc::gemm_bf16_kernel<0, 128, 64, 3> : pafc::gemm_bf16_kernel<0>;
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PAFC_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);

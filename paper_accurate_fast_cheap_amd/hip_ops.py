@@ -12,6 +12,59 @@ from . import _lib
 from ._lib import c_int, c_void_p
 
 
+# ---- dispatch thresholds: ONE table ---------------------------------------------------------------------------------------
+# Which kernel family serves a projection depends on how many rows it has.  Every threshold lives here, with the record that
+# justifies it; `PAFC_DISPATCH="name=value,name=value"` overrides any of them for A/B runs (the per-name variables of earlier
+# rounds -- PAFC_OWN_GEMM_MIN_ROWS, PAFC_LDS_RESIDENT_MIN_ROWS, PAFC_SPLIT_GEMM_MIN_ROWS, PAFC_SKINNY_MAX_ROWS,
+# PAFC_GEMM_TUNE_MIN_ROWS -- are still read).  bench.py sets none of them: what it measures is this table.
+#
+#   name                   default  meaning, and where the number comes from
+#   skinny_max_rows            640  bf16 projections of a streaming chunk step with at most this many rows run on
+#                                   csrc/gemm_skinny.hip (one launch on the ~4.7 us floor).  8 streams x 78 rows still win over
+#                                   tiled kernels, 16 lose: profiles/r03g_streaming_streams_vs_few_rows_limit.txt
+#   own_gemm_min_rows            1  bf16 projections with at least this many rows (that are not few-rows launches) run on the
+#                                   hand-written tiled GEMMs (gemm_ph.hip 256-wide tiles when they fill the chip, else
+#                                   gemm_bf16.hip 128 x 128 / 128 x 64 / 64 x 64).  Was 8192 while the small kernel only had
+#                                   128 x 128 tiles; with the tile variants it ties or beats the library's picks from 1 024
+#                                   rows up on every layer shape but w_2 (K = 2048: 14.5 vs 10.5 us at 1 024 rows, 20.7 vs
+#                                   17.4 at 3 992) and wins the stacked r/k/v product by 5-7 us:
+#                                   profiles/r04d_gemm_mid_rows_own_tiles_vs_library.txt.  No library GEMM is left in a bf16 pass.
+#   lds_resident_min_rows     2048  the one-pass LoRA kernels (128 KiB of weights staged into LDS per block) from this many
+#                                   rows on, below it shift/lerp + small GEMMs; the chunk step always takes the one-pass
+#                                   kernels (fewer launches).  c2 sweep: profiles/r03c_bench_c2_knobs.txt (2048 best of
+#                                   2048 / 4096 / 8192)
+#   split_gemm_min_rows      16384  fp32 activations on the bf16 matrix cores as hi + lo planes (3 MFMAs per product, ~2^-16
+#                                   relative) from this many rows on; below it the library's exact fp32 products, which is
+#                                   also what the 1e-3 parity tests of short inputs run: DESIGN section 4 "split operands"
+#   ln_fold_min_rows         24576  unmasked bf16 inputs of at least this many rows take the schedule with three LayerNorms
+#                                   folded into the 256-wide GEMMs either side of them (needs full grids of 256 x 256 tiles:
+#                                   3 x the row count at which they fill the chip): profiles/r03d / r03e
+#   gemm_tune_min_rows       32768  library (fp32) GEMMs of at least this many rows measure the library's candidates once
+#                                   (explicit plan objects; never under graph capture): DESIGN section 4, round-1 fault
+# C side (csrc/gemm_bf16.hip): PAFC_PH_MIN_FILL (percent of the CUs the 256-wide tiles must cover before the 256-wide kernel
+# takes a problem; default 45, c2 sweep 75 / 45 / 25 / 15 within 1.5 % of each other) and PAFC_GEMM_TILE (force a tile of the
+# small kernel) are A/B switches of the kernels themselves.
+DISPATCH = dict(skinny_max_rows=640, own_gemm_min_rows=1, lds_resident_min_rows=2048, split_gemm_min_rows=16384,
+                ln_fold_min_rows=24576, gemm_tune_min_rows=32768)
+
+
+def _load_dispatch():
+    legacy = dict(skinny_max_rows="PAFC_SKINNY_MAX_ROWS", own_gemm_min_rows="PAFC_OWN_GEMM_MIN_ROWS",
+                  lds_resident_min_rows="PAFC_LDS_RESIDENT_MIN_ROWS", split_gemm_min_rows="PAFC_SPLIT_GEMM_MIN_ROWS",
+                  gemm_tune_min_rows="PAFC_GEMM_TUNE_MIN_ROWS")
+    for name, env in legacy.items():
+        if os.environ.get(env):
+            DISPATCH[name] = int(os.environ[env])
+    for item in filter(None, os.environ.get("PAFC_DISPATCH", "").split(",")):
+        name, _, value = item.partition("=")
+        if name.strip() not in DISPATCH:
+            raise ValueError(f"PAFC_DISPATCH: unknown threshold {name!r} (known: {sorted(DISPATCH)})")
+        DISPATCH[name.strip()] = int(value)
+
+
+_load_dispatch()
+
+
 def train_kernels_enabled() -> bool:
     """PAFC_TRAIN_KERNELS=0: the training step differentiates through the framework's own operators (A/B measurements)."""
     import os
@@ -718,7 +771,7 @@ class _LinearPlans:
         import threading
         self.lock = threading.Lock()
         self.tune = os.environ.get("PAFC_GEMM_TUNE", "1") != "0"
-        self.tune_min_rows = int(os.environ.get("PAFC_GEMM_TUNE_MIN_ROWS", "32768"))
+        self.tune_min_rows = DISPATCH["gemm_tune_min_rows"]
 
     def get(self, key):
         plan = self.plans.get(key)
@@ -808,7 +861,7 @@ def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
 
 # fp32 GEMMs of long inputs run on the bf16 matrix cores with split operands (csrc/gemm_ph.hip: three bf16 products per fp32
 # product, fp32 accumulation, ~2^-16 relative); shorter ones keep the library's exact fp32 kernels.
-_SPLIT_GEMM_MIN_ROWS = int(os.environ.get("PAFC_SPLIT_GEMM_MIN_ROWS", "16384"))
+_SPLIT_GEMM_MIN_ROWS = DISPATCH["split_gemm_min_rows"]
 _split_weights = {}      # id(weight) -> (stamp, [hi | hi | lo] planes, weakref to the weight); bounded
 
 # Derived copies of parameters (stacked / transposed / split / LayerNorm-folded weights of the inference plans) are keyed on
@@ -843,9 +896,6 @@ def split_weight_cached(weight: torch.Tensor) -> torch.Tensor:
     return ent[1]
 
 
-_LONG_K_OWN_MIN_ROWS = int(os.environ.get("PAFC_LONG_K_OWN_MIN_ROWS", "8192"))
-
-
 def linear_fused(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: str = "none") -> torch.Tensor:
     """act(x @ weight.T + bias) with the epilogue fused: bf16 operands on the hand-written GEMM (K % 64 == 0, N % 8 == 0),
     long fp32 inputs on the same kernel with split operands, anything else on the library GEMM."""
@@ -854,11 +904,6 @@ def linear_fused(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     if (x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_cuda and weight.is_contiguous()
             and skinny_ok(rows, N, K) and act != "glu"):         # a streaming chunk: the few-rows kernel
         return gemm_skinny(x.reshape(-1, K), weight, bias, act).view(x.shape[:-1] + (N,))
-    if (x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_cuda and K >= 4096 and N <= 1024
-            and SKINNY_MAX_ROWS < rows < _LONG_K_OWN_MIN_ROWS and act in ("none", "silu")):
-        # a long K over a few thousand rows (Linear(9728, 512) behind the subsampling of 16-64 streams or of a batch of
-        # 2 000-frame windows): too few 128 x 128 tiles to fill the chip and 152 K-steps each -- the library splits K
-        return linear_bias_act(x, weight, bias, act)
     if x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and K % 64 == 0 and N % 8 == 0:
         return gemm_bf16(x.reshape(-1, K), weight, bias, act).view(x.shape[:-1] + (N,))
     if (x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_cuda and K % 128 == 0 and N % 8 == 0 and N >= 256
@@ -886,10 +931,10 @@ def tmix_lora_mix4(x: torch.Tensor, t: torch.Tensor, w2t: torch.Tensor, maa: tor
     return z
 
 
-# The one-pass LoRA kernels stage 128 KiB of weights into LDS per block: worth it from a few thousand rows on (30-minute
+# The one-pass LoRA kernels stage 128 KiB of weights into LDS per block: worth it from a couple of thousand rows on (30-minute
 # file: 45 k rows, a c2 batch: ~16 k) and, as ONE launch instead of two or three, in the launch-bound streaming chunk step
-# (`one_pass=True`, fused.layer_forward_carry); in between the small-GEMM path.  PAFC_LDS_RESIDENT_MIN_ROWS overrides (tests, A/B).
-_LDS_RESIDENT_MIN_ROWS = int(os.environ.get("PAFC_LDS_RESIDENT_MIN_ROWS", "8192"))
+# (`one_pass=True`, fused.layer_forward_carry); below it the small-GEMM path (DISPATCH table at the top of this file).
+_LDS_RESIDENT_MIN_ROWS = DISPATCH["lds_resident_min_rows"]
 
 
 def tmix_lora_down(x: torch.Tensor, maa_x: torch.Tensor, w1n: torch.Tensor, reverse0: bool = False,
@@ -1056,7 +1101,7 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
     return out
 
 
-SKINNY_MAX_ROWS = int(os.environ.get("PAFC_SKINNY_MAX_ROWS", "640"))     # above (measured: 8 streams of 64-frame chunks still win, 16 lose): the library
+SKINNY_MAX_ROWS = DISPATCH["skinny_max_rows"]      # (the table at the top of this file)
 
 
 _chunk_step = threading.local()

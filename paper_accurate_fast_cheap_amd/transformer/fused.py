@@ -188,16 +188,19 @@ def eligible(layer: nn.Module) -> bool:
             and layer.size % 8 == 0 and layer.size <= 1024)
 
 
-# Below this many rows the library's small-problem kernels (split-K, narrow tiles) win: a streaming chunk step of 65 rows per
-# stream measured 2.1 ms on the library against 2.8 ms on the 128 x 128 hand-written tiles, 64 streams (4 160 rows) 4.2 vs 4.7.
-_OWN_GEMM_MIN_ROWS = int(os.environ.get("PAFC_OWN_GEMM_MIN_ROWS", "8192"))
+# bf16 projections with at least this many rows run on the hand-written tiled GEMMs (hip_ops.DISPATCH: since the small kernel has
+# 128 x 64 / 64 x 64 tile variants that is every row count that is not a few-rows launch of a chunk step); unmasked inputs of
+# at least _LN_FOLD_MIN_ROWS rows take the folded-LayerNorm schedule.
+_OWN_GEMM_MIN_ROWS = hip_ops.DISPATCH["own_gemm_min_rows"]
+_LN_FOLD_MIN_ROWS = hip_ops.DISPATCH["ln_fold_min_rows"]
 
 
 def _own_gemm(x: torch.Tensor, w: torch.Tensor) -> bool:
-    """bf16 projections of long inputs run on the hand-written GEMM (csrc/gemm_ph.hip / gemm_bf16.hip); short ones (streaming
-    chunks) and fp32 ones on the library."""
-    return (x.dtype == torch.bfloat16 and w.shape[-1] % 64 == 0 and w.shape[-2] % 8 == 0
-            and x.numel() // w.shape[-1] >= _OWN_GEMM_MIN_ROWS)
+    """bf16 projections run on the hand-written GEMMs (csrc/gemm_ph.hip / gemm_bf16.hip) -- except the few rows of a
+    streaming chunk step (csrc/gemm_skinny.hip, asked first); fp32 ones on the library or as split operands."""
+    rows = x.numel() // w.shape[-1]
+    return (x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.shape[-1] % 64 == 0 and w.shape[-2] % 8 == 0
+            and rows >= _OWN_GEMM_MIN_ROWS and not hip_ops.skinny_ok(rows, w.shape[-2], w.shape[-1]))
 
 
 def _skinny(x: torch.Tensor, w: torch.Tensor, glu: bool = False) -> bool:
@@ -260,10 +263,10 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
         for d in range(nd):
             torch.bmm(t[d].view(M, 4, -1).transpose(0, 1), plan.W2[d], out=m[d])
         z = hip_ops.tmix_mix4(h, m, plan.maa4)                                              # (4, nd, M, C)
-    if own_gemm and M >= _OWN_GEMM_MIN_ROWS:     # short inputs: the library's small-problem kernels, as in proj()
-        rkv = hip_ops.gemm_bf16(z[:3].view(3 * nd, M, C), plan.Wrkv_n)                      # (3nd, M, C), one launch
-    elif own_gemm and hip_ops.skinny_ok(M, C, C):  # a chunk step: the few-rows kernel
+    if own_gemm and hip_ops.skinny_ok(M, C, C):  # a chunk step: the few-rows kernel
         rkv = hip_ops.gemm_skinny(z[:3].view(3 * nd, M, C), plan.Wrkv_n)
+    elif own_gemm and M >= _OWN_GEMM_MIN_ROWS:
+        rkv = hip_ops.gemm_bf16(z[:3].view(3 * nd, M, C), plan.Wrkv_n)                      # (3nd, M, C), one launch
     else:
         rkv = torch.bmm(z[:3].view(3 * nd, M, C), plan.Wrkv)
     if own_gemm:
@@ -360,7 +363,7 @@ def lnfold_eligible(plan: LayerPlan, x: torch.Tensor, lens: Optional[torch.Tenso
     """Long unmasked bf16 inputs (the 30-minute file, equal-length windows): enough rows for the 256-wide tiles to fill
     the chip; a ragged batch keeps the LayerNorm passes (they also apply the padding masks)."""
     return (plan.lnf is not None and lens is None and x.dtype == torch.bfloat16 and x.is_cuda
-            and x.numel() // x.shape[-1] >= 3 * _OWN_GEMM_MIN_ROWS)
+            and x.numel() // x.shape[-1] >= _LN_FOLD_MIN_ROWS)
 
 
 def layer_forward_lnfold(plan: LayerPlan, x: torch.Tensor, st: torch.Tensor, next_norm: Optional[nn.LayerNorm], next_fold: bool):
@@ -408,7 +411,7 @@ def layer_forward_lnfold(plan: LayerPlan, x: torch.Tensor, st: torch.Tensor, nex
 
 
 # fp32 streams shorter than this keep the library's fp32 GEMMs (exact fp32 products; small problems do not fill 256-wide tiles)
-_SPLIT_GEMM_MIN_ROWS = int(os.environ.get("PAFC_SPLIT_GEMM_MIN_ROWS", "16384"))
+_SPLIT_GEMM_MIN_ROWS = hip_ops.DISPATCH["split_gemm_min_rows"]
 
 
 def split_eligible(plan: LayerPlan, x: torch.Tensor) -> bool:
@@ -509,17 +512,17 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict],
         shift = h.new_zeros(B, 1, C)
     elif shift.dtype != h.dtype or not shift.is_contiguous():
         shift = shift.to(h.dtype).contiguous()
-    few = True if M < _OWN_GEMM_MIN_ROWS else None       # launch-bound: one kernel each for the two LoRA chains
+    few = True                                           # the chunk step is launch-bound: one kernel each for the two LoRA chains
     sk = h.dtype == torch.bfloat16 and hip_ops.skinny_ok(M, C, C)     # a handful of rows: the few-rows GEMM and its fusions
     if sk:   # token shift + lerp as the operand producer of the down-projection (one ~5 us launch)
         t = hip_ops.gemm_skinny(h.view(M, C), plan.W1n[0], None, "tanh", mix_maa=plan.maa_x_n[0], mix_prev=shift, mix_T=T).view(1, M, -1)
     else:
         t = hip_ops.tmix_lora_down(h, plan.maa_x_n, plan.W1n, prev=shift, one_pass=few)
     z = hip_ops.tmix_lora_mix4(h, t, plan.W2t, plan.maa4, prev=shift)                         # (4, 1, M, C)
-    if M >= _OWN_GEMM_MIN_ROWS:
-        rkv = hip_ops.gemm_bf16(z[:3].view(3, M, C), plan.Wrkv_n).view(3, B, T, C)
-    elif hip_ops.skinny_ok(M, C, C):
+    if hip_ops.skinny_ok(M, C, C):
         rkv = hip_ops.gemm_skinny(z[:3].view(3, M, C), plan.Wrkv_n).view(3, B, T, C)
+    elif M >= _OWN_GEMM_MIN_ROWS:
+        rkv = hip_ops.gemm_bf16(z[:3].view(3, M, C), plan.Wrkv_n).view(3, B, T, C)
     else:
         rkv = torch.bmm(z[:3].view(3, M, C), plan.Wrkv).view(3, B, T, C)
     # (the decay chain and the r / k / v projections are independent, but as two branches of the captured graph -- a second HIP
