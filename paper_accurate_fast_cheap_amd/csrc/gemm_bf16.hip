@@ -286,9 +286,10 @@ static int ph_tile_m(long M, int N, int K, int batch, int act, bool has_residual
     const int cus = pafc::device_cus();
     const long nt = (N + 255) / 256;
     // too few big tiles: the small-tile kernel fills the chip better.  PAFC_PH_MIN_FILL (percent of the CUs the 256-wide tiles
-    // must cover, default 45) moves the line for A/B runs: a c2 pass (ragged decode batches, two in flight on streams of their
-    // own) measured 75 / 45 / 25 / 15 within 1.5 % of each other (profiles/r03c_bench_c2_knobs.txt)
-    static const long min_fill = [] { const char *e = getenv("PAFC_PH_MIN_FILL"); const long v = e ? atol(e) : 45; return v > 0 ? v : 45; }();
+    // must cover, default 75) moves the line for A/B runs: a c2 pass measured 75 / 45 / 25 / 15 within 1.5 % of each other
+    // (profiles/r03c_bench_c2_knobs.txt); at 3 992 rows (a batch of 2 000-frame windows: 50 % fill) the 128 x 128 kernel takes
+    // w_1 in 18.6 us against 21.1 on half a grid of 256-wide tiles (profiles/r04e_windows_2000x8_kernels_*.txt)
+    static const long min_fill = [] { const char *e = getenv("PAFC_PH_MIN_FILL"); const long v = e ? atol(e) : 75; return v > 0 ? v : 75; }();
     if (((M + 255) / 256) * nt * batch * 100 < (long)cus * min_fill) return 0;
     long best_cost = -1;
     int best = 0;

@@ -29,10 +29,11 @@ from ._lib import c_int, c_void_p
 #                                   rows up on every layer shape but w_2 (K = 2048: 14.5 vs 10.5 us at 1 024 rows, 20.7 vs
 #                                   17.4 at 3 992) and wins the stacked r/k/v product by 5-7 us:
 #                                   profiles/r04d_gemm_mid_rows_own_tiles_vs_library.txt.  No library GEMM is left in a bf16 pass.
-#   lds_resident_min_rows     2048  the one-pass LoRA kernels (128 KiB of weights staged into LDS per block) from this many
+#   lds_resident_min_rows     8192  the one-pass LoRA kernels (128 KiB of weights staged into LDS per block) from this many
 #                                   rows on, below it shift/lerp + small GEMMs; the chunk step always takes the one-pass
-#                                   kernels (fewer launches).  c2 sweep: profiles/r03c_bench_c2_knobs.txt (2048 best of
-#                                   2048 / 4096 / 8192)
+#                                   kernels (fewer launches).  At 3 992 rows the one-pass down-projection takes 27.6 us
+#                                   against 6.0 + 6.5 for the two small kernels (profiles/r04e_windows_2000x8_kernels_*.txt);
+#                                   a c2 pass measured 2048 / 4096 / 8192 within 1 % (profiles/r03c_bench_c2_knobs.txt)
 #   split_gemm_min_rows      16384  fp32 activations on the bf16 matrix cores as hi + lo planes (3 MFMAs per product, ~2^-16
 #                                   relative) from this many rows on; below it the library's exact fp32 products, which is
 #                                   also what the 1e-3 parity tests of short inputs run: DESIGN section 4 "split operands"
@@ -42,9 +43,8 @@ from ._lib import c_int, c_void_p
 #   gemm_tune_min_rows       32768  library (fp32) GEMMs of at least this many rows measure the library's candidates once
 #                                   (explicit plan objects; never under graph capture): DESIGN section 4, round-1 fault
 # C side (csrc/gemm_bf16.hip): PAFC_PH_MIN_FILL (percent of the CUs the 256-wide tiles must cover before the 256-wide kernel
-# takes a problem; default 45, c2 sweep 75 / 45 / 25 / 15 within 1.5 % of each other) and PAFC_GEMM_TILE (force a tile of the
-# small kernel) are A/B switches of the kernels themselves.
-DISPATCH = dict(skinny_max_rows=640, own_gemm_min_rows=1, lds_resident_min_rows=2048, split_gemm_min_rows=16384,
+# takes a problem; default 75) and PAFC_GEMM_TILE (force a tile of the small kernel) are A/B switches of the kernels themselves.
+DISPATCH = dict(skinny_max_rows=640, own_gemm_min_rows=1, lds_resident_min_rows=8192, split_gemm_min_rows=16384,
                 ln_fold_min_rows=24576, gemm_tune_min_rows=32768)
 
 

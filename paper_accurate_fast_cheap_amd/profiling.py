@@ -45,9 +45,14 @@ def op_timer(name: str, sample: int = 1, **meta):
 
 
 def summary():
-    """{name: {"n": launches, "avg_ms": mean device time, "meta": last meta}} -- call after a synchronize."""
+    """{name: {"n": launches, "avg_ms": mean device time, "meta": last meta, "total_ms", "flops_total": sum of the timed
+    launches' meta["flops"] (None when absent), "records": [(ms, meta), ...]}} -- call after a synchronize.  Ragged workloads
+    (every launch another shape) divide the totals; fixed shapes can use avg_ms with the last meta."""
     out = {}
     for name, recs in _records.items():
         ms = [a.elapsed_time(b) for a, b, _ in recs]
-        out[name] = {"n": len(ms), "avg_ms": sum(ms) / len(ms), "meta": recs[-1][2]}
+        fl = [m.get("flops") for _, _, m in recs]
+        out[name] = {"n": len(ms), "avg_ms": sum(ms) / len(ms), "meta": recs[-1][2], "total_ms": sum(ms),
+                     "flops_total": sum(fl) if all(f is not None for f in fl) else None,
+                     "records": [(t, m) for t, (_, _, m) in zip(ms, recs)]}
     return out

@@ -428,7 +428,7 @@ def test_headline_bf16_layernorm_folded_schedule_vs_oracle(hip, monkeypatch):
                 p.normal_(0, 0.1)
     ctc = CTC(200, 512).eval()
     xs = synth.randn((1, 30000, 80), 905, 2.0)
-    monkeypatch.setattr(fused, "_OWN_GEMM_MIN_ROWS", 2048)          # 3 x 2048 < 7 499 rows: the folded schedule is taken
+    monkeypatch.setattr(fused, "_LN_FOLD_MIN_ROWS", 6144)           # < 7 499 rows: the folded schedule is taken
     calls = []
     real = hip_ops.gemm_bf16_ln
     monkeypatch.setattr(hip_ops, "gemm_bf16_ln", lambda *a, **k: (calls.append(1), real(*a, **k))[1])

@@ -3,7 +3,8 @@
 
 Whole-run --stats are dominated by MIOpen's one-off solver search during warm-up (naive_conv_* kernels); the
 steady state is the last step, delimited by the CTC log-softmax kernel that ends each step.
-usage: prof_last_step.py <kernel_trace.csv> [n_top]"""
+usage: prof_last_step.py <kernel_trace.csv> [n_top] [batches_per_step]   (windowed / c2 runs: a step is that many batches,
+each closed by its own log-softmax)"""
 import collections
 import csv
 import sys
@@ -14,7 +15,8 @@ def main():
     top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ends = [r for r in rows if "SoftMaxForward" in r["Kernel_Name"] or "log_softmax_kernel" in r["Kernel_Name"]]
-    t0 = int(ends[-2]["End_Timestamp"]) if len(ends) >= 2 else 0
+    nb = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    t0 = int(ends[-1 - nb]["End_Timestamp"]) if len(ends) > nb else 0
     t1 = int(ends[-1]["End_Timestamp"]) if ends else int(rows[-1]["End_Timestamp"])
     last = [r for r in rows if t0 < int(r["Start_Timestamp"]) and int(r["End_Timestamp"]) <= t1]
     agg = collections.defaultdict(lambda: [0, 0])
