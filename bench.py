@@ -513,14 +513,16 @@ def main():
         mfma = {"peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "kernels": {},
                 "note": None if args.dtype == "bf16" else
                 "f32 model + bf16 slot: every fp32 product is three bf16 MFMAs (hi*hi + lo*hi + hi*lo); `achieved` counts the "
-                "ALGORITHMIC flops (2 K N per row), so a kernel at the matrix peak would read frac = 1/3"}
+                "EXECUTED matrix flops (3 x 2 K N per row), i.e. the matrix cores' utilisation; algorithmic flops are a third"}
         for name, rec in sorted(prof.items()):
             fl = rec["meta"].get("flops") if isinstance(rec.get("meta"), dict) else None
             if fl:
                 tf = fl / (rec["avg_ms"] * 1e-3) / 1e12
                 label = ("subsampling conv2 (hand-written implicit GEMM)" if name == "conv3x3s2"
+                         else "subsampling conv2, split operands (hand-written implicit GEMM, 3 MFMAs per product)" if name == "conv3x3s2_split"
                          else "hand-written GEMM K x N [x batch] = " + name.split("_", 1)[1] if name.startswith("gemm_")
-                         else "library GEMM K x N = " + name.split("_", 1)[1])
+                         else "hand-written split-operand GEMM (3 MFMAs per fp32 product) K x N = " + name.split("_", 1)[1]
+                         if name.startswith("gemm3_") else "library GEMM K x N = " + name.split("_", 1)[1])
                 ent = {"achieved": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
                        "avg_us": round(rec["avg_ms"] * 1e3, 1), "launches": rec["n"]}
                 # the other side of the roofline for the projections of ONE long sequence (c3): the activations cross HBM once
