@@ -131,6 +131,41 @@ def streaming_leg(feats32: torch.Tensor, device, seconds: float = 600.0, chunk: 
             "frames_compared": int(n), "finite": bool(torch.isfinite(y.float()).all())}
 
 
+def streaming_lookahead_leg(feats32: torch.Tensor, device, seconds: float = 300.0, chunk: int = 64):
+    """The same stream on the uni-directional model AS SHIPPED (non-causal conv, k = 31: giga.rwkv_uni_ds4k31nc_12le.*.yaml:14-16):
+    every layer emits 15 frames behind its input (encoder.forward_chunk_lookahead; 12 x 15 frames = 7.2 s behind the audio,
+    exact, nothing recomputed); module path, no graph -- ms per chunk over the second of two passes."""
+    from paper_accurate_fast_cheap_amd.utils.init_model import init_model
+    conf = encoder_conf()
+    conf.update(selfattention_layer_type="rwkv_tmix60", rnn_att_direction="uni", causal=False, cnn_module_kernel=31)
+    configs = dict(encoder="conformer", encoder_conf=conf, input_dim=80, output_dim=VOCAB, ctc="ctc",
+                   ctc_conf={"ctc_blank_id": 0}, model_conf={}, dataset_conf={})
+
+    class A:
+        checkpoint = None
+
+    torch.manual_seed(777)
+    model, _ = init_model(A(), configs)
+    enc = model.eval().to(torch.bfloat16).to(device).encoder
+    x = feats32[:, :int(seconds * 100)].to(device=device, dtype=torch.bfloat16)
+    sub, ctx = enc.embed.subsampling_rate, enc.embed.right_context + 1
+    nchunks = len(range(0, x.shape[1] - ctx + 1, sub * chunk))
+    with torch.no_grad():
+        enc.stream_chunks_lookahead(x, chunk)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        y = enc.stream_chunks_lookahead(x, chunk)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        whole, _ = enc(x, torch.tensor([x.shape[1]], dtype=torch.int32, device=device))
+        diff = (y.float() - whole.float()).abs()
+    return {"workload": f"streaming with state carry, the shipped uni YAML (NON-causal conv k = 31, 15 frames of look-ahead per layer): "
+                        f"{x.shape[1] / 100.0:.0f} s in {chunk}-frame chunks, one stream, bf16, module path",
+            "algorithmic_latency_frames": 15 * len(enc.encoders), "chunks": nchunks, "ms_per_chunk": round(dt * 1e3 / nchunks, 3),
+            "audio_sec_per_sec": round(x.shape[1] / 100.0 / dt, 1), "frames_out": int(y.shape[1]), "frames_whole": int(whole.shape[1]),
+            "max_abs_vs_whole_sequence": round(float(diff.max()), 4), "mean_abs_vs_whole_sequence": round(float(diff.mean()), 5)}
+
+
 def c2_batches(device, dtype, rank: int = 0, world: int = 1):
     """BASELINE configs[1]: 5715 utterances with lengths U[1 s, 20 s] (GigaSpeech DEV size and segment filter),
     cut from one long synthetic signal, sharded by length over the ranks, sorted, decode batches of 64
@@ -598,6 +633,7 @@ def main():
                                 "(hi + lo planes, three bf16 products per fp32 product), bf16 slot"}
         del m2, fb2
         out["extra"]["streaming"] = streaming_leg(feats32, device)
+        out["extra"]["streaming_lookahead"] = streaming_lookahead_leg(feats32, device)
         # BASELINE configs[1] and the paper's window shape, on the package's defaults (no knob is set anywhere in this file)
         out["extra"]["c2"] = c2_leg(model, device)
         out["extra"]["windows_2000x8"] = windows_leg(model, feats32.to(device=device, dtype=torch.bfloat16), device)

@@ -319,6 +319,50 @@ class BaseEncoder(torch.nn.Module):
             eager(c)
         return torch.cat(outs, 1)
 
+    @torch.no_grad()
+    def forward_chunk_lookahead(self, xs: torch.Tensor, state: Optional[list] = None, final: bool = False
+                                ) -> Tuple[torch.Tensor, list]:
+        """Streaming step with state carry for the uni-directional model AS SHIPPED -- non-causal conv module, k = 31
+        (conf/rwkv/giga.rwkv_uni_ds4k31nc_12le.trans-longutts.yaml:14-16) -- where forward_chunk_carry's causal-conv cache
+        does not apply: every layer finalises a frame only when the 15 frames behind it have arrived
+        (ConformerEncoderLayer.forward_lookahead), so layer l runs 15 l frames behind the input and the encoder emits
+        frames 15 x num_blocks (= 180 frames, 7.2 s for 12 layers) behind it; nothing is recomputed, nothing approximated:
+        over a whole stream the concatenated outputs equal forward() of the whole utterance (the reference's own
+        forward_chunk restarts the recurrence per chunk and zero-pads the conv at every chunk edge, encoder.py:231-339).
+        xs: (B, time, F) input window (the windows of forward_chunk_by_chunk; may be None with final=True to drain);
+        returns (the output frames finalised by this call (B, v, D) -- v = 0 while the pipeline fills --, state)."""
+        state = state or [None] * len(self.encoders)
+        if xs is not None:
+            masks = torch.ones(xs.size(0), 1, xs.size(1), device=xs.device, dtype=torch.bool)
+            if self.global_cmvn is not None:
+                xs = self.global_cmvn(xs)
+            xs, _, _ = self.embed(xs, masks, 0)
+        else:
+            ref = state[0]["cu"]
+            xs = ref.new_zeros(ref.size(0), 0, ref.size(2))
+        new_state = []
+        for layer, carry in zip(self.encoders, state):
+            xs, c = layer.forward_lookahead(xs, carry, final)
+            new_state.append(c)
+        if self.normalize_before and xs.size(1) > 0:
+            xs = self.after_norm(xs)
+        return xs, new_state
+
+    @torch.no_grad()
+    def stream_chunks_lookahead(self, xs: torch.Tensor, decoding_chunk_size: int) -> torch.Tensor:
+        """A whole utterance (B, T, F) through forward_chunk_lookahead window by window, drained at the end: (B, T', D), equal
+        to forward() of the utterance."""
+        assert decoding_chunk_size > 0
+        sub, ctx = self.embed.subsampling_rate, self.embed.right_context + 1
+        stride, window = sub * decoding_chunk_size, (decoding_chunk_size - 1) * sub + ctx
+        T = xs.size(1)
+        starts = list(range(0, T - ctx + 1, stride))
+        outs, state = [], None
+        for i, c in enumerate(starts):
+            y, state = self.forward_chunk_lookahead(xs[:, c:min(c + window, T)], state, final=(i == len(starts) - 1))
+            outs.append(y)
+        return torch.cat(outs, 1)
+
     def _windows_independent(self, xs: torch.Tensor):
         """The fused plan when the windows of forward_chunk_by_chunk do not depend on each other: recurrent slot (its
         att_cache stays empty), a non-causal conv module (its cnn_cache stays empty) and a positional encoding that

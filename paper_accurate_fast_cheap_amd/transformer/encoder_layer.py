@@ -112,3 +112,57 @@ class ConformerEncoderLayer(nn.Module):
         if self.conv_module is not None:
             x = self.norm_final(x)
         return x, new
+
+    def forward_lookahead(self, x: torch.Tensor, carry: Optional[dict], final: bool = False) -> Tuple[torch.Tensor, dict]:
+        """One chunk WITH state carry for the model the reference ships for the uni-directional slot: a NON-causal conv module
+        (conf/rwkv/giga.rwkv_uni_ds4k31nc_12le.trans-longutts.yaml:14-16: cnn_module_kernel 31, `# causal: true` commented
+        out), whose depthwise convolution reads (k - 1) / 2 = 15 frames either side of a frame (convolution.py:56-60,128).
+        Streaming it exactly means each layer EMITS 15 frames behind what it has received: the macaron FFN and the slot run on
+        the new frames at once (they look back only), the conv branch finalises the frames whose right context has arrived,
+        the second FFN and norm_final follow those.  x: (B, m, C) new frames (m may be 0); carry: {"shift", "wkv"} as
+        forward_carry plus "cu" -- the depthwise convolution's input (GLU output) of the last <= k - 1 frames, starting as
+        (k - 1) / 2 zero frames = the module's own left padding -- and "x2" -- the residual stream behind the slot for the
+        frames not yet emitted.  final: the stream ends: (k - 1) / 2 zero frames of right padding drain the layer.
+        Returns (the frames finalised by this call (B, v, C), new carry); over a whole stream the concatenated outputs equal
+        the layer's whole-sequence forward."""
+        from ..hip_ops import depthwise_conv1d_cl, linear
+        from ..rwkv_v6.rwkv_wrapper import RWKV_TmixWrapper
+        slot, cm = self.self_attn, self.conv_module
+        if type(slot) is not RWKV_TmixWrapper or not self.normalize_before or cm is None or cm.lorder > 0 or not cm.use_layer_norm:
+            raise NotImplementedError("look-ahead carry: uni-directional slot, pre-norm, non-causal conv module with layer_norm")
+        carry = dict(carry or {})
+        B, m, C = x.shape
+        half = (cm.kernel_size - 1) // 2
+        if "cu" not in carry:
+            carry["cu"] = x.new_zeros(B, half, C)                       # the non-causal module's left zero padding
+            carry["x2"] = x.new_zeros(B, 0, C)
+        if m > 0:
+            if self.feed_forward_macaron is not None:
+                x = x + self.ff_scale * self.feed_forward_macaron(self.norm_ff_macaron(x))
+            h = self.norm_mha(x)
+            qd = h.dtype
+            if slot.do_bfloat16:
+                h = h.to(torch.bfloat16)
+            att, carry["shift"], carry["wkv"] = slot.tmix_block.forward_state(h.contiguous(), carry.get("shift"), carry.get("wkv"))
+            x2 = x + att.to(qd)
+            u = torch.nn.functional.glu(linear(self.norm_conv(x2), cm.pointwise_conv1.weight.squeeze(-1), cm.pointwise_conv1.bias), dim=-1)
+            U = torch.cat([carry["cu"], u], dim=1)
+            X2 = torch.cat([carry["x2"], x2], dim=1)
+        else:
+            U, X2 = carry["cu"], carry["x2"]
+        if final:
+            U = torch.cat([U, U.new_zeros(B, half, C)], dim=1)          # right zero padding
+        v = max(0, U.size(1) - 2 * half)                                # frames whose whole window has arrived
+        assert v <= X2.size(1)
+        if v > 0:
+            dw = depthwise_conv1d_cl(U.contiguous(), cm.depthwise_conv.weight, cm.depthwise_conv.bias, left_pad=0, out_len=v)
+            c = linear(cm.activation(cm.norm(dw)), cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias)
+            y = X2[:, :v] + c
+            y = y + self.ff_scale * self.feed_forward(self.norm_ff(y))
+            y = self.norm_final(y)
+        else:
+            y = x.new_zeros(B, 0, C)
+        keep = min(U.size(1), 2 * half)
+        carry["cu"] = U[:, U.size(1) - keep:].contiguous()
+        carry["x2"] = X2[:, v:].contiguous()
+        return y, carry

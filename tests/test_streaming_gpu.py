@@ -210,3 +210,54 @@ def test_state_carry_stream_full_size_sixty_seconds_vs_oracle(hip):
     assert float(e_hip.max()) <= 1.5 * float(e_ref.max()) + 1e-2
     valid = torch.ones(1, 1499, dtype=torch.bool)
     _token_parity(logp, ref_logp, valid, 0.25, "streaming full-size 60 s vs matched-precision whole-sequence oracle")
+
+
+@pytest.mark.parametrize("chunk", [4, 16])
+@pytest.mark.parametrize("variant", ["uni_bf16slot", "uni_bf16model", "uni_f32"])
+def test_lookahead_stream_of_the_shipped_uni_model_vs_reference_whole_sequence(hip, variant, chunk):
+    """The uni-directional model AS SHIPPED (conf/rwkv/giga.rwkv_uni_ds4k31nc_12le.trans-longutts.yaml:14-16: non-causal conv,
+    k = 31, 15 frames of look-ahead per layer) streamed with state carry: every layer emits 15 frames behind its input
+    (forward_chunk_lookahead), the stream is drained at the end -- against the REFERENCE's whole-sequence forward: the golden
+    captured from the reference's classes (utterance 0 of the ragged batch is full length, so its rows are the whole-sequence
+    pass of that utterance) and the oracle on a fresh longer utterance.  Interior frames and both ends (zero padding of the
+    depthwise convolution at the sequence edges) are covered: the comparison is over ALL frames."""
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_reduced_" + ("uni_bf16slot" if variant == "uni_f32" else variant))
+    conf = dict(g["conf"])
+    assert conf["cnn_module_kernel"] == 31 and not conf.get("causal", False) and conf["selfattention_layer_type"] == "rwkv_tmix60"
+    sd = {k: v for k, v in _sd(g).items() if not k.startswith("global_cmvn")}
+    if variant == "uni_f32":
+        conf["rwkv_do_bfloat16"] = False
+        sd = {k: v.float() for k, v in sd.items()}
+    enc = ConformerEncoder(80, **conf)
+    enc.load_state_dict(sd)
+    wm = variant == "uni_bf16model"
+    dt = torch.bfloat16 if wm else torch.float32
+    if wm:
+        enc = enc.to(torch.bfloat16)
+        sd = {k: v.bfloat16() for k, v in sd.items()}
+    enc = enc.cuda().eval()
+    fresh = synth.randn((1, 4 * 83 + 5, 80), 907, 2.0).to(dt)
+    ref_fresh, _ = EO.encoder_forward(fresh, torch.tensor([fresh.size(1)]), sd, conf, env={})
+    cases = [("fresh", fresh, ref_fresh)]
+    if variant != "uni_f32":       # the goldens carry a non-trivial CMVN, the comparison above does not: both paths are covered
+        from paper_accurate_fast_cheap_amd.transformer.cmvn import GlobalCMVN
+        enc_g = ConformerEncoder(80, global_cmvn=GlobalCMVN(torch.zeros(80), torch.ones(80)), **conf)
+        enc_g.load_state_dict(_sd(g))
+        enc_g = (enc_g.to(torch.bfloat16) if wm else enc_g).cuda().eval()
+        cases.append(("golden", g["xs"][0:1].to(dt), g["out"][0:1]))
+    for name, x, want in cases:
+        e = enc_g if name == "golden" else enc
+        with torch.no_grad():
+            got = e.stream_chunks_lookahead(x.cuda(), chunk)
+            # the pipeline really is delayed: the first call of a 12 x 15-frame... here 2 x 15-frame look-ahead emits nothing
+            y0, st = e.forward_chunk_lookahead(x[:, :(chunk - 1) * 4 + 7].cuda(), None)
+            assert y0.shape[1] == max(0, chunk - 15 * len(e.encoders)) and st[0]["cu"].shape[1] == min(30, 15 + chunk)
+        assert got.shape == want.shape, (got.shape, want.shape)
+        d = (got.float().cpu() - want.float()).abs()
+        parity_log.record(f"streaming/look-ahead (non-causal k=31) reduced {variant} chunk {chunk} vs whole-sequence {name}",
+                          max_abs_err=float(d.max()), mean_abs_err=float(d.mean()))
+        if variant == "uni_f32":
+            assert bool((d <= 1e-3 * want.float().abs() + 2.5e-4).all()) and float(d.mean()) <= 2e-5, float(d.max())
+        else:
+            assert float(d.max()) <= 0.18 and float(d.mean()) <= 1.4e-2, (name, float(d.max()), float(d.mean()))
