@@ -122,6 +122,14 @@ __device__ __forceinline__ float act_apply(float v) {
     return v;
 }
 
+// cache policy of the output stores (buffer_store aux bits: 1 = sc0, 2 = nt, 16 = sc1).  Measured with nt = non-temporal (round 4,
+// profiles/r04i_step_hbm_bytes_nt_stores.txt): the w_1 GEMM's A-panel re-reads halve (147 -> 72 MB per launch: the 128 KiB a
+// tile writes no longer evict the panel from the XCD's 4 MiB L2) and w_1 / w_2 gain 3 %, but every 64-byte half line a store
+// instruction writes goes to memory on its own (writes +35 %), the CTC head (N = 5000) loses 45 % and the step is unchanged
+// (21.60 vs 21.70 ms): default policy kept
+#ifndef PH_ST_AUX
+#define PH_ST_AUX 0
+#endif
 #define PH_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -524,15 +532,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         if constexpr (OUT == 0) {
             u32x4p w{0u, 0u, 0u, 0u};
             if (live) w = u32x4p{pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
-            __builtin_amdgcn_raw_buffer_store_b128(w, Or, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(w, Or, off, 0, PH_ST_AUX);
         } else if constexpr (OUT == 1) {
             u32x4p w0{0u, 0u, 0u, 0u}, w1{0u, 0u, 0u, 0u};
             if (live) {
                 w0 = u32x4p{__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
                 w1 = u32x4p{__float_as_uint(o[4]), __float_as_uint(o[5]), __float_as_uint(o[6]), __float_as_uint(o[7])};
             }
-            __builtin_amdgcn_raw_buffer_store_b128(w0, Or, off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(w1, Or, ok ? off + 16 : PH_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(w0, Or, off, 0, PH_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(w1, Or, ok ? off + 16 : PH_OOB, 0, PH_ST_AUX);
         } else {
             u32x4p wh{0u, 0u, 0u, 0u}, wl{0u, 0u, 0u, 0u};
             if (live) {
@@ -543,8 +551,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
                 for (int e = 0; e < 8; ++e) lo[e] = o[e] - hf[e];
                 wl = u32x4p{pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(lo[4], lo[5]), pack_bf16(lo[6], lo[7])};
             }
-            __builtin_amdgcn_raw_buffer_store_b128(wh, Or, off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(wl, Or, ok ? off + (unsigned)(p.lo_off * 2) : PH_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(wh, Or, off, 0, PH_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(wl, Or, ok ? off + (unsigned)(p.lo_off * 2) : PH_OOB, 0, PH_ST_AUX);
         }
     };
     // LNF: the rows' statistics.  8 partial (sum, sum of squares) pairs per row, [M][8] float2; the descriptor starts at the
