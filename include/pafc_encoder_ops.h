@@ -371,6 +371,24 @@ int pafc_gemm_ph_ex2(long M, int N, int K, int batch, const void *A, long lda, l
 int pafc_conv3x3s2_nhwc_split_ph(int B, int T1, int F1, int Ci, int Co, const void *in_planes, const void *w3_tap_co_3ci,
                                  const float *bias, void *out_planes, int relu, int tile_m, pafc_stream_t stream);
 
+/* Element-wise groups of the TRAINING step, one kernel forward and one backward each (csrc/train_elementwise.hip).
+ *
+ * Residual branch with dropout -- `x = x + dropout(y)` / `x + ff_scale * dropout(y)`, wenet/transformer/encoder_layer.py:
+ * 205-206,232,247,254-255 -- replacing the framework's dropout + scale + cast + add (forward) and masked scale + scale + cast
+ * (backward):   forward:  out = x + (scale / (1 - p)) * keep * y        backward: dy = (scale / (1 - p)) * keep * dout
+ * (dx = dout needs no kernel).  keep = [u >= p] with u a counter-based uniform of (seed, offset, element index): the mask is
+ * never stored, the backward call passes the forward call's (seed, offset).  p = 0: plain x + scale * y.
+ * backward = 0: x (dtype_x), y (dtype_y) -> out (dtype_x);  backward = 1: x = dout (dtype_x) -> out = dy (dtype_y), y unused.
+ * (dtype_x, dtype_y) = (f32, bf16) [fp32 stream, bf16 branch: autocast], (f32, f32), (bf16, bf16).  n % 8 == 0, 16-byte
+ * aligned pointers, contiguous tensors. */
+int pafc_residual_dropout(int backward, int dtype_x, int dtype_y, long n, const void *x, const void *y, void *out, float scale,
+                          float p, unsigned long long seed, unsigned long long offset, pafc_stream_t stream);
+/* `dropout(activation(h))` of the feed-forward module with activation SiLU (positionwise_feed_forward.py:47-55):
+ *   forward:  out = bf16(silu(h)) * keep / (1 - p)        backward: dh = dout * keep / (1 - p) * silu'(h)
+ * h, dout, out in `dtype` (f32 or bf16); same mask generator; n % 8 == 0. */
+int pafc_silu_dropout(int backward, int dtype, long n, const void *h, const void *dout, void *out, float p,
+                      unsigned long long seed, unsigned long long offset, pafc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

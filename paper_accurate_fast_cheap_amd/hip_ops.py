@@ -253,6 +253,112 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, out_dtype: torch.dtype = torch.fl
     return (dw, db) if want_bias else dw
 
 
+# ---- element-wise groups of the training step (csrc/train_elementwise.hip) ------------------------------------------------
+_dropout_calls = 0       # per-process counter: the `offset` of the mask generator (seed = torch's CPU seed)
+
+
+def _next_dropout_stream():
+    global _dropout_calls
+    _dropout_calls += 1
+    return int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, _dropout_calls
+
+
+def _bind_train_elementwise():
+    L = _bind()
+    if not getattr(L, "_pafc_te_bound", False):
+        from ctypes import c_float, c_long, c_ulonglong
+        _lib._sig(L.pafc_residual_dropout, c_int, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                  c_ulonglong, c_ulonglong, c_void_p)
+        _lib._sig(L.pafc_silu_dropout, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p, c_float, c_ulonglong, c_ulonglong,
+                  c_void_p)
+        L._pafc_te_bound = True
+    return L
+
+
+class _ResidualDropout(torch.autograd.Function):
+    """out = x + scale * dropout(y, p): one kernel; backward dx = dout (no kernel), dy = one kernel, mask recomputed."""
+
+    @staticmethod
+    def forward(ctx, x, y, scale, p):
+        L = _bind_train_elementwise()
+        x, y = x.contiguous(), y.contiguous()
+        seed, off = _next_dropout_stream() if p > 0 else (0, 0)
+        out = torch.empty_like(x)
+        _lib.check(L.pafc_residual_dropout(0, _lib.dtype_code(x.dtype), _lib.dtype_code(y.dtype), x.numel(), _lib.ptr(x), _lib.ptr(y),
+                                           _lib.ptr(out), float(scale), float(p), seed, off, _lib.stream_of(x)), "pafc_residual_dropout")
+        ctx.meta = (float(scale), float(p), seed, off, y.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        scale, p, seed, off, ydt = ctx.meta
+        dy = None
+        if ctx.needs_input_grad[1]:
+            L = _bind_train_elementwise()
+            g = g.contiguous()
+            dy = torch.empty(g.shape, dtype=ydt, device=g.device)
+            _lib.check(L.pafc_residual_dropout(1, _lib.dtype_code(g.dtype), _lib.dtype_code(ydt), g.numel(), _lib.ptr(g), None,
+                                               _lib.ptr(dy), scale, p, seed, off, _lib.stream_of(g)), "pafc_residual_dropout")
+        return (g if ctx.needs_input_grad[0] else None), dy, None, None
+
+
+class _SiluDropout(torch.autograd.Function):
+    """dropout(silu(h), p): one kernel forward, one backward (from h and the recomputed mask; silu(h) is not kept)."""
+
+    @staticmethod
+    def forward(ctx, h, p):
+        L = _bind_train_elementwise()
+        h = h.contiguous()
+        seed, off = _next_dropout_stream() if p > 0 else (0, 0)
+        out = torch.empty_like(h)
+        _lib.check(L.pafc_silu_dropout(0, _lib.dtype_code(h.dtype), h.numel(), _lib.ptr(h), None, _lib.ptr(out), float(p), seed, off,
+                                       _lib.stream_of(h)), "pafc_silu_dropout")
+        ctx.save_for_backward(h)
+        ctx.meta = (float(p), seed, off)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (h,) = ctx.saved_tensors
+        p, seed, off = ctx.meta
+        L = _bind_train_elementwise()
+        g = g.contiguous()
+        dh = torch.empty_like(h)
+        _lib.check(L.pafc_silu_dropout(1, _lib.dtype_code(h.dtype), h.numel(), _lib.ptr(h), _lib.ptr(g), _lib.ptr(dh), p, seed, off,
+                                       _lib.stream_of(h)), "pafc_silu_dropout")
+        return dh, None
+
+
+def train_elementwise_eligible(x: torch.Tensor, y: Optional[torch.Tensor] = None) -> bool:
+    """The fused element-wise training kernels serve this call: GPU training step with the hand-written kernels on, fp32 or
+    bf16 contiguous-izable tensors whose size is a multiple of 8 (a 512-wide stream always is)."""
+    if not (train_kernels_enabled() and x.is_cuda and torch.is_grad_enabled() and x.numel() % 8 == 0 and x.numel() > 0):
+        return False
+    pairs = {(torch.float32, torch.bfloat16), (torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16)}
+    if y is not None:
+        return (x.dtype, y.dtype) in pairs and y.shape == x.shape and y.is_cuda
+    return x.dtype in (torch.float32, torch.bfloat16)
+
+
+def residual_dropout(x: torch.Tensor, y: torch.Tensor, scale: float, p: float, training: bool) -> torch.Tensor:
+    """x + scale * dropout(y, p) (encoder_layer.py:205-255) as one kernel forward and one backward in the GPU training step;
+    the framework's operators otherwise."""
+    p = float(p) if training else 0.0
+    if train_elementwise_eligible(x, y) and (x.requires_grad or y.requires_grad):
+        return _ResidualDropout.apply(x, y, float(scale), p)
+    d = torch.nn.functional.dropout(y, p, training=training) if p > 0 else y
+    return x + (d if scale == 1.0 else scale * d)
+
+
+def silu_dropout(h: torch.Tensor, p: float, training: bool) -> torch.Tensor:
+    """dropout(silu(h), p) (positionwise_feed_forward.py:47-55) as one kernel forward and one backward in the GPU training step."""
+    p = float(p) if training else 0.0
+    if train_elementwise_eligible(h) and h.requires_grad:
+        return _SiluDropout.apply(h, p)
+    a = torch.nn.functional.silu(h)
+    return torch.nn.functional.dropout(a, p, training=training) if p > 0 else a
+
+
 # bf16 copies of fp32 master weights for the training step.  Under autocast every projection casts its weight and bias on
 # every step (~400 small launches).  Inside `with train_shadows():` (utils.train_utils.train_step wraps the forward pass in
 # it) the copy is kept beside the parameter and ALL copies are brought up to date by one multi-tensor copy when the context

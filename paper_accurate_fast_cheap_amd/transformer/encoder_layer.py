@@ -61,7 +61,13 @@ class ConformerEncoderLayer(nn.Module):
             y = fn(norm(x) if pre else x)
             if isinstance(y, tuple):
                 y, side["cache"] = y
-            x = x + (drop(y) if scale == 1.0 else scale * drop(y))
+            if x.is_cuda and torch.is_grad_enabled():
+                # GPU training step: residual + scale * dropout(branch) as ONE kernel forward and one backward
+                # (hip_ops.residual_dropout; falls back to the operators below when the kernels do not take the call)
+                from ..hip_ops import residual_dropout
+                x = residual_dropout(x, y, scale, drop.p, self.training)
+            else:
+                x = x + (drop(y) if scale == 1.0 else scale * drop(y))
             return x if pre else norm(x)
 
         if self.feed_forward_macaron is not None:

@@ -14,7 +14,11 @@ class PositionwiseFeedForward(torch.nn.Module):
 
     def forward(self, xs: torch.Tensor) -> torch.Tensor:
         if xs.is_cuda and torch.is_grad_enabled():      # training on the GPU: weight gradients through gemm_tn
-            from ..hip_ops import linear
-            h = self.dropout(self.activation(linear(xs, self.w_1.weight, self.w_1.bias)))
+            from ..hip_ops import linear, silu_dropout
+            h = linear(xs, self.w_1.weight, self.w_1.bias)
+            if isinstance(self.activation, torch.nn.SiLU):     # activation + dropout: one pass forward, one backward
+                h = silu_dropout(h, self.dropout.p, self.training)
+            else:
+                h = self.dropout(self.activation(h))
             return linear(h, self.w_2.weight, self.w_2.bias)
         return self.w_2(self.dropout(self.activation(self.w_1(xs))))

@@ -1118,3 +1118,87 @@ def test_layernorm_folded_into_the_gemms_either_side(hip, M):
         want = F.silu(lin) if act == "silu" else F.glu(lin, dim=-1)
         torch.testing.assert_close(got.float(), want, rtol=2 ** -6, atol=3e-2)
         assert float((got.float() - want).abs().mean()) < 4e-3
+
+
+@pytest.mark.parametrize("xd,yd", [(torch.float32, torch.bfloat16), (torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("scale,p", [(1.0, 0.0), (0.5, 0.0), (1.0, 0.1), (0.5, 0.3)])
+def test_residual_dropout_training_kernel(hip, xd, yd, scale, p):
+    """x + scale * dropout(y, p) (encoder_layer.py:205-255) as one kernel forward / one backward: p = 0 equals the operator chain
+    (one rounding instead of several: within an ulp of the output dtype); p > 0: every element is either x (dropped) or
+    x + scale / (1 - p') y (kept) with p' the realised 16-bit rate, the dropped share is p within sampling error, the backward
+    pass regenerates the SAME mask, dx is the incoming gradient, and a step is reproducible under torch.manual_seed."""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    n = (37, 123, 512)
+    x = synth.randn(n, 1).to(xd).cuda().requires_grad_()
+    y = synth.randn(n, 2).to(yd).cuda().requires_grad_()
+    g = synth.randn(n, 3).to(xd).cuda()
+    torch.manual_seed(11)
+    hip_ops._dropout_calls = 0
+    out = hip_ops.residual_dropout(x, y, scale, p, training=True)
+    assert out.dtype == xd and out.grad_fn is not None and type(out.grad_fn).__name__.startswith("_ResidualDropout")
+    out.backward(g)
+    assert torch.equal(x.grad, g) and y.grad.dtype == yd
+    thr = 0 if p == 0 else int(p * 65536 + 0.5)
+    s = scale / (1 - thr / 65536)
+    kept = x.detach().float() + s * y.detach().float()
+    eps = 2 ** -7 if xd == torch.bfloat16 else 1e-6
+    if p == 0:
+        torch.testing.assert_close(out.float(), kept, rtol=eps, atol=eps)
+        torch.testing.assert_close(y.grad.float(), s * g.float(), rtol=2 ** -7 if yd == torch.bfloat16 else 1e-6, atol=1e-6)
+        # and the same numbers as the operator chain the module would run
+        ref = x.detach() + (y.detach() if scale == 1.0 else scale * y.detach())
+        torch.testing.assert_close(out.float(), ref.float(), rtol=2 * eps, atol=2 * eps)
+        return
+    is_kept = (out.float() - kept).abs() <= eps * kept.abs() + 1e-6
+    is_drop = out.float() == x.detach().float()
+    assert bool((is_kept | is_drop).all())
+    drop_mask = is_drop & ~is_kept
+    frac = float(drop_mask.float().mean())
+    assert abs(frac - p) < 4 * (p * (1 - p) / x.numel()) ** 0.5 + 1e-3, frac
+    # backward: the same mask
+    gy = y.grad.float()
+    assert bool((gy[drop_mask] == 0).all())
+    torch.testing.assert_close(gy[~drop_mask], (s * g.float())[~drop_mask], rtol=2 ** -7 if yd == torch.bfloat16 else 1e-6, atol=1e-6)
+    # no structure along rows or columns (a counter-based generator indexed by the element)
+    assert abs(float(drop_mask.float().mean(dim=(0, 1)).std()) - (p * (1 - p) / (n[0] * n[1])) ** 0.5) < 0.01
+    # reproducible: same seed + same call index -> same mask; another call index -> another mask
+    torch.manual_seed(11)
+    hip_ops._dropout_calls = 0
+    again = hip_ops.residual_dropout(x, y, scale, p, training=True)
+    assert torch.equal(again, out)
+    other = hip_ops.residual_dropout(x, y, scale, p, training=True)
+    assert not torch.equal(other, out)
+    # eval: no dropout, framework operators
+    ev = hip_ops.residual_dropout(x.detach(), y.detach(), scale, p, training=False)
+    torch.testing.assert_close(ev.float(), (x.detach().float() + scale * y.detach().float()), rtol=2 * eps, atol=2 * eps)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_silu_dropout_training_kernel(hip, dt, p):
+    """dropout(silu(h), p) of the feed-forward module (positionwise_feed_forward.py:47-55), one kernel each way: forward
+    against F.silu (rounded to the activation dtype, then scaled), backward against the analytic derivative on the same mask."""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    n = (61, 50, 2048)
+    h = (synth.randn(n, 5) * 2).to(dt).cuda().requires_grad_()
+    g = synth.randn(n, 6).to(dt).cuda()
+    torch.manual_seed(12)
+    hip_ops._dropout_calls = 0
+    out = hip_ops.silu_dropout(h, p, training=True)
+    assert out.dtype == dt and type(out.grad_fn).__name__.startswith("_SiluDropout")
+    out.backward(g)
+    thr = 0 if p == 0 else int(p * 65536 + 0.5)
+    s = 1 / (1 - thr / 65536)
+    hf = h.detach().float()
+    act = F.silu(hf).to(dt).float()
+    keep = (out.float() != 0) | (act == 0)
+    eps = 2 ** -7 if dt == torch.bfloat16 else 2e-6
+    torch.testing.assert_close(out.float()[keep], (s * act)[keep], rtol=eps, atol=1e-6)
+    if p == 0:
+        assert bool(keep.all())
+    else:
+        assert abs(float((~keep).float().mean()) - p) < 2e-3
+    sg = torch.sigmoid(hf)
+    want = s * g.float() * sg * (1 + hf * (1 - sg))
+    assert bool((h.grad.float()[~keep] == 0).all())
+    torch.testing.assert_close(h.grad.float()[keep], want[keep], rtol=2 * eps, atol=2e-3 if dt == torch.bfloat16 else 1e-5)
