@@ -267,9 +267,9 @@ def _bind_train_elementwise():
     L = _bind()
     if not getattr(L, "_pafc_te_bound", False):
         from ctypes import c_float, c_long, c_ulonglong
-        _lib._sig(L.pafc_residual_dropout, c_int, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p, c_float, c_float,
-                  c_ulonglong, c_ulonglong, c_void_p)
-        _lib._sig(L.pafc_silu_dropout, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p, c_float, c_ulonglong, c_ulonglong,
+        _lib._sig(L.pafc_residual_dropout, c_int, c_int, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                  c_ulonglong, c_ulonglong, c_void_p)         # (the first entry is the return type)
+        _lib._sig(L.pafc_silu_dropout, c_int, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p, c_float, c_ulonglong, c_ulonglong,
                   c_void_p)
         L._pafc_te_bound = True
     return L
@@ -297,7 +297,7 @@ class _ResidualDropout(torch.autograd.Function):
             L = _bind_train_elementwise()
             g = g.contiguous()
             dy = torch.empty(g.shape, dtype=ydt, device=g.device)
-            _lib.check(L.pafc_residual_dropout(1, _lib.dtype_code(g.dtype), _lib.dtype_code(ydt), g.numel(), _lib.ptr(g), None,
+            _lib.check(L.pafc_residual_dropout(1, _lib.dtype_code(g.dtype), _lib.dtype_code(ydt), g.numel(), _lib.ptr(g), _lib.ptr(None),
                                                _lib.ptr(dy), scale, p, seed, off, _lib.stream_of(g)), "pafc_residual_dropout")
         return (g if ctx.needs_input_grad[0] else None), dy, None, None
 
@@ -311,7 +311,7 @@ class _SiluDropout(torch.autograd.Function):
         h = h.contiguous()
         seed, off = _next_dropout_stream() if p > 0 else (0, 0)
         out = torch.empty_like(h)
-        _lib.check(L.pafc_silu_dropout(0, _lib.dtype_code(h.dtype), h.numel(), _lib.ptr(h), None, _lib.ptr(out), float(p), seed, off,
+        _lib.check(L.pafc_silu_dropout(0, _lib.dtype_code(h.dtype), h.numel(), _lib.ptr(h), _lib.ptr(None), _lib.ptr(out), float(p), seed, off,
                                        _lib.stream_of(h)), "pafc_silu_dropout")
         ctx.save_for_backward(h)
         ctx.meta = (float(p), seed, off)
