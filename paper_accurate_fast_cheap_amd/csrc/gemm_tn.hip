@@ -172,11 +172,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
         }
 }
 
-// dW = sum of the S partials, in order; out_f32 or out_bf16 (exactly one is non-null)
+// dW = sum of the S partials, in order; out_f32 or out_bf16 (exactly one is non-null).  The bias gradient's partials ride in
+// the same launch: indices [n4, n4 + nb4) reduce bias_part (stride nb4) into the bias outputs.
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(long n4, int S, long stride4, const float4 *__restrict__ part,
-                                                             float4 *__restrict__ out_f32, uint2 *__restrict__ out_bf16) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
+                                                             float4 *__restrict__ out_f32, uint2 *__restrict__ out_bf16,
+                                                             long nb4, const float4 *__restrict__ bias_part,
+                                                             float4 *__restrict__ bias_f32, uint2 *__restrict__ bias_bf16) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4 + nb4) return;
+    if (i >= n4) {                                   // (block-uniform except in one block)
+        i -= n4; part = bias_part; stride4 = nb4; out_f32 = bias_f32; out_bf16 = bias_bf16;
+    }
     float4 a = part[i];
     for (int s = 1; s < S; ++s) {
         const float4 b = part[(long)s * stride4 + i];
@@ -232,13 +238,10 @@ extern "C" int pafc_gemm_tn_bf16(long R, int M, int N, const void *dy, long lda,
         hipSuccess)
         return PAFC_ERR_LAUNCH;
     hipLaunchKernelGGL(pafc::gemm_tn_kernel, dim3(p.mtiles * p.ntiles, p.S), dim3(256), lds, s, p);
-    const long n4 = (long)M * N / 4;
-    hipLaunchKernelGGL(pafc::gemm_tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, n4, p.S, n4,
+    const long n4 = (long)M * N / 4, nb4 = dbias ? M / 4 : 0;
+    hipLaunchKernelGGL(pafc::gemm_tn_reduce_kernel, dim3((unsigned)((n4 + nb4 + 255) / 256)), dim3(256), 0, s, n4, p.S, n4,
                        (const float4 *)workspace, dw_dtype == PAFC_F32 ? (float4 *)dw : nullptr,
-                       dw_dtype == PAFC_BF16 ? (uint2 *)dw : nullptr);
-    if (dbias)
-        hipLaunchKernelGGL(pafc::gemm_tn_reduce_kernel, dim3((unsigned)((M / 4 + 255) / 256)), dim3(256), 0, s, (long)(M / 4),
-                           p.S, (long)(M / 4), (const float4 *)p.bias_part, dw_dtype == PAFC_F32 ? (float4 *)dbias : nullptr,
-                           dw_dtype == PAFC_BF16 ? (uint2 *)dbias : nullptr);
+                       dw_dtype == PAFC_BF16 ? (uint2 *)dw : nullptr, nb4, (const float4 *)p.bias_part,
+                       dw_dtype == PAFC_F32 ? (float4 *)dbias : nullptr, dw_dtype == PAFC_BF16 ? (uint2 *)dbias : nullptr);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }

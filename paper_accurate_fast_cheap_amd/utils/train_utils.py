@@ -137,9 +137,23 @@ def train_step(model: torch.nn.Module, batch: dict, optimizer: torch.optim.Optim
             info["updated"] = bool(torch.isfinite(grad_norm)) and scaler.get_scale() >= scale_before
         else:
             grad_norm = clip_grad_norm_(params, grad_clip)
-            if torch.isfinite(grad_norm):       # train_utils.py:702-711: skip the update on inf / nan
-                if (clip_hard_maxvalue == float("inf") or step_index < clip_hard_warmup
-                        or float(grad_norm) <= clip_hard_maxvalue):
+            hard = not (clip_hard_maxvalue == float("inf") or step_index < clip_hard_warmup)
+            if (not hard and grad_norm.is_cuda and getattr(optimizer, "_step_supports_amp_scaling", False)
+                    and getattr(optimizer, "found_inf", None) is None):
+                # the skip-on-inf / nan decision (train_utils.py:702-711) taken ON THE DEVICE: a fused optimizer reads a
+                # `found_inf` flag (the GradScaler protocol) and leaves parameters, moments and step counts alone when it is
+                # set -- no host synchronisation between backward and the update, the host keeps queueing the next step.
+                # info["updated"] is then a 0-dim bool tensor (bool() of it synchronises, like any tensor).
+                finite = torch.isfinite(grad_norm)
+                optimizer.found_inf = (~finite).to(torch.float32).reshape(())
+                optimizer.grad_scale = None
+                try:
+                    optimizer.step()
+                finally:
+                    optimizer.found_inf = None
+                info["updated"] = finite
+            elif torch.isfinite(grad_norm):     # train_utils.py:702-711: skip the update on inf / nan
+                if not hard or float(grad_norm) <= clip_hard_maxvalue:
                     optimizer.step()
                     info["updated"] = True
         info["grad_norm"] = grad_norm.detach()

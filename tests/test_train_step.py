@@ -108,6 +108,47 @@ def test_train_step_updates_and_skips_nonfinite(hip):
     assert all(torch.equal(before[n], p.detach()) for n, p in model.named_parameters())
 
 
+@pytest.mark.gpu
+def test_train_step_fused_optimizer_skips_nonfinite_on_the_device(hip):
+    """With a fused optimizer the skip-on-inf / nan decision (train_utils.py:702-711) is taken on the device (the optimizer's
+    `found_inf` flag): no host synchronisation in the step, info["updated"] is a 0-dim bool tensor; a NaN batch leaves the
+    parameters, both Adam moments and the step counts exactly as they were, a finite batch updates as the unfused path does."""
+    from paper_accurate_fast_cheap_amd.utils.init_model import init_model
+    from paper_accurate_fast_cheap_amd.utils.train_utils import train_step
+    g = load_golden("encoder_reduced_f32")
+    cfg = dict(encoder="conformer", encoder_conf=dict(g["conf"], dropout_rate=0.0, positional_dropout_rate=0.0), input_dim=80,
+               output_dim=50, ctc="ctc", ctc_conf={"ctc_blank_id": 0}, model_conf={}, dataset_conf={})
+
+    class A:
+        checkpoint = None
+    batch = {"feats": synth.randn((4, 120, 80), 1, 2.0), "feats_lengths": torch.tensor([120, 100, 90, 64]),
+             "target": torch.randint(1, 50, (4, 6), generator=torch.Generator().manual_seed(2)),
+             "target_lengths": torch.tensor([6, 5, 4, 3])}
+    runs = {}
+    for fused in (True, False):
+        torch.manual_seed(3)
+        model, _ = init_model(A(), cfg)
+        model = model.cuda()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=fused)
+        info = train_step(model, batch, opt, torch.device("cuda"), grad_clip=0.1)
+        assert bool(info["updated"]) and (isinstance(info["updated"], torch.Tensor) == fused)
+        runs[fused] = {n: p.detach().clone() for n, p in model.named_parameters()}
+        if fused:
+            snap = {n: p.detach().clone() for n, p in model.named_parameters()}
+            st = {i: {k: v.detach().clone() for k, v in s_.items() if torch.is_tensor(v)} for i, s_ in enumerate(opt.state.values())}
+            bad = dict(batch, feats=batch["feats"] * float("nan"))
+            info = train_step(model, bad, opt, torch.device("cuda"), grad_clip=0.1)
+            assert isinstance(info["updated"], torch.Tensor) and not bool(info["updated"])
+            assert all(torch.equal(snap[n], p.detach()) for n, p in model.named_parameters())
+            for i, s_ in enumerate(opt.state.values()):
+                for k, v in s_.items():
+                    if torch.is_tensor(v):
+                        assert torch.equal(st[i][k], v), k            # exp_avg, exp_avg_sq and step untouched
+            assert getattr(opt, "found_inf", None) is None
+    for n in runs[True]:       # the first Adam step is lr * sign-like: elements whose gradient is ~0 may differ by a fraction of lr = 1e-4
+        torch.testing.assert_close(runs[True][n], runs[False][n], rtol=1e-5, atol=2e-5)
+
+
 _DDP_WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["PAFC_ROOT"])
