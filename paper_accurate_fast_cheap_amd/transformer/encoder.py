@@ -349,18 +349,97 @@ class BaseEncoder(torch.nn.Module):
         return xs, new_state
 
     @torch.no_grad()
-    def stream_chunks_lookahead(self, xs: torch.Tensor, decoding_chunk_size: int) -> torch.Tensor:
+    def _lookahead_fused_step(self, xs: torch.Tensor, state: list) -> torch.Tensor:
+        """One STEADY-STATE look-ahead step on the fused chunk-step kernels (fused.layer_forward_lookahead): every layer takes
+        T frames and emits T frames, the carries are the fixed buffers "U" / "X2" / "shift" / "wkv" updated where they lie
+        (the form a captured hipGraph needs).  xs: (1, window, F) input window; returns the (1, T, D) frames finalised."""
+        from . import fused
+        from .. import hip_ops
+        masks = torch.ones(1, 1, xs.size(1), device=xs.device, dtype=torch.bool)
+        if self.global_cmvn is not None:
+            xs = self.global_cmvn(xs)
+        with hip_ops.chunk_step():
+            xs, _, _ = self.embed(xs, masks, 0)
+            if getattr(self, "_carry_plans", None) is None:
+                self._carry_plans = [fused.LayerPlan(l) for l in self.encoders]
+            plans = self._carry_plans
+            n = len(plans)
+            tail = self.after_norm if self.normalize_before else None
+            h, pending = None, []
+            for i, carry in enumerate(state):
+                plans[i].refresh()
+                nxt = plans[i + 1].layer.norm_ff_macaron if i + 1 < n else tail
+                xs, h = fused.layer_forward_lookahead(plans[i], xs, carry, h, nxt, pending)
+            torch._foreach_copy_([d for d, _ in pending], [s_ for _, s_ in pending])
+        return h if tail is not None else xs
+
+    @torch.no_grad()
+    def stream_chunks_lookahead(self, xs: torch.Tensor, decoding_chunk_size: int, use_graph: bool = True) -> torch.Tensor:
         """A whole utterance (B, T, F) through forward_chunk_lookahead window by window, drained at the end: (B, T', D), equal
-        to forward() of the utterance."""
+        to forward() of the utterance.  One bf16 stream on the GPU: once the pipeline is full (every layer holds its 30 + 15
+        carried frames: after ceil(15 L / chunk) + 1 windows) each full window is a STEADY-STATE step -- T frames in, T frames
+        out of every layer -- which runs on the fused chunk-step kernels over fixed carry buffers and is replayed from a
+        captured hipGraph (as stream_chunks does for the causal model); the windows that fill the pipeline, a shorter last
+        window and the final drain take the module path."""
         assert decoding_chunk_size > 0
         sub, ctx = self.embed.subsampling_rate, self.embed.right_context + 1
         stride, window = sub * decoding_chunk_size, (decoding_chunk_size - 1) * sub + ctx
         T = xs.size(1)
         starts = list(range(0, T - ctx + 1, stride))
         outs, state = [], None
-        for i, c in enumerate(starts):
-            y, state = self.forward_chunk_lookahead(xs[:, c:min(c + window, T)], state, final=(i == len(starts) - 1))
+        i = 0
+        n = len(starts)
+        halves = [((l.conv_module.kernel_size - 1) // 2 if l.conv_module is not None else 0) for l in self.encoders]
+        fill = -(-sum(halves) // decoding_chunk_size) + 1          # windows until every layer emits a full chunk per step
+        from . import fused
+        fused_ok = (use_graph and xs.is_cuda and self.fused_inference and not self.training and xs.dtype == torch.bfloat16
+                    and decoding_chunk_size >= 2 * max(halves + [0]) and all(fused.lookahead_eligible(l, xs) for l in self.encoders))
+        steady = [j for j in range(n - 1) if starts[j] + window <= T]          # full windows that are not the last one
+        if fused_ok and len(steady) >= fill + 4:
+            while i < fill:
+                y, state = self.forward_chunk_lookahead(xs[:, starts[i]:starts[i] + window], state)
+                outs.append(y)
+                i += 1
+            ok = all(st["cu"].size(1) == 2 * hf and st["x2"].size(1) == hf for st, hf in zip(state, halves))
+            if ok:
+                Tc = decoding_chunk_size
+                bufs = []
+                for st, hf in zip(state, halves):        # the public carries -> fixed buffers with room for a chunk behind them
+                    U = st["cu"].new_zeros(1, 2 * hf + Tc, st["cu"].size(2))
+                    U[:, :2 * hf] = st["cu"]
+                    X2 = st["x2"].new_zeros(1, hf + Tc, st["x2"].size(2))
+                    X2[:, :hf] = st["x2"]
+                    bufs.append({"U": U, "X2": X2, "shift": st["shift"].clone().contiguous(), "wkv": st["wkv"].clone().contiguous()})
+                static_in = xs[:, starts[i]:starts[i] + window].clone()
+                side = torch.cuda.Stream(device=xs.device)               # one eager step on a side stream warms every kernel up
+                side.wait_stream(torch.cuda.current_stream(xs.device))
+                with torch.cuda.stream(side):
+                    outs.append(self._lookahead_fused_step(static_in, bufs).clone())
+                torch.cuda.current_stream(xs.device).wait_stream(side)
+                i += 1
+                graph = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(graph):
+                        y_static = self._lookahead_fused_step(static_in, bufs)
+                except RuntimeError as e:                 # only a refused capture falls back to eager fused steps
+                    torch.cuda.synchronize(xs.device)
+                    if "captur" not in str(e).lower():
+                        raise
+                    graph = None
+                while i in steady:
+                    static_in.copy_(xs[:, starts[i]:starts[i] + window])
+                    if graph is not None:
+                        graph.replay()
+                        outs.append(y_static.clone())
+                    else:
+                        outs.append(self._lookahead_fused_step(static_in, bufs).clone())
+                    i += 1
+                state = [{"cu": b["U"][:, :2 * hf].clone(), "x2": b["X2"][:, :hf].clone(), "shift": b["shift"], "wkv": b["wkv"]}
+                         for b, hf in zip(bufs, halves)]
+        while i < n:
+            y, state = self.forward_chunk_lookahead(xs[:, starts[i]:min(starts[i] + window, T)], state, final=(i == n - 1))
             outs.append(y)
+            i += 1
         return torch.cat(outs, 1)
 
     def _windows_independent(self, xs: torch.Tensor):

@@ -618,6 +618,81 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict],
     return out, new, hn
 
 
+def lookahead_eligible(layer: nn.Module, x: torch.Tensor) -> bool:
+    """The steady-state look-ahead chunk step (non-causal conv module, the shipped uni YAML) on the fused kernels: one bf16
+    stream, uni-directional bf16 slot, pre-norm, layer_norm conv module with an odd kernel <= 31."""
+    cm = layer.conv_module
+    return (cm is not None and type(layer.self_attn) is RWKV_TmixWrapper and layer.normalize_before
+            and layer.feed_forward_macaron is not None and cm.use_layer_norm and cm.lorder == 0 and cm.kernel_size % 2 == 1
+            and isinstance(cm.activation, nn.SiLU) and isinstance(layer.feed_forward.activation, nn.SiLU)
+            and isinstance(layer.feed_forward_macaron.activation, nn.SiLU) and cm.kernel_size <= 31
+            and layer.size % 64 == 0 and layer.size <= 1024 and x.is_cuda and x.dtype == torch.bfloat16 and x.size(0) == 1
+            and bool(layer.self_attn.do_bfloat16))
+
+
+def layer_forward_lookahead(plan: LayerPlan, x: torch.Tensor, carry: dict, h0: Optional[torch.Tensor], next_norm: Optional[nn.LayerNorm],
+                            pending: list):
+    """ConformerEncoderLayer.forward_lookahead in its STEADY state -- T new frames in, T finalised frames out, 15 frames
+    behind -- on the fused chunk-step kernels, one stream, every carry a fixed buffer updated where it lies (the form a captured
+    hipGraph step needs):  carry["U"] (1, 2 half + T, C) = the depthwise convolution's input, the last 2 half frames of the
+    previous steps in front and this step's GLU output written behind them; carry["X2"] (1, half + T, C) = the residual stream
+    behind the slot, the `half` frames not yet emitted in front; "shift" (1, 1, C), "wkv" (1, H, N, N).  The small refreshes
+    (tails to the front, last frame to "shift") are appended to `pending` as (destination, source) pairs: ONE multi-tensor
+    copy after the last layer performs them (T >= 2 half, so no pair overlaps itself).
+    Returns (layer output for the T emitted frames, next_norm(output) or None)."""
+    L = plan.layer
+    cm = L.conv_module
+    B, T, C = x.shape
+    half = (cm.kernel_size - 1) // 2
+    U, X2, shift, s_in = carry["U"], carry["X2"], carry["shift"], carry["wkv"]
+    assert B == 1 and U.shape == (1, 2 * half + T, C) and X2.shape == (1, half + T, C) and T >= 2 * half
+    M = T
+    x = x.contiguous()
+    if h0 is None:
+        _, h0, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff_macaron.weight, L.norm_ff_macaron.bias, want_x=False, eps=L.norm_ff_macaron.eps)
+    x = _ffn_residual(L.feed_forward_macaron, h0, x, L.ff_scale, plan.b2_macaron, inplace=False)
+    _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_mha.weight, L.norm_mha.bias, want_x=False, eps=L.norm_mha.eps)
+    # slot: token shift + lerp as the down-projection's operand, LoRA-up + lerps, r / k / v, decay LoRA, scan from / into the state
+    t = hip_ops.gemm_skinny(h.view(M, C), plan.W1n[0], None, "tanh", mix_maa=plan.maa_x_n[0], mix_prev=shift, mix_T=T).view(1, M, -1)
+    z = hip_ops.tmix_lora_mix4(h, t, plan.W2t, plan.maa4, prev=shift)
+    rkv = hip_ops.gemm_skinny(z[:3].view(3, M, C), plan.Wrkv_n).view(3, B, T, C)
+    td = hip_ops.gemm_skinny(z[3].view(M, C), plan.D1n[0], None, "tanh")
+    w = hip_ops.gemm_skinny(td, plan.D2n[0], plan.time_decay.view(C), round_first=True).view(B, T, C)
+    if hip_ops.wkv6_single_chunk(B, T, C, plan.u[0].shape[0]):
+        y, _ = wkv6_forward(rkv[0], rkv[1], rkv[2], w, plan.u[0], s_in=s_in, s_out=s_in)
+    else:
+        y, s_out = wkv6_forward(rkv[0], rkv[1], rkv[2], w, plan.u[0], s_in=s_in, want_state=True)
+        s_in.copy_(s_out)
+    pending.append((shift, h[:, -1:]))
+    # ln_x folded into the output projection; the new rows of the residual stream go BEHIND the frames still waiting in X2
+    wo, bo, cso, epo = plan.carry_folds()["out"]
+    x2new = X2[0, half:]
+    hip_ops.gemm_skinny(y.view(M, C), wo, bo, residual=x.view(M, C), out=x2new, ln_self=True, ln_csum=cso, ln_eps=epo)
+    # conv branch, front half: norm_conv -> pointwise_conv1 + GLU, written behind the cached rows of U
+    _, hc, _ = hip_ops.add_layernorm(x2new.view(1, T, C), None, 1.0, L.norm_conv.weight, L.norm_conv.bias, want_x=False, eps=L.norm_conv.eps)
+    pw1 = cm.pointwise_conv1
+    hip_ops.gemm_skinny(hc.view(M, C), pw1.weight.view(2 * C, C), pw1.bias, "glu", out=U[0, 2 * half:])
+    # back half, on the T frames whose window is now complete (centres = rows [half, half + T) of U = rows [0, T) of X2)
+    dw = hip_ops.depthwise_conv1d_cl(U, cm.depthwise_conv.weight, cm.depthwise_conv.bias, 0, T)
+    pw2 = cm.pointwise_conv2
+    x3 = hip_ops.gemm_skinny(dw.view(M, C), pw2.weight.view(C, C), pw2.bias, residual=X2[0, :T],
+                             norm_silu=(cm.norm.weight, cm.norm.bias, cm.norm.eps))
+    pending.append((U[:, :2 * half], U[:, T:T + 2 * half]))
+    pending.append((X2[:, :half], X2[:, T:T + half]))
+    w1, b1, cs1, ep1 = plan.carry_folds()["ff"]
+    hid = hip_ops.gemm_skinny(x3, w1, b1, "silu", ln_self=True, ln_csum=cs1, ln_eps=ep1)
+    x4 = proj(hid, L.feed_forward.w_2.weight, plan.b2, "none", alpha=L.ff_scale, residual=x3, inplace=True).view(B, T, C)
+    if next_norm is not None and next_norm.eps == L.norm_final.eps:
+        _, out, hn = hip_ops.add_layernorm(x4, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False, gamma2=next_norm.weight,
+                                           beta2=next_norm.bias, eps=L.norm_final.eps)
+        return out, hn
+    _, out, _ = hip_ops.add_layernorm(x4, None, 1.0, L.norm_final.weight, L.norm_final.bias, want_x=False, eps=L.norm_final.eps)
+    hn = None
+    if next_norm is not None:
+        _, hn, _ = hip_ops.add_layernorm(out, None, 1.0, next_norm.weight, next_norm.bias, want_x=False, eps=next_norm.eps)
+    return out, hn
+
+
 class EncoderPlan:
     def __init__(self, encoders: nn.ModuleList):
         self.layers = [LayerPlan(l) for l in encoders]

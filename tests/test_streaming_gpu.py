@@ -152,16 +152,20 @@ def test_state_carry_stream_vs_reference_whole_sequence(hip, prec, chunk):
                 assert float(d.max()) <= 0.18 and float(d.mean()) <= 1.4e-2, (name, rname, float(d.max()), float(d.mean()))
 
 
-def test_state_carry_stream_full_size_sixty_seconds_vs_oracle(hip):
-    """The bench's streaming leg at FULL size: the 12 x 512 uni-directional encoder (causal conv, k = 15), whole-model bf16,
-    60 s of audio streamed in 64-frame chunks with state carry from the captured hipGraph -- against the matched-precision
+@pytest.mark.parametrize("conv", ["causal_k15", "shipped_noncausal_k31"])
+def test_state_carry_stream_full_size_sixty_seconds_vs_oracle(hip, conv):
+    """The bench's streaming legs at FULL size: the 12 x 512 uni-directional encoder, whole-model bf16, 60 s of audio streamed
+    in 64-frame chunks with state carry from the captured hipGraph -- (a) causal conv k = 15 (stream_chunks), (b) the shipped
+    YAML's non-causal conv k = 31 with its 15-frame look-ahead per layer (stream_chunks_lookahead: fused steady-state steps
+    replayed from a graph, module path while the 180-frame pipeline fills and drains) -- against the matched-precision
     oracle's whole-sequence forward (every op rounds to bf16) and the exact model (same bf16-valued parameters, fp32
     arithmetic), element-wise and by CTC token."""
     import bench
     from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
     from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
     conf = bench.encoder_conf()
-    conf.update(selfattention_layer_type="rwkv_tmix60", rnn_att_direction="uni", causal=True, cnn_module_kernel=15)
+    causal = conv == "causal_k15"
+    conf.update(selfattention_layer_type="rwkv_tmix60", rnn_att_direction="uni", causal=causal, cnn_module_kernel=15 if causal else 31)
     torch.manual_seed(777)
     enc = ConformerEncoder(80, **conf).eval()
     with torch.no_grad():
@@ -185,15 +189,16 @@ def test_state_carry_stream_full_size_sixty_seconds_vs_oracle(hip):
     encb, ctcb = enc.to(torch.bfloat16).cuda().eval(), ctc.to(torch.bfloat16).cuda().eval()
     with torch.no_grad():
         encb.fused_inference = True
-        out = encb.stream_chunks(xs.cuda(), 64, use_graph=True)
-        assert getattr(encb, "_carry_plans", None) is not None
-        eager = encb.stream_chunks(xs.cuda(), 64, use_graph=False)
+        stream = encb.stream_chunks if causal else encb.stream_chunks_lookahead
+        out = stream(xs.cuda(), 64, use_graph=True)
+        assert getattr(encb, "_carry_plans", None) is not None            # the fused chunk-step kernels really ran
+        eager = stream(xs.cuda(), 64, use_graph=False)                    # (look-ahead: the module path throughout)
         logp = ctcb.log_softmax(out)
     assert out.shape == ref.shape == (1, 1499, 512)
     o, r, x = out.float().cpu()[0], ref.float()[0], exact[0]
     d_ref, e_hip, e_ref = (o - r).abs(), (o - x).abs(), (r - x).abs()
     d_eg = (out.float() - eager.float()).abs()
-    parity_log.record("streaming/full-size 12-layer uni bf16, 60 s in 64-frame chunks (graph) vs whole-sequence oracle",
+    parity_log.record(f"streaming/full-size 12-layer uni bf16 {conv}, 60 s in 64-frame chunks (graph) vs whole-sequence oracle",
                       vs_matched_oracle_max=float(d_ref.max()), vs_matched_oracle_mean=float(d_ref.mean()),
                       hip_vs_exact_max=float(e_hip.max()), hip_vs_exact_mean=float(e_hip.mean()),
                       oracle_bf16_vs_exact_max=float(e_ref.max()), oracle_bf16_vs_exact_mean=float(e_ref.mean()),
@@ -209,10 +214,10 @@ def test_state_carry_stream_full_size_sixty_seconds_vs_oracle(hip):
     assert float(e_hip.mean()) <= 1.1 * float(e_ref.mean()) + 1e-3
     assert float(e_hip.max()) <= 1.5 * float(e_ref.max()) + 1e-2
     valid = torch.ones(1, 1499, dtype=torch.bool)
-    _token_parity(logp, ref_logp, valid, 0.25, "streaming full-size 60 s vs matched-precision whole-sequence oracle")
+    _token_parity(logp, ref_logp, valid, 0.25, f"streaming full-size 60 s {conv} vs matched-precision whole-sequence oracle")
 
 
-@pytest.mark.parametrize("chunk", [4, 16])
+@pytest.mark.parametrize("chunk", [4, 16, 32])
 @pytest.mark.parametrize("variant", ["uni_bf16slot", "uni_bf16model", "uni_f32"])
 def test_lookahead_stream_of_the_shipped_uni_model_vs_reference_whole_sequence(hip, variant, chunk):
     """The uni-directional model AS SHIPPED (conf/rwkv/giga.rwkv_uni_ds4k31nc_12le.trans-longutts.yaml:14-16: non-causal conv,
@@ -237,7 +242,7 @@ def test_lookahead_stream_of_the_shipped_uni_model_vs_reference_whole_sequence(h
         enc = enc.to(torch.bfloat16)
         sd = {k: v.bfloat16() for k, v in sd.items()}
     enc = enc.cuda().eval()
-    fresh = synth.randn((1, 4 * 83 + 5, 80), 907, 2.0).to(dt)
+    fresh = synth.randn((1, 4 * 32 * 11 + 5, 80), 907, 2.0).to(dt)       # 11 windows of 32: the fused steady-state steps get their turn
     ref_fresh, _ = EO.encoder_forward(fresh, torch.tensor([fresh.size(1)]), sd, conf, env={})
     cases = [("fresh", fresh, ref_fresh)]
     if variant != "uni_f32":       # the goldens carry a non-trivial CMVN, the comparison above does not: both paths are covered
@@ -249,7 +254,13 @@ def test_lookahead_stream_of_the_shipped_uni_model_vs_reference_whole_sequence(h
     for name, x, want in cases:
         e = enc_g if name == "golden" else enc
         with torch.no_grad():
+            e._carry_plans = None
             got = e.stream_chunks_lookahead(x.cuda(), chunk)
+            if wm and chunk >= 30 and name == "fresh":      # whole-bf16 stream, chunk >= 2 x 15: the fused + graphed steady state ran
+                assert e._carry_plans is not None
+                eager = e.stream_chunks_lookahead(x.cuda(), chunk, use_graph=False)
+                dd = (got.float() - eager.float()).abs()
+                assert float(dd.max()) <= 0.18 and float(dd.mean()) <= 1.4e-2
             # the pipeline really is delayed: the first call of a 12 x 15-frame... here 2 x 15-frame look-ahead emits nothing
             y0, st = e.forward_chunk_lookahead(x[:, :(chunk - 1) * 4 + 7].cuda(), None)
             assert y0.shape[1] == max(0, chunk - 15 * len(e.encoders)) and st[0]["cu"].shape[1] == min(30, 15 + chunk)
