@@ -78,11 +78,22 @@ def dtype_code(dt: torch.dtype) -> int:
     raise PafcError(f"kernels take float32 or bfloat16, got {dt}")
 
 
+# Host cost matters: a decode batch of short utterances is ~300 launches whose GPU time is below what Python needs to issue
+# them (5.8 ms per encoder pass before, 4.2 ms after this and the cached plan stamps: profiles/r04o_host_issue_time.txt).
+# torch.cuda.current_stream() builds a Stream object per call (~4 us); the raw-stream query is a plain C call.  Pointers and the
+# stream stay c_void_p OBJECTS: ctypes passes those pointer-sized whatever a function's declared argtypes say.
 def ptr(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_of(t: torch.Tensor) -> c_void_p:
+    """torch's CURRENT stream on the tensor's device as a raw hipStream_t: the stream the kernels launch on."""
+    if _raw_stream is not None:
+        idx = t.device.index
+        return c_void_p(_raw_stream(idx if idx is not None else torch.cuda.current_device()))
     return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 

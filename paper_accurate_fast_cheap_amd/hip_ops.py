@@ -532,12 +532,13 @@ def _bind2():
     P, I = c_void_p, c_int
     _lib._sig(L.pafc_add_layernorm, I, I, I, I, I, P, P, c_float, P, I, I, P, P, P, P, c_long, I, I, P, P, P, c_long,
               c_float, P)
-    _lib._sig(L.pafc_tmix_shift_mix, I, I, I, I, I, I, P, P, P, P, P)
-    _lib._sig(L.pafc_tmix_mix4, I, I, I, I, I, I, P, P, P, P, P)
+    # (first entry = return type; the argument lists are checked against include/*.h by tests/test_abi.py)
+    _lib._sig(L.pafc_tmix_shift_mix, I, I, I, I, I, I, I, P, P, P, P, P)
+    _lib._sig(L.pafc_tmix_mix4, I, I, I, I, I, I, I, P, P, P, P, P)
     _lib._sig(L.pafc_tmix_lora_mix4_bf16, I, I, I, I, I, I, P, P, P, P, P, P)
-    _lib._sig(L.pafc_tmix_shift_mix_prev, I, I, I, I, I, I, P, P, P, P, P, P)
+    _lib._sig(L.pafc_tmix_shift_mix_prev, I, I, I, I, I, I, I, P, P, P, P, P, P)
     _lib._sig(L.pafc_tmix_lora_mix4_bf16_prev, I, I, I, I, I, I, P, P, P, P, P, P, P)
-    _lib._sig(L.pafc_tmix_lora_down_bf16_prev, I, I, I, I, I, I, P, P, P, P, P, P)
+    _lib._sig(L.pafc_tmix_lora_down_bf16_prev, I, I, I, I, I, I, I, P, P, P, P, P, P)
     L._pafc_glue_bound = True
     return L
 

@@ -2,7 +2,6 @@
 
 `with op_timer("wkv6_fwd") as t:` brackets a C-ABI call with two events recorded on torch's current stream --
 the stream the kernels are launched on -- when profiling is enabled, and is free otherwise."""
-import contextlib
 from collections import defaultdict
 
 import torch
@@ -26,22 +25,47 @@ def enable_recording(flag: bool):
     _enabled = flag
 
 
-@contextlib.contextmanager
+class _Null:
+    """The disabled timer: one shared object, nothing allocated per call (the op wrappers sit on the launch path of
+    launch-bound batches)."""
+    __slots__ = ()
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _Null()
+
+
+class _Timed:
+    __slots__ = ("name", "meta", "a", "b")
+
+    def __init__(self, name, meta):
+        self.name, self.meta = name, meta
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+        return None
+
+    def __exit__(self, *exc):
+        self.b.record()
+        _records[self.name].append((self.a, self.b, self.meta))
+        return False
+
+
 def op_timer(name: str, sample: int = 1, **meta):
     """sample = n: time only every n-th call of this name (frequent ops: the events themselves cost ~2 us each)."""
     if not _enabled:
-        yield
-        return
+        return _NULL
     _calls[name] += 1
     if sample > 1 and (_calls[name] - 1) % sample:
-        yield
-        return
-    a = torch.cuda.Event(enable_timing=True)
-    b = torch.cuda.Event(enable_timing=True)
-    a.record()
-    yield
-    b.record()
-    _records[name].append((a, b, meta))
+        return _NULL
+    return _Timed(name, meta)
 
 
 def summary():

@@ -49,17 +49,24 @@ class LayerPlan:
         self.refresh()
 
     def _current_stamp(self):
-        L = self.layer
-        ps = [p for b in self.blocks for p in b.parameters()] + [L.feed_forward_macaron.w_2.bias, L.feed_forward.w_2.bias,
-                                                                    L.conv_module.pointwise_conv1.weight,
-                                                                    L.conv_module.pointwise_conv1.bias,
-                                                                    L.feed_forward_macaron.w_1.weight, L.feed_forward_macaron.w_2.weight,
-                                                                    L.feed_forward.w_1.weight, L.feed_forward.w_2.weight,
-                                                                    L.conv_module.pointwise_conv2.weight,
-                                                                    L.norm_ff_macaron.weight, L.norm_ff_macaron.bias, L.norm_ff.weight,
-                                                                    L.norm_ff.bias, L.norm_conv.weight, L.norm_conv.bias,
-                                                                    L.feed_forward_macaron.w_1.bias, L.feed_forward.w_1.bias]
-        return (hip_ops.param_epoch(),) + tuple((p.data_ptr(), p._version, p.dtype) for p in ps if p is not None)
+        # (storage, in-place version, dtype) of every parameter the plan derives something from, and the parameter epoch
+        # (hip_ops.param_epoch: fused optimizers move parameters without touching Tensor._version).  The parameter OBJECTS are
+        # looked up once per epoch -- walking the modules on every forward cost 90 us per layer of a launch-bound decode batch.
+        ep = hip_ops.param_epoch()
+        if getattr(self, "_stamp_params", None) is None or self._stamp_epoch != ep:
+            L = self.layer
+            ps = [p for b in self.blocks for p in b.parameters()] + [L.feed_forward_macaron.w_2.bias, L.feed_forward.w_2.bias,
+                                                                        L.conv_module.pointwise_conv1.weight,
+                                                                        L.conv_module.pointwise_conv1.bias,
+                                                                        L.feed_forward_macaron.w_1.weight, L.feed_forward_macaron.w_2.weight,
+                                                                        L.feed_forward.w_1.weight, L.feed_forward.w_2.weight,
+                                                                        L.conv_module.pointwise_conv2.weight,
+                                                                        L.norm_ff_macaron.weight, L.norm_ff_macaron.bias, L.norm_ff.weight,
+                                                                        L.norm_ff.bias, L.norm_conv.weight, L.norm_conv.bias,
+                                                                        L.feed_forward_macaron.w_1.bias, L.feed_forward.w_1.bias]
+            self._stamp_params = [p for p in ps if p is not None]
+            self._stamp_epoch = ep
+        return (ep,) + tuple((p.data_ptr(), p._version, p.dtype) for p in self._stamp_params)
 
     def refresh(self):
         stamp = self._current_stamp()

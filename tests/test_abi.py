@@ -133,3 +133,26 @@ def test_torch_ops_wkv6_schema_matches_the_reference_binding(so_path):
     t = torch.zeros(1, 4, 64)
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.wkv6.forward_fp32(1, 4, 64, 1, t, t, t, t, torch.zeros(1, 64), torch.empty(1, 4, 64))
+
+
+def test_ctypes_signatures_have_the_arity_of_the_header_prototypes():
+    """Every `_lib._sig(L.pafc_x, restype, *argtypes)` in the package declares exactly as many arguments as the prototype of
+    pafc_x in include/*.h has (a short list lets ctypes pass the tail by its default rules: a Python int as a 32-bit C int --
+    a truncated pointer or stream handle)."""
+    import glob
+    import re
+    hdr = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "include", "*.h")))
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|size_t|void|long)\s+(pafc_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    src = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "paper_accurate_fast_cheap_amd", "**", "*.py"), recursive=True))
+    seen = 0
+    for m in re.finditer(r"_sig\(\s*\w+\.(pafc_\w+)\s*,(.*?)\)\n", src, flags=re.S):
+        name, rest = m.group(1), m.group(2)
+        n = len([a for a in rest.replace("\n", " ").split(",") if a.strip()]) - 1          # minus the return type
+        assert name in protos, f"{name}: bound but not declared in include/*.h"
+        assert protos[name] == n, f"{name}: header has {protos[name]} arguments, the binding declares {n}"
+        seen += 1
+    assert seen >= 40

@@ -132,7 +132,7 @@ def test_linear_plans_are_bounded_explicit_and_capture_safe(hip, monkeypatch):
     dev = torch.device("cuda", torch.cuda.current_device())
     hip_ops._linear_plans.pop(dev, None)
     monkeypatch.setattr(hip_ops._LinearPlans, "CAP", 8)
-    monkeypatch.setenv("PAFC_GEMM_TUNE_MIN_ROWS", "64")
+    monkeypatch.setitem(hip_ops.DISPATCH, "gemm_tune_min_rows", 64)      # (the table is read when a plan owner is created)
     w = synth.randn((128, 64), 2, 0.1).to(torch.bfloat16).cuda()
     b = synth.randn((128,), 3, 0.2).to(torch.bfloat16).cuda()
     for rows in range(40, 72):                                   # 32 distinct problems through an 8-entry table
