@@ -316,9 +316,33 @@ void launch_pass_c(const FwdParams &p, dim3 grid, hipStream_t stream) {
     hipLaunchKernelGGL((wkv6_mfma_kernel<ET, true>), grid, dim3(64), 0, stream, p);
 }
 
+// A short bf16 sequence walked as one chunk (a streaming step: T = 64, 8 heads per stream) has 2-4 blocks of 16 steps and only
+// B * H * ndir waves: wkv6_few_blocks_kernel runs its blocks side by side in one launch.  Measured (round 4,
+// profiles/r04p_streaming_chunk_step_kernel_stats_few_blocks.csv): 19.3 us per launch against 17.3 us for the serial walk of
+// the same chunk by one wave per head -- each wave now pays a cold operand fetch twice (its pass A body, then its pass C body),
+// the 16 KiB carried state read per wave and a workgroup barrier, while the serial walk prefetches block n + 1 under block n;
+// per-block arithmetic was never the limit at 8 waves on the chip.  Kept behind PAFC_WKV6_FEW=1 (tested), not the default.
+template <int NW>
+int launch_few_blocks(const FwdParams &p, int ndir, hipStream_t stream) {
+    constexpr size_t lds = few_blocks_lds_bytes<NW>();
+    auto kern = wkv6_few_blocks_kernel<NW>;
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PAFC_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(1, p.B * p.H, ndir), dim3(64 * NW), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
 template <typename ET>
 int launch_fwd(FwdParams &p, int ndir, bool any_final, hipStream_t stream) {
     const bool mfma = use_mfma();
+    if constexpr (sizeof(ET) == 2) {
+        const int nb = (p.T + 15) / 16;
+        if (mfma && p.NC == 1 && nb >= 2 && nb <= 4 && (long)p.B * p.H * ndir * nb <= 2048) {
+            const char *e = getenv("PAFC_WKV6_FEW"), *c = getenv("PAFC_WKV6_PASS_C");
+            if ((e && e[0] == '1') && !(c && c[0] == 'l'))
+                return nb == 2 ? launch_few_blocks<2>(p, ndir, stream) : nb == 3 ? launch_few_blocks<3>(p, ndir, stream)
+                                                                                  : launch_few_blocks<4>(p, ndir, stream);
+        }
+    }
     if (p.NC > 1) {
         p.nc_local = any_final ? p.NC : p.NC - 1;
         dim3 ga(p.nc_local, p.B * p.H, ndir);

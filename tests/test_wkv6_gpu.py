@@ -266,3 +266,31 @@ def test_torch_ops_wkv6_as_the_reference_calls_them(hip, dtype, suffix):
     with pytest.raises(Exception):      # checked, not asserted: a transposed (non-contiguous) operand is refused
         fwd_op(B, T, C, H, leaves[0].detach().transpose(0, 1).contiguous().transpose(0, 1), *[t.detach() for t in leaves[1:]],
                torch.empty_like(y))
+
+
+@pytest.mark.parametrize("T", [17, 33, 48, 64])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_few_blocks_kernel_matches_the_oracle(hip, monkeypatch, T, reverse):
+    """wkv6_few_blocks_kernel (opt-in, PAFC_WKV6_FEW=1): the 2-4 blocks of a short bf16 sequence side by side in one launch,
+    carried state in, new state out (also in place) -- against the C restatement of wkv6state_cuda.cu:6-65 and against the
+    default serial walk of the same inputs."""
+    from oracle import wkv6_oracle as WO
+    from paper_accurate_fast_cheap_amd.rwkv_v6.wkv6_op import wkv6_forward
+    B, C, H = 2, 128, 2
+    bf = torch.bfloat16
+    r, k, v = (synth.randn((B, T, C), 300 + i, 0.5).to(bf) for i in range(3))
+    w = (synth.randn((B, T, C), 303) - 2.0).to(bf)
+    u = synth.randn((H, 64), 304, 0.3).to(bf)
+    s0 = synth.randn((B, H, 64, 64), 305, 0.5)
+    y_ref, s_ref = WO.forward(r, k, v, w, u, s_in=s0, want_state=True, reverse=reverse)
+    args = [t.cuda() for t in (r, k, v, w, u)]
+    y_serial, s_serial = wkv6_forward(*args, s_in=s0.cuda(), want_state=True, reverse=reverse)
+    monkeypatch.setenv("PAFC_WKV6_FEW", "1")
+    y, s1 = wkv6_forward(*args, s_in=s0.cuda(), want_state=True, reverse=reverse)
+    state = s0.cuda().clone()
+    y2, s2 = wkv6_forward(*args, s_in=state, s_out=state, reverse=reverse)        # in place
+    assert s2.data_ptr() == state.data_ptr() and torch.equal(y2, y) and torch.equal(s2, s1)
+    torch.testing.assert_close(y.float().cpu(), y_ref.float(), rtol=2 ** -7, atol=2e-2)
+    torch.testing.assert_close(s1.cpu(), s_ref, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(y.float(), y_serial.float(), rtol=2 ** -7, atol=2e-2)
+    torch.testing.assert_close(s1, s_serial, rtol=1e-4, atol=1e-4)
