@@ -38,6 +38,7 @@ struct FwdParams {
     int B, T, C, H;
     int L, NC;           // chunk length (multiple of TT unless == T) and number of chunks
     int nc_local;        // chunks whose local state pass A must produce (NC-1, or NC when a final state is wanted)
+    int prio;            // wave priority scheme of pass C (PAFC_WKV6_PRIO): 2 = raised for a block's MFMA-dense tail (default), 0 = none
     float *ws_state;     // [ndir][B][H][NC][N(j)][N(i)]
     float *ws_decay;     // [ndir][B][H][NC][N(j)]
 };
@@ -352,6 +353,11 @@ int launch_fwd(FwdParams &p, int ndir, bool any_final, hipStream_t stream) {
         hipLaunchKernelGGL(wkv6_scan_kernel, gb, dim3(256), 0, stream, p);
     }
     dim3 gc(p.NC, p.B * p.H, ndir);
+    // pass C raises its wave priority for the MFMA-dense tail of every block (intra-block term + state update) and drops it for
+    // the VALU chains of the next one: the partner wave of the SIMD, which is in the other phase, keeps issuing.  Measured over the
+    // bench step (round 4): 228.3 -> 221.2 us per bidirectional launch on one box, 221.0 -> 217.8 on another; a static priority
+    // for every second wave changed nothing.  PAFC_WKV6_PRIO=0 switches it off (A/B).
+    { const char *e = getenv("PAFC_WKV6_PRIO"); p.prio = e ? atoi(e) : 2; }
     if (mfma) launch_pass_c<ET>(p, gc, stream);
     else hipLaunchKernelGGL((wkv6_chunk_kernel<ET, true>), gc, dim3(64), 0, stream, p);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
