@@ -13,7 +13,7 @@ timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d $O/write -o run --output-format 
 echo write >> $O/progress.log
 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/sq -o run --output-format csv -- $CMD > $O/sq.log 2>&1
 echo sq >> $O/progress.log
-for d in stats fetch write sq; do f=$(find $O/$d -name "*.csv" | head -20); for g in $f; do cp $g $O/$d/$(basename $g); done; done
+# (rocprofv3 -o run writes the csv files straight into each -d directory)
 ls $O/stats $O/fetch | head
 mkdir -p gpurun_out/wkv_traffic
 python3 tools/summarize_wkv_pmc.py $O gpurun_out/wkv_traffic/$1_wkv6_bidir_T44998_bf16 | tail -40
