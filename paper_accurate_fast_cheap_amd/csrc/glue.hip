@@ -475,6 +475,11 @@ typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float tanh_as_gemm_epilogue(float v) {   // the form gemm_bf16.hip / gemm_ph.hip apply (act 2)
     return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * v) + 1.f);
 }
+__device__ __forceinline__ unsigned pack_bf16_rne(float lo, float hi) {     // round to nearest even and pack: one v_cvt_pk_bf16_f32
+    typedef float f32x2r __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2r __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2r{lo, hi}, bf16x2r));
+}
 __device__ __forceinline__ unsigned pack_bf16_exact(float lo, float hi) {   // both already bf16 values
     return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
 }
@@ -623,10 +628,10 @@ __global__ __launch_bounds__(NW * 64) void tmix_lora_down_kernel(int T, long row
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const float xx = round_bf16((has_nb ? xn[e] : 0.f) - xc[e]);
-                o[e] = round_bf16(xc[e] + round_bf16(xx * mm[e]));
+                o[e] = xc[e] + round_bf16(xx * mm[e]);              // (rounded by the packing conversion below: one v_cvt_pk per pair)
             }
-            const u32x4g bq = {pack_bf16_exact(o[0], o[1]), pack_bf16_exact(o[2], o[3]), pack_bf16_exact(o[4], o[5]),
-                               pack_bf16_exact(o[6], o[7])};
+            const u32x4g bq = {pack_bf16_rne(o[0], o[1]), pack_bf16_rne(o[2], o[3]), pack_bf16_rne(o[4], o[5]),
+                               pack_bf16_rne(o[6], o[7])};
 #pragma unroll
             for (int np = 0; np < 4; ++np)
 #pragma unroll
