@@ -285,12 +285,18 @@ static int ph_tile_m(long M, int N, int K, int batch, int act, bool has_residual
     if (has_residual && act != 0) return 0;
     const int cus = pafc::device_cus();
     const long nt = (N + 255) / 256;
-    // too few big tiles: the small-tile kernel fills the chip better.  PAFC_PH_MIN_FILL (percent of the CUs the 256-wide tiles
-    // must cover, default 75) moves the line for A/B runs: a c2 pass measured 75 / 45 / 25 / 15 within 1.5 % of each other
-    // (profiles/r03c_bench_c2_knobs.txt); at 3 992 rows (a batch of 2 000-frame windows: 50 % fill) the 128 x 128 kernel takes
-    // w_1 in 18.6 us against 21.1 on half a grid of 256-wide tiles (profiles/r04e_windows_2000x8_kernels_*.txt)
-    static const long min_fill = [] { const char *e = getenv("PAFC_PH_MIN_FILL"); const long v = e ? atol(e) : 75; return v > 0 ? v : 75; }();
-    if (((M + 255) / 256) * nt * batch * 100 < (long)cus * min_fill) return 0;
+    // Which family: measured at 3 992 - 32 000 rows on every layer shape (profiles/r04s_gemm_tile_choice_by_rows.txt), one round
+    // of the 128-wide kernel (two co-resident 128 x 128 tiles per CU) takes ~19 us at K = 512 where one round of 256-wide tiles takes
+    // 23-28 us whatever its fill, and a second round of the small kernel brings it to 29-33 us.  So: the 128-wide kernel while its
+    // tiles fit ONE round (<= 2 per CU), the 256-wide one beyond.  (Round 3's rule -- 256-wide tiles must cover 75 % of the CUs
+    // -- sent N = 512 products of 18 000-24 000 rows, a batch of 9 000-frame windows or a long decode batch, to two rounds of
+    // the small kernel: 28.9 instead of 23.7 us.)  PAFC_PH_MIN_FILL=<percent> brings that rule back for A/B runs.
+    static const long min_fill = [] { const char *e = getenv("PAFC_PH_MIN_FILL"); return e ? atol(e) : 0L; }();
+    if (min_fill > 0) {
+        if (((M + 255) / 256) * nt * batch * 100 < (long)cus * min_fill) return 0;
+    } else if (((M + 127) / 128) * ((N + 127) / 128) * batch <= 2L * cus) {
+        return 0;
+    }
     long best_cost = -1;
     int best = 0;
     for (int tm = 256; tm >= 192; tm -= 64) {

@@ -42,8 +42,10 @@ from ._lib import c_int, c_void_p
 #                                   3 x the row count at which they fill the chip): profiles/r03d / r03e
 #   gemm_tune_min_rows       32768  library (fp32) GEMMs of at least this many rows measure the library's candidates once
 #                                   (explicit plan objects; never under graph capture): DESIGN section 4, round-1 fault
-# C side (csrc/gemm_bf16.hip): PAFC_PH_MIN_FILL (percent of the CUs the 256-wide tiles must cover before the 256-wide kernel
-# takes a problem; default 75) and PAFC_GEMM_TILE (force a tile of the small kernel) are A/B switches of the kernels themselves.
+# C side (csrc/gemm_bf16.hip): which GEMM family takes a problem is decided by rounds -- the 128-wide kernel while its 128 x 128
+# tiles fit one round of two per CU, the 256-wide phase-pipelined kernel beyond (profiles/r04s_gemm_tile_choice_by_rows.txt);
+# PAFC_PH_MIN_FILL=<percent> (round 3's rule: 256-wide tiles must cover that share of the CUs) and PAFC_GEMM_TILE (force a tile
+# of the small kernel) are A/B switches of the kernels themselves.
 DISPATCH = dict(skinny_max_rows=640, own_gemm_min_rows=1, lds_resident_min_rows=8192, split_gemm_min_rows=16384,
                 ln_fold_min_rows=24576, gemm_tune_min_rows=32768)
 
