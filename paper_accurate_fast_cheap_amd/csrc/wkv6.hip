@@ -297,7 +297,9 @@ void launch_pass_a(const FwdParams &p, dim3 grid, hipStream_t stream) {
     if constexpr (sizeof(ET) == 2) {
         const char *e = getenv("PAFC_WKV6_PASS_A");
         if (!(e && e[0] == 'l')) {
-            hipLaunchKernelGGL(wkv6_pass_a_cl_kernel, grid, dim3(64), 0, stream, p);
+            // the variant without a decay bias issues neither the add nor its rounding (a tenth of the per-step arithmetic)
+            if (p.d[0].wb != nullptr || p.d[1].wb != nullptr) hipLaunchKernelGGL(wkv6_pass_a_cl_kernel<true>, grid, dim3(64), 0, stream, p);
+            else hipLaunchKernelGGL(wkv6_pass_a_cl_kernel<false>, grid, dim3(64), 0, stream, p);
             return;
         }
     }
@@ -310,7 +312,8 @@ void launch_pass_c(const FwdParams &p, dim3 grid, hipStream_t stream) {
     if constexpr (sizeof(ET) == 2) {
         const char *e = getenv("PAFC_WKV6_PASS_C");
         if (!(e && e[0] == 'l')) {
-            hipLaunchKernelGGL(wkv6_pass_c_cl_kernel, grid, dim3(64), 0, stream, p);
+            if (p.d[0].wb != nullptr || p.d[1].wb != nullptr) hipLaunchKernelGGL(wkv6_pass_c_cl_kernel<true>, grid, dim3(64), 0, stream, p);
+            else hipLaunchKernelGGL(wkv6_pass_c_cl_kernel<false>, grid, dim3(64), 0, stream, p);
             return;
         }
     }

@@ -1073,6 +1073,11 @@ def tmix_lora_down(x: torch.Tensor, maa_x: torch.Tensor, w1n: torch.Tensor, reve
     return gemm_bf16(xxx.view(ndir, B * T, C), w1n, act="tanh")
 
 
+def decay_lora_one_pass(rows: int, C: int, H: int) -> bool:
+    """Does decay_lora take its one-pass kernel (where a bias costs nothing) at this size?"""
+    return C == 512 and H == 64 and rows >= _LDS_RESIDENT_MIN_ROWS
+
+
 def decay_lora(zw: torch.Tensor, d1n: torch.Tensor, d2n: torch.Tensor, bias: Optional[torch.Tensor] = None,
                one_pass: Optional[bool] = None):
     """bf16: w = bf16(bf16(tanh(zw d1n^T)) d2n^T) [+ bias] in one pass.  zw (ndir, rows, C), d1n (ndir, H, C), d2n (ndir, C, H),
@@ -1092,7 +1097,7 @@ def decay_lora(zw: torch.Tensor, d1n: torch.Tensor, d2n: torch.Tensor, bias: Opt
     for a in (zw, d1n, d2n) + ((bias,) if bias is not None else ()):
         if not a.is_contiguous() or a.dtype != torch.bfloat16:
             raise _lib.PafcError("decay_lora: contiguous bf16 tensors")
-    if C == 512 and H == 64 and (rows >= _LDS_RESIDENT_MIN_ROWS if one_pass is None else one_pass):
+    if C == 512 and H == 64 and (decay_lora_one_pass(rows, C, H) if one_pass is None else one_pass):
         w = torch.empty_like(zw)
         from .profiling import op_timer
         with op_timer("decay_lora"):

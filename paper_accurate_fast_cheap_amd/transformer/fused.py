@@ -277,8 +277,12 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
     else:
         rkv = torch.bmm(z[:3].view(3 * nd, M, C), plan.Wrkv)
     if own_gemm:
-        # decay LoRA in one pass (the 64-wide hidden tensor stays on chip); uni: time_decay rides along
-        w = hip_ops.decay_lora(z[3], plan.D1n, plan.D2n, plan.time_decay.view(nd, C) if nd == 1 else None)
+        # decay LoRA in one pass (the 64-wide hidden tensor stays on chip); there time_decay rides along, rounded where the
+        # reference's `self.time_decay + lora` rounds (src/model.py:289), and the scan runs its variant without a bias, which
+        # issues neither the add nor the rounding per step (in both of its passes).  Below the one-pass size a bias would be
+        # an extra pass over w: the bidirectional scan adds it itself.
+        bias_in_lora = nd == 1 or hip_ops.decay_lora_one_pass(M, C, plan.D1n.shape[1])
+        w = hip_ops.decay_lora(z[3], plan.D1n, plan.D2n, plan.time_decay.view(nd, C) if bias_in_lora else None)
     else:
         w = torch.bmm(torch.tanh(torch.bmm(z[3], plan.D1)), plan.D2)
     if nd == 1 and not own_gemm:
@@ -288,7 +292,7 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
         ys = wkv6_forward_bidir(
             (rkv[0].view(B, T, C), rkv[2].view(B, T, C), rkv[4].view(B, T, C), w[0].view(B, T, C), plan.u[0]),
             (rkv[1].view(B, T, C), rkv[3].view(B, T, C), rkv[5].view(B, T, C), w[1].view(B, T, C), plan.u[1]),
-            w_bias=(plan.time_decay[0].view(-1), plan.time_decay[1].view(-1)))
+            w_bias=None if own_gemm and bias_in_lora else (plan.time_decay[0].view(-1), plan.time_decay[1].view(-1)))
     else:
         ys = (wkv6_forward(rkv[0].view(B, T, C), rkv[1].view(B, T, C), rkv[2].view(B, T, C), w[0].view(B, T, C),
                            plan.u[0]),)
