@@ -58,8 +58,10 @@ int pafc_abi_version(void);
 
 /* Hardware self-check of the in-row lane permutations the matrix-core kernel relies on (DPP control codes): writes,
  * for x = lane + 1, 4 results per lane [lane^1, lane^2, mirror in the 8-lane half (i -> 7-i), mirror in the 16-lane
- * row (i -> 15-i)] into out_64x4 (device, 256 floats); tests compare them with the definitions. */
-int pafc_selftest_lane_ops(float *out_64x4, pafc_stream_t stream);
+ * row (i -> 15-i)] into out[0:256], and the exchanges between the four 16-lane rows (v_permlane16_swap / v_permlane32_swap with
+ * both operands x): [x at my position in the even row of my row pair, in the odd row of my pair, in the lower 32 lanes, in the
+ * upper 32 lanes] into out[256:512] (device, 512 floats); tests compare them with the definitions. */
+int pafc_selftest_lane_ops(float *out_2x64x4, pafc_stream_t stream);
 
 /* ---- workspace sizing -------------------------------------------------------------------- */
 /* Chunk length the library would pick for this shape (fills the 256 CUs; returns T when the

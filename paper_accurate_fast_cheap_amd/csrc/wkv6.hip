@@ -747,9 +747,9 @@ extern "C" {
 
 int pafc_abi_version(void) { return 1; }
 
-int pafc_selftest_lane_ops(float *out_64x4, pafc_stream_t stream) {
-    if (!out_64x4) return PAFC_ERR_NULL_POINTER;
-    hipLaunchKernelGGL(pafc::lane_ops_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_64x4);
+int pafc_selftest_lane_ops(float *out_2x64x4, pafc_stream_t stream) {
+    if (!out_2x64x4) return PAFC_ERR_NULL_POINTER;
+    hipLaunchKernelGGL(pafc::lane_ops_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_2x64x4);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 

@@ -158,17 +158,21 @@ def test_matrix_core_and_valu_kernels_agree(hip, dtype, monkeypatch):
 def test_lane_ops_selftest(hip):
     """The in-row lane exchanges of the matrix-core kernel (DPP control codes) do what their names say."""
     import ctypes
-    out = torch.zeros(64, 4, device="cuda")
+    out = torch.zeros(2, 64, 4, device="cuda")
     hip.pafc_selftest_lane_ops.restype = ctypes.c_int
     rc = hip.pafc_selftest_lane_ops(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     torch.cuda.synchronize()
-    o = out.cpu()
+    o, o2 = out[0].cpu(), out[1].cpu()
     for lane in range(64):
         row, t = lane & ~15, lane & 15
         x = lambda l: float(l + 1)
         exp = [x(lane ^ 1), x(lane ^ 2), x(row + (t & 8) + 7 - (t & 7)), x(row + 15 - t)]
         assert o[lane].tolist() == exp, (lane, o[lane].tolist(), exp)
+        # the exchanges between 16-lane rows (pass C's quad products): my position in the even / odd row of my row pair,
+        # in the lower / upper 32 lanes
+        exp2 = [x((lane & ~16)), x(lane | 16), x(lane & ~32), x(lane | 32)]
+        assert o2[lane].tolist() == exp2, (lane, o2[lane].tolist(), exp2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
