@@ -38,6 +38,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    variant = os.environ.get("PAFC_SO_PATH")     # A/B measurements: a variant of the library built by csrc.build --extra / --out
+    if variant:
+        if not os.path.exists(variant):
+            raise PafcError(f"PAFC_SO_PATH={variant} does not exist")
+        _lib = _bind(ctypes.CDLL(variant))
+        return _lib
     if not os.path.exists(SO_PATH):
         raise PafcError(
             f"{SO_PATH} is missing: the HIP extension has not been built "
@@ -47,7 +53,11 @@ def lib():
         raise PafcError(
             f"{SO_PATH} was not built from the sources in this tree (libpafc_hip.so.json: {_build.built_key()}, sources: "
             f"{_build.source_key()}): rebuild with python -m paper_accurate_fast_cheap_amd.csrc.build")
-    L = ctypes.CDLL(SO_PATH)
+    _lib = _bind(ctypes.CDLL(SO_PATH))
+    return _lib
+
+
+def _bind(L):
     P, I, Z = c_void_p, c_int, c_size_t
     _sig(L.pafc_abi_version, I)
     _sig(L.pafc_wkv6_pick_chunk_len, I, I, I, I, I, I)
@@ -61,8 +71,7 @@ def lib():
     _sig(L.pafc_wkv6_backward, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, I, I, P, Z, P)
     _sig(L.pafc_wkv6_backward_state, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P, Z, P)
     _sig(L.pafc_ctc_greedy, I, I, I, I, I, P, P, I, P, P, P, P, P)
-    _lib = L
-    return _lib
+    return L
 
 
 def check(code: int, what: str):

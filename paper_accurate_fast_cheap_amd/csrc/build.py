@@ -63,7 +63,12 @@ def stale() -> bool:
     return not os.path.exists(OUT) or built_key() != source_key()
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, extra_flags=None, out: str = None) -> str:
+    """Build the library.  `extra_flags` / `out` build a VARIANT from the same sources with additional compiler flags into another
+    file (A/B measurements of a flag: `_lib` loads it when PAFC_SO_PATH names it); the tree's own library is left alone."""
+    variant = bool(extra_flags) or out is not None
+    if variant:
+        return _build_variant(list(extra_flags or []), out or (OUT + ".variant"), verbose)
     if not force and not stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -101,5 +106,34 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return OUT
 
 
+def _build_variant(extra, out, verbose):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    vdir = os.path.join(OBJ, "variant_" + hashlib.sha256(" ".join(extra).encode()).hexdigest()[:8])
+    os.makedirs(vdir, exist_ok=True)
+    hdr_key = _sha(_headers(), " ".join(_CFLAGS + extra))
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(vdir, f"{os.path.basename(src)}.{_sha([src], hdr_key)}.o")
+        objs.append(obj)
+        if not os.path.exists(obj):
+            jobs.append(([hipcc] + CFLAGS + extra + ["-c", src, "-o", obj + ".tmp"], obj))
+
+    def run(job):
+        cmd, obj = job
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        os.replace(obj + ".tmp", obj)
+
+    if jobs:
+        with ThreadPoolExecutor(max(1, min(len(jobs), int(os.environ.get("PAFC_BUILD_JOBS", "8"))))) as ex:
+            list(ex.map(run, jobs))
+    subprocess.check_call([hipcc] + objs + LDFLAGS + ["-o", out])
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    # python -m ...csrc.build [--force] [-v] [--extra "<flags>" --out <file>]
+    extra = sys.argv[sys.argv.index("--extra") + 1].split() if "--extra" in sys.argv else None
+    out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, extra_flags=extra, out=out))
