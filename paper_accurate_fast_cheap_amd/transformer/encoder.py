@@ -87,7 +87,9 @@ class BaseEncoder(torch.nn.Module):
     def _forward_graphed(self, xs: torch.Tensor, xs_lens: torch.Tensor):
         """Replay the forward of this (B, T, dtype) shape from a captured hipGraph; the first sighting of a shape runs
         eagerly (returns None), the second one captures.  Outputs are copies: the graph's own buffers are reused."""
-        key = (tuple(xs.shape), xs.dtype, xs_lens.dtype)
+        # keyed by the issuing stream as well: a graph replays into its own buffers, so batches in flight on two streams
+        # (two decode batches overlapping each other's launch-bound stretches) need a graph each
+        key = (tuple(xs.shape), xs.dtype, xs_lens.dtype, torch.cuda.current_stream(xs.device).cuda_stream)
         ent = self._graphs.get(key)
         if ent is None:
             self._graphs[key] = "seen"

@@ -766,7 +766,7 @@ def test_graph_cache_replays_recurring_batch_shapes(hip):
         want = [enc(x, l) for x, l in zip(xs, lens)]
         enc.graph_cache_size = 1
         got = [enc(x, l) for x, l in zip(xs, lens)]
-        assert isinstance(enc._graphs[((3, 95, 80), torch.float32, torch.int64)], tuple)
+        assert isinstance(enc._graphs[((3, 95, 80), torch.float32, torch.int64, torch.cuda.current_stream().cuda_stream)], tuple)
         other = enc(xs[0][:, :71], torch.tensor([71, 30, 9], device="cuda"))         # another shape: eager, then captured
         other2 = enc(xs[0][:, :71], torch.tensor([71, 30, 9], device="cuda"))
         assert sum(isinstance(v, tuple) for v in enc._graphs.values()) == 1            # bounded: the older graph is gone
@@ -774,6 +774,46 @@ def test_graph_cache_replays_recurring_batch_shapes(hip):
         assert torch.equal(wm, gm)
         torch.testing.assert_close(gy, wy, rtol=1e-4, atol=2e-5)
     torch.testing.assert_close(other[0], other2[0], rtol=1e-4, atol=2e-5)
+
+
+def test_graph_cache_two_batches_in_flight(hip):
+    """Two decode batches in flight on two HIP streams (bench.py's window leg): the graph cache keeps one graph per (shape,
+    stream), the replays of the two streams overlap, and every batch's output equals its one-stream replay bit for bit."""
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_reduced_f32")
+    sd = {k: v for k, v in _sd(g).items() if not k.startswith("global_cmvn")}
+    enc = ConformerEncoder(80, **g["conf"])
+    enc.load_state_dict(sd)
+    enc = enc.cuda().eval().to(torch.bfloat16)
+    xs = [synth.randn((4, 203, 80), 300 + i, 2.0).cuda().to(torch.bfloat16) for i in range(6)]
+    lens = torch.tensor([203, 203, 203, 203], device="cuda")
+    side = [torch.cuda.Stream() for _ in range(2)]
+
+    def one_pass(streams):
+        main = torch.cuda.current_stream()
+        for s_ in streams:
+            s_.wait_stream(main)
+        outs = []
+        for i, x in enumerate(xs):
+            if streams:
+                with torch.cuda.stream(streams[i % 2]):
+                    outs.append(enc(x, lens)[0])
+            else:
+                outs.append(enc(x, lens)[0])
+        for s_ in streams:
+            main.wait_stream(s_)
+        torch.cuda.synchronize()
+        return outs
+
+    with torch.no_grad():
+        enc.graph_cache_size = 4
+        for _ in range(3):                       # seen, captured, replayed
+            single = one_pass([])
+        for _ in range(3):
+            double = one_pass(side)
+        assert sum(isinstance(v, tuple) for v in enc._graphs.values()) == 3       # the main stream's graph + one per side stream
+    for a, b in zip(single, double):
+        assert torch.equal(a, b)
 
 
 def test_minimal_and_ragged_edge_inputs(hip):
