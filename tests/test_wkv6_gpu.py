@@ -65,6 +65,26 @@ def test_bidir_one_launch(hip, dtype):
     torch.testing.assert_close(yb.cpu().float(), WO.forward(*b, reverse=True).float(), **_tol(dtype))
 
 
+@pytest.mark.parametrize("B,T,chunk", [(2, 203, 32), (1, 1000, 0), (3, 77, 10 ** 6)])
+def test_decay_bias_inside_the_scan_equals_bias_added_before_it(hip, B, T, chunk):
+    """`time_decay + lora` (src/model.py:289, one bf16 rounding) either inside the scan (w_bias: the kernel variants that add
+    and round per step, both passes) or beforehand (what the decay-LoRA kernel does when it carries the bias; the scan then runs
+    the variants without a bias): the SAME arithmetic, so the outputs must be bit-identical; and both equal the oracle on the
+    pre-added input.  T = 203 / 77 / 1000 end in ragged 16-step blocks (the liveness branch of pass C)."""
+    from paper_accurate_fast_cheap_amd.rwkv_v6.wkv6_op import wkv6_forward_bidir
+    C, H = 512, 8
+    f, b = _inputs(B, T, C, H, 900 + T, torch.bfloat16), _inputs(B, T, C, H, 950 + T, torch.bfloat16)
+    wbf, wbb = (synth.randn((C,), 990 + i, 0.7).to(torch.bfloat16) for i in range(2))
+    pre = lambda a, wb: a[:3] + [(a[3].float() + wb.float()).to(torch.bfloat16)] + a[4:]
+    fg, bg = [t.cuda() for t in f], [t.cuda() for t in b]
+    inside = wkv6_forward_bidir(fg, bg, chunk_len=chunk, w_bias=(wbf.cuda(), wbb.cuda()))
+    before = wkv6_forward_bidir([t.cuda() for t in pre(f, wbf)], [t.cuda() for t in pre(b, wbb)], chunk_len=chunk)
+    for y_in, y_pre in zip(inside, before):
+        assert torch.equal(y_in, y_pre)
+    torch.testing.assert_close(before[0].cpu().float(), WO.forward(*pre(f, wbf)).float(), **_tol(torch.bfloat16))
+    torch.testing.assert_close(before[1].cpu().float(), WO.forward(*pre(b, wbb), reverse=True).float(), **_tol(torch.bfloat16))
+
+
 def test_strong_decay_does_not_underflow_to_nan(hip):
     """w up to +3 -> d = exp(-20): chunk decay products reach 0 exactly; the scan only multiplies, so
     the result must stay finite and equal the serial answer ('Decay underflow')."""
