@@ -38,6 +38,16 @@ int pafc_dwconv1d_cl(int dtype, int B, int T_in, int C, int K, int left_pad, int
 int pafc_dwconv1d_cl_ex(int dtype, int B, int T_in, int C, int K, int left_pad, int T_out, const void *x, long ldx,
                         const void *w, const void *bias, void *y, int act, const int32_t *lens, pafc_stream_t stream);
 
+/* The depthwise convolution with the conv module's LayerNorm + SiLU as its epilogue -- `self.activation(self.norm(x))` after
+ * `depthwise_conv`, wenet/transformer/convolution.py:131-138 with cnn_module_norm: layer_norm -- in one pass:
+ *   y = SiLU(LayerNorm_C(conv(x)) * gamma + beta), every intermediate rounded to bf16 where the module chain stores one
+ *   (convolution output, LayerNorm output), two-pass variance.
+ * bf16 only, C == 512 (a block of the kernel owns all the channels of its frames), K in {15, 31}; other shapes: PAFC_ERR_UNSUPPORTED
+ * (callers then run pafc_dwconv1d_cl + pafc_add_layernorm).  x: (B, T_in, ldx >= C) (ldx: row stride in elements), gamma / beta: (C). */
+int pafc_dwconv1d_cl_ln_silu(int dtype, int B, int T_in, int C, int K, int left_pad, int T_out, const void *x, long ldx,
+                             const void *w, const void *bias, const void *gamma, const void *beta, float eps, void *y,
+                             const int32_t *lens, pafc_stream_t stream);
+
 /* Gradients of the same convolution for the training step (config c4; the reference differentiates nn.Conv1d through
  * autograd: convolution.py:131 under train_utils.py:646-660).  The input gradient is the forward kernel itself on dy with
  * the taps reversed and left_pad' = K - 1 - left_pad; this entry point is the other half:

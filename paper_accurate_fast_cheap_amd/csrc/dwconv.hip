@@ -6,6 +6,7 @@
 // 8-byte f32x2 access, so a wave touches 256/512 contiguous bytes of a row) and TO consecutive output frames.
 // The K taps of its two channels live in registers; every input row of the tile (+halo) is loaded once and
 // scattered into the <= K output accumulators it feeds, with all indices compile-time (full unroll).
+#include <stdlib.h>
 #include "pafc_common.h"
 #include "../../include/pafc_encoder_ops.h"
 
@@ -34,11 +35,20 @@ template <> struct Pair<bf16_t> {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
-// ACT: 0 plain, 1 GLU on the input (x is (.., 2C)), 2 SiLU on the output (Mamba-2's conv1d + SiLU)
+// The conv module's LayerNorm + SiLU (convolution.py:134-138: `self.activation(self.norm(x))`) applied by the convolution's own
+// epilogue: a block already owns ALL the channels of its 16 output frames (C = 512 = 256 lanes x 2), so the rows' statistics are
+// two block reductions and the normalised rows never make a round trip through memory as the convolution's raw output.
+struct LnTail {
+    const void *gamma, *beta;   // (C), element type
+    float eps;
+};
+
+// ACT: 0 plain, 1 GLU on the input (x is (.., 2C)), 2 SiLU on the output (Mamba-2's conv1d + SiLU),
+//      3 = y = SiLU(LayerNorm_C(conv output)), every intermediate rounded where the module chain rounds it (C == 512 only)
 template <typename ET, int K, int ACT>
 __global__ __launch_bounds__(256) void dwconv_kernel(int T_in, int C, int left_pad, int T_out, const ET *__restrict__ x,
                                                      long ldx, const ET *__restrict__ w, const ET *__restrict__ bias,
-                                                     ET *__restrict__ y, const int32_t *__restrict__ lens) {
+                                                     ET *__restrict__ y, const int32_t *__restrict__ lens, const LnTail ln) {
     constexpr bool GLU = ACT == 1;
     const int c = (blockIdx.y * 256 + threadIdx.x) * 2;
     if (c >= C) return;
@@ -105,6 +115,50 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int T_in, int C, int left_p
         }
     }
     ET *yb = y + (size_t)b * T_out * C + c;
+    if constexpr (ACT == 3) {
+        // rows = my 16 output frames, all 512 channels in this block: u = the convolution output as the module chain stores it
+        // (rounded), LayerNorm with the two-pass variance of add_layernorm_kernel, rounded, SiLU, rounded.
+        __shared__ __attribute__((aligned(16))) float red[256 * 20];     // [lane of the block][16 rows (+ 4 pad)]
+        __shared__ __attribute__((aligned(16))) float tot[TO];
+        const int tid = threadIdx.x, rr = tid >> 4, jj = tid & 15;
+        auto block_sums = [&](const float (&v)[TO]) {     // tot[r] = sum over the block's 256 lanes of v[r]
+#pragma unroll
+            for (int q = 0; q < TO / 4; ++q)
+                *reinterpret_cast<float4 *>(&red[tid * 20 + 4 * q]) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            __syncthreads();
+            float p = 0.f;                               // lane (row rr, part jj): lanes 16 jj .. 16 jj + 15 of row rr
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p += red[(16 * jj + i) * 20 + rr];
+            p += __shfl_xor(p, 1, 64); p += __shfl_xor(p, 2, 64); p += __shfl_xor(p, 4, 64); p += __shfl_xor(p, 8, 64);
+            if (jj == 0) tot[rr] = p;
+            __syncthreads();
+        };
+        float u0[TO], u1[TO], sv[TO];
+#pragma unroll
+        for (int o = 0; o < TO; ++o) { u0[o] = Pair<ET>::round(a0[o]); u1[o] = Pair<ET>::round(a1[o]); sv[o] = u0[o] + u1[o]; }
+        block_sums(sv);
+        const float inv_c = 1.f / (float)C;
+        float mean[TO];
+#pragma unroll
+        for (int o = 0; o < TO; ++o) {
+            mean[o] = tot[o] * inv_c;
+            const float d0 = u0[o] - mean[o], d1 = u1[o] - mean[o];
+            sv[o] = fmaf(d1, d1, d0 * d0);
+        }
+        __syncthreads();                                 // every lane has read tot before the second reduction overwrites it
+        block_sums(sv);
+        const float2 gv = Pair<ET>::load((const ET *)ln.gamma + c), bt = Pair<ET>::load((const ET *)ln.beta + c);
+#pragma unroll
+        for (int o = 0; o < TO; ++o) {
+            const float rstd = rsqrtf(tot[o] * inv_c + ln.eps);
+            float o0 = Pair<ET>::round(fmaf((u0[o] - mean[o]) * rstd, gv.x, bt.x));
+            float o1 = Pair<ET>::round(fmaf((u1[o] - mean[o]) * rstd, gv.y, bt.y));
+            o0 = o0 * sigmoidf_(o0);
+            o1 = o1 * sigmoidf_(o1);
+            if (t0 + o < T_out) Pair<ET>::store(yb + (size_t)(t0 + o) * C, make_float2(o0, o1));
+        }
+        return;
+    }
 #pragma unroll
     for (int o = 0; o < TO; ++o) {
         if (ACT == 2) {   // SiLU of the rounded convolution output, as the framework's two ops compute it
@@ -118,29 +172,36 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int T_in, int C, int left_p
 
 template <typename ET, int K>
 int launch(int B, int T_in, int C, int left_pad, int T_out, const void *x, long ldx, const void *w, const void *bias,
-           void *y, int act, const int32_t *lens, hipStream_t s) {
+           void *y, int act, const int32_t *lens, const LnTail &ln, hipStream_t s) {
     dim3 grid((T_out + TO - 1) / TO, (C / 2 + 255) / 256, B), block(256);
     if (act == 1)
         hipLaunchKernelGGL((dwconv_kernel<ET, K, 1>), grid, block, 0, s, T_in, C, left_pad, T_out, (const ET *)x, ldx,
-                           (const ET *)w, (const ET *)bias, (ET *)y, lens);
+                           (const ET *)w, (const ET *)bias, (ET *)y, lens, ln);
     else if (act == 2)
         hipLaunchKernelGGL((dwconv_kernel<ET, K, 2>), grid, block, 0, s, T_in, C, left_pad, T_out, (const ET *)x, ldx,
-                           (const ET *)w, (const ET *)bias, (ET *)y, lens);
-    else
+                           (const ET *)w, (const ET *)bias, (ET *)y, lens, ln);
+    else if (act == 3) {
+        if constexpr (K == 31 || K == 15) {        // the conv module's kernel sizes (conf/rwkv/*.yaml: cnn_module_kernel)
+            hipLaunchKernelGGL((dwconv_kernel<ET, K, 3>), grid, block, 0, s, T_in, C, left_pad, T_out, (const ET *)x, ldx,
+                               (const ET *)w, (const ET *)bias, (ET *)y, lens, ln);
+        } else {
+            return PAFC_ERR_UNSUPPORTED;
+        }
+    } else
         hipLaunchKernelGGL((dwconv_kernel<ET, K, 0>), grid, block, 0, s, T_in, C, left_pad, T_out, (const ET *)x, ldx,
-                           (const ET *)w, (const ET *)bias, (ET *)y, lens);
+                           (const ET *)w, (const ET *)bias, (ET *)y, lens, ln);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 
 template <typename ET>
 int dispatch_k(int K, int B, int T_in, int C, int left_pad, int T_out, const void *x, long ldx, const void *w,
-               const void *bias, void *y, int act, const int32_t *lens, hipStream_t s) {
+               const void *bias, void *y, int act, const int32_t *lens, const LnTail &ln, hipStream_t s) {
     switch (K) {
-        case 31: return launch<ET, 31>(B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
-        case 15: return launch<ET, 15>(B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
-        case 7: return launch<ET, 7>(B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
-        case 4: return launch<ET, 4>(B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
-        case 3: return launch<ET, 3>(B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
+        case 31: return launch<ET, 31>(B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, ln, s);
+        case 15: return launch<ET, 15>(B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, ln, s);
+        case 7: return launch<ET, 7>(B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, ln, s);
+        case 4: return launch<ET, 4>(B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, ln, s);
+        case 3: return launch<ET, 3>(B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, ln, s);
         default: return PAFC_ERR_UNSUPPORTED;
     }
 }
@@ -261,10 +322,22 @@ extern "C" int pafc_dwconv1d_cl_ex(int dtype, int B, int T_in, int C, int K, int
         B > 65535 || act < 0 || act > 2 || ldx < (act == 1 ? 2L * C : (long)C) || (ldx % 2))
         return PAFC_ERR_BAD_DIMS;
     hipStream_t s = (hipStream_t)stream;
+    const pafc::LnTail none{nullptr, nullptr, 0.f};
     if (dtype == PAFC_BF16)
-        return pafc::dispatch_k<pafc::bf16_t>(K, B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
-    if (dtype == PAFC_F32) return pafc::dispatch_k<float>(K, B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, s);
+        return pafc::dispatch_k<pafc::bf16_t>(K, B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, none, s);
+    if (dtype == PAFC_F32) return pafc::dispatch_k<float>(K, B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, act, lens, none, s);
     return PAFC_ERR_DTYPE;
+}
+
+extern "C" int pafc_dwconv1d_cl_ln_silu(int dtype, int B, int T_in, int C, int K, int left_pad, int T_out, const void *x, long ldx,
+                                        const void *w, const void *bias, const void *gamma, const void *beta, float eps, void *y,
+                                        const int32_t *lens, pafc_stream_t stream) {
+    if (!x || !w || !y || !gamma || !beta) return PAFC_ERR_NULL_POINTER;
+    if (B <= 0 || T_in <= 0 || T_out <= 0 || left_pad < 0 || B > 65535 || ldx < C || (ldx % 2)) return PAFC_ERR_BAD_DIMS;
+    if (C != 512 || (K != 31 && K != 15)) return PAFC_ERR_UNSUPPORTED;      // one block = all the channels of its frames
+    if (dtype != PAFC_BF16) return PAFC_ERR_DTYPE;
+    const pafc::LnTail ln{gamma, beta, eps};
+    return pafc::dispatch_k<pafc::bf16_t>(K, B, T_in, C, left_pad, T_out, x, ldx, w, bias, y, 3, lens, ln, (hipStream_t)stream);
 }
 
 extern "C" size_t pafc_dwconv1d_cl_wgrad_workspace_bytes(int B, int T_out, int C, int K) {

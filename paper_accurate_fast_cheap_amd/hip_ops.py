@@ -40,6 +40,11 @@ from ._lib import c_int, c_void_p
 #   ln_fold_min_rows         24576  unmasked bf16 inputs of at least this many rows take the schedule with three LayerNorms
 #                                   folded into the 256-wide GEMMs either side of them (needs full grids of 256 x 256 tiles:
 #                                   3 x the row count at which they fill the chip): profiles/r03d / r03e
+#   dwconv_ln_silu_max_rows  24575  up to this many rows the conv module's LayerNorm + SiLU is the depthwise convolution's epilogue
+#                                   (one launch and one round trip less per layer: c2 +0.4-2 %, 2 000-frame windows +1.3 %, same box);
+#                                   the 30-minute sequence measured the same or 0.2 ms slower with it (the convolution kernel is
+#                                   latency-bound at two waves per SIMD and the epilogue's two block reductions add to that), so
+#                                   long inputs keep the two kernels
 #   gemm_tune_min_rows       32768  library (fp32) GEMMs of at least this many rows measure the library's candidates once
 #                                   (explicit plan objects; never under graph capture): DESIGN section 4, round-1 fault
 # C side (csrc/gemm_bf16.hip): which GEMM family takes a problem is decided by rounds -- the 128-wide kernel while its 128 x 128
@@ -47,7 +52,7 @@ from ._lib import c_int, c_void_p
 # PAFC_PH_MIN_FILL=<percent> (round 3's rule: 256-wide tiles must cover that share of the CUs) and PAFC_GEMM_TILE (force a tile
 # of the small kernel) are A/B switches of the kernels themselves.
 DISPATCH = dict(skinny_max_rows=640, own_gemm_min_rows=1, lds_resident_min_rows=8192, split_gemm_min_rows=16384,
-                ln_fold_min_rows=24576, gemm_tune_min_rows=32768)
+                ln_fold_min_rows=24576, gemm_tune_min_rows=32768, dwconv_ln_silu_max_rows=24575)
 
 
 def _load_dispatch():
@@ -103,6 +108,40 @@ def depthwise_conv1d_cl(x: torch.Tensor, weight: torch.Tensor, bias: Optional[to
                                   _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), int(glu), _lib.ptr(lens),
                                   _lib.stream_of(x))
     _lib.check(rc, "pafc_dwconv1d_cl")
+    return y
+
+
+def dwconv_ln_silu_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Does the convolution kernel carry the conv module's LayerNorm + SiLU for this input (bf16, 512 channels, k = 15 / 31)?"""
+    return (x.numel() // x.shape[-1] <= DISPATCH["dwconv_ln_silu_max_rows"] and x.dtype == torch.bfloat16 and x.is_cuda
+            and x.shape[-1] == 512 and weight.shape[-1] in (15, 31))
+
+
+def depthwise_conv1d_cl_ln_silu(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], left_pad: int, out_len: int,
+                                gamma: torch.Tensor, beta: torch.Tensor, eps: float, lens: Optional[torch.Tensor] = None):
+    """SiLU(LayerNorm(depthwise_conv1d_cl(x, ...))) in one pass (convolution.py:131-138 with cnn_module_norm: layer_norm): the
+    convolution's epilogue normalises its own rows.  x (B, T, 512) bf16, weight (512, 1, K), K in {15, 31}."""
+    _lib.require_gpu(x, weight, bias, gamma, beta, lens)
+    B, T, C = x.shape
+    K = weight.shape[-1]
+    if not dwconv_ln_silu_ok(x, weight) or weight.shape != (C, 1, K) or any(
+            t is not None and (t.dtype != x.dtype or not t.is_contiguous()) for t in (weight, bias, gamma, beta)):
+        raise _lib.PafcError("depthwise_conv1d_cl_ln_silu: bf16, C = 512, K in (15, 31), contiguous parameters in the activation dtype")
+    if x.stride(2) != 1 or x.stride(0) != T * x.stride(1):
+        raise _lib.PafcError("depthwise_conv1d_cl_ln_silu: x (B, T, C) with unit channel stride")
+    if lens is not None and lens.dtype != torch.int32:
+        raise _lib.PafcError("lens must be int32")
+    L = _bind()
+    if not getattr(L, "_pafc_dwln_bound", False):
+        from ctypes import c_float, c_long
+        _lib._sig(L.pafc_dwconv1d_cl_ln_silu, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p,
+                  c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p)
+        L._pafc_dwln_bound = True
+    y = torch.empty(B, out_len, C, dtype=x.dtype, device=x.device)
+    rc = L.pafc_dwconv1d_cl_ln_silu(_lib.dtype_code(x.dtype), B, T, C, K, left_pad, out_len, _lib.ptr(x), x.stride(1), _lib.ptr(weight),
+                                    _lib.ptr(bias), _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(y), _lib.ptr(lens),
+                                    _lib.stream_of(x))
+    _lib.check(rc, "pafc_dwconv1d_cl_ln_silu")
     return y
 
 

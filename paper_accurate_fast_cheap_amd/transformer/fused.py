@@ -312,6 +312,16 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
     return proj(ycat, plan.Wo, None).view(B, T, C)
 
 
+def _dwconv_norm_silu(cm, p: torch.Tensor, left_pad: int, T: int) -> torch.Tensor:
+    """activation(norm(depthwise_conv(p))) of the conv module (convolution.py:131-138): one pass when the convolution kernel
+    can normalise its own rows (bf16, 512 channels, LayerNorm as the module's norm, SiLU), else convolution + LayerNorm pass."""
+    if hip_ops.dwconv_ln_silu_ok(p, cm.depthwise_conv.weight):
+        return hip_ops.depthwise_conv1d_cl_ln_silu(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, left_pad, T,
+                                                   cm.norm.weight, cm.norm.bias, cm.norm.eps)
+    dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, left_pad, T)
+    return hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)[1]
+
+
 def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optional[torch.Tensor],
                   next_norm: Optional[nn.LayerNorm]) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """x: residual stream (B, T, C); h = norm_ff_macaron(x), already computed by the previous step.
@@ -347,11 +357,11 @@ def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optio
     if plan.pw1_glu is not None and h.dtype == torch.bfloat16:
         # F.glu rides on pointwise_conv1 (half the write, and the depthwise kernel no longer recomputes sigmoids)
         p = _pw1_glu(plan, h.view(B * Tc, C)).view(B, Tc, C)
-        dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, left_pad, T)
+        g = _dwconv_norm_silu(cm, p, left_pad, T)
     else:
         p = F.linear(h, cm.pointwise_conv1.weight.squeeze(-1), cm.pointwise_conv1.bias)
         dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, left_pad, T, glu=True)
-    _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
+        _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
     if not masked:
         x = proj(g, cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, "none", residual=x, inplace=True)
         _, h, _ = hip_ops.add_layernorm(x, None, 1.0, L.norm_ff.weight, L.norm_ff.bias, want_x=False, eps=L.norm_ff.eps)
@@ -398,8 +408,7 @@ def layer_forward_lnfold(plan: LayerPlan, x: torch.Tensor, st: torch.Tensor, nex
     slot_forward(plan, h, residual=x2.view(B, T, C), stats=st2)
     w, b, cs = F["pw1"]
     p = G(x2, w, b, st2, act="glu", csum=cs, eps=L.norm_conv.eps).view(B, T, C)
-    dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, (cm.kernel_size - 1) // 2, T)
-    _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
+    g = _dwconv_norm_silu(cm, p, (cm.kernel_size - 1) // 2, T)
     st3 = new_stats()
     G(g.view(M, C), cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, st3, residual=x2, out=x2)
     w, b, cs = F["ff"]

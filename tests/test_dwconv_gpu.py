@@ -26,6 +26,34 @@ def test_dwconv_matches_conv1d(hip, dtype, B, T, C, K, glu):
     torch.testing.assert_close(got.float(), ref, **tol)
 
 
+@pytest.mark.parametrize("B,T,K,causal", [(1, 1, 31, False), (2, 50, 31, False), (3, 97, 15, False), (2, 77, 15, True), (1, 1000, 31, False)])
+@pytest.mark.parametrize("mean_shift", [0.0, 40.0])
+def test_dwconv_with_layernorm_silu_epilogue(hip, B, T, K, causal, mean_shift):
+    """The conv module's `activation(norm(depthwise_conv(x)))` (convolution.py:131-138) in one kernel against (i) the two-kernel
+    path it replaces (same roundings; the row sums are added in another order: at most one bf16 step apart) and (ii) the fp32
+    module chain on the bf16-rounded intermediates.  Ragged last tile (T % 16), masked lengths, the causal form, rows with a
+    mean far from zero (two-pass variance), non-trivial gamma / beta."""
+    from paper_accurate_fast_cheap_amd.hip_ops import add_layernorm, depthwise_conv1d_cl, depthwise_conv1d_cl_ln_silu
+    C, bf = 512, torch.bfloat16
+    Tin, left = (T + K - 1, 0) if causal else (T, (K - 1) // 2)
+    x = synth.randn((B, Tin, C), 11).to(bf)
+    w = synth.randn((C, 1, K), 12, 0.2).to(bf)
+    b = (synth.randn((C,), 13, 0.1) + mean_shift).to(bf)
+    gamma, beta = (1 + synth.randn((C,), 14, 0.3)).to(bf), synth.randn((C,), 15, 0.2).to(bf)
+    lens = None if causal else torch.tensor([Tin, max(1, Tin // 2), max(1, Tin - 3)][:B], dtype=torch.int32).cuda()
+    g = [t.cuda() for t in (x, w, b, gamma, beta)]
+    got = depthwise_conv1d_cl_ln_silu(g[0], g[1], g[2], left, T, g[3], g[4], 1e-5, lens=lens)
+    dw = depthwise_conv1d_cl(g[0], g[1], g[2], left, T, lens=lens)
+    two = add_layernorm(dw, None, 1.0, g[3], g[4], silu=True, eps=1e-5)[1]
+    assert got.shape == two.shape and torch.isfinite(got).all()
+    d = (got.float() - two.float()).abs()
+    assert float(d.max()) <= 2 ** -7 * float(two.float().abs().max()) + 1e-3, float(d.max())
+    assert float((got != two).float().mean()) < 0.02          # all but a few ties of the reduction order are bit-identical
+    ln = F.layer_norm(dw.float(), (C,), gamma.float().cuda(), beta.float().cuda(), 1e-5).to(bf).float()
+    ref = (ln * torch.sigmoid(ln)).to(bf)
+    torch.testing.assert_close(got.float(), ref.float(), rtol=2 ** -6, atol=2e-2)
+
+
 def test_dwconv_causal_form(hip):
     from paper_accurate_fast_cheap_amd.hip_ops import depthwise_conv1d_cl
     B, T, C, K = 2, 41, 128, 15
