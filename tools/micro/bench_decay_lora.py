@@ -14,7 +14,8 @@ fused = lambda: hip_ops.decay_lora(zw, d1n, d2n)
 ws, wf = separate(), fused()
 print("w max diff", (wf.float() - ws.float()).abs().max().item(), "mean", (wf.float() - ws.float()).abs().mean().item())
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-runs = {"two GEMMs": separate, "one pass": fused}
+bias = (torch.randn(nd, C, device='cuda') * 0.5).to(bf)
+runs = {"two GEMMs": separate, "one pass": fused, "one pass + bias": lambda: hip_ops.decay_lora(zw, d1n, d2n, bias)}
 res = {k: [] for k in runs}
 for _ in range(7):
     for k, f in runs.items():
