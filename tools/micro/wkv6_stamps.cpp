@@ -43,7 +43,8 @@ int main(int argc, char **argv) {
     if (with_bias) { hipMalloc(&wb, C * 2); hipMemset(wb, 0, C * 2); }
     const size_t wsb = pafc_wkv6_fwd_workspace_bytes(B, T, C, H, 2, 0);
     void *ws = nullptr;
-    hipMalloc(&ws, wsb ? wsb : 16);
+    const size_t wsb2 = 4 * wsb + 16;           // room for the head-group experiment's shorter chunks
+    hipMalloc(&ws, wsb2);
 #ifdef PAFC_WKV6_STAMPS
     unsigned long long *st;
     const size_t nst = (size_t)2 * B * H * 4096 * 12;
@@ -51,6 +52,36 @@ int main(int argc, char **argv) {
     hipMemset(st, 0, nst * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(pafc::g_wkv_stamps), &st, sizeof(st));
 #endif
+    // experiment: the heads in `groups` launches of H / groups heads each (same row stride; a group's k, v, w read by its pass A
+    // may still be in the Infinity Cache when its pass C reads them again)
+    const int groups = argc > 4 ? atoi(argv[4]) : 1;
+    if (groups > 1) {
+        hipEvent_t g0, g1; hipEventCreate(&g0); hipEventCreate(&g1);
+        const int Hg = H / groups;
+        float gbest = 1e9f, gsum = 0;
+        for (int rep = 0; rep < 23; ++rep) {
+            hipEventRecord(g0, 0);
+            for (int g = 0; g < groups; ++g) {
+                const size_t o = (size_t)g * Hg * 64;
+                pafc::DirArgs da[2] = {{dev[0][0] + o, dev[0][1] + o, dev[0][2] + o, dev[0][3] + o, dev[0][5] + o, dev[0][4] + o, nullptr, nullptr, 0, nullptr},
+                                       {dev[1][0] + o, dev[1][1] + o, dev[1][2] + o, dev[1][3] + o, dev[1][5] + o, dev[1][4] + o, nullptr, nullptr, 1, nullptr}};
+                pafc::FwdParams p{};
+                p.d[0] = da[0]; p.d[1] = da[1];
+                p.B = B; p.T = T; p.C = C; p.H = Hg;
+                int L = pafc::pick_chunk_len(B, T, Hg, 2);
+                L = (L + 15) / 16 * 16; if (L >= T) L = T;
+                p.L = L; p.NC = (T + L - 1) / L;
+                p.ws_state = (float *)ws;
+                p.ws_decay = p.ws_state + (size_t)2 * B * Hg * p.NC * (64 * 64);
+                if (pafc::ws_bytes(B, T, Hg, 2, L) > wsb2) { printf("workspace\n"); return 1; }
+                pafc::launch_fwd<pafc::bf16_t>(p, 2, false, 0);
+            }
+            hipEventRecord(g1, 0); hipEventSynchronize(g1);
+            float ms; hipEventElapsedTime(&ms, g0, g1);
+            if (rep >= 3) { gsum += ms; if (ms < gbest) gbest = ms; }
+        }
+        printf("%d head groups: %.1f us mean, %.1f us best of 20\n", groups, gsum / 20 * 1e3, gbest * 1e3);
+    }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f, sum = 0;
