@@ -172,27 +172,24 @@ def c2_batches(device, dtype, rank: int = 0, world: int = 1):
     """BASELINE configs[1]: 5715 utterances with lengths U[1 s, 20 s] (GigaSpeech DEV size and segment filter),
     cut from one long synthetic signal, sharded by length over the ranks, sorted by length, decode batches of 64
     (local/go-SF-dev-one-model-paper.sh:27), issued longest first.  Returns (batches, fbank ms charged to this shard, the source features on the CPU)."""
-    from paper_accurate_fast_cheap_amd.utils.sharding import shard_units
+    from paper_accurate_fast_cheap_amd.utils.sharding import decode_batches, shard_units
     g = torch.Generator().manual_seed(777)
     lens_all = torch.randint(100, 2001, (5715,), generator=g).tolist()
-    mine = sorted(shard_units(lens_all, rank, world), key=lambda i: lens_all[i])
+    plan = decode_batches(shard_units(lens_all, rank, world), lens_all, 64)     # sorted by length, longest batch first
+    mine = [i for ids in plan for i in ids]
     wave = synthetic_waveform(600.0, 777 + rank)
     long_feats, fbank_ms = front_end(wave, device)
     fbank_ms *= sum(lens_all[i] for i in mine) / float(long_feats.shape[1])
     src = long_feats[0].to(dtype)
     batches = []
-    for b0 in range(0, len(mine), 64):
-        ids = mine[b0:b0 + 64]
+    for ids in plan:
         L = [lens_all[i] for i in ids]
         fb = torch.zeros(len(ids), max(L), 80, dtype=src.dtype, device=device)
         for j, (i, n) in enumerate(zip(ids, L)):
             off = (i * 7919) % (src.shape[0] - 2001)
             fb[j, :n] = src[off:off + n]
         batches.append((fb, torch.tensor(L, dtype=torch.int32, device=device)))
-    # longest batches first: the host issues a long batch far faster than the GPU runs it, so by the time the short batches come
-    # (whose ~300 launches take the host longer than the GPU needs for them) they are already queued; ascending order starves the
-    # GPU over the first third of the pass (same box: 76 800-77 100 ascending, 78 100-79 200 descending).  Same batches, same tokens.
-    batches.reverse()
+    # (issue order: utils.sharding.decode_batches -- same box: 76 800-77 100 shortest first, 78 100-79 200 longest first)
     return batches, fbank_ms, long_feats.cpu()
 
 

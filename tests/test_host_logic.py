@@ -121,6 +121,18 @@ def test_bench_windows_follow_the_reference_batcher():
     assert len(whole) == 1 and whole[0][1].tolist() == [46]
 
 
+def test_decode_batches_sorted_by_length_longest_batch_first():
+    from paper_accurate_fast_cheap_amd.utils.sharding import decode_batches
+    lens = [int(x) for x in torch.randint(100, 2001, (331,), generator=torch.Generator().manual_seed(5))]
+    units = list(range(0, 331, 2))
+    plan = decode_batches(units, lens, 64)
+    assert sorted(i for b in plan for i in b) == units                                  # every unit once
+    assert [len(b) for b in plan] == [len(units) % 64 or 64] + [64] * (len(units) // 64 - (len(units) % 64 == 0))
+    flat = [lens[i] for b in reversed(plan) for i in b]
+    assert flat == sorted(flat)                                                           # neighbours in length share a batch
+    assert max(lens[i] for i in plan[0]) == max(lens[i] for i in units)                   # ... and the longest batch is issued first
+
+
 def test_shard_units_balanced_and_complete():
     from paper_accurate_fast_cheap_amd.utils.sharding import shard_units
     g = torch.Generator().manual_seed(0)
