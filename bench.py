@@ -282,15 +282,16 @@ def c2_leg(model, device):
     return leg
 
 
-def windows_leg(model, feats, device, chunk: int = 2000, batch: int = 8, nstreams: int = 2):
+def windows_leg(model, feats, device, chunk: int = 2000, batch: int = 8, nstreams: int = 3):
     """The paper's sweep shape (local/go-run-encoder-rtf.single-gpu-3x3-g5.sh:58-62) beside the headline: the same 30-minute
     file as windows of `chunk` frames in batches of `batch`, encoder + CTC log-softmax + greedy tokens, hipGraph cache for the
-    recurring batch shape, two batches in flight on two streams (as for c2), package-default dispatch; 2 warm-up + 3 timed passes."""
+    recurring batch shape, three window batches in flight on three streams (one box: 1 / 2 / 3 / 4 in flight = 38 000 / 53 300 /
+    59 900 / 50 400 audio-sec/sec), package-default dispatch; 2 warm-up + 3 timed passes."""
     from paper_accurate_fast_cheap_amd.transformer.search import ctc_greedy_search
     batches = list(windows(feats, chunk, batch))
     frames = int(sum(int(l.sum()) for _, l in batches))
     old = model.encoder.graph_cache_size
-    model.encoder.graph_cache_size = 4          # two shapes (full batches, the last one) x two streams
+    model.encoder.graph_cache_size = 2 * nstreams   # two shapes (full batches, the last one) x the streams
     try:
         step, toks = make_step(model, batches, device, nstreams=nstreams, greedy=ctc_greedy_search)
         sec = timed_passes(step, 3, 2)
@@ -298,7 +299,7 @@ def windows_leg(model, feats, device, chunk: int = 2000, batch: int = 8, nstream
         model.encoder.graph_cache_size = old
         model.encoder._graphs.clear()
     return {"workload": f"the 30-minute file as windows of {chunk} frames x batch {batch} (encoder-rtf.py:354-385), encoder + CTC + "
-                        f"greedy tokens, hipGraph replay of the recurring batch shape, two batches in flight, package-default dispatch, bf16",
+                        f"greedy tokens, hipGraph replay of the recurring batch shape, {nstreams} batches in flight, package-default dispatch, bf16",
             "batches": len(batches), "passes": 3, "ms_per_pass": round(sec * 1e3, 3),
             "audio_sec_per_sec": round(frames / 100.0 / sec, 1), "token_checksum": token_checksum(toks)}
 
@@ -459,9 +460,9 @@ def main():
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         progress = open(os.path.join(ROOT, "gpurun_out", "bench_c2_progress.log"), "a")
 
-    # batches in flight: two for the ragged decode batches of c2 and for the window batches of --chunk-size (their launch-bound
-    # stretches overlap); the one-sequence headline has one batch per step
-    nstreams = (args.streams or 2) if (args.workload == "c2" or args.chunk_size > 0) else 1
+    # batches in flight: two for the ragged decode batches of c2, three for the window batches of --chunk-size (their launch-bound
+    # stretches overlap; measured 1-4, see windows_leg); the one-sequence headline has one batch per step
+    nstreams = (args.streams or (2 if args.workload == "c2" else 3)) if (args.workload == "c2" or args.chunk_size > 0) else 1
     if args.chunk_size > 0 and nstreams > 1:
         model.encoder.graph_cache_size = max(model.encoder.graph_cache_size, 2 * nstreams)
     step, last_tokens = make_step(model, batches, device, nstreams, greedy, progress)
