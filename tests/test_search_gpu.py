@@ -191,6 +191,15 @@ def test_decode_windows_stitches_long_form(hip):
     assert singles == out["windows"]
     beam = decode_windows(model, feats, 600, 2, mode="ctc_prefix_beam_search", beam_size=4)
     assert len(beam["windows"]) == 5 and beam["token_start_ms"] is None
+    # batches in flight on streams (default 3): same token lists and times as one batch at a time; a file with many batches
+    # of a recurring shape also goes through the encoder's hipGraph replays (one graph per shape and stream)
+    one = decode_windows(model, feats, 600, 2, streams=1)
+    assert one["windows"] == out["windows"] and one["token_start_ms"] == out["token_start_ms"]
+    long_feats = (torch.randn(1, 600 * 2 * 9 + 250, 80, device="cuda", generator=g) * 2 + 8).to(torch.bfloat16)   # 10 batches
+    a = decode_windows(model, long_feats, 600, 2, streams=3)
+    b = decode_windows(model, long_feats, 600, 2, streams=1)
+    assert len(a["windows"]) == 19 and a["windows"] == b["windows"] and a["token_start_ms"] == b["token_start_ms"]
+    assert model.encoder.graph_cache_size == 0                  # the scheduler's cache setting does not outlive the call
 
 
 def test_batches_in_flight_on_two_streams_decode_to_the_same_tokens(hip):
