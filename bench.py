@@ -287,21 +287,23 @@ def windows_leg(model, feats, device, chunk: int = 2000, batch: int = 8, nstream
     file as windows of `chunk` frames in batches of `batch`, encoder + CTC log-softmax + greedy tokens, hipGraph cache for the
     recurring batch shape, three window batches in flight on three streams (one box: 1 / 2 / 3 / 4 in flight = 38 000 / 53 300 /
     59 900 / 50 400 audio-sec/sec), package-default dispatch; 2 warm-up + 3 timed passes."""
-    from paper_accurate_fast_cheap_amd.transformer.search import ctc_greedy_search
-    batches = list(windows(feats, chunk, batch))
-    frames = int(sum(int(l.sum()) for _, l in batches))
+    from paper_accurate_fast_cheap_amd.utils.longform import decode_windows
+    nb = -(-feats.shape[1] // (chunk * batch))
     old = model.encoder.graph_cache_size
-    model.encoder.graph_cache_size = 2 * nstreams   # two shapes (full batches, the last one) x the streams
+    last = {}
+
+    def step():           # the package's own window scheduler, token lists fetched and stitched inside the timed region
+        last["out"] = decode_windows(model, feats, chunk, batch, streams=nstreams)
     try:
-        step, toks = make_step(model, batches, device, nstreams=nstreams, greedy=ctc_greedy_search)
         sec = timed_passes(step, 3, 2)
     finally:
         model.encoder.graph_cache_size = old
         model.encoder._graphs.clear()
-    return {"workload": f"the 30-minute file as windows of {chunk} frames x batch {batch} (encoder-rtf.py:354-385), encoder + CTC + "
-                        f"greedy tokens, hipGraph replay of the recurring batch shape, {nstreams} batches in flight, package-default dispatch, bf16",
-            "batches": len(batches), "passes": 3, "ms_per_pass": round(sec * 1e3, 3),
-            "audio_sec_per_sec": round(frames / 100.0 / sec, 1), "token_checksum": token_checksum(toks)}
+    return {"workload": f"the 30-minute file as windows of {chunk} frames x batch {batch} (encoder-rtf.py:354-385) through "
+                        f"utils.longform.decode_windows: encoder + CTC + greedy tokens + stitching, hipGraph replay of the recurring "
+                        f"batch shape, {nstreams} batches in flight, package-default dispatch, bf16",
+            "batches": nb, "passes": 3, "ms_per_pass": round(sec * 1e3, 3),
+            "audio_sec_per_sec": round(feats.shape[1] / 100.0 / sec, 1), "token_checksum": token_checksum([last["out"]["windows"]])}
 
 
 def build_model(dtype: str, device):

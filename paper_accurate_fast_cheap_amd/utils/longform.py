@@ -39,10 +39,22 @@ def window_offsets_ms(n_windows: int, chunk_size: int, input_frame_ms: float = 1
     return [i * chunk_size * input_frame_ms for i in range(n_windows)]
 
 
+_SIDE = {}
+
+
+def _side_streams(device: torch.device, n: int):
+    """The same n side streams for every call on a device: the encoder's graph cache is keyed by (shape, stream), so fresh
+    streams per file would mean fresh captures per file."""
+    have = _SIDE.setdefault(torch.device(device).index or 0, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
+
+
 @torch.no_grad()
 def decode_windows(model, feats: torch.Tensor, chunk_size: int, batch_size: int, mode: str = "ctc_greedy_search",
                    beam_size: int = 10, input_frame_ms: float = 10.0, output_frame_ms: float = 40.0, streams: int = 3,
-                   **decode_kw) -> Dict[str, object]:
+                   graph_cache: bool = True, **decode_kw) -> Dict[str, object]:
     """Decode a long file window by window with `model.decode` and stitch the token sequences.
 
     Returns {"tokens": all token ids in order, "windows": per-window token lists, "window_start_ms": start time of each
@@ -50,7 +62,7 @@ def decode_windows(model, feats: torch.Tensor, chunk_size: int, batch_size: int,
     else None}.  Shards naturally: give each rank a contiguous range of batches (utils/sharding.py).
 
     GPU greedy search: `streams` window batches are in flight on HIP streams of their own, each replayed from the encoder's
-    hipGraph of its (shape, stream) -- a batch of 2 000-frame windows is a string of ~300 kernels of 10-20 us, which one
+    hipGraph of its (shape, stream) once the shape has been seen twice on that stream (`graph_cache`) -- a batch of 2 000-frame windows is a string of ~300 kernels of 10-20 us, which one
     stream cannot keep the chip busy with (one box, 8 x 2 000 frames per batch: 1 / 2 / 3 / 4 in flight = 38 000 / 53 300 /
     59 900 / 50 400 audio-sec/sec) -- and the token lists come back once, after the last batch is queued."""
     windows: List[List[int]] = []
@@ -61,28 +73,24 @@ def decode_windows(model, feats: torch.Tensor, chunk_size: int, batch_size: int,
         batches = list(feats_batcher(feats, chunk_size, batch_size, feats.device))
         n_side = max(1, min(int(streams), len(batches)))
         main = torch.cuda.current_stream(feats.device)
-        side = [torch.cuda.Stream(device=feats.device) for _ in range(n_side)] if n_side > 1 else []
+        side = _side_streams(feats.device, n_side) if n_side > 1 else []
         for s_ in side:
             s_.wait_stream(main)                   # the batches above were cut on the caller's stream
         enc_mod = getattr(model, "encoder", None)
-        old_cache = getattr(enc_mod, "graph_cache_size", None)
-        if old_cache is not None and len(batches) > 2 * n_side:      # a recurring shape: graphs pay for themselves
-            enc_mod.graph_cache_size = max(old_cache, 2 * n_side)    # (full batches, the last one) x streams
+        if graph_cache and getattr(enc_mod, "graph_cache_size", None) is not None and len(batches) > 1:
+            # the window shape recurs batch after batch and file after file: the encoder keeps a graph per (shape, stream).  The
+            # setting is left in place for the next file (the graphs pin their activations: encoder.graph_cache_size = 0 and
+            # encoder._graphs.clear() release them)
+            enc_mod.graph_cache_size = max(enc_mod.graph_cache_size, 2 * n_side)    # (full batches, the last one) x streams
         pending = []
-        try:
-            for i, (fb, lens) in enumerate(batches):
-                with (torch.cuda.stream(side[i % n_side]) if side else contextlib.nullcontext()):
-                    enc, mask = model._forward_encoder(fb, lens)
-                    logp = model.ctc_logprobs(enc)
-                    pending.append(ctc_greedy(logp.contiguous(), mask.squeeze(1).sum(1), decode_kw.get("blank_id", 0),
-                                              want_frames=True))
-            for s_ in side:
-                main.wait_stream(s_)
-        finally:
-            if old_cache is not None:
-                enc_mod.graph_cache_size = old_cache
-                if hasattr(enc_mod, "_trim_graphs"):
-                    enc_mod._trim_graphs()           # graphs beyond the caller's own bound go (each pins its activations)
+        for i, (fb, lens) in enumerate(batches):
+            with (torch.cuda.stream(side[i % n_side]) if side else contextlib.nullcontext()):
+                enc, mask = model._forward_encoder(fb, lens)
+                logp = model.ctc_logprobs(enc)
+                pending.append(ctc_greedy(logp.contiguous(), mask.squeeze(1).sum(1), decode_kw.get("blank_id", 0),
+                                          want_frames=True))
+        for s_ in side:
+            main.wait_stream(s_)
         for tk, nt, fr in pending:
             tk, nt, fr = tk.cpu(), nt.cpu(), fr.cpu()
             for i in range(tk.shape[0]):

@@ -199,7 +199,11 @@ def test_decode_windows_stitches_long_form(hip):
     a = decode_windows(model, long_feats, 600, 2, streams=3)
     b = decode_windows(model, long_feats, 600, 2, streams=1)
     assert len(a["windows"]) == 19 and a["windows"] == b["windows"] and a["token_start_ms"] == b["token_start_ms"]
-    assert model.encoder.graph_cache_size == 0                  # the scheduler's cache setting does not outlive the call
+    assert model.encoder.graph_cache_size == 6                  # (two shapes) x (three streams), kept for the next file ...
+    c = decode_windows(model, long_feats, 600, 2, streams=3)    # ... which is replayed from the graphs of the first
+    assert c["windows"] == a["windows"]
+    assert sum(isinstance(v, tuple) for v in model.encoder._graphs.values()) >= 3
+    assert decode_windows(model, feats, 600, 2, streams=2, graph_cache=False)["windows"] == out["windows"]
 
 
 def test_batches_in_flight_on_two_streams_decode_to_the_same_tokens(hip):
