@@ -194,28 +194,15 @@ def c2_batches(device, dtype, rank: int = 0, world: int = 1):
 
 
 def make_step(model, batches, device, nstreams: int = 1, greedy=None, progress=None):
-    """One pass over `batches`: encoder + CTC log-softmax (+ greedy tokens) per batch, `nstreams` batches in flight on HIP
-    streams of their own.  Returns (step function, the list the last pass's token lists are left in)."""
-    side = [torch.cuda.Stream(device=device) for _ in range(nstreams)] if nstreams > 1 else []
+    """One pass over `batches` through the package's own decode loop (utils.longform.greedy_decode_batches): encoder + CTC
+    log-softmax (+ greedy tokens when `greedy` is given) per batch, `nstreams` batches in flight on HIP streams of their own.
+    Returns (step function, the list the last pass's token lists are left in)."""
+    from paper_accurate_fast_cheap_amd.utils.longform import greedy_decode_batches
     last_tokens = []
 
     def step():
-        main = torch.cuda.current_stream(device)
-        for s_ in side:
-            s_.wait_stream(main)
-        last_tokens.clear()
-        logp = None
-        for i, (fb, lens) in enumerate(batches):
-            ctx = torch.cuda.stream(side[i % nstreams]) if side else contextlib.nullcontext()
-            with ctx:
-                enc, mask = model._forward_encoder(fb, lens)
-                logp = model.ctc_logprobs(enc)
-                if greedy is not None:            # c2 = encoder + CTC log-softmax + greedy tokens (search.py:106-121)
-                    last_tokens.append(greedy(logp, mask.squeeze(1).sum(1), 0, defer=bool(side)))
-        for s_ in side:
-            main.wait_stream(s_)
-        if side:                              # the token lists come back once per pass, not once per batch
-            last_tokens[:] = [f() for f in last_tokens]
+        toks, logp = greedy_decode_batches(model, batches, streams=nstreams, want_tokens=greedy is not None)
+        last_tokens[:] = toks or []          # c2 = encoder + CTC log-softmax + greedy tokens (search.py:106-121)
         if progress is not None:
             progress.write(f"{time.strftime('%H:%M:%S')} pass over {len(batches)} batches queued\n")
             progress.flush()

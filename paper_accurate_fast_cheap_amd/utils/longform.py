@@ -52,6 +52,36 @@ def _side_streams(device: torch.device, n: int):
 
 
 @torch.no_grad()
+def greedy_decode_batches(model, batches, streams: int = 2, blank_id: int = 0, want_tokens: bool = True):
+    """One pass over decode batches [(feats (B, T, F), lengths (B,)), ...] already resident on the GPU: encoder + CTC
+    log-softmax (+ greedy search, search.py:106-121) per batch, `streams` batches in flight on HIP streams of their own
+    (the launch-bound stretches of one batch overlap the other's), the token lists fetched once after the last batch is queued
+    (`ctc_greedy_search(defer=True)`: nothing in the loop waits for the device).  The decode loop of recognize.py around
+    `model.decode` (wenet/bin/recognize.py, `--batch_size`), without its per-batch host round trip.
+    Returns (token lists per batch -- List[List[DecodeResult]] -- or None, log-probabilities of the last batch).
+    Give the batches longest first (utils.sharding.decode_batches): see there."""
+    from ..transformer.search import ctc_greedy_search
+    if not batches:
+        return ([] if want_tokens else None), None
+    device = batches[0][0].device
+    n_side = max(1, min(int(streams), len(batches)))
+    main = torch.cuda.current_stream(device)
+    side = _side_streams(device, n_side) if n_side > 1 else []
+    for s_ in side:
+        s_.wait_stream(main)
+    pending, logp = [], None
+    for i, (fb, lens) in enumerate(batches):
+        with (torch.cuda.stream(side[i % n_side]) if side else contextlib.nullcontext()):
+            enc, mask = model._forward_encoder(fb, lens)
+            logp = model.ctc_logprobs(enc)
+            if want_tokens:
+                pending.append(ctc_greedy_search(logp, mask.squeeze(1).sum(1), blank_id, defer=True))
+    for s_ in side:
+        main.wait_stream(s_)
+    return ([f() for f in pending] if want_tokens else None), logp
+
+
+@torch.no_grad()
 def decode_windows(model, feats: torch.Tensor, chunk_size: int, batch_size: int, mode: str = "ctc_greedy_search",
                    beam_size: int = 10, input_frame_ms: float = 10.0, output_frame_ms: float = 40.0, streams: int = 3,
                    graph_cache: bool = True, **decode_kw) -> Dict[str, object]:

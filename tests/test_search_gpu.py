@@ -239,3 +239,9 @@ def test_batches_in_flight_on_two_streams_decode_to_the_same_tokens(hip):
             main.wait_stream(s)
         got = [[list(r.tokens) for r in f()] for f in pending]
     assert got == want and any(len(t) > 0 for b in want for t in b)
+    # the package's decode loop (what bench.py times): one, two and three batches in flight give the same lists
+    from paper_accurate_fast_cheap_amd.utils.longform import greedy_decode_batches
+    for n in (1, 2, 3):
+        toks, logp = greedy_decode_batches(model, batches, streams=n)
+        assert [[list(r.tokens) for r in b] for b in toks] == want and logp.shape[0] == batches[-1][0].shape[0]
+    assert greedy_decode_batches(model, batches, streams=2, want_tokens=False)[0] is None
