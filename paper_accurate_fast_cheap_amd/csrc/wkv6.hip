@@ -38,7 +38,7 @@ struct FwdParams {
     int B, T, C, H;
     int L, NC;           // chunk length (multiple of TT unless == T) and number of chunks
     int nc_local;        // chunks whose local state pass A must produce (NC-1, or NC when a final state is wanted)
-    int prio;            // wave priority scheme of pass C (PAFC_WKV6_PRIO): 2 = raised for a block's MFMA-dense tail (default), 0 = none
+    int prio;            // wave priority scheme of pass C (PAFC_WKV6_PRIO): 3 = raised from the level operands on (default), 2 = tail only, 0 = none
     float *ws_state;     // [ndir][B][H][NC][N(j)][N(i)]
     float *ws_decay;     // [ndir][B][H][NC][N(j)]
 };
@@ -356,11 +356,13 @@ int launch_fwd(FwdParams &p, int ndir, bool any_final, hipStream_t stream) {
         hipLaunchKernelGGL(wkv6_scan_kernel, gb, dim3(256), 0, stream, p);
     }
     dim3 gc(p.NC, p.B * p.H, ndir);
-    // pass C raises its wave priority for the MFMA-dense tail of every block (intra-block term + state update) and drops it for
-    // the VALU chains of the next one: the partner wave of the SIMD, which is in the other phase, keeps issuing.  Measured over the
-    // bench step (round 4): 228.3 -> 221.2 us per bidirectional launch on one box, 221.0 -> 217.8 on another; a static priority
-    // for every second wave changed nothing.  PAFC_WKV6_PRIO=0 switches it off (A/B).
-    { const char *e = getenv("PAFC_WKV6_PRIO"); p.prio = e ? atoi(e) : 2; }
+    // pass C raises its wave priority for the second half of every block -- from the level operands through the inter-block term,
+    // the intra-block term and the state update (scheme 3) -- and drops it for the loads and decay chains of the next one: the
+    // partner wave of the SIMD, which is in the other phase, keeps issuing.  Round 4, first session: scheme 2 (the MFMA-dense tail
+    // only) 228.3 -> 221.2 us per bidirectional launch; with the second session's block (fewer MFMAs at the tail, cheaper splits)
+    // scheme 3 wins: stand-alone 207-209 (none / scheme 2) -> 197-202, in the model 204 -> 196 us on one box; raising it from the
+    // block's start or for the front half only changed nothing.  PAFC_WKV6_PRIO=0 / 2 select none / the tail-only scheme (A/B).
+    { const char *e = getenv("PAFC_WKV6_PRIO"); p.prio = e ? atoi(e) : 3; }
     if (mfma) launch_pass_c<ET>(p, gc, stream);
     else hipLaunchKernelGGL((wkv6_chunk_kernel<ET, true>), gc, dim3(64), 0, stream, p);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
