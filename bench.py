@@ -636,11 +636,11 @@ def main():
             except Exception as e:     # noqa: BLE001 -- recorded, not swallowed
                 out["extra"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 torch.cuda.synchronize()
-        leg("streaming", streaming_leg, feats32, device)
-        leg("streaming_lookahead", streaming_lookahead_leg, feats32, device)
         # BASELINE configs[1] and the paper's window shape, on the package's defaults (no knob is set anywhere in this file)
         leg("c2", c2_leg, model, device)
         leg("windows_2000x8", lambda: windows_leg(model, feats32.to(device=device, dtype=torch.bfloat16), device))
+        leg("streaming", streaming_leg, feats32, device)
+        leg("streaming_lookahead", streaming_lookahead_leg, feats32, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, feats32, conf, min(args.cpu_sample_frames, FRAMES))
     else:
