@@ -77,6 +77,22 @@ __global__ void rate_kernel(float *out, int iters, float a, float b, unsigned lo
             REP8(asm volatile("v_lshlrev_b32 %0, 16, %0\n v_lshlrev_b32 %1, 16, %1\n v_lshlrev_b32 %2, 16, %2\n v_lshlrev_b32 %3, 16, %3\n"
                               "v_lshlrev_b32 %4, 16, %4\n v_lshlrev_b32 %5, 16, %5\n v_lshlrev_b32 %6, 16, %6\n v_lshlrev_b32 %7, 16, %7\n"
                               : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));)
+        } else if constexpr (WHICH == 16) {  // v_exp_f16
+            REP8(asm volatile("v_exp_f16 %0, %0\n v_exp_f16 %1, %1\n v_exp_f16 %2, %2\n v_exp_f16 %3, %3\n"
+                              "v_exp_f16 %4, %4\n v_exp_f16 %5, %5\n v_exp_f16 %6, %6\n v_exp_f16 %7, %7\n"
+                              : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));)
+        } else if constexpr (WHICH == 17) {  // v_rcp_f16
+            REP8(asm volatile("v_rcp_f16 %0, %0\n v_rcp_f16 %1, %1\n v_rcp_f16 %2, %2\n v_rcp_f16 %3, %3\n"
+                              "v_rcp_f16 %4, %4\n v_rcp_f16 %5, %5\n v_rcp_f16 %6, %6\n v_rcp_f16 %7, %7\n"
+                              : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));)
+        } else if constexpr (WHICH == 18) {  // v_rcp_f32
+            REP8(asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
+                              "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+                              : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));)
+        } else if constexpr (WHICH == 19) {  // v_permlane32_swap
+            REP8(asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                              "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                              : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));)
         } else if constexpr (WHICH == 8) {   // v_mul_f32 with a DPP row permutation
             REP8(asm volatile("v_mul_f32_dpp %0, %0, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mul_f32_dpp %1, %1, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
                               "v_mul_f32_dpp %2, %2, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mul_f32_dpp %3, %3, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
@@ -142,6 +158,10 @@ int main() {
         rate<12>("v_and_b32", w, out, ghz);
         rate<15>("v_lshlrev_b32", w, out, ghz);
         rate<13>("v_dot2_f32_bf16 (VOP3P)", w, out, ghz);
+        rate<18>("v_rcp_f32", w, out, ghz);
+        rate<16>("v_exp_f16", w, out, ghz);
+        rate<17>("v_rcp_f16", w, out, ghz);
+        rate<19>("v_permlane32_swap_b32", w, out, ghz);
     }
     // split check: random magnitudes over the whole exponent range, plus denormals, zeros, exact bf16 values, ties
     const int n = 1 << 22;
