@@ -146,6 +146,15 @@ int pafc_gemm_skinny_bf16_ex(long M, int N, int K, int batch, const void *A, lon
                              float *ln_stats_out, const void *mix_maa, const void *mix_prev, int mix_T, const void *norm_gamma,
                              const void *norm_beta, float norm_eps, pafc_stream_t stream);
 
+/* The decay LoRA of the time-mix for a handful of rows in ONE launch (src/model.py:286-289):
+ *   w = bf16(bf16(tanh(x D1)) D2) + time_decay, rounded again -- the two few-rows GEMMs of the chunk step
+ *   (pafc_gemm_skinny_bf16_ex with act = 2, then with round_first) with the 64-wide hidden tile kept in LDS; same K split, same
+ *   order of the partial sums and same roundings, so the result is bit-identical to the two launches.
+ *   x: (M, ldx >= C) bf16 rows; d1n: (H = 64, C) = time_decay_w1^T; d2n: (C, H) = time_decay_w2^T; bias: (C) time_decay or NULL
+ *   (NULL: no second rounding); out: (M, ldo >= C). */
+int pafc_decay_lora_skinny_bf16(long M, int C, int H, const void *x, long ldx, const void *d1n, const void *d2n, const void *bias,
+                                void *out, long ldo, pafc_stream_t stream);
+
 /* Token shift + first lerp of the time-mix for ndir directions from one read of x (src/model.py:274-276):
  *   xx_d = shift_d(x) - x,  out[d] = x + xx_d * maa_x_d;   shift_0 = x_{t-1} (or x_{t+1} when reverse0), shift_1 = x_{t+1}
  * x: (B, T, C); maa_x0/1: (C); out: (ndir, B, T, C).  Zero beyond the sequence ends, like ZeroPad2d((0,0,1,-1)). */

@@ -56,6 +56,10 @@ struct SkParams {
     const bf16_t *mix_maa; // token shift + lerp as the operand's producer: maa_x [K], or null
     const bf16_t *mix_prev;// [M / T][K] the frame before each sequence (streaming carry), or null = zero
     int T;                 // rows per sequence (mix)
+    const bf16_t *lora_x;  // PROD 3: the operand is bf16(tanh(x W1^T)) (K = 64 wide), formed here from x [M][K1] (row stride ldx) ...
+    const bf16_t *lora_w1; // ... and W1 [K][K1] (K1 innermost): the decay LoRA's two products in one launch (src/model.py:286-289)
+    long ldx;
+    int K1;
 };
 
 __device__ __forceinline__ float sk_act(float v, int act) {
@@ -79,7 +83,7 @@ __device__ __forceinline__ unsigned sk_pack(float lo, float hi) {   // both alre
 template <int MT, bool GLU, int NWV, int PROD>
 __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const SkParams p) {
     constexpr int NB = GLU ? 2 : 1;
-    constexpr bool MIX = PROD == 1, NRM = PROD == 2;
+    constexpr bool MIX = PROD == 1, NRM = PROD == 2, LOR = PROD == 3;
     constexpr int KB = (MIX || NRM) ? 2 : (MT <= 2 ? 8 : (MT <= 5 ? 4 : 2));   // K-steps (of 32) whose operands are in flight together
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, qq = lane >> 4;
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const SkParams p)
     for (int i = 0; i < MT; ++i) {
         long r = m0 + i * 16 + r16;
         if (r > p.M - 1) r = p.M - 1;
-        arow[i] = A + r * p.lda + 8 * qq;
+        arow[i] = LOR ? nullptr : A + r * p.lda + 8 * qq;
         if constexpr (MIX) {
             const long b = r / p.T, t = r - b * p.T;
             has_nb[i] = t > 0 || p.mix_prev != nullptr;
@@ -145,6 +149,57 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const SkParams p)
         }
         __syncthreads();                                  // (s_red is used again below when ln_self is on)
     }
+    // LOR: the 64-wide hidden tile t = bf16(tanh(x W1^T)) of the block's rows, formed here (every column block forms it again:
+    // 16 rows x 64 x K1 multiply-adds, nothing next to a second launch) with the K split, the partial sums' order and the
+    // roundings of the separate tanh GEMM, and left in LDS as the operand rows of the main product.
+    __shared__ __attribute__((aligned(16))) bf16_t s_hid[LOR ? MT * 16 : 1][LOR ? 64 + 8 : 8];
+    if constexpr (LOR) {
+        static_assert(MT == 1 && !GLU && NWV == 4, "LOR: one row tile per block, four waves (wave tau finishes hidden tile tau)");
+        __shared__ float s_lor[NWV][4][4][64];            // [wave][tau][reg][lane]: the waves' K-shares of the hidden tile
+        const int nk1 = p.K1 / 32;
+        const int k0 = (int)((long)wave * nk1 / NWV), k1 = (int)((long)(wave + 1) * nk1 / NWV);
+        long r = m0 + r16;
+        if (r > p.M - 1) r = p.M - 1;
+        const bf16_t *xrow = p.lora_x + r * p.ldx + 8 * qq;
+        f32x4s a1[4] = {f32x4s{0.f, 0.f, 0.f, 0.f}, f32x4s{0.f, 0.f, 0.f, 0.f}, f32x4s{0.f, 0.f, 0.f, 0.f}, f32x4s{0.f, 0.f, 0.f, 0.f}};
+        for (int kb = k0; kb < k1; kb += 4) {            // four K-steps' operands in flight together
+            uint4 xf[4], wf1[4][4];
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+                if (kb + s_ < k1) {
+                    xf[s_] = *reinterpret_cast<const uint4 *>(xrow + (kb + s_) * 32);
+#pragma unroll
+                    for (int tau = 0; tau < 4; ++tau)
+                        wf1[s_][tau] = *reinterpret_cast<const uint4 *>(p.lora_w1 + (long)(16 * tau + r16) * p.K1 + (kb + s_) * 32 + 8 * qq);
+                }
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+                if (kb + s_ < k1) {
+#pragma unroll
+                    for (int tau = 0; tau < 4; ++tau)
+                        a1[tau] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8s, wf1[s_][tau]),
+                                                                          __builtin_bit_cast(bf16x8s, xf[s_]), a1[tau], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int tau = 0; tau < 4; ++tau)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s_lor[wave][tau][e][lane] = a1[tau][e];
+        __syncthreads();
+        {   // wave tau finishes hidden columns 16 tau .. + 15: lane (r16, qq) owns columns 16 tau + 4 qq .. + 3 of row r16
+            const int tau = wave;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) sum += s_lor[w][tau][e][lane];
+                v[e] = round_bf16(sk_act(sum, 2));
+            }
+            *reinterpret_cast<uint2 *>(&s_hid[r16][16 * tau + 4 * qq]) = uint2{sk_pack(v[0], v[1]), sk_pack(v[2], v[3])};
+        }
+        __syncthreads();
+    }
     f32x4s acc[MT][NB];
     float ls1[MT], ls2[MT];
 #pragma unroll
@@ -164,7 +219,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(const SkParams p)
 #pragma unroll
             for (int g = 0; g < NB; ++g) wf[s][g] = *reinterpret_cast<const uint4 *>(wrow[g] + k);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[s][i] = *reinterpret_cast<const uint4 *>(arow[i] + k);
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (LOR) af[s][i] = *reinterpret_cast<const uint4 *>(&s_hid[i * 16 + r16][k + 8 * qq]);
+                else af[s][i] = *reinterpret_cast<const uint4 *>(arow[i] + k);
+            }
             if constexpr (MIX) {
                 mf[s] = *reinterpret_cast<const uint4 *>(p.mix_maa + k + 8 * qq);
 #pragma unroll
@@ -383,6 +441,21 @@ extern "C" int pafc_gemm_skinny_bf16_ex(long M, int N, int K, int batch, const v
         else if (mt <= 5) pafc::launch_sk<5, false, 4, 0>(p, batch, s);
         else pafc::launch_sk<8, false, 4, 0>(p, batch, s);
     }
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+extern "C" int pafc_decay_lora_skinny_bf16(long M, int C, int H, const void *x, long ldx, const void *d1n, const void *d2n,
+                                           const void *bias, void *out, long ldo, pafc_stream_t stream) {
+    if (!x || !d1n || !d2n || !out) return PAFC_ERR_NULL_POINTER;
+    if (M <= 0 || C <= 0) return PAFC_ERR_BAD_DIMS;
+    if (H != 64 || C % 32 != 0 || C % 16 != 0 || ldx % 8 || ldx < C || ldo % 4 || ldo < C) return PAFC_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)d1n | (uintptr_t)d2n) & 15 || ((uintptr_t)out & 7) || ((uintptr_t)bias & 7)) return PAFC_ERR_UNSUPPORTED;
+    pafc::SkParams p{};
+    p.A = nullptr; p.W = (const pafc::bf16_t *)d2n; p.bias = (const pafc::bf16_t *)bias; p.out = (pafc::bf16_t *)out;
+    p.M = M; p.lda = H; p.ldw = H; p.ldo = ldo; p.N = C; p.K = H; p.alpha = 1.f; p.act = 0; p.round_first = bias != nullptr;
+    p.inv_c = 1.f / (float)H;
+    p.lora_x = (const pafc::bf16_t *)x; p.lora_w1 = (const pafc::bf16_t *)d1n; p.ldx = ldx; p.K1 = C;
+    pafc::launch_sk<1, false, 4, 3>(p, 1, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
 

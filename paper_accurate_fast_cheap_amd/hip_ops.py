@@ -1279,6 +1279,28 @@ def skinny_ok(rows: int, N: int, K: int, glu: bool = False) -> bool:
             and N % (32 if glu else 16) == 0)
 
 
+def decay_lora_skinny(x: torch.Tensor, d1n: torch.Tensor, d2n: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The decay LoRA for a handful of rows in one launch: bf16(bf16(tanh(x d1n^T)) d2n^T) [+ bias, rounded again] -- bit-identical
+    to gemm_skinny(gemm_skinny(x, d1n, None, "tanh"), d2n, bias, round_first=True) (include/pafc_encoder_ops.h:
+    pafc_decay_lora_skinny_bf16).  x (M, C) bf16 rows (unit column stride), d1n (64, C), d2n (C, 64), bias (C) -> (M, C)."""
+    _lib.require_gpu(x, d1n, d2n, bias)
+    M, C = x.shape
+    H = d1n.shape[0]
+    if x.dtype != torch.bfloat16 or x.stride(1) != 1 or d1n.shape != (H, C) or d2n.shape != (C, H) or \
+            not (d1n.is_contiguous() and d2n.is_contiguous()) or (bias is not None and (bias.numel() != C or not bias.is_contiguous())):
+        raise _lib.PafcError("decay_lora_skinny: x (M, C) bf16 rows, d1n (H, C), d2n (C, H), bias (C), contiguous weights")
+    L = _bind2()
+    if not getattr(L, "_pafc_dls_bound", False):
+        _lib._sig(L.pafc_decay_lora_skinny_bf16, c_int, ctypes.c_long, c_int, c_int, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_void_p,
+                  c_void_p, ctypes.c_long, c_void_p)
+        L._pafc_dls_bound = True
+    out = torch.empty((M, C), dtype=x.dtype, device=x.device)
+    rc = L.pafc_decay_lora_skinny_bf16(M, C, H, _lib.ptr(x), x.stride(0), _lib.ptr(d1n), _lib.ptr(d2n), _lib.ptr(bias), _lib.ptr(out), C,
+                                       _lib.stream_of(x))
+    _lib.check(rc, "pafc_decay_lora_skinny_bf16")
+    return out
+
+
 def gemm_skinny(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none", alpha: float = 1.0,
                 residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None,
                 ln_csum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5, stats_out: Optional[torch.Tensor] = None,

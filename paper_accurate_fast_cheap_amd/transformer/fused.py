@@ -548,7 +548,9 @@ def layer_forward_carry(plan: LayerPlan, x: torch.Tensor, carry: Optional[dict],
     # (the decay chain and the r / k / v projections are independent, but as two branches of the captured graph -- a second HIP
     # stream forked and joined by events -- the step got 25 % SLOWER, 1.33 -> 1.66 ms: cross-queue dependencies cost more than
     # the 5 us they hide; one stream)
-    if sk:   # two short launches: tanh(z_w D1), then bf16(. D2) + time_decay rounded where the reference's op chain rounds
+    if sk and plan.D1n.shape[1] == 64:   # one short launch: bf16(tanh(z_w D1)) in LDS, then bf16(. D2) + time_decay, rounded
+        w = hip_ops.decay_lora_skinny(z[3].view(M, C), plan.D1n[0], plan.D2n[0], plan.time_decay.view(C)).view(B, T, C)   # as the op chain rounds
+    elif sk:
         td = hip_ops.gemm_skinny(z[3].view(M, C), plan.D1n[0], None, "tanh")
         w = hip_ops.gemm_skinny(td, plan.D2n[0], plan.time_decay.view(C), round_first=True).view(B, T, C)
     else:
@@ -676,8 +678,11 @@ def layer_forward_lookahead(plan: LayerPlan, x: torch.Tensor, carry: dict, h0: O
     t = hip_ops.gemm_skinny(h.view(M, C), plan.W1n[0], None, "tanh", mix_maa=plan.maa_x_n[0], mix_prev=shift, mix_T=T).view(1, M, -1)
     z = hip_ops.tmix_lora_mix4(h, t, plan.W2t, plan.maa4, prev=shift)
     rkv = hip_ops.gemm_skinny(z[:3].view(3, M, C), plan.Wrkv_n).view(3, B, T, C)
-    td = hip_ops.gemm_skinny(z[3].view(M, C), plan.D1n[0], None, "tanh")
-    w = hip_ops.gemm_skinny(td, plan.D2n[0], plan.time_decay.view(C), round_first=True).view(B, T, C)
+    if plan.D1n.shape[1] == 64:
+        w = hip_ops.decay_lora_skinny(z[3].view(M, C), plan.D1n[0], plan.D2n[0], plan.time_decay.view(C)).view(B, T, C)
+    else:
+        td = hip_ops.gemm_skinny(z[3].view(M, C), plan.D1n[0], None, "tanh")
+        w = hip_ops.gemm_skinny(td, plan.D2n[0], plan.time_decay.view(C), round_first=True).view(B, T, C)
     if hip_ops.wkv6_single_chunk(B, T, C, plan.u[0].shape[0]):
         y, _ = wkv6_forward(rkv[0], rkv[1], rkv[2], w, plan.u[0], s_in=s_in, s_out=s_in)
     else:

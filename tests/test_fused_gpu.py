@@ -337,6 +337,27 @@ def test_gemm_bf16_strided_rows_and_errors(hip):
         gemm_bf16(a.float(), w.float())
 
 
+@pytest.mark.parametrize("M", [1, 16, 64, 78, 130, 640])
+def test_decay_lora_skinny_equals_its_two_launches(hip, M):
+    """The chunk step's decay LoRA in one launch (hidden tile in LDS) against the two few-rows GEMMs it replaces: bit-identical
+    (same K split, same order of the partial sums, same roundings), with and without the time_decay bias; and against the fp32
+    op chain with the reference's roundings (src/model.py:286-289)."""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    C, H, bf = 512, 64, torch.bfloat16
+    x = synth.randn((M, C), 40 + M, 1.0).to(bf).cuda()
+    d1n = (synth.randn((H, C), 41, 0.05)).to(bf).cuda()
+    d2n = (synth.randn((C, H), 42, 0.3)).to(bf).cuda()
+    bias = synth.randn((C,), 43, 1.0).to(bf).cuda()
+    for b in (bias, None):
+        one = hip_ops.decay_lora_skinny(x, d1n, d2n, b)
+        td = hip_ops.gemm_skinny(x, d1n, None, "tanh")
+        two = hip_ops.gemm_skinny(td, d2n, b, round_first=b is not None)
+        assert torch.equal(one, two)
+    t_ref = torch.tanh(x.float() @ d1n.float().t()).to(bf)
+    ref = ((t_ref.float() @ d2n.float().t()).to(bf).float() + bias.float()).to(bf)
+    torch.testing.assert_close(hip_ops.decay_lora_skinny(x, d1n, d2n, bias).float(), ref.float(), rtol=2 ** -6, atol=2e-2)
+
+
 @pytest.mark.parametrize("M,N,K,Z", [(64, 2048, 512, 1), (65, 512, 2048, 1), (78, 512, 512, 3), (1, 512, 512, 1), (17, 64, 1024, 2),
                                      (130, 512, 512, 1), (160, 2048, 512, 1)])
 @pytest.mark.parametrize("act", ["none", "silu", "tanh", "relu"])
