@@ -36,6 +36,8 @@ VOCAB = 5000
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
 VALU_PEAK_TFLOPS = 157.3
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PFLOP/s headline figure is with 2:1 sparsity)
+PRECISION = {"bf16slot": "fp32 model + bf16 time-mix slot (the YAML default, the reference's own precision)",
+             "bf16": "whole-model bf16 (a mode the reference's bidirectional wrapper cannot run)"}
 
 
 def encoder_conf():
@@ -234,12 +236,13 @@ def timed_passes(step, passes: int, warmup: int = 1):
     return (time.perf_counter() - t0) / passes
 
 
-def c2_leg(model, device):
+def c2_leg(model, device, dtype: str = "bf16slot"):
     """BASELINE configs[1] beside the headline, on the package's default dispatch: the full synthetic DEV-shaped set (5715
-    utterances, decode batch 64), encoder + CTC + greedy tokens, two decode batches in flight, 1 warm-up + 2 timed passes."""
+    utterances, decode batch 64), encoder + CTC + greedy tokens, two decode batches in flight, 1 warm-up + 2 timed passes,
+    in the precision of `model` (dtype "bf16slot": fp32 features and model, bf16 time-mix slot; "bf16": everything bf16)."""
     from paper_accurate_fast_cheap_amd import profiling
     from paper_accurate_fast_cheap_amd.transformer.search import ctc_greedy_search
-    batches, _, _ = c2_batches(device, torch.bfloat16)
+    batches, _, _ = c2_batches(device, torch.bfloat16 if dtype == "bf16" else torch.float32)
     frames = int(sum(int(l.sum()) for _, l in batches))
     step, toks = make_step(model, batches, device, nstreams=2, greedy=ctc_greedy_search)
     profiling.enable_recording(False)
@@ -252,7 +255,7 @@ def c2_leg(model, device):
     profiling.enable_recording(False)
     prof = profiling.summary()
     leg = {"workload": "c2: 5715 synthetic DEV-shaped utterances (1-20 s), decode batches of 64 sorted by length, encoder + CTC "
-                       "log-softmax + greedy tokens, two batches in flight, package-default dispatch, bf16",
+                       "log-softmax + greedy tokens, two batches in flight, package-default dispatch, " + PRECISION[dtype],
            "utterances": 5715, "batches": len(batches), "passes": 2, "frames_per_pass": frames,
            "ms_per_pass": round(sec * 1e3, 2), "audio_sec_per_sec": round(frames / 100.0 / sec, 1),
            "token_checksum": checksum, "tokens_total": int(sum(len(getattr(r, "tokens", r)) for b in toks for r in b))}
@@ -269,7 +272,7 @@ def c2_leg(model, device):
     return leg
 
 
-def windows_leg(model, feats, device, chunk: int = 2000, batch: int = 8, nstreams: int = 3):
+def windows_leg(model, feats, device, chunk: int = 2000, batch: int = 8, nstreams: int = 3, dtype: str = "bf16slot"):
     """The paper's sweep shape (local/go-run-encoder-rtf.single-gpu-3x3-g5.sh:58-62) beside the headline: the same 30-minute
     file as windows of `chunk` frames in batches of `batch`, encoder + CTC log-softmax + greedy tokens, hipGraph cache for the
     recurring batch shape, three window batches in flight on three streams (one box: 1 / 2 / 3 / 4 in flight = 38 000 / 53 300 /
@@ -288,7 +291,7 @@ def windows_leg(model, feats, device, chunk: int = 2000, batch: int = 8, nstream
         model.encoder._graphs.clear()
     return {"workload": f"the 30-minute file as windows of {chunk} frames x batch {batch} (encoder-rtf.py:354-385) through "
                         f"utils.longform.decode_windows: encoder + CTC + greedy tokens + stitching, hipGraph replay of the recurring "
-                        f"batch shape, {nstreams} batches in flight, package-default dispatch, bf16",
+                        f"batch shape, {nstreams} batches in flight, package-default dispatch, " + PRECISION[dtype],
             "batches": nb, "passes": 3, "ms_per_pass": round(sec * 1e3, 3),
             "audio_sec_per_sec": round(feats.shape[1] / 100.0 / sec, 1), "token_checksum": token_checksum([last["out"]["windows"]])}
 
@@ -326,8 +329,8 @@ def cpu_baseline(model, feats_cpu_f32, conf, sample_frames: int):
         EO.ctc_log_softmax(out, csd)
         dt = time.time() - t0
     return {"value": round(sample_frames / 100.0 / dt, 3), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
-            "precision": "f32 model + bf16 time-mix slot (the reference's YAML default; the GPU headline is whole-model bf16, "
-                         "the GPU figure in this precision is extra.f32_model_bf16_slot_*)",
+            "precision": "f32 model + bf16 time-mix slot (the reference's YAML default; the GPU headline's precision with "
+                         "--dtype bf16slot, the default)",
             "sample": f"first {sample_frames / 100:.0f} s of the same synthetic file, one sequence, fp32 graph with the "
                       f"bf16 time-mix slot, {threads} torch/OpenMP threads, {dt:.1f} s wall"}
 
@@ -357,6 +360,102 @@ def scan_traffic(meta):
     return None, None
 
 
+def scan_roofline(prof, copy_gbs):
+    """The `roofline` object: the bidirectional WKV-6 scan (its three kernels per launch) from the event timers of the profiled
+    steps; algorithmic bytes per DESIGN.md section 4: B*T'*C*(4 reads + 1 write)*elem per direction."""
+    rec = prof.get("wkv6_fwd_bidir") or prof.get("wkv6_fwd")
+    if not rec:
+        return None
+    # HBM bytes per launch from the rocprofv3 PMC passes of the same op and shape ON THE PRESENT KERNEL SOURCES, else null
+    traffic, traffic_file = scan_traffic(rec["meta"])
+    m = rec["meta"]
+    alg_bytes = m["B"] * m["T"] * m["C"] * 5 * m["elem_bytes"] * m["ndir"]
+    alg_flops = m["B"] * m["T"] * m["C"] * 448 * m["ndir"]
+    sec = rec["avg_ms"] * 1e-3
+    return {"kernel": "wkv6 forward scan, both directions (chunk_state + state_scan + chunk_output kernels)",
+            "bound": "hbm", "achieved": round(alg_bytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": traffic_file,
+            "launches": rec["n"], "avg_launch_us": round(rec["avg_ms"] * 1e3, 1),
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "measured_copy_gbs": copy_gbs,
+            "frac_of_measured_copy": round(alg_bytes / sec / 1e9 / copy_gbs, 4) if copy_gbs else None,
+            "valu_tflops": round(alg_flops / sec / 1e12, 2),
+            "valu_frac": round(alg_flops / sec / 1e12 / VALU_PEAK_TFLOPS, 4)}
+
+
+def mfma_object(prof, dtype: str, one_sequence: bool, copy_gbs):
+    """The `mfma` object: achieved TFLOP/s of every dense kernel of the profiled steps against the dense bf16 MFMA peak.  For the
+    fp32 model (dtype "bf16slot") every fp32 product is three bf16 MFMAs and `achieved` counts the EXECUTED matrix flops."""
+    mfma = {"peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "kernels": {},
+            "note": None if dtype == "bf16" else
+            "f32 model + bf16 slot: every fp32 product is three bf16 MFMAs (hi*hi + lo*hi + hi*lo); `achieved` counts the "
+            "EXECUTED matrix flops (3 x 2 K N per row), i.e. the matrix cores' utilisation; algorithmic flops are a third"}
+    for name, rec in sorted(prof.items()):
+        fl = rec["meta"].get("flops") if isinstance(rec.get("meta"), dict) else None
+        if not fl:
+            continue
+        tf = fl / (rec["avg_ms"] * 1e-3) / 1e12
+        label = ("subsampling conv2 (hand-written implicit GEMM)" if name == "conv3x3s2"
+                 else "subsampling conv2, split operands (hand-written implicit GEMM, 3 MFMAs per product)" if name == "conv3x3s2_split"
+                 else "hand-written GEMM K x N [x batch] = " + name.split("_", 1)[1] if name.startswith("gemm_")
+                 else "hand-written split-operand GEMM (3 MFMAs per fp32 product) K x N = " + name.split("_", 1)[1]
+                 if name.startswith("gemm3_") else "library GEMM K x N = " + name.split("_", 1)[1])
+        ent = {"achieved": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+               "avg_us": round(rec["avg_ms"] * 1e3, 1), "launches": rec["n"]}
+        # the other side of the roofline for the projections of ONE long sequence (c3): the activations cross HBM once
+        # (in + out [+ residual]; the weights stay in L2), which for the N = 512 shapes takes longer than the
+        # multiplies at the MFMA peak -- `frac` alone cannot reach 1 there (DESIGN section 4, "Two-sided roofline")
+        dims = name.split("_", 1)[1].split("x") if name.startswith("gemm_") else None
+        if dims and one_sequence and copy_gbs and dtype == "bf16":
+            K_, N_, Z_ = int(dims[0]), int(dims[1]), int(dims[2]) if len(dims) > 2 else 1
+            rows_ = fl / (2.0 * K_ * N_ * Z_)
+            n_out = N_ // 2 if (K_, N_) == (512, 1024) else N_                 # pointwise_conv1 + GLU writes half
+            has_res = Z_ == 1 and N_ == 512 and K_ in (512, 1024, 2048)          # w_2, slot output, pointwise_conv2
+            byts = rows_ * Z_ * (K_ + n_out + (N_ if has_res else 0)) * 2
+            floor_mfma, floor_hbm = fl / (MFMA_PEAK_TFLOPS * 1e12), byts / (copy_gbs * 1e9)
+            floor_spec = byts / (HBM_PEAK_GBS * 1e9)
+            ent.update(hbm_bytes=int(byts), mfma_floor_us=round(floor_mfma * 1e6, 1),
+                       hbm_floor_us_at_8tbs=round(floor_spec * 1e6, 1),
+                       hbm_floor_us_at_measured_copy=round(floor_hbm * 1e6, 1),
+                       # the roofline the contract prescribes: spec peaks on both sides (8 TB/s, 2.5 PFLOP/s) ...
+                       frac_of_two_sided_roofline=round(max(floor_mfma, floor_spec) / (rec["avg_ms"] * 1e-3), 4),
+                       # ... and against the copy rate this box sustains (what a perfect kernel could reach here)
+                       frac_of_two_sided_roofline_at_measured_copy=round(max(floor_mfma, floor_hbm) / (rec["avg_ms"] * 1e-3), 4))
+        mfma["kernels"][label] = ent
+    return mfma
+
+
+def whole_model_bf16_leg(feats32, device, steps: int, copy_gbs):
+    """The same 30-minute file as one sequence through the whole-model-bf16 encoder (encoder-rtf.py --bf16): rounds 1-4's headline,
+    kept as a secondary figure.  The reference's bidirectional wrapper cannot run this mode (it returns .float() into a bf16
+    LayerNorm, rwkv_wrapper_bidirectional.py:55-56); here the slot returns the query dtype.  `steps` timed steps after 2 warm-up
+    steps, then profiled steps for the scan's roofline and the GEMMs' matrix-core fractions in this mode."""
+    from paper_accurate_fast_cheap_amd import profiling
+    m2, _ = build_model("bf16", device)
+    fb2 = feats32.to(device=device, dtype=torch.bfloat16)
+    ln2 = torch.tensor([feats32.shape[1]], dtype=torch.int32, device=device)
+    profiling.enable_recording(False)
+    with torch.no_grad():
+        for _ in range(2):
+            m2.ctc_logprobs(m2._forward_encoder(fb2, ln2)[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m2.ctc_logprobs(m2._forward_encoder(fb2, ln2)[0])
+        torch.cuda.synchronize()
+        ms2 = (time.perf_counter() - t0) / steps * 1e3
+        profiling.enable(True)
+        for _ in range(min(steps, 3)):
+            m2.ctc_logprobs(m2._forward_encoder(fb2, ln2)[0])
+        torch.cuda.synchronize()
+        profiling.enable_recording(False)
+    prof = profiling.summary()
+    return {"workload": "the same file as one sequence, " + PRECISION["bf16"], "steps": steps, "ms_per_step": round(ms2, 3),
+            "audio_sec_per_sec": round(feats32.shape[1] / 100.0 / (ms2 * 1e-3), 1),
+            "roofline": scan_roofline(prof, copy_gbs), "mfma": mfma_object(prof, "bf16", True, copy_gbs)}
+
+
 def spawn_ranks(n: int, argv, script: str = None) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as a child torchrun -- the parent has made
     no GPU call -- relay their output and return the child's exit code (wenet's recipe launches the same way,
@@ -378,9 +477,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16slot"],
-                    help="bf16: whole model bf16 (BASELINE configs[1], encoder-rtf.py --bf16); "
-                         "bf16slot: fp32 model with the bf16 time-mix slot (the YAML default)")
+    ap.add_argument("--dtype", default="bf16slot", choices=["bf16", "bf16slot"],
+                    help="bf16slot (default): fp32 model with the bf16 time-mix slot -- the YAML default and what the paper's RTF sweep "
+                         "ran (go-run-encoder-rtf.single-gpu-3x3-g5.sh:33-41 passes no --bf16), the precision the reference itself "
+                         "can run; bf16: whole model bf16 (encoder-rtf.py --bf16), which the reference's bidirectional wrapper "
+                         "cannot run (it returns .float() into a bf16 LayerNorm, rwkv_wrapper_bidirectional.py:55-56)")
     ap.add_argument("--workload", default="c3", choices=["c3", "c2"],
                     help="c3 (default, the metric's workload): one 30-min file per GPU; c2: 5715 DEV-shaped utterances "
                          "(1-20 s) sharded over the GPUs, decode batch 64, CTC greedy tokens (parity-suite workload)")
@@ -519,64 +620,9 @@ def main():
         copy_gbs = round(10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
         del a, bq
 
-    rec = prof.get("wkv6_fwd_bidir") or prof.get("wkv6_fwd")
-    roofline = None
-    # HBM bytes per launch from the rocprofv3 PMC passes of the same op and shape ON THE PRESENT KERNEL SOURCES, else null
-    traffic, traffic_file = scan_traffic(rec["meta"]) if rec else (None, None)
-    if rec:
-        m = rec["meta"]
-        alg_bytes = m["B"] * m["T"] * m["C"] * 5 * m["elem_bytes"] * m["ndir"]
-        alg_flops = m["B"] * m["T"] * m["C"] * 448 * m["ndir"]
-        sec = rec["avg_ms"] * 1e-3
-        roofline = {"kernel": "wkv6 forward scan, both directions (chunk_state + state_scan + chunk_output kernels)",
-                    "bound": "hbm", "achieved": round(alg_bytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": traffic_file,
-                    "launches": rec["n"], "avg_launch_us": round(rec["avg_ms"] * 1e3, 1),
-                    "algorithmic_bytes_per_launch": alg_bytes,
-                    "measured_copy_gbs": copy_gbs,
-                    "frac_of_measured_copy": round(alg_bytes / sec / 1e9 / copy_gbs, 4) if copy_gbs else None,
-                    "valu_tflops": round(alg_flops / sec / 1e12, 2),
-                    "valu_frac": round(alg_flops / sec / 1e12 / VALU_PEAK_TFLOPS, 4)}
-
+    roofline = scan_roofline(prof, copy_gbs)
     # MFMA utilisation of the dense kernels, from the same event timers: achieved TFLOP/s against the dense bf16 peak
-    mfma = None
-    if True:       # both precisions: the fp32 model's projections are split-operand products on the same bf16 matrix cores
-        mfma = {"peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "kernels": {},
-                "note": None if args.dtype == "bf16" else
-                "f32 model + bf16 slot: every fp32 product is three bf16 MFMAs (hi*hi + lo*hi + hi*lo); `achieved` counts the "
-                "EXECUTED matrix flops (3 x 2 K N per row), i.e. the matrix cores' utilisation; algorithmic flops are a third"}
-        for name, rec in sorted(prof.items()):
-            fl = rec["meta"].get("flops") if isinstance(rec.get("meta"), dict) else None
-            if fl:
-                tf = fl / (rec["avg_ms"] * 1e-3) / 1e12
-                label = ("subsampling conv2 (hand-written implicit GEMM)" if name == "conv3x3s2"
-                         else "subsampling conv2, split operands (hand-written implicit GEMM, 3 MFMAs per product)" if name == "conv3x3s2_split"
-                         else "hand-written GEMM K x N [x batch] = " + name.split("_", 1)[1] if name.startswith("gemm_")
-                         else "hand-written split-operand GEMM (3 MFMAs per fp32 product) K x N = " + name.split("_", 1)[1]
-                         if name.startswith("gemm3_") else "library GEMM K x N = " + name.split("_", 1)[1])
-                ent = {"achieved": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
-                       "avg_us": round(rec["avg_ms"] * 1e3, 1), "launches": rec["n"]}
-                # the other side of the roofline for the projections of ONE long sequence (c3): the activations cross HBM once
-                # (in + out [+ residual]; the weights stay in L2), which for the N = 512 shapes takes longer than the
-                # multiplies at the MFMA peak -- `frac` alone cannot reach 1 there ("Two-sided roofline")
-                dims = name.split("_", 1)[1].split("x") if name.startswith("gemm_") else None
-                if dims and args.workload == "c3" and args.chunk_size <= 0 and copy_gbs and args.dtype == "bf16":
-                    K_, N_, Z_ = int(dims[0]), int(dims[1]), int(dims[2]) if len(dims) > 2 else 1
-                    rows_ = fl / (2.0 * K_ * N_ * Z_)
-                    n_out = N_ // 2 if (K_, N_) == (512, 1024) else N_                 # pointwise_conv1 + GLU writes half
-                    has_res = Z_ == 1 and N_ == 512 and K_ in (512, 1024, 2048)          # w_2, slot output, pointwise_conv2
-                    byts = rows_ * Z_ * (K_ + n_out + (N_ if has_res else 0)) * 2
-                    floor_mfma, floor_hbm = fl / (MFMA_PEAK_TFLOPS * 1e12), byts / (copy_gbs * 1e9)
-                    floor_spec = byts / (HBM_PEAK_GBS * 1e9)
-                    ent.update(hbm_bytes=int(byts), mfma_floor_us=round(floor_mfma * 1e6, 1),
-                               hbm_floor_us_at_8tbs=round(floor_spec * 1e6, 1),
-                               hbm_floor_us_at_measured_copy=round(floor_hbm * 1e6, 1),
-                               # the roofline the contract prescribes: spec peaks on both sides (8 TB/s, 2.5 PFLOP/s) ...
-                               frac_of_two_sided_roofline=round(max(floor_mfma, floor_spec) / (rec["avg_ms"] * 1e-3), 4),
-                               # ... and against the copy rate this box sustains (what a perfect kernel could reach here)
-                               frac_of_two_sided_roofline_at_measured_copy=round(max(floor_mfma, floor_hbm) / (rec["avg_ms"] * 1e-3), 4))
-                mfma["kernels"][label] = ent
+    mfma = mfma_object(prof, args.dtype, args.workload == "c3" and args.chunk_size <= 0, copy_gbs)
 
     out = {
         "metric": "audio-sec/sec (1/RTF) GigaSpeech long-form encode",
@@ -607,38 +653,33 @@ def main():
                       "audio_sec_per_sec_encoder_plus_fbank": round(
                           frames_per_step / 100.0 / (elapsed / args.steps + fbank_ms * 1e-3), 2)},
     }
-    # the precision mode the reference itself can run (fp32 model, bf16 time-mix slot: the YAML default) beside the headline:
-    # same file, same timed region, a few steps after the headline's (N = 1, c3 only; --no-extra skips it)
+    # secondary legs beside the headline (N = 1, c3 one-sequence only; --no-extra skips them): BASELINE configs[1] (c2) and the
+    # paper's window shape in the HEADLINE precision on the package's defaults (no knob is set anywhere in this file), the
+    # streaming legs (configs[2]; a uni-directional whole-bf16 model, which the reference's uni wrapper does run:
+    # rwkv_wrapper.py:57-83 returns the query dtype), and the other precision mode's one-sequence figure
     out["extra"] = None
-    if rank == 0 and world == 1 and args.workload == "c3" and args.dtype == "bf16" and args.chunk_size <= 0 and not args.no_extra:
+    failed_legs = []
+    if rank == 0 and world == 1 and args.workload == "c3" and args.chunk_size <= 0 and not args.no_extra:
         del batches
-        m2, _ = build_model("bf16slot", device)
-        fb2, ln2 = feats32.to(device), torch.tensor([feats32.shape[1]], dtype=torch.int32, device=device)
-        with torch.no_grad():
-            for _ in range(2):
-                m2.ctc_logprobs(m2._forward_encoder(fb2, ln2)[0])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                m2.ctc_logprobs(m2._forward_encoder(fb2, ln2)[0])
-            torch.cuda.synchronize()
-            ms2 = (time.perf_counter() - t0) / 3 * 1e3
-        out["extra"] = {"f32_model_bf16_slot_ms_per_step": round(ms2, 3),
-                        "f32_model_bf16_slot_audio_sec_per_sec": round(frames_per_step / 100.0 / (ms2 * 1e-3), 1),
-                        "note": "rwkv_do_bfloat16 on an fp32 model (conf/rwkv/*.yaml as shipped): fp32 residual stream, every fp32 "
-                                "projection and both subsampling convolutions on the bf16 matrix cores with split operands "
-                                "(hi + lo planes, three bf16 products per fp32 product), bf16 slot"}
-        del m2, fb2
-        # secondary legs: a failure in one of them is reported in its place and never costs the headline line
-        def leg(name, fn, *a):
-            try:
-                out["extra"][name] = fn(*a)
-            except Exception as e:     # noqa: BLE001 -- recorded, not swallowed
+        out["extra"] = {}
+
+        def leg(name, fn, *a, **kw):      # a failure in a leg is reported in its place, never costs the headline line, and
+            try:                           # turns the exit code non-zero after the line is printed
+                out["extra"][name] = fn(*a, **kw)
+            except (RuntimeError, ValueError, AssertionError, KeyError, OSError) as e:
                 out["extra"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
-                torch.cuda.synchronize()
-        # BASELINE configs[1] and the paper's window shape, on the package's defaults (no knob is set anywhere in this file)
-        leg("c2", c2_leg, model, device)
-        leg("windows_2000x8", lambda: windows_leg(model, feats32.to(device=device, dtype=torch.bfloat16), device))
+                failed_legs.append(name)
+                try:
+                    torch.cuda.synchronize()
+                except RuntimeError:
+                    pass
+        other = "bf16" if args.dtype == "bf16slot" else "bf16slot"
+        if other == "bf16":
+            leg("whole_model_bf16", whole_model_bf16_leg, feats32, device, min(args.steps, 10), copy_gbs)
+        leg("c2", c2_leg, model, device, args.dtype)
+        wfeats = feats32.to(device=device, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+        leg("windows_2000x8", windows_leg, model, wfeats, device, dtype=args.dtype)
+        del wfeats
         leg("streaming", streaming_leg, feats32, device)
         leg("streaming_lookahead", streaming_lookahead_leg, feats32, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -649,6 +690,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if failed_legs:
+        sys.exit(f"bench.py: secondary leg(s) failed: {', '.join(failed_legs)} (the headline line above is complete)")
 
 
 if __name__ == "__main__":

@@ -295,13 +295,24 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, out_dtype: torch.dtype = torch.fl
 
 
 # ---- element-wise groups of the training step (csrc/train_elementwise.hip) ------------------------------------------------
-_dropout_calls = 0       # per-process counter: the `offset` of the mask generator (seed = torch's CPU seed)
+_dropout_calls = 0       # fallback counter when the device generator exposes no offset
 
 
-def _next_dropout_stream():
+def _next_dropout_stream(device=None):
+    """(seed, call index) of the next keep mask, drawn from torch's generator of the device: seed = its seed, index = its Philox
+    offset, which is advanced by one step of four like any framework dropout.  `torch.manual_seed` therefore restarts the
+    sequence, and an activation-checkpoint recompute -- which restores the device RNG state (`preserve_rng_state`) -- draws the
+    masks of the original forward pass again (a process-wide counter would not)."""
     global _dropout_calls
-    _dropout_calls += 1
-    return int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, _dropout_calls
+    try:
+        idx = device.index if device is not None and device.index is not None else torch.cuda.current_device()
+        g = torch.cuda.default_generators[idx]
+        off = int(g.get_offset())
+        g.set_offset(off + 4)
+        return int(g.initial_seed()) & 0xFFFFFFFFFFFFFFFF, off // 4 + 1
+    except (RuntimeError, IndexError, AttributeError):
+        _dropout_calls += 1
+        return int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, _dropout_calls
 
 
 def _bind_train_elementwise():
@@ -323,7 +334,7 @@ class _ResidualDropout(torch.autograd.Function):
     def forward(ctx, x, y, scale, p):
         L = _bind_train_elementwise()
         x, y = x.contiguous(), y.contiguous()
-        seed, off = _next_dropout_stream() if p > 0 else (0, 0)
+        seed, off = _next_dropout_stream(x.device) if p > 0 else (0, 0)
         out = torch.empty_like(x)
         _lib.check(L.pafc_residual_dropout(0, _lib.dtype_code(x.dtype), _lib.dtype_code(y.dtype), x.numel(), _lib.ptr(x), _lib.ptr(y),
                                            _lib.ptr(out), float(scale), float(p), seed, off, _lib.stream_of(x)), "pafc_residual_dropout")
@@ -350,7 +361,7 @@ class _SiluDropout(torch.autograd.Function):
     def forward(ctx, h, p):
         L = _bind_train_elementwise()
         h = h.contiguous()
-        seed, off = _next_dropout_stream() if p > 0 else (0, 0)
+        seed, off = _next_dropout_stream(h.device) if p > 0 else (0, 0)
         out = torch.empty_like(h)
         _lib.check(L.pafc_silu_dropout(0, _lib.dtype_code(h.dtype), h.numel(), _lib.ptr(h), _lib.ptr(None), _lib.ptr(out), float(p), seed, off,
                                        _lib.stream_of(h)), "pafc_silu_dropout")
@@ -375,6 +386,11 @@ def train_elementwise_eligible(x: torch.Tensor, y: Optional[torch.Tensor] = None
     bf16 contiguous-izable tensors whose size is a multiple of 8 (a 512-wide stream always is)."""
     if not (train_kernels_enabled() and x.is_cuda and torch.is_grad_enabled() and x.numel() % 8 == 0 and x.numel() > 0):
         return False
+    # the kernels want 16-byte aligned pointers: a contiguous view at an odd storage offset keeps the framework's operators
+    # (a non-contiguous tensor is copied into a fresh, aligned allocation by the Function)
+    for t in (x, y):
+        if t is not None and t.is_contiguous() and t.data_ptr() % 16:
+            return False
     pairs = {(torch.float32, torch.bfloat16), (torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16)}
     if y is not None:
         return (x.dtype, y.dtype) in pairs and y.shape == x.shape and y.is_cuda
@@ -1029,6 +1045,34 @@ def bump_param_epoch() -> None:
     _param_epoch += 1
 
 
+class DerivedFill:
+    """Which stream issued the kernels that FILL a set of derived tensors (a plan's stacked / split / folded weights).  The fill
+    is asynchronous: a forward pass on ANOTHER stream (utils.longform runs decode batches on side streams that only wait for the
+    caller's stream) must wait for it before its kernels read the tensors.  `DerivedFill()` right after the fill records an event
+    on the filling stream; `use()` at the top of every consumer makes the current stream wait for that event the first time it
+    meets the fill (one dictionary look-up afterwards).  Under graph capture nothing is waited for: an eager pass on the same
+    stream always precedes a capture (the graph caches capture a shape's SECOND sighting)."""
+    __slots__ = ("event", "seen")
+
+    def __init__(self, device=None):
+        self.event, self.seen = None, set()
+        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            st = torch.cuda.current_stream(device)
+            self.event = torch.cuda.Event()
+            self.event.record(st)
+            self.seen.add(st.cuda_stream)
+
+    def use(self, device=None) -> None:
+        if self.event is None:
+            return
+        raw = _lib._raw_stream(device.index if device is not None and device.index is not None else torch.cuda.current_device()) \
+            if _lib._raw_stream is not None else torch.cuda.current_stream(device).cuda_stream
+        if raw in self.seen or torch.cuda.is_current_stream_capturing():
+            return
+        torch.cuda.current_stream(device).wait_event(self.event)
+        self.seen.add(raw)
+
+
 
 def split_weight_cached(weight: torch.Tensor) -> torch.Tensor:
     """[hi | hi | lo] planes of a weight, cached per weight OBJECT: an entry is valid only for the very tensor it was made
@@ -1040,7 +1084,10 @@ def split_weight_cached(weight: torch.Tensor) -> torch.Tensor:
     if ent is None or ent[0] != stamp or ent[2]() is not weight:
         if len(_split_weights) > 64:
             _split_weights.clear()
-        ent = _split_weights[id(weight)] = (stamp, split_planes(weight.detach().contiguous(), triple=True), weakref.ref(weight))
+        planes = split_planes(weight.detach().contiguous(), triple=True)
+        ent = _split_weights[id(weight)] = (stamp, planes, weakref.ref(weight), DerivedFill(weight.device))
+    else:
+        ent[3].use(weight.device)            # filled on another stream: that fill first
     return ent[1]
 
 

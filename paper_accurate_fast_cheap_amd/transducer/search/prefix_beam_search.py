@@ -170,23 +170,30 @@ class PrefixBeamSearch:
             # launch-bound loop (~25 small kernels per frame): two eager frames warm every library handle, then the
             # body is captured into a hipGraph and replayed for the remaining frames.  MIOpen's RNN call is not
             # capturable (it sizes its workspace inside the call), so the LSTM runs through the framework's own cell.
-            try:
-                with torch.backends.cudnn.flags(enabled=False):
-                    side = torch.cuda.Stream(device=device)
-                    side.wait_stream(torch.cuda.current_stream(device))
-                    with torch.cuda.stream(side):
-                        frame(); frame()
-                    torch.cuda.current_stream(device).wait_stream(side)
-                    done = 2
-                    graph = torch.cuda.CUDAGraph()
+            with torch.backends.cudnn.flags(enabled=False):
+                side = torch.cuda.Stream(device=device)
+                side.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(side):
+                    frame(); frame()
+                torch.cuda.current_stream(device).wait_stream(side)
+                done = 2
+                graph = torch.cuda.CUDAGraph()
+                try:
                     with torch.cuda.graph(graph):
                         frame()
+                except RuntimeError as e:
+                    # only a REFUSED capture (an operation the stream capture does not permit in this build) finishes eagerly --
+                    # nothing ran during the failed capture, so t_dev still stands behind the two warm-up frames; a failing
+                    # launch or a PafcError inside the frame is a real error and surfaces
+                    from ..._lib import PafcError
+                    torch.cuda.synchronize(device)
+                    if isinstance(e, PafcError) or "captur" not in str(e).lower():
+                        raise
+                    graph = None
+                if graph is not None:          # errors of the replays are genuine kernel / launch errors: not swallowed
                     for _ in range(T - done):
                         graph.replay()
                     done = T
-            except Exception:   # capture unsupported in this build: finish eagerly from wherever t_dev stands
-                torch.cuda.synchronize(device)
-                done = int(t_dev.item())
         for _ in range(T - done):
             frame()
         toks, lens_n, scores = st.finish()

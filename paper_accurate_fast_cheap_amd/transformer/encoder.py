@@ -20,6 +20,21 @@ from .encoder_layer import ConformerEncoderLayer
 from .positionwise_feed_forward import PositionwiseFeedForward
 
 
+def _bump_epoch():
+    from .. import hip_ops
+    hip_ops.bump_param_epoch()
+
+
+def _capture_refused(e: BaseException) -> bool:
+    """Is this the runtime refusing an operation under stream capture (hipErrorStreamCapture* -- a synchronising call, an
+    allocation the graph pool cannot serve, a capture-unsafe library call), as opposed to an error of the work itself?"""
+    from .._lib import PafcError
+    if isinstance(e, PafcError):
+        return False
+    msg = str(e).lower()
+    return "captur" in msg
+
+
 class BaseEncoder(torch.nn.Module):
     def __init__(self, input_size: int, output_size: int = 256, attention_heads: int = 4, linear_units: int = 2048,
                  num_blocks: int = 6, dropout_rate: float = 0.1, positional_dropout_rate: float = 0.1,
@@ -48,6 +63,10 @@ class BaseEncoder(torch.nn.Module):
         # graph of the whole forward; 0 = off.  Each graph pins its activations, hence opt-in and bounded.
         self.graph_cache_size = 0
         self._graphs = {}
+        self._graphs_token = None              # the parameter state the cached graphs were captured on (_weights_token)
+        self._wt_epoch, self._wt_tensors = None, []
+        # a checkpoint load rewrites parameters in place (Tensor._version moves) and may be followed by anything: new epoch
+        self.register_load_state_dict_post_hook(lambda module, incompatible: _bump_epoch())
 
     def _fused(self, xs: torch.Tensor):
         """The fused executor's plan when this call may use it (no autograd, GPU, eligible layers), else None."""
@@ -63,6 +82,25 @@ class BaseEncoder(torch.nn.Module):
 
     def output_size(self) -> int:
         return self._output_size
+
+    def _apply(self, fn, *args, **kwargs):
+        """model.to() / .cuda() / .half(): the parameters move to new storage -- every derived copy and captured graph is stale."""
+        _bump_epoch()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _weights_token(self):
+        """Cheap identity of the parameter state a captured graph depends on: the process-wide parameter epoch (train_step,
+        train() / eval(), .to(), load_state_dict) and the sum of the in-place versions of every parameter and buffer (an
+        optimizer step that is not fused, `p.add_()`, `copy_()`).  The tensor list is looked up once per epoch."""
+        from .. import hip_ops
+        ep = hip_ops.param_epoch()
+        if self._wt_epoch != ep:
+            self._wt_tensors = list(self.parameters()) + list(self.buffers())
+            self._wt_epoch = ep
+        v = 0
+        for t in self._wt_tensors:
+            v += t._version
+        return ep, v
 
     def train(self, mode: bool = True):
         """train() / eval(): the inference plans' derived weight copies are keyed on Tensor._version, which fused optimizers
@@ -89,6 +127,13 @@ class BaseEncoder(torch.nn.Module):
         eagerly (returns None), the second one captures.  Outputs are copies: the graph's own buffers are reused."""
         # keyed by the issuing stream as well: a graph replays into its own buffers, so batches in flight on two streams
         # (two decode batches overlapping each other's launch-bound stretches) need a graph each
+        # A captured graph holds the ADDRESSES of the plans' derived weight tensors (stacked / folded / split copies) and never
+        # calls plan.refresh(): after any parameter change the graphs of the old state are dropped (their derived tensors have been
+        # freed or are about to be), and the shape is captured again on its second sighting.
+        token = self._weights_token()
+        if token != self._graphs_token:
+            self._graphs.clear()
+            self._graphs_token = token
         key = (tuple(xs.shape), xs.dtype, xs_lens.dtype, torch.cuda.current_stream(xs.device).cuda_stream)
         ent = self._graphs.get(key)
         if ent is None:
@@ -104,7 +149,9 @@ class BaseEncoder(torch.nn.Module):
                 ent = self._graphs[key] = (graph, sx, sl, oy, om)
                 self._graphs[key] = self._graphs.pop(key)     # newest last, then drop the oldest graphs beyond the bound
                 self._trim_graphs()
-            except Exception:                      # not capturable in this configuration: stay eager for this shape
+            except RuntimeError as e:              # a REFUSED capture (an operation the capture mode does not permit): this shape
+                if not _capture_refused(e):        # stays eager; anything else -- a failing launch, a PafcError -- surfaces
+                    raise
                 torch.cuda.synchronize(xs.device)
                 self._graphs[key] = "eager"
                 return None

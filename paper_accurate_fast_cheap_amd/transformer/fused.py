@@ -69,8 +69,11 @@ class LayerPlan:
         return (ep,) + tuple((p.data_ptr(), p._version, p.dtype) for p in self._stamp_params)
 
     def refresh(self):
+        """Rebuild the derived tensors when a parameter they come from has changed; either way, make the CURRENT stream wait for
+        the stream that filled them (hip_ops.DerivedFill: decode batches in flight on side streams share one plan)."""
         stamp = self._current_stamp()
         if stamp == self._stamp:
+            self._fill.use()
             return
         bl = self.blocks
         with torch.no_grad():
@@ -93,6 +96,7 @@ class LayerPlan:
             self._refresh_split()
             self._refresh_lnfold()
         self._stamp = stamp
+        self._fill = hip_ops.DerivedFill()
 
     def _refresh_lnfold(self):
         """bf16 layer, C = 512: the three pre-norm LayerNorms whose consumer is a projection (norm_ff_macaron -> w_1,
@@ -125,6 +129,7 @@ class LayerPlan:
         into that projection (csrc/gemm_skinny.hip, statistics formed in the launch): W' = bf16(gamma * W), b' = b + W beta,
         csum = row sums of the ROUNDED W'.  Built on first use, rebuilt when the parameters change (refresh)."""
         if getattr(self, "_carry_folds", None) is not None and self._carry_folds[0] == self._stamp:
+            self._carry_folds[2].use()
             return self._carry_folds[1]
         L = self.layer
 
@@ -135,7 +140,7 @@ class LayerPlan:
             return wp, bf.to(torch.bfloat16).contiguous(), wp.float().sum(-1).contiguous(), norm.eps
 
         folds = dict(out=fold(self.Wo, None, self.blocks[0].ln_x), ff=fold(L.feed_forward.w_1.weight, L.feed_forward.w_1.bias, L.norm_ff))
-        self._carry_folds = (self._stamp, folds)
+        self._carry_folds = (self._stamp, folds, hip_ops.DerivedFill())
         return folds
 
     def _refresh_split(self):

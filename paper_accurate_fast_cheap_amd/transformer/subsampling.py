@@ -59,6 +59,10 @@ class Conv2dSubsampling4(BaseSubsampling):
                         # the object would see a new `_w_lin` with `_version` 0 after every weight update)
                         self._w_lin_3 = split_planes(self._w_lin, triple=True)
             self._nhwc_stamp = stamp
+            from ..hip_ops import DerivedFill
+            self._nhwc_fill = DerivedFill(x.device)      # batches in flight on other streams wait for this fill first
+        else:
+            self._nhwc_fill.use(x.device)
         if x.dtype == torch.bfloat16 and C % 128 == 0 and 256 % (C // 8) == 0:
             # conv1 + ReLU: write-bound direct kernel (its output is the largest tensor of the whole pass);
             # conv2 + ReLU: hand-written implicit GEMM on the matrix cores; NHWC in and out

@@ -510,6 +510,85 @@ def test_bf16slot_full_size_split_operand_path_vs_oracle(hip, monkeypatch):
     _token_parity(logp, ref_logp, valid, 0.08, "bf16slot full size, split-operand GEMMs")
 
 
+def test_bf16slot_token_lists_through_a_head_that_decides(hip):
+    """Token LISTS in the reference's own precision (fp32 model + bf16 slot, the bench headline) through a head that decides.
+    A c2-shaped ragged batch of 24 utterances (1-6 s) through the full-size 12-layer model; the CTC head reads the leading
+    principal direction(s) of the oracle's output (token = sign pattern of the top n components, blank = zero row, V padded
+    to 16), through the product's CTC module and GPU greedy search (search.py:106-121) for the HIP output and the oracle's own
+    restatement for the reference.  With e_t = that frame's max |dlogp| (HIP vs oracle), a frame is DECIDED when the oracle's
+    top-2 margin exceeds 2 e_t.  Asserted: (i) every utterance all of whose frames are decided yields the oracle's token list
+    (collapsed, blanks removed); (ii) >= 90 % of ALL utterances do (a flip at a sign change moves the change by a frame, which the
+    collapse absorbs -- lists differ only where the projection grazes zero).  Recorded in profiles/parity_r05.json."""
+    import itertools
+    import bench
+    from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    from paper_accurate_fast_cheap_amd.transformer.search import ctc_greedy_search
+    conf = bench.encoder_conf()
+    torch.manual_seed(777)
+    enc = ConformerEncoder(80, **conf).eval()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.02)
+    g = torch.Generator().manual_seed(4242)
+    lens = torch.sort(torch.randint(100, 601, (24,), generator=g), descending=True).values
+    xs = synth.randn((24, int(lens[0]), 80), 911, 2.0)
+    for b, n in enumerate(lens.tolist()):
+        xs[b, n:] = 0
+    sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    ref, ref_masks = EO.encoder_forward(xs, lens, sd, conf, env={})
+    valid = ref_masks.squeeze(1)
+    enc = enc.cuda()
+    with torch.no_grad():
+        out, masks = enc(xs.cuda(), lens.cuda())
+    assert out.dtype == torch.float32 and torch.equal(masks.cpu(), ref_masks)
+    X = ref[valid]
+    mu = X.mean(0)
+    _, _, V = torch.pca_lowrank(X - mu, q=8, center=False, niter=4)
+    C = X.shape[1]
+    olens = ref_masks.squeeze(1).sum(1)
+    for npc in (1, 3):
+        P = V[:, :npc]
+        rows = [torch.zeros(C)] + [(P * torch.tensor(pat)).sum(1) for pat in itertools.product([1.0, -1.0], repeat=npc)]
+        W = torch.zeros(16, C)
+        W[:len(rows)] = torch.stack(rows)
+        b = -(W @ mu)
+        b[len(rows):] = -60.0
+        head = CTC(16, C)
+        head.load_state_dict({"ctc_lo.weight": W, "ctc_lo.bias": b})
+        with torch.no_grad():
+            lp_hip_dev = head.cuda().eval().log_softmax(out)
+            toks_hip = [list(r.tokens) for r in ctc_greedy_search(lp_hip_dev, masks.squeeze(1).sum(1), 0)]
+        lp_hip = lp_hip_dev.float().cpu()
+        lp_ref = EO.ctc_log_softmax(ref, {"ctc.ctc_lo.weight": W, "ctc.ctc_lo.bias": b})
+        toks_ref = EO.ctc_greedy_search(lp_ref, olens, 0)
+        nv = len(rows)
+        top2 = lp_ref.topk(2, dim=-1).values
+        margin = top2[..., 0] - top2[..., 1]
+        e_t = (lp_hip - lp_ref)[..., :nv].abs().max(-1).values
+        decided = (margin > 2 * e_t) | ~valid
+        same_frame = (lp_hip.argmax(-1) == lp_ref.argmax(-1)) | ~valid
+        assert bool((same_frame | ~decided).all())               # (a decided frame cannot flip: the bound on e_t is what is tested)
+        full = decided.all(1)
+        equal = torch.tensor([a == b_ for a, b_ in zip(toks_hip, toks_ref)])
+        n_utt = len(toks_ref)
+        parity_log.record(f"bf16slot token lists, decisive head n={npc}", utterances=n_utt, vocab=nv,
+                          utterances_fully_decided=int(full.sum()), token_lists_equal=int(equal.sum()),
+                          token_lists_equal_among_fully_decided=int((equal & full).sum()),
+                          frames=int(valid.sum()), frames_flipped=int((~same_frame).sum()),
+                          frames_undecided=int((~decided).sum()), tokens_reference=int(sum(len(t) for t in toks_ref)),
+                          max_abs_dlogp=float((e_t * valid).max()))
+        print(f"[bf16slot token lists n={npc}] {int(equal.sum())} of {n_utt} utterances decode to the oracle's token list "
+              f"({int(full.sum())} fully decided, all of them equal: {bool((equal | ~full).all())}); "
+              f"{int((~same_frame).sum())} of {int(valid.sum())} frames flipped, {int((~decided).sum())} undecided; "
+              f"{sum(len(t) for t in toks_ref)} reference tokens")
+        assert sum(len(t) for t in toks_ref) > 10 * n_utt         # a real token sequence per utterance, not a constant
+        assert bool((equal | ~full).all()), "a fully decided utterance decodes to another token list"
+        if npc == 1:
+            assert int(equal.sum()) >= 0.9 * n_utt, (int(equal.sum()), n_utt)
+
+
 @pytest.mark.parametrize("variant", ["bf16slot", "f32", "uni_bf16slot"])
 def test_forward_chunk_by_chunk_golden(hip, variant):
     """BaseEncoder.forward_chunk_by_chunk vs the reference's own output (tests/golden/make_goldens_r2.py): the batched
@@ -814,6 +893,112 @@ def test_graph_cache_two_batches_in_flight(hip):
         assert sum(isinstance(v, tuple) for v in enc._graphs.values()) == 3       # the main stream's graph + one per side stream
     for a, b in zip(single, double):
         assert torch.equal(a, b)
+
+
+def test_graph_cache_follows_parameter_updates(hip):
+    """A captured graph holds the addresses of the plans' derived weights and never refreshes them: after ANY parameter change
+    -- an in-place update (optimizer step: Tensor._version moves), load_state_dict, a fused-optimizer style write behind torch's
+    back followed by hip_ops.bump_param_epoch(), .to() -- the next decode_windows must not replay a stale graph.  Compared with
+    the eager pass of an identical model after every change."""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    from paper_accurate_fast_cheap_amd.utils.init_model import init_model
+    from paper_accurate_fast_cheap_amd.utils.longform import decode_windows
+    g = load_golden("encoder_reduced_f32")
+    conf = dict(g["conf"], rwkv_do_bfloat16=True)
+    configs = dict(encoder="conformer", encoder_conf=conf, input_dim=80, output_dim=40, ctc="ctc",
+                   ctc_conf={"ctc_blank_id": 0}, model_conf={}, dataset_conf={})
+
+    class A:
+        checkpoint = None
+
+    torch.manual_seed(5)
+    model, _ = init_model(A(), configs)
+    model = model.eval().to(torch.bfloat16).cuda()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.05)
+    feats = synth.randn((1, 6 * 4 * 203, 80), 77, 2.0).cuda().to(torch.bfloat16)
+
+    def eager_reference():              # a FRESH model with the same parameters, no graph, one stream
+        ref, _ = init_model(A(), configs)
+        ref = ref.eval().to(torch.bfloat16).cuda()
+        ref.load_state_dict(model.state_dict())
+        return decode_windows(ref, feats, 203, 4, streams=1, graph_cache=False)
+
+    def graphed():
+        out = None
+        for _ in range(3):                    # seen, captured, replayed
+            out = decode_windows(model, feats, 203, 4, streams=2)
+        assert any(isinstance(v, tuple) for v in model.encoder._graphs.values())
+        return out
+
+    first = graphed()
+    assert first["windows"] == eager_reference()["windows"]
+    changes = []
+    with torch.no_grad():
+        w = model.encoder.encoders[0].feed_forward.w_2.weight
+        w.mul_(-1.0)                                                        # in place: _version moves
+        changes.append("in-place update")
+        got = graphed()
+        assert got["windows"] == eager_reference()["windows"], changes[-1]
+        assert got["windows"] != first["windows"]                           # (the change matters)
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        k0 = "encoder.encoders.1.self_attn.rwkv_wrapper_forward.tmix_block.output.weight"
+        sd[k0] = -sd[k0]
+        model.load_state_dict(sd)
+        changes.append("load_state_dict")
+        got2 = graphed()
+        assert got2["windows"] == eager_reference()["windows"], changes[-1]
+        model.encoder.encoders[1].feed_forward.w_1.weight.data.neg_()        # .data write: no version bump -> the caller's duty
+        hip_ops.bump_param_epoch()
+        changes.append("data write + bump_param_epoch")
+        got3 = graphed()
+        assert got3["windows"] == eager_reference()["windows"], changes[-1]
+    model.encoder.graph_cache_size = 0
+    model.encoder._graphs.clear()
+
+
+def test_graph_capture_errors_surface(hip, monkeypatch):
+    """Only a REFUSED capture makes a shape fall back to eager execution; an error of the captured work itself (a failing launch,
+    a PafcError from the C ABI) is raised to the caller, not swallowed."""
+    from paper_accurate_fast_cheap_amd import _lib
+    from paper_accurate_fast_cheap_amd.transformer import fused
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_reduced_f32")
+    sd = {k: v for k, v in _sd(g).items() if not k.startswith("global_cmvn")}
+    enc = ConformerEncoder(80, **g["conf"])
+    enc.load_state_dict(sd)
+    enc = enc.cuda().eval()
+    x = synth.randn((2, 95, 80), 31, 2.0).cuda()
+    lens = torch.tensor([95, 60], device="cuda")
+    real = fused.encoder_layers_forward
+    with torch.no_grad():
+        want = enc(x, lens)[0]
+        enc.graph_cache_size = 2
+        enc(x, lens)                                                       # first sighting: eager
+
+        def failing(*a, **kw):
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.PafcError("pafc_add_layernorm: PAFC_ERR_LAUNCH (injected)")
+            return real(*a, **kw)
+        monkeypatch.setattr(fused, "encoder_layers_forward", failing)
+        with pytest.raises(_lib.PafcError, match="injected"):
+            enc(x, lens)                                                   # second sighting: capture -> the error surfaces
+        torch.cuda.synchronize()
+        enc._graphs.clear()
+        enc(x, lens)
+
+        def refused(*a, **kw):
+            if torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize()                                   # an operation the capture mode does not permit
+            return real(*a, **kw)
+        monkeypatch.setattr(fused, "encoder_layers_forward", refused)
+        got = enc(x, lens)[0]                                              # capture refused -> eager for this shape
+        assert "eager" in enc._graphs.values()
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=2e-5)
+    enc.graph_cache_size = 0
+    enc._graphs.clear()
 
 
 def test_minimal_and_ragged_edge_inputs(hip):

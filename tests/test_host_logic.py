@@ -240,3 +240,36 @@ def test_inference_plans_follow_fused_optimizer_updates():
     e0 = hip_ops.param_epoch()
     hip_ops.bump_param_epoch()
     assert hip_ops.param_epoch() == e0 + 1
+
+
+def test_graph_cache_token_follows_every_kind_of_parameter_change():
+    """BaseEncoder._weights_token -- what the hipGraph cache of `forward` is keyed on besides (shape, stream): it moves with an
+    in-place update (Tensor._version), load_state_dict, .to() (new storage) and the parameter epoch; it stays put between two
+    forwards that change nothing.  (The graphs themselves need a GPU: tests/test_encoder_gpu.py.)"""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_reduced_f32")
+    enc = ConformerEncoder(80, **g["conf"]).eval()
+    t0 = enc._weights_token()
+    assert enc._weights_token() == t0
+    with torch.no_grad():
+        enc.encoders[1].feed_forward.w_2.weight.mul_(2.0)
+    t1 = enc._weights_token()
+    assert t1 != t0
+    enc.load_state_dict({k: v.clone() for k, v in enc.state_dict().items()})
+    t2 = enc._weights_token()
+    assert t2 != t1 and t2[0] > t1[0]                 # a load is a new epoch
+    enc.to(torch.float64)
+    t3 = enc._weights_token()
+    assert t3[0] > t2[0]                              # new storage: new epoch, and the tensor list is looked up again
+    assert all(t.dtype == torch.float64 for t in enc._wt_tensors if t.is_floating_point())
+    hip_ops.bump_param_epoch()
+    assert enc._weights_token()[0] == t3[0] + 1
+
+
+def test_derived_fill_is_a_no_op_without_a_gpu():
+    from paper_accurate_fast_cheap_amd import hip_ops
+    f = hip_ops.DerivedFill()
+    f.use()
+    if not torch.cuda.is_available():
+        assert f.event is None

@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""The paper's encoder-RTF sweep on one MI355X: chunk size x batch size over one synthetic 30-minute file.
+
+Reference: examples/gigaspeech/s0/local/go-run-encoder-rtf.single-gpu-3x3-g5.sh:59-61 sweeps
+chunk_size in {2000, 4000, 9000, 15000, 20000, 40000, 60000, 100000, 200000} x batch_size in {4, 8, 1, 10, 12, 14} through
+wenet/bin/encoder-rtf.py (warm-up 3 batches, :41), and tools/rtf/get-rtf-tables.py:9-27 reads `final_rtf`,
+`minutes of audio processed per sec` and `max_vram` out of each run into per-model tables with chunk sizes as rows and batch
+sizes as columns.  This tool runs the same grid in ONE process, through the package's own window scheduler
+(utils.longform.decode_windows: encoder + CTC log-softmax + greedy tokens + stitching inside the timing, `--streams` window
+batches in flight, hipGraph replay of the recurring batch shape), in the headline precision (fp32 model + bf16 time-mix slot;
+`--dtype bf16` for the whole-model-bf16 mode), and writes
+
+  <out>.jsonl   one record per point: ms per pass, audio-sec/sec, minutes of audio per second, final_rtf, max VRAM (MB),
+                the share of the one-sequence rate, the token checksum of the pass and whether it equals the checksum of an
+                eager one-stream pass over the same windows (no graph, no side stream)
+  <out>.md      the tables, chunk sizes as rows and batch sizes as columns (the layout of get-rtf-tables.py's per-model tables)
+
+Usage (GPU box):  python tools/rtf_sweep.py [--dtype bf16slot|bf16] [--streams 3] [--passes 3] [--out profiles/r05_rtf_sweep]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CHUNKS = [2000, 4000, 9000, 15000, 20000, 40000, 60000, 100000, 200000]
+BATCHES = [1, 4, 8, 10, 12, 14]
+
+
+def table(records, key, fmt, title):
+    chunks = sorted({r["chunk_size"] for r in records})
+    batches = sorted({r["batch_size"] for r in records})
+    cell = {(r["chunk_size"], r["batch_size"]): r for r in records}
+    w = 12
+    lines = [f"### rwkv_bi_12L-GPU - {title}", "",
+             "|" + "Chunk Size".center(w + 2) + "|" + "".join(f"BS {b}".center(w + 2) + "|" for b in batches),
+             "|" + "-" * (w + 2) + "|" + "".join("-" * (w + 2) + "|" for _ in batches)]
+    for c in chunks:
+        row = "|" + str(c).center(w + 2) + "|"
+        for b in batches:
+            r = cell.get((c, b))
+            row += (fmt(r[key]) if r is not None and r.get(key) is not None else "-").center(w + 2) + "|"
+        lines.append(row)
+    return "\n".join(lines) + "\n"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16slot", choices=["bf16slot", "bf16"])
+    ap.add_argument("--streams", type=int, default=3)
+    ap.add_argument("--passes", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chunks", default=",".join(map(str, CHUNKS)))
+    ap.add_argument("--batches", default=",".join(map(str, BATCHES)))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "rtf_sweep"))
+    ap.add_argument("--no-eager-check", action="store_true", help="skip the eager one-stream pass behind the token checksum")
+    args = ap.parse_args()
+    from paper_accurate_fast_cheap_amd import _lib
+    from paper_accurate_fast_cheap_amd.utils.longform import decode_windows
+    _lib.lib()
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    model, _ = bench.build_model(args.dtype, device)
+    wave = bench.synthetic_waveform(bench.AUDIO_SECONDS, 777)
+    feats, _ = bench.front_end(wave, device)
+    if args.dtype == "bf16":
+        feats = feats.to(torch.bfloat16)
+    frames = feats.shape[1]
+    lens = torch.tensor([frames], dtype=torch.int32, device=device)
+    enc = model.encoder
+
+    def one_sequence():
+        model.ctc_logprobs(model._forward_encoder(feats, lens)[0])
+    one_ms = bench.timed_passes(one_sequence, max(args.passes, 3), 2) * 1e3
+    one_rate = frames / 100.0 / (one_ms * 1e-3)
+    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+    records = []
+    with open(args.out + ".jsonl", "w") as fj:
+        head = {"one_sequence_ms": round(one_ms, 3), "one_sequence_audio_sec_per_sec": round(one_rate, 1), "dtype": args.dtype,
+                "precision": bench.PRECISION[args.dtype], "frames": frames, "streams": args.streams,
+                "device": torch.cuda.get_device_name(0)}
+        fj.write(json.dumps(head) + "\n")
+        fj.flush()
+        for b in [int(v) for v in args.batches.split(",")]:
+            for c in [int(v) for v in args.chunks.split(",")]:
+                enc.graph_cache_size = 0
+                enc._graphs.clear()
+                torch.cuda.empty_cache()
+                torch.cuda.reset_peak_memory_stats(device)
+                last = {}
+
+                def step():
+                    last["out"] = decode_windows(model, feats, c, b, streams=args.streams)
+                sec = bench.timed_passes(step, args.passes, args.warmup)
+                vram = torch.cuda.max_memory_allocated(device) / 1024 / 1024
+                checksum = bench.token_checksum([last["out"]["windows"]])
+                rec = {"chunk_size": c, "batch_size": b, "batches_per_pass": -(-frames // (c * b)), "ms_per_pass": round(sec * 1e3, 3),
+                       "audio_sec_per_sec": round(frames / 100.0 / sec, 1), "minutes_per_sec": round(frames / 100.0 / 60.0 / sec, 2),
+                       "final_rtf": round(sec / (frames / 100.0), 9), "vram": round(vram, 2),
+                       "share_of_one_sequence": round(frames / 100.0 / sec / one_rate, 4), "token_checksum": checksum,
+                       "tokens": len(last["out"]["tokens"])}
+                if not args.no_eager_check:
+                    enc.graph_cache_size = 0
+                    enc._graphs.clear()
+                    with torch.no_grad():
+                        eager = decode_windows(model, feats, c, b, streams=1, graph_cache=False)
+                    torch.cuda.synchronize()
+                    rec["token_checksum_equals_eager_pass"] = bench.token_checksum([eager["windows"]]) == checksum
+                records.append(rec)
+                fj.write(json.dumps(rec) + "\n")
+                fj.flush()
+                print(f"{time.strftime('%H:%M:%S')} chunk {c:6d} x batch {b:2d}: {rec['ms_per_pass']:8.2f} ms  "
+                      f"{rec['audio_sec_per_sec']:9.0f} audio-sec/sec  {rec['share_of_one_sequence']:.2f} of one sequence  "
+                      f"tokens == eager: {rec.get('token_checksum_equals_eager_pass')}", flush=True)
+    enc.graph_cache_size = 0
+    enc._graphs.clear()
+    with open(args.out + ".md", "w") as fm:
+        fm.write(f"# Encoder RTF sweep, one MI355X, {bench.PRECISION[args.dtype]}\n\n"
+                 f"One synthetic 30-minute file ({frames} frames), `utils.longform.decode_windows` (encoder + CTC log-softmax + greedy "
+                 f"tokens + stitching inside the timing), {args.streams} window batches in flight, {args.warmup} warm-up + {args.passes} "
+                 f"timed passes per point.  The same file as ONE sequence: {one_ms:.2f} ms = {one_rate:.0f} audio-sec/sec.  Grid and "
+                 f"table layout: go-run-encoder-rtf.single-gpu-3x3-g5.sh:59-61, tools/rtf/get-rtf-tables.py.\n\n")
+        fm.write(table(records, "minutes_per_sec", lambda v: f"{v:.2f}", "Minutes of Audio Processed per Second") + "\n")
+        fm.write(table(records, "audio_sec_per_sec", lambda v: f"{v:.0f}", "audio-sec/sec (1/RTF)") + "\n")
+        fm.write(table(records, "share_of_one_sequence", lambda v: f"{v:.2f}", "share of the one-sequence rate") + "\n")
+        fm.write(table(records, "vram", lambda v: f"{v:.2f}", "Max VRAM Usage (MB)") + "\n")
+        if not args.no_eager_check:
+            fm.write(table(records, "token_checksum_equals_eager_pass", lambda v: "yes" if v else "NO",
+                           "token checksum equals the eager one-stream pass") + "\n")
+    print("wrote", args.out + ".jsonl", args.out + ".md")
+
+
+if __name__ == "__main__":
+    main()
