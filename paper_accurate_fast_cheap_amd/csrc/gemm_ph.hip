@@ -41,7 +41,18 @@
 // (M x 2K), W' = [hi_w | hi_w | lo_w] (N x 3K), and the K walk of A visits hi, lo, hi (`a_soff`): three bf16 products on
 // the fast path instead of one fp32 product at 1/16 of the rate.  The planes may also alternate in blocks ([hi 512 | lo 512]
 // per pixel: what the split convolution writes and Linear(9728, 512) then reads).
+//
+// Round 5 (SPL): the three products share their operand fragments.  The walk above stages the hi plane of A twice and the
+// hi plane of W twice (3 x 64 KiB of LDS-DMA and 3 x 24 fragment reads per wave for 64 fp32-equivalent columns).  With SPL a
+// K-step covers 32 columns of BOTH planes: an LDS row is [hi 32 | lo 32] (the same 128-byte rows, units, swizzle, phases and
+// counted waits -- only the DMA source of chunks 4-7 moves to the lo plane), the fragment a lane reads at `ks = 0` is hi and at
+// `ks = 1` lo, and a phase multiplies hi_w hi_a + hi_w lo_a + lo_w hi_a from the fragments it holds: 24 MFMAs per phase instead
+// of 16 behind the same reads, barriers and DMA -- two K-steps (2 x 64 KiB, 2 x 24 reads) per 64 columns, a third less operand
+// traffic per product and a third more matrix work per barrier pair.  A and W keep their layouts ([hi | lo] / [hi | hi | lo]).
+// PAFC_SPLIT_WALK=hilohi selects the round-3 walk for A/B runs.
 #include <climits>
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "pafc_common.h"
@@ -72,6 +83,9 @@ struct PhParams {
     // (pb_shift = 31: one block, the row is [hi K | lo K]); pb_bytes = bytes of one plane block.
     int nk1, pb_shift;
     long pb_bytes;
+    // SPL: K-steps per tile (32 columns of both planes each), and the byte offset of the lo plane from the hi plane inside a
+    // row of A / of W (pb_shift then counts in 32-column steps)
+    int nsteps, a_lo, w_lo;
     long lo_off;                      // OUT 2: column offset of the lo plane inside an output row
     // LayerNorm folded into the GEMMs either side of it (LNF): row statistics as 8 partial (sum, sum of squares) pairs per
     // row, float2 [M][8] -- written by the GEMM that produces the row (LNF 2: one pair per 64-column wave slice of the
@@ -152,7 +166,7 @@ constexpr unsigned PH_OOB = 0xC0000000u;       // a byte offset beyond every des
 //       1 = consumer (SiLU or GLU, alpha 1): A is the UN-normalised stream, W / bias are W' / b', the epilogue applies
 //       rstd (acc - mean csum) + b' per row.  The normalised tensor never exists in memory (encoder_layer.py:201-259 writes
 //       and re-reads it once per sub-block).
-template <bool GLU, int ACT, int RES, int OUT, bool CONV = false, int LNF = 0>
+template <bool GLU, int ACT, int RES, int OUT, bool CONV = false, int LNF = 0, bool SPL = false>
 __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     constexpr int BN = PBN;
     constexpr int UA = 128 * 128;                 // bytes of an A unit: 128 rows x 64 k
@@ -168,6 +182,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     // counted waits of the next tile's first K-step rely on the exact number
     constexpr int NST = 8 * (GLU ? 1 : 2) * (OUT == 0 ? 1 : 2) + (LNF == 2 ? 8 : 0);
     static_assert(LNF == 0 || (OUT == 0 && !CONV), "LayerNorm folding: bf16 GEMMs");
+    static_assert(!SPL || LNF == 0, "shared-fragment split operands: not with a folded LayerNorm");
     static_assert(LNF != 1 || (RES == 0 && (GLU || ACT == 1)), "LNF 1: the w_1 (SiLU) / pointwise_conv1 (GLU) projections");
     static_assert(LNF != 2 || RES == 1, "LNF 2: a residual GEMM");
     static_assert(!(GLU && (ACT != 0 || RES != 0)), "GLU excludes an activation and a residual");
@@ -182,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     const long nblk = (long)p.mtiles * p.ntiles;
     const long total = nblk * p.batch;
     const long per = total / 8;
-    const int nt = p.K / PBK;                     // K-steps per tile: even, >= 2 (checked on the host)
+    const int nt = SPL ? p.nsteps : p.K / PBK;    // K-steps per tile: even, >= 2 (checked on the host)
 
     // CONV: input offset of output position m (its tap (0, 0) pixel)
     auto pix_off = [&](long m) -> long {
@@ -235,8 +250,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         for (int j = 0; j < DA; ++j) {
             const int u = (wave * DA + j) * 8 + sub;                             // 0..127: wave-row group u >> 6, row u & 63
             const int row = (u >> 6) * 128 + h * 64 + (u & 63);
-            a_off[h][j] = CONV ? (unsigned)(pix_off(T.m0 + row) - pix_off(T.m0) + 16 * (pch ^ sub))
-                               : (unsigned)((long)row * p.lda * 2 + 16 * (pch ^ sub));
+            // source chunk sc of the 128-byte row; SPL: chunks 0-3 = 32 columns of the hi plane, 4-7 = the same columns of lo
+            const int sc = pch ^ sub;
+            const unsigned coff = SPL ? (unsigned)(16 * (sc & 3) + (sc >> 2) * p.a_lo) : (unsigned)(16 * sc);
+            a_off[h][j] = CONV ? (unsigned)(pix_off(T.m0 + row) - pix_off(T.m0)) + coff
+                               : (unsigned)((long)row * p.lda * 2) + coff;
         }
     };
     auto b_offsets = [&]() {
@@ -248,12 +266,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
                 const int u = (wave * DB + j) * 8 + sub;                         // 0..127: wave column group u >> 5, row u & 31
                 const int r = u & 31;                                            // MFMA tile r >> 4, its n index r & 15
                 const int pc = ((r & 15) >> 2) * 8 + (r >> 4) * 4 + (r & 3);     // -> column inside the half (see the head comment)
-                b_off[h][j] = (unsigned)((long)((u >> 5) * 64 + h * 32 + pc) * (CONV ? p.CiW : p.ldw) * 2 + 16 * (pch ^ sub));
+                const int sc = pch ^ sub;
+                const unsigned coff = SPL ? (unsigned)(16 * (sc & 3) + (sc >> 2) * p.w_lo) : (unsigned)(16 * sc);
+                b_off[h][j] = (unsigned)((long)((u >> 5) * 64 + h * 32 + pc) * (CONV ? p.CiW : p.ldw) * 2) + coff;
             }
     };
     // wave-uniform byte offset of K-step kt inside a row of A / W (all scalar arithmetic)
     auto a_soff = [&](int kt) -> unsigned {
-        if constexpr (!CONV) {
+        if constexpr (SPL && !CONV) {              // 32-column steps inside plane blocks [hi PB | lo PB]
+            const int blk = kt >> p.pb_shift, c = kt - (blk << p.pb_shift);
+            return (unsigned)(blk * 2 * p.pb_bytes + c * 64);
+        } else if constexpr (SPL) {                // implicit GEMM: (tap, 32-channel slice); the pixel is [hi Ci | lo Ci]
+            const int tap = (kt * p.inv_spt) >> 16, kc = kt - tap * p.spt;
+            const int dt = (tap * 11) >> 5, df = tap - 3 * dt;
+            return (unsigned)(((dt * p.F1 + df) * p.CiA) * 2 + kc * 64);
+        } else if constexpr (!CONV) {
             const int seg = (kt >= p.nk1) + (kt >= 2 * p.nk1);           // hi, lo, hi (plain bf16 A: always 0)
             const int r = kt - seg * p.nk1;
             const int blk = r >> p.pb_shift, c = r - (blk << p.pb_shift);
@@ -266,9 +293,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         }
     };
     auto w_soff = [&](int kt) -> unsigned {
-        if constexpr (!CONV) return kt * 128;
+        if constexpr (!CONV) return kt * (SPL ? 64 : 128);
         const int tap = (kt * p.inv_spt) >> 16, kc = kt - tap * p.spt;
-        return (unsigned)(tap * p.N * p.CiW * 2 + kc * 128);
+        return (unsigned)(tap * p.N * p.CiW * 2 + kc * (SPL ? 64 : 128));
     };
     auto stage_a = [&](const Tile &T, int h, int buf, int kt) {
 #ifdef PH_ABL_NODMA
@@ -390,13 +417,24 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
 #else
         if (half_on[mi]) {   // wave-uniform, one branch per phase: a 64-row half beyond the tile's rows costs nothing
 #endif
+            if constexpr (SPL) {
+                // fragments [.][0] = hi plane, [.][1] = lo plane of the same 32 columns: hi_w hi_a + hi_w lo_a + lo_w hi_a
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+                for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)   // transposed product: D[n][m], a lane owns 4 consecutive n of one m
-                        acc[mi][nj][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bqf[j][ks], af[i][ks], acc[mi][nj][i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j)
+                            acc[mi][nj][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bqf[j][pr == 2], af[i][pr == 1], acc[mi][nj][i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)   // transposed product: D[n][m], a lane owns 4 consecutive n of one m
+                            acc[mi][nj][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bqf[j][ks], af[i][ks], acc[mi][nj][i][j], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -721,12 +759,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
     PH_WAIT(0);                                   // the (empty) prefetch of a tile that does not exist: nothing in flight at exit
 }
 
-template <bool GLU, int ACT, int RES, int OUT, bool CONV = false, int LNF = 0>
+template <bool GLU, int ACT, int RES, int OUT, bool CONV = false, int LNF = 0, bool SPL = false>
 int launch_ph(const PhParams &p, int batch, hipStream_t s) {
     // two K-steps (128 KiB) + a bias slot per wave
     // (LNF 1: + a csum slot per wave + the tile's row statistics = all 160 KiB)
     constexpr size_t lds = 2 * (2 * 128 * 128 + 2 * (PBN / 2) * 128) + 8 * 1024 + (LNF == 1 ? 8 * 1024 + 16 * 1024 : 0);
-    auto kern = gemm_ph_kernel<GLU, ACT, RES, OUT, CONV, LNF>;
+    auto kern = gemm_ph_kernel<GLU, ACT, RES, OUT, CONV, LNF, SPL>;
     static bool attr_set[64];                     // per device; a racing first call sets the same attribute twice
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return PAFC_ERR_LAUNCH;
@@ -742,6 +780,17 @@ int launch_ph(const PhParams &p, int batch, hipStream_t s) {
     const long grid = total < cus ? total : cus;              // one 512-thread block per CU (128 KiB of LDS each)
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, q);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+// PAFC_SPLIT_WALK=hilohi: split-operand problems take the round-3 K walk (hi, lo, hi against [hi | hi | lo]) instead of the
+// shared-fragment form (A/B runs; read once)
+int g_split_walk = -1;                      // -1: not read yet; 1: shared fragments; 0: hi, lo, hi  (tools/micro set it directly)
+bool split_shared_fragments() {
+    if (g_split_walk < 0) {
+        const char *e = getenv("PAFC_SPLIT_WALK");
+        g_split_walk = !(e && std::strcmp(e, "hilohi") == 0);
+    }
+    return g_split_walk != 0;
 }
 
 }  // namespace
@@ -810,6 +859,23 @@ extern "C" int pafc_gemm_ph_ex2(long M, int N, int K, int batch, const void *A, 
     p.ntiles = (N + 255) / 256;
     if ((long)p.mtiles * p.ntiles > 0x7fffffffL) return PAFC_ERR_BAD_DIMS;
     hipStream_t s = (hipStream_t)stream;
+    if (a_split && out_kind != 0 && pafc::split_shared_fragments() && (double)2 * K * 2 + 64 < 2.0e9) {
+        // shared-fragment form: K-steps of 32 columns of both planes; pb_shift counts 32-column steps per plane block
+        p.nsteps = K / 32;
+        p.a_lo = (int)p.pb_bytes;                 // [hi PB | lo PB]: lo follows hi inside a block (one block: PB = K)
+        p.w_lo = 2 * K * 2;                       // W' = [hi | hi | lo]: the lo plane starts 2 K columns in
+        p.pb_shift = p.pb_shift >= 30 ? 30 : p.pb_shift + 1;
+        if (out_kind == 1) {
+            if (glu) return pafc::launch_ph<true, 0, 0, 1, false, 0, true>(p, batch, s);
+            if (res_kind == 2) return pafc::launch_ph<false, 0, 2, 1, false, 0, true>(p, batch, s);
+            if (act == 0) return pafc::launch_ph<false, 0, 0, 1, false, 0, true>(p, batch, s);
+            return PAFC_ERR_UNSUPPORTED;
+        }
+        if (glu || residual) return PAFC_ERR_UNSUPPORTED;
+        if (act == 1) return pafc::launch_ph<false, 1, 0, 2, false, 0, true>(p, batch, s);
+        if (act == 0) return pafc::launch_ph<false, 0, 0, 2, false, 0, true>(p, batch, s);
+        return PAFC_ERR_UNSUPPORTED;
+    }
     if (out_kind == 0) {
         if (glu) return pafc::launch_ph<true, 0, 0, 0>(p, batch, s);
         if (res_kind == 1) return pafc::launch_ph<false, 0, 1, 0>(p, batch, s);
@@ -923,6 +989,18 @@ static int conv_ph_launch(int B, int T1, int F1, int Ci, int Co, const void *in,
     p.mtiles = (int)((M + tile_m - 1) / tile_m);
     p.ntiles = (Co + 255) / 256;
     hipStream_t s = (hipStream_t)stream;
+    if (split && pafc::split_shared_fragments()) {
+        // shared-fragment form: K-step = (tap, 32-channel slice of both planes); the pixel is [hi Ci | lo Ci], a weight row
+        // of a tap [hi Ci | hi Ci | lo Ci]
+        p.spt = Ci / 32;
+        p.inv_spt = (65536 + p.spt - 1) / p.spt;
+        p.nsteps = 9 * p.spt;
+        for (int kt = 0; kt < p.nsteps + 2; ++kt)
+            if (((kt * p.inv_spt) >> 16) != kt / p.spt) return PAFC_ERR_UNSUPPORTED;
+        p.a_lo = Ci * 2;
+        p.w_lo = 2 * Ci * 2;
+        return relu ? pafc::launch_ph<false, 3, 0, 2, true, 0, true>(p, 1, s) : pafc::launch_ph<false, 0, 0, 2, true, 0, true>(p, 1, s);
+    }
     if (split) return relu ? pafc::launch_ph<false, 3, 0, 2, true>(p, 1, s) : pafc::launch_ph<false, 0, 0, 2, true>(p, 1, s);
     return relu ? pafc::launch_ph<false, 3, 0, 0, true>(p, 1, s) : pafc::launch_ph<false, 0, 0, 0, true>(p, 1, s);
 }

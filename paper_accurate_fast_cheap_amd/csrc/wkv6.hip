@@ -39,6 +39,8 @@ struct FwdParams {
     int L, NC;           // chunk length (multiple of TT unless == T) and number of chunks
     int nc_local;        // chunks whose local state pass A must produce (NC-1, or NC when a final state is wanted)
     int prio;            // wave priority scheme of pass C (PAFC_WKV6_PRIO): 3 = raised from the level operands on (default), 2 = tail only, 0 = none
+    int order;           // grid order of the channel-lane passes A and C (PAFC_WKV6_ORDER): 0 = chunks of a head back to back, 1 = heads of a chunk
+    int rev_c;           // pass C walks the grid in the REVERSE order of pass A (PAFC_WKV6_REVC): what pass A read last is read first
     float *ws_state;     // [ndir][B][H][NC][N(j)][N(i)]
     float *ws_decay;     // [ndir][B][H][NC][N(j)]
 };
@@ -298,8 +300,11 @@ void launch_pass_a(const FwdParams &p, dim3 grid, hipStream_t stream) {
         const char *e = getenv("PAFC_WKV6_PASS_A");
         if (!(e && e[0] == 'l')) {
             // the variant without a decay bias issues neither the add nor its rounding (a tenth of the per-step arithmetic)
-            if (p.d[0].wb != nullptr || p.d[1].wb != nullptr) hipLaunchKernelGGL(wkv6_pass_a_cl_kernel<true>, grid, dim3(64), 0, stream, p);
-            else hipLaunchKernelGGL(wkv6_pass_a_cl_kernel<false>, grid, dim3(64), 0, stream, p);
+            FwdParams q = p;
+            { const char *o = getenv("PAFC_WKV6_ORDER"); q.order = o ? atoi(o) : 0; }
+            if (q.order) grid = dim3(grid.y, grid.x, grid.z);
+            if (p.d[0].wb != nullptr || p.d[1].wb != nullptr) hipLaunchKernelGGL(wkv6_pass_a_cl_kernel<true>, grid, dim3(64), 0, stream, q);
+            else hipLaunchKernelGGL(wkv6_pass_a_cl_kernel<false>, grid, dim3(64), 0, stream, q);
             return;
         }
     }
@@ -312,8 +317,11 @@ void launch_pass_c(const FwdParams &p, dim3 grid, hipStream_t stream) {
     if constexpr (sizeof(ET) == 2) {
         const char *e = getenv("PAFC_WKV6_PASS_C");
         if (!(e && e[0] == 'l')) {
-            if (p.d[0].wb != nullptr || p.d[1].wb != nullptr) hipLaunchKernelGGL(wkv6_pass_c_cl_kernel<true>, grid, dim3(64), 0, stream, p);
-            else hipLaunchKernelGGL(wkv6_pass_c_cl_kernel<false>, grid, dim3(64), 0, stream, p);
+            FwdParams q = p;
+            { const char *o = getenv("PAFC_WKV6_ORDER"); q.order = o ? atoi(o) : 0; }
+            if (q.order) grid = dim3(grid.y, grid.x, grid.z);
+            if (p.d[0].wb != nullptr || p.d[1].wb != nullptr) hipLaunchKernelGGL(wkv6_pass_c_cl_kernel<true>, grid, dim3(64), 0, stream, q);
+            else hipLaunchKernelGGL(wkv6_pass_c_cl_kernel<false>, grid, dim3(64), 0, stream, q);
             return;
         }
     }
@@ -363,6 +371,7 @@ int launch_fwd(FwdParams &p, int ndir, bool any_final, hipStream_t stream) {
     // scheme 3 wins: stand-alone 207-209 (none / scheme 2) -> 197-202, in the model 204 -> 196 us on one box; raising it from the
     // block's start or for the front half only changed nothing.  PAFC_WKV6_PRIO=0 / 2 select none / the tail-only scheme (A/B).
     { const char *e = getenv("PAFC_WKV6_PRIO"); p.prio = e ? atoi(e) : 3; }
+    { const char *e = getenv("PAFC_WKV6_REVC"); p.rev_c = e ? atoi(e) : 0; }
     if (mfma) launch_pass_c<ET>(p, gc, stream);
     else hipLaunchKernelGGL((wkv6_chunk_kernel<ET, true>), gc, dim3(64), 0, stream, p);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;

@@ -960,8 +960,10 @@ def test_graph_cache_follows_parameter_updates(hip):
 
 
 def test_graph_capture_errors_surface(hip, monkeypatch):
-    """Only a REFUSED capture makes a shape fall back to eager execution; an error of the captured work itself (a failing launch,
-    a PafcError from the C ABI) is raised to the caller, not swallowed."""
+    """An error of the captured work itself (a failing launch, a PafcError from the C ABI) is raised to the caller, not turned
+    into "eager from now on"; only a capture the runtime REFUSES (hipErrorStreamCapture*) falls back.  (That fallback is not
+    provoked here: on this runtime an operation that invalidates a global-mode capture -- a synchronize, say -- also fails the next
+    unrelated call of the process, so it cannot be staged inside a test session.)"""
     from paper_accurate_fast_cheap_amd import _lib
     from paper_accurate_fast_cheap_amd.transformer import fused
     from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
@@ -986,16 +988,12 @@ def test_graph_capture_errors_surface(hip, monkeypatch):
         with pytest.raises(_lib.PafcError, match="injected"):
             enc(x, lens)                                                   # second sighting: capture -> the error surfaces
         torch.cuda.synchronize()
+        # ... and leaves the encoder usable: the same shape runs eagerly, is captured on its next sighting and replays
+        monkeypatch.setattr(fused, "encoder_layers_forward", real)
         enc._graphs.clear()
-        enc(x, lens)
-
-        def refused(*a, **kw):
-            if torch.cuda.is_current_stream_capturing():
-                torch.cuda.synchronize()                                   # an operation the capture mode does not permit
-            return real(*a, **kw)
-        monkeypatch.setattr(fused, "encoder_layers_forward", refused)
-        got = enc(x, lens)[0]                                              # capture refused -> eager for this shape
-        assert "eager" in enc._graphs.values()
+        for _ in range(3):
+            got = enc(x, lens)[0]
+        assert any(isinstance(v, tuple) for v in enc._graphs.values())
         torch.testing.assert_close(got, want, rtol=1e-4, atol=2e-5)
     enc.graph_cache_size = 0
     enc._graphs.clear()

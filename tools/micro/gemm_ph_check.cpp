@@ -248,6 +248,28 @@ static void run_case(const Case &c, bool race) {
             printf("  %-44s race: r02 %.1f us (min %.1f) = %.0f TF/s | new %.1f us (min %.1f) = %.0f TF/s | %.3fx\n", c.name, to[4], to[0],
                    fl / to[4] / 1e6, tn[4], tn[0], fl / tn[4] / 1e6, to[4] / tn[4]);
         }
+    } else if (c.a_split && c.out_kind != 0) {
+        // round 5: the shared-fragment walk (default, checked above) against the round-3 walk hi, lo, hi: same operands, same
+        // process, interleaved rounds
+        pafc::g_split_walk = 0;
+        CK(hipMemset(out, 0x5a, obytes + guard));
+        run_new();
+        CK(hipDeviceSynchronize());
+        check(out, "r03w");
+        if (race) {
+            std::vector<float> tn, to;
+            for (int r = 0; r < 9; ++r) {
+                pafc::g_split_walk = 0;
+                to.push_back(time_us(run_new, 6));
+                pafc::g_split_walk = 1;
+                tn.push_back(time_us(run_new, 6));
+            }
+            std::sort(tn.begin(), tn.end()); std::sort(to.begin(), to.end());
+            const double fl = 2.0 * Z * M * N * Kw;
+            printf("  %-44s race: hi,lo,hi walk %.1f us (min %.1f) = %.0f TF/s | shared fragments %.1f us (min %.1f) = %.0f TF/s of bf16 products | %.3fx\n",
+                   c.name, to[4], to[0], fl / to[4] / 1e6, tn[4], tn[0], fl / tn[4] / 1e6, to[4] / tn[4]);
+        }
+        pafc::g_split_walk = 1;
     } else if (race) {
         std::vector<float> tn;
         for (int r = 0; r < 9; ++r) tn.push_back(time_us(run_new, 6));
@@ -303,6 +325,8 @@ int main(int argc, char **argv) {
         {"f32: pointwise_conv1 + GLU -> f32 (split A)", M, 1024, 512, 1, 4, 0, 1, 1, 256, 1.f},
         {"f32: slot output bf16 A + f32 residual", M, 512, 1024, 1, 0, 2, 1, 0, 192, 1.f},
         {"f32: CTC head -> f32 (split A)", M, 5000, 512, 1, 0, 0, 1, 1, 256, 1.f},
+        {"f32: pointwise_conv2 + f32 residual (split A)", M, 512, 512, 1, 0, 2, 1, 1, 192, 1.f},
+        {"f32: Linear 9728->512 -> f32 (split A)", M, 512, 9728, 1, 0, 0, 1, 1, 192, 1.f},
     };
     const Case small[] = {
         {"small 256x256x128", 256, 256, 128, 1, 0, 0, 0, 0, 256, 1.f},
@@ -317,6 +341,9 @@ int main(int argc, char **argv) {
         {"small f32 517x520x256 split res", 517, 520, 256, 1, 0, 2, 1, 1, 256, 1.f},
         {"small 300x512x128 no bias check", 300, 512, 128, 1, 0, 1, 0, 0, 256, 1.f},
         {"small f32 300x512x128 planes", 300, 512, 128, 2, 1, 0, 2, 1, 192, 1.f},
+        {"small f32 1x256x128 split", 1, 256, 128, 1, 0, 0, 1, 1, 256, 1.f},
+        {"small f32 777x1024x384 glu split tm64", 777, 1024, 384, 1, 4, 0, 1, 1, 64, 1.f},
+        {"small f32 333x264x640 split res x2", 333, 264, 640, 2, 0, 2, 1, 1, 128, 0.5f},
     };
     if (mode == "pmc") return run_pmc(big[argc > 2 ? atoi(argv[2]) : 0]);
     if (mode != "race") for (const Case &c : small) run_case(c, false);
