@@ -43,7 +43,7 @@ PRECISION = {"bf16slot": "fp32 model + bf16 time-mix slot (the YAML default, the
 _T0 = time.time()
 
 
-def progress(msg: str) -> None:
+def stage(msg: str) -> None:
     """One line per stage on stderr (rank 0): a long run is never silent, and a stage that hangs is named."""
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
@@ -537,7 +537,7 @@ def main():
     from paper_accurate_fast_cheap_amd import _lib, profiling
     _lib.lib()  # fail loudly, before anything else, if the HIP extension is missing
 
-    progress("library loaded; building the model")
+    stage("library loaded; building the model")
     model, configs = build_model(args.dtype, device)
     conf = configs["encoder_conf"]
     if args.workload == "c3" and args.chunk_size > 0:
@@ -577,12 +577,12 @@ def main():
         import resource
         return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0     # Linux: KiB
 
-    progress(f"inputs resident ({frames_per_step} frames per step); warm-up")
+    stage(f"inputs resident ({frames_per_step} frames per step); warm-up")
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
         barrier()
-        progress("warm-up done; timed steps")
+        stage("warm-up done; timed steps")
         torch.cuda.reset_peak_memory_stats(device)
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -598,7 +598,7 @@ def main():
         torch.cuda.synchronize()
         profiling.enable_recording(False)
     prof = profiling.summary()
-    progress(f"timed region {elapsed * 1e3 / args.steps:.3f} ms per step; profiled steps done")
+    stage(f"timed region {elapsed * 1e3 / args.steps:.3f} ms per step; profiled steps done")
 
     if world > 1:
         rdev = device if args.dist_backend == "nccl" else torch.device("cpu")
@@ -677,7 +677,7 @@ def main():
         out["extra"] = {}
 
         def leg(name, fn, *a, **kw):      # a failure in a leg is reported in its place, never costs the headline line, and
-            progress(f"leg {name}")
+            stage(f"leg {name}")
             try:                           # turns the exit code non-zero after the line is printed
                 out["extra"][name] = fn(*a, **kw)
             except (RuntimeError, ValueError, AssertionError, KeyError, OSError) as e:
@@ -697,7 +697,7 @@ def main():
         leg("streaming", streaming_leg, feats32, device)
         leg("streaming_lookahead", streaming_lookahead_leg, feats32, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        progress("cpu baseline")
+        stage("cpu baseline")
         out["cpu_baseline"] = cpu_baseline(model, feats32, conf, min(args.cpu_sample_frames, FRAMES))
     else:
         out["cpu_baseline"] = None

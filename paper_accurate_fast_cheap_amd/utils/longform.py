@@ -39,6 +39,14 @@ def window_offsets_ms(n_windows: int, chunk_size: int, input_frame_ms: float = 1
     return [i * chunk_size * input_frame_ms for i in range(n_windows)]
 
 
+def merged_batch_size(chunk_size: int, batch_size: int, merge_frames: int) -> int:
+    """Windows per launch when consecutive batches are merged: the largest whole multiple of batch_size whose windows hold at
+    most merge_frames input frames, never fewer than batch_size (merge_frames <= 0: batch_size, one forward per batch)."""
+    if merge_frames <= 0:
+        return batch_size
+    return max(1, merge_frames // (chunk_size * batch_size)) * batch_size
+
+
 _SIDE = {}
 
 
@@ -84,7 +92,7 @@ def greedy_decode_batches(model, batches, streams: int = 2, blank_id: int = 0, w
 @torch.no_grad()
 def decode_windows(model, feats: torch.Tensor, chunk_size: int, batch_size: int, mode: str = "ctc_greedy_search",
                    beam_size: int = 10, input_frame_ms: float = 10.0, output_frame_ms: float = 40.0, streams: int = 3,
-                   graph_cache: bool = True, **decode_kw) -> Dict[str, object]:
+                   graph_cache: bool = True, merge_frames: int = 0, **decode_kw) -> Dict[str, object]:
     """Decode a long file window by window with `model.decode` and stitch the token sequences.
 
     Returns {"tokens": all token ids in order, "windows": per-window token lists, "window_start_ms": start time of each
@@ -100,6 +108,7 @@ def decode_windows(model, feats: torch.Tensor, chunk_size: int, batch_size: int,
     if mode == "ctc_greedy_search" and feats.is_cuda:
         # same search, plus the first-frame index of every token (the kernel reports it for free)
         from ..hip_ops import ctc_greedy
+        batch_size = merged_batch_size(chunk_size, batch_size, merge_frames)
         batches = list(feats_batcher(feats, chunk_size, batch_size, feats.device))
         n_side = max(1, min(int(streams), len(batches)))
         main = torch.cuda.current_stream(feats.device)

@@ -194,6 +194,11 @@ def test_feats_batcher_windows_like_the_reference():
     assert [l.tolist() for _, l in feats_batcher(x[:, :800], 100, 4)] == [[100] * 4, [100] * 4]
     assert [l.tolist() for _, l in feats_batcher(x[:, :42], 100, 4)] == [[42]]
     assert window_offsets_ms(3, 2000) == [0.0, 20000.0, 40000.0]
+    # merged launches: whole multiples of the batch, at most merge_frames input frames, never below one batch
+    from paper_accurate_fast_cheap_amd.utils.longform import merged_batch_size
+    assert merged_batch_size(2000, 8, 0) == 8 and merged_batch_size(2000, 8, 180000) == 88
+    assert merged_batch_size(2000, 1, 180000) == 90 and merged_batch_size(100000, 4, 180000) == 4
+    assert merged_batch_size(9000, 14, 180000) == 14 and merged_batch_size(4000, 10, 200000) == 50
 
 
 def test_few_rows_gemm_is_scoped_to_a_chunk_step():

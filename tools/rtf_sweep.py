@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--batches", default=",".join(map(str, BATCHES)))
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "rtf_sweep"))
     ap.add_argument("--no-eager-check", action="store_true", help="skip the eager one-stream pass behind the token checksum")
+    ap.add_argument("--merge-frames", type=int, default=0,
+                    help="decode_windows(merge_frames=...): consecutive batches run as one launch of up to this many input frames "
+                         "(0 = one forward per batch, the reference's literal schedule)")
     args = ap.parse_args()
     from paper_accurate_fast_cheap_amd import _lib
     from paper_accurate_fast_cheap_amd.utils.longform import decode_windows
@@ -83,7 +86,7 @@ def main():
     records = []
     with open(args.out + ".jsonl", "w") as fj:
         head = {"one_sequence_ms": round(one_ms, 3), "one_sequence_audio_sec_per_sec": round(one_rate, 1), "dtype": args.dtype,
-                "precision": bench.PRECISION[args.dtype], "frames": frames, "streams": args.streams,
+                "precision": bench.PRECISION[args.dtype], "frames": frames, "streams": args.streams, "merge_frames": args.merge_frames,
                 "device": torch.cuda.get_device_name(0)}
         fj.write(json.dumps(head) + "\n")
         fj.flush()
@@ -96,7 +99,7 @@ def main():
                 last = {}
 
                 def step():
-                    last["out"] = decode_windows(model, feats, c, b, streams=args.streams)
+                    last["out"] = decode_windows(model, feats, c, b, streams=args.streams, merge_frames=args.merge_frames)
                 sec = bench.timed_passes(step, args.passes, args.warmup)
                 vram = torch.cuda.max_memory_allocated(device) / 1024 / 1024
                 checksum = bench.token_checksum([last["out"]["windows"]])
@@ -123,7 +126,10 @@ def main():
     with open(args.out + ".md", "w") as fm:
         fm.write(f"# Encoder RTF sweep, one MI355X, {bench.PRECISION[args.dtype]}\n\n"
                  f"One synthetic 30-minute file ({frames} frames), `utils.longform.decode_windows` (encoder + CTC log-softmax + greedy "
-                 f"tokens + stitching inside the timing), {args.streams} window batches in flight, {args.warmup} warm-up + {args.passes} "
+                 f"tokens + stitching inside the timing), {args.streams} window batches in flight, "
+                 + (f"consecutive batches merged into launches of up to {args.merge_frames} frames, " if args.merge_frames else
+                    "one forward per batch (the reference's literal schedule), ")
+                 + f"{args.warmup} warm-up + {args.passes} "
                  f"timed passes per point.  The same file as ONE sequence: {one_ms:.2f} ms = {one_rate:.0f} audio-sec/sec.  Grid and "
                  f"table layout: go-run-encoder-rtf.single-gpu-3x3-g5.sh:59-61, tools/rtf/get-rtf-tables.py.\n\n")
         fm.write(table(records, "minutes_per_sec", lambda v: f"{v:.2f}", "Minutes of Audio Processed per Second") + "\n")
