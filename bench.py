@@ -536,6 +536,9 @@ def main():
 
     from paper_accurate_fast_cheap_amd import _lib, profiling
     _lib.lib()  # fail loudly, before anything else, if the HIP extension is missing
+    if os.environ.get("PAFC_BENCH_WATCHDOG"):      # diagnostics: dump every thread's Python stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PAFC_BENCH_WATCHDOG"]), exit=True)
 
     stage("library loaded; building the model")
     model, configs = build_model(args.dtype, device)

@@ -34,9 +34,14 @@ from ._lib import c_int, c_void_p
 #                                   kernels (fewer launches).  At 3 992 rows the one-pass down-projection takes 27.6 us
 #                                   against 6.0 + 6.5 for the two small kernels (profiles/r04e_windows_2000x8_kernels_*.txt);
 #                                   a c2 pass measured 2048 / 4096 / 8192 within 1 % (profiles/r03c_bench_c2_knobs.txt)
-#   split_gemm_min_rows      16384  fp32 activations on the bf16 matrix cores as hi + lo planes (3 MFMAs per product, ~2^-16
-#                                   relative) from this many rows on; below it the library's exact fp32 products, which is
-#                                   also what the 1e-3 parity tests of short inputs run: DESIGN section 4 "split operands"
+#   split_gemm_min_rows       1024  fp32 activations of a model with the bf16 slot on the bf16 matrix cores as hi + lo planes
+#                                   (3 MFMAs per product, ~2^-16 relative) from this many rows on; below it the library's exact
+#                                   fp32 products (pure-fp32 models -- rwkv_do_bfloat16: False, the 1e-3 parity bar -- always
+#                                   take those).  Was 16384 until round 5: at 1 536 - 24 000 rows the split kernel at its best
+#                                   tile height takes 28 / 35 / 48 / 78 / 90 / 138 us for w_1 where the library takes 37 / 76 /
+#                                   137 / 256 / 273 / 507 (profiles/r05_split_mid_rows.txt; only w_2 below 4 000 rows is faster
+#                                   on the library, 32-74 vs 72-74 us): 2 000-frame windows x 8 20 600 -> 33 200 audio-sec/sec,
+#                                   c2 in this precision 44 200; DESIGN section 4 "split operands"
 #   ln_fold_min_rows         24576  unmasked bf16 inputs of at least this many rows take the schedule with three LayerNorms
 #                                   folded into the 256-wide GEMMs either side of them (needs full grids of 256 x 256 tiles:
 #                                   3 x the row count at which they fill the chip): profiles/r03d / r03e
@@ -51,7 +56,7 @@ from ._lib import c_int, c_void_p
 # tiles fit one round of two per CU, the 256-wide phase-pipelined kernel beyond (profiles/r04s_gemm_tile_choice_by_rows.txt);
 # PAFC_PH_MIN_FILL=<percent> (round 3's rule: 256-wide tiles must cover that share of the CUs) and PAFC_GEMM_TILE (force a tile
 # of the small kernel) are A/B switches of the kernels themselves.
-DISPATCH = dict(skinny_max_rows=640, own_gemm_min_rows=1, lds_resident_min_rows=8192, split_gemm_min_rows=16384,
+DISPATCH = dict(skinny_max_rows=640, own_gemm_min_rows=1, lds_resident_min_rows=8192, split_gemm_min_rows=1024,
                 ln_fold_min_rows=24576, gemm_tune_min_rows=32768, dwconv_ln_silu_max_rows=24575)
 
 
@@ -685,7 +690,7 @@ def gemm_bf16_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
                                     residual.stride(0) if residual is not None else 0, _lib.ptr(out), out.stride(0), float(alpha),
                                     _ACTS[act], 1 if csum is not None else 2, _lib.ptr(stats), _lib.ptr(csum),
                                     int(ln_c or (K if csum is not None else N)),
-                                    float(eps), _ph_tile_m(M, N), _lib.stream_of(a))
+                                    float(eps), _ph_tile_m(M, N, min_tm=128), _lib.stream_of(a))
     _lib.check(rc, "pafc_gemm_bf16_ph_ln")
     return out
 
@@ -709,13 +714,15 @@ def split_planes(x: torch.Tensor, triple: bool = False) -> torch.Tensor:
     return out
 
 
-def _ph_tile_m(M: int, N: int, batch: int = 1) -> int:
+def _ph_tile_m(M: int, N: int, batch: int = 1, min_tm: int = 64) -> int:
     """Rows per tile of the phase-pipelined GEMM for this problem (the count that needs the fewest rounds of one-tile-per-CU
     work, a round weighted by its rows plus a fixed per-tile part worth ~64 rows), as csrc/gemm_bf16.hip:ph_tile_m."""
     cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
     nt = (N + 255) // 256
     best = None
-    for tm in (256, 192, 128):
+    for tm in (256, 192, 128, 64):      # (64: a few thousand fp32 rows as split operands, profiles/r05_split_mid_rows.txt)
+        if tm < min_tm:
+            continue
         tiles = ((M + tm - 1) // tm) * nt * batch
         cost = ((tiles + cus - 1) // cus) * (tm + 64)
         if best is None or cost < best[0]:
@@ -1720,7 +1727,7 @@ def conv_sub_f32split_planes(x: torch.Tensor, w1: torch.Tensor, b1: Optional[tor
     from .profiling import op_timer
     with op_timer("conv3x3s2_split", flops=2.0 * B * T2 * F2 * C * 9 * C * 3):
         rc = L.pafc_conv3x3s2_nhwc_split_ph(B, T1, F1, C, C, _lib.ptr(y1), _lib.ptr(w2_3), _lib.ptr(b2), _lib.ptr(out), 1,
-                                            _ph_tile_m(B * T2 * F2, C), st)
+                                            _ph_tile_m(B * T2 * F2, C, min_tm=128), st)
     _lib.check(rc, "pafc_conv3x3s2_nhwc_split_ph")
     return out
 

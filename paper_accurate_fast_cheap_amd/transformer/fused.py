@@ -406,8 +406,19 @@ def layer_forward_lnfold(plan: LayerPlan, x: torch.Tensor, st: torch.Tensor, nex
     new_stats = lambda: torch.empty((M, 8, 2), dtype=torch.float32, device=x.device)
     x2 = x.view(M, C)
     w, b, cs = F["ffm"]
-    hid = G(x2, w, b, st, act="silu", csum=cs, eps=L.norm_ff_macaron.eps)
-    x2 = hip_ops.gemm_bf16(hid, L.feed_forward_macaron.w_2.weight, plan.b2_macaron, "none", alpha=L.ff_scale, residual=x2)
+    rb = _FFN_ROW_BLOCK
+    if rb > 0:
+        # experiment (PAFC_FFN_ROW_BLOCK=<rows>): w_1 -> w_2 per row block, so that the block's hidden slice (rows x 2048 bf16) is
+        # still in the 256 MiB Infinity Cache when w_2 reads it back.  Measured and NOT the default: DESIGN section 4, round 5
+        xn = torch.empty_like(x2)
+        for r0 in range(0, M, rb):
+            r1 = min(M, r0 + rb)
+            hb = G(x2[r0:r1], w, b, st[r0:r1], act="silu", csum=cs, eps=L.norm_ff_macaron.eps)
+            hip_ops.gemm_bf16(hb, L.feed_forward_macaron.w_2.weight, plan.b2_macaron, "none", alpha=L.ff_scale, residual=x2[r0:r1], out=xn[r0:r1])
+        x2 = xn
+    else:
+        hid = G(x2, w, b, st, act="silu", csum=cs, eps=L.norm_ff_macaron.eps)
+        x2 = hip_ops.gemm_bf16(hid, L.feed_forward_macaron.w_2.weight, plan.b2_macaron, "none", alpha=L.ff_scale, residual=x2)
     _, h, _ = hip_ops.add_layernorm(x2.view(B, T, C), None, 1.0, L.norm_mha.weight, L.norm_mha.bias, want_x=False, eps=L.norm_mha.eps)
     st2 = new_stats()
     slot_forward(plan, h, residual=x2.view(B, T, C), stats=st2)
@@ -417,8 +428,14 @@ def layer_forward_lnfold(plan: LayerPlan, x: torch.Tensor, st: torch.Tensor, nex
     st3 = new_stats()
     G(g.view(M, C), cm.pointwise_conv2.weight.squeeze(-1), cm.pointwise_conv2.bias, st3, residual=x2, out=x2)
     w, b, cs = F["ff"]
-    hid = G(x2, w, b, st3, act="silu", csum=cs, eps=L.norm_ff.eps)
-    hip_ops.gemm_bf16(hid, L.feed_forward.w_2.weight, plan.b2, "none", alpha=L.ff_scale, residual=x2, out=x2)
+    if rb > 0:
+        for r0 in range(0, M, rb):
+            r1 = min(M, r0 + rb)
+            hb = G(x2[r0:r1], w, b, st3[r0:r1], act="silu", csum=cs, eps=L.norm_ff.eps)
+            hip_ops.gemm_bf16(hb, L.feed_forward.w_2.weight, plan.b2, "none", alpha=L.ff_scale, residual=x2[r0:r1], out=x2[r0:r1])
+    else:
+        hid = G(x2, w, b, st3, act="silu", csum=cs, eps=L.norm_ff.eps)
+        hip_ops.gemm_bf16(hid, L.feed_forward.w_2.weight, plan.b2, "none", alpha=L.ff_scale, residual=x2, out=x2)
     xo = x2.view(B, T, C)
     if next_fold:       # the next layer's first pre-norm is folded too: it wants this layer's output and its statistics
         stn = new_stats()
@@ -433,6 +450,9 @@ def layer_forward_lnfold(plan: LayerPlan, x: torch.Tensor, st: torch.Tensor, nex
                                        gamma2=next_norm.weight if next_norm is not None else None,
                                        beta2=next_norm.bias if next_norm is not None else None, eps=L.norm_final.eps)
     return out, hn
+
+
+_FFN_ROW_BLOCK = int(os.environ.get("PAFC_FFN_ROW_BLOCK", "0"))
 
 
 # fp32 streams shorter than this keep the library's fp32 GEMMs (exact fp32 products; small problems do not fill 256-wide tiles)

@@ -469,8 +469,8 @@ def test_bf16slot_full_size_vs_oracle(hip):
 
 
 def test_bf16slot_full_size_split_operand_path_vs_oracle(hip, monkeypatch):
-    """The same comparison with the long-form schedule of this precision forced onto the ragged batch (it starts at 16 384
-    rows by default): every fp32 projection of the layer, Linear(9728, 512) and the CTC head on the bf16 matrix cores with
+    """The same comparison with the split-operand schedule of this precision (the default from 1 024 rows on) and with the
+    library's exact fp32 products forced onto the same ragged batch: every fp32 projection of the layer, Linear(9728, 512) and the CTC head on the bf16 matrix cores with
     split operands, fp32 residual stream, bf16 slot.  Same bounds as the library-GEMM path above, and the two agree with
     each other to the noise of the bf16 slot."""
     import bench
@@ -493,6 +493,8 @@ def test_bf16slot_full_size_split_operand_path_vs_oracle(hip, monkeypatch):
     ref_logp = EO.ctc_log_softmax(ref, {"ctc." + k: v for k, v in ctc.state_dict().items()})
     enc, ctc = enc.cuda(), ctc.cuda()
     with torch.no_grad():
+        monkeypatch.setattr(fused, "_SPLIT_GEMM_MIN_ROWS", 1 << 40)       # the library's exact fp32 products first
+        monkeypatch.setattr(hip_ops, "_SPLIT_GEMM_MIN_ROWS", 1 << 40)
         lib_out, _ = enc(xs.cuda(), lens.cuda())
         monkeypatch.setattr(fused, "_SPLIT_GEMM_MIN_ROWS", 0)
         monkeypatch.setattr(hip_ops, "_SPLIT_GEMM_MIN_ROWS", 0)

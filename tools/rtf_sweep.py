@@ -109,12 +109,23 @@ def main():
                        "share_of_one_sequence": round(frames / 100.0 / sec / one_rate, 4), "token_checksum": checksum,
                        "tokens": len(last["out"]["tokens"])}
                 if not args.no_eager_check:
+                    # the same schedule without graph replay and without side streams must decode the same tokens; with merged
+                    # launches also: how many WINDOWS decode to the token list of the literal one-forward-per-batch pass (kernel
+                    # choice -- GEMM family, scan chunking -- follows the rows per launch, so a near-tie may flip; on a random-init
+                    # head most frames are near-ties)
                     enc.graph_cache_size = 0
                     enc._graphs.clear()
                     with torch.no_grad():
-                        eager = decode_windows(model, feats, c, b, streams=1, graph_cache=False)
-                    torch.cuda.synchronize()
-                    rec["token_checksum_equals_eager_pass"] = bench.token_checksum([eager["windows"]]) == checksum
+                        eager = decode_windows(model, feats, c, b, streams=1, graph_cache=False, merge_frames=args.merge_frames)
+                        torch.cuda.synchronize()
+                        rec["token_checksum_equals_eager_pass"] = bench.token_checksum([eager["windows"]]) == checksum
+                        if args.merge_frames:
+                            lit = decode_windows(model, feats, c, b, streams=1, graph_cache=False)
+                            torch.cuda.synchronize()
+                            same = sum(1 for x, y in zip(lit["windows"], last["out"]["windows"]) if x == y)
+                            rec["windows"] = len(lit["windows"])
+                            rec["windows_equal_to_literal_schedule"] = same
+                            rec["tokens_literal_schedule"] = len(lit["tokens"])
                 records.append(rec)
                 fj.write(json.dumps(rec) + "\n")
                 fj.flush()
