@@ -408,6 +408,15 @@ int pafc_residual_dropout(int backward, int dtype_x, int dtype_y, long n, const 
 int pafc_silu_dropout(int backward, int dtype, long n, const void *h, const void *dout, void *out, float p,
                       unsigned long long seed, unsigned long long offset, pafc_stream_t stream);
 
+/* bf16 transposed copies of many matrices in ONE launch -- the training step's weights in (K, N) layout, so that the input
+ * gradient dX = dY W of every nn.Linear (autograd through positionwise_feed_forward.py:47-55, convolution.py:118-141,
+ * src/model.py:286-324 under train_utils.py:609-729) is the forward GEMM pafc_gemm_bf16(dY, W^T).  `table` points to n
+ * descriptors of 32 bytes in DEVICE memory: { const void *src; void *dst; int rows, cols, src_f32, tile0; } -- src (rows, cols)
+ * row-major fp32 (src_f32 = 1) or bf16, dst (cols, rows) row-major bf16, tile0 = the running sum of
+ * ceil(rows / 64) * ceil(cols / 64) over the earlier descriptors; total_tiles = that sum over all n.  Sources and destinations
+ * must not overlap; nothing is allocated, the launch is asynchronous on `stream`. */
+int pafc_multi_transpose_bf16(const void *table, int n, int total_tiles, pafc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,6 +133,51 @@ inline unsigned thr_of(float p) {   // keep iff u16 >= thr: P(drop) = thr / 6553
 }
 
 }  // namespace
+
+// ---- multi-tensor transpose + cast: the training step's bf16 weight copies in (K, N) layout ---------------------------------
+// One launch for ALL weights: dX = dY W is the forward GEMM against W^T, and W changes every step.  The table (device memory)
+// holds one descriptor per tensor; a block of 256 threads moves one 64 x 64 tile through LDS (reads along the source rows,
+// writes along the destination rows: both sides in whole 128 / 256-byte segments) and finds its tensor by a binary search over
+// the tile offsets.
+struct TrDesc {
+    const void *src;      // (rows, cols) row-major, fp32 or bf16
+    void *dst;            // (cols, rows) row-major bf16
+    int rows, cols;
+    int src_f32;          // 1: fp32 source, 0: bf16
+    int tile0;            // first tile of this tensor in the grid
+};
+
+__global__ __launch_bounds__(256) void multi_transpose_kernel(const TrDesc *__restrict__ tab, int n) {
+    __shared__ unsigned short tile[64][66];
+    int lo = 0, hi = n - 1;
+    const int t = blockIdx.x;
+    while (lo < hi) {                       // last descriptor with tile0 <= t (uniform over the block)
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].tile0 <= t) lo = mid; else hi = mid - 1;
+    }
+    const TrDesc d = tab[lo];
+    const int tc = (d.cols + 63) >> 6;
+    const int lt = t - d.tile0, r0 = (lt / tc) * 64, c0 = (lt % tc) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty * 16 + i, c = c0 + tx;
+        unsigned short v = 0;
+        if (r < d.rows && c < d.cols) {
+            const size_t o = (size_t)r * d.cols + c;
+            v = d.src_f32 ? (unsigned short)f32_to_bf16_bits(reinterpret_cast<const float *>(d.src)[o])
+                          : reinterpret_cast<const unsigned short *>(d.src)[o];
+        }
+        tile[ty * 16 + i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty * 16 + i, r = r0 + tx;          // destination row c, column r
+        if (c < d.cols && r < d.rows) reinterpret_cast<unsigned short *>(d.dst)[(size_t)c * d.rows + r] = tile[tx][ty * 16 + i];
+    }
+}
+
 }  // namespace pafc
 
 using pafc::bf16_t;
@@ -183,5 +228,18 @@ extern "C" int pafc_silu_dropout(int backward, int dtype, long n, const void *h,
     } else {
         return PAFC_ERR_UNSUPPORTED;
     }
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+// bf16 transposed copies of many matrices in ONE launch (include/pafc_encoder_ops.h).  `table`: n descriptors of 32 bytes in
+// DEVICE memory -- { const void *src; void *dst; int rows, cols, src_f32, tile0; } with tile0 = the running sum of
+// ceil(rows / 64) * ceil(cols / 64) over the earlier tensors; total_tiles = that sum over all n.
+extern "C" int pafc_multi_transpose_bf16(const void *table, int n, int total_tiles, pafc_stream_t stream) {
+    if (!table) return PAFC_ERR_NULL_POINTER;
+    if (n <= 0 || total_tiles <= 0) return PAFC_ERR_BAD_DIMS;
+    if (((uintptr_t)table & 7) != 0) return PAFC_ERR_ALIGNMENT;
+    static_assert(sizeof(pafc::TrDesc) == 32, "descriptor layout is part of the ABI");
+    hipLaunchKernelGGL(pafc::multi_transpose_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                       (const pafc::TrDesc *)table, n);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }

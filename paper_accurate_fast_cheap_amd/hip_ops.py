@@ -77,6 +77,11 @@ def _load_dispatch():
 _load_dispatch()
 
 
+def train_gemms_own() -> bool:
+    """PAFC_TRAIN_OWN_GEMMS=0: forward and input-gradient products of the training step's nn.Linear go to the library (A/B)."""
+    return os.environ.get("PAFC_TRAIN_OWN_GEMMS", "1") != "0"
+
+
 def train_kernels_enabled() -> bool:
     """PAFC_TRAIN_KERNELS=0: the training step differentiates through the framework's own operators (A/B measurements)."""
     import os
@@ -431,11 +436,23 @@ _shadows = {}      # id(parameter) -> [weak reference to the parameter, bf16 cop
 _shadows_on = False
 
 
+def _param_of(p: torch.Tensor) -> torch.Tensor:
+    """The parameter behind a reshaping view of it (a 1 x 1 convolution's `weight.squeeze(-1)`: a new tensor object on every
+    call, which a registry keyed by object identity would never find again), else the tensor itself."""
+    b = getattr(p, "_base", None)
+    if b is not None and isinstance(b, torch.nn.Parameter) and b.numel() == p.numel() and b.is_contiguous() and p.is_contiguous():
+        return b
+    return p
+
+
 def _bf16_shadow(p: torch.Tensor) -> torch.Tensor:
     if p.dtype == torch.bfloat16:
         return p
     if not _shadows_on:
         return p.to(torch.bfloat16)
+    base = _param_of(p)
+    if base is not p:
+        return _bf16_shadow(base).view(p.shape)
     ent = _shadows.get(id(p))
     if ent is not None and ent[0]() is p and ent[1].device == p.device and ent[1].shape == p.shape:
         return ent[1]                                # refreshed when the context was entered
@@ -453,8 +470,71 @@ def _param_as(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return p.detach().to(dtype)
 
 
+_shadows_t = {}    # id(parameter) -> [weak reference, bf16 copy of the TRANSPOSED matrix (K, N), (param epoch, version) of the copy]
+_tr_table = None   # (signature, device table of pafc_multi_transpose_bf16 descriptors, n, total tiles)
+
+
+def _bf16_shadow_t(w: torch.Tensor) -> torch.Tensor:
+    """bf16 (K, N) copy of a weight (N, K) -- a parameter or a reshaping view of one -- for the input-gradient GEMM dX = dY W.
+    The copies live beside their parameters; ALL of them are refreshed by ONE launch when train_shadows() is entered
+    (pafc_multi_transpose_bf16) and stamped with the parameter epoch and the parameter's in-place version: a copy whose stamp is
+    not the present one (a backward pass outside train_step, an update behind the registry's back) is re-made on the spot."""
+    global _tr_table
+    N, K = w.shape
+    p = _param_of(w)
+    stamp = (_param_epoch, p._version)
+    ent = _shadows_t.get(id(p))
+    if ent is not None and ent[0]() is p and ent[1].device == p.device and tuple(ent[1].shape) == (K, N):
+        if ent[2] != stamp:
+            with torch.no_grad():
+                ent[1].copy_(p.detach().view(N, K).t())
+            ent[2] = stamp
+        return ent[1]
+    if not isinstance(p, torch.nn.Parameter):
+        return w.detach().t().to(torch.bfloat16).contiguous()     # not a parameter: nothing to keep it beside
+    sh = p.detach().view(N, K).t().to(torch.bfloat16).contiguous()
+    _shadows_t[id(p)] = [weakref.ref(p), sh, stamp]
+    _tr_table = None
+    return sh
+
+
+def _refresh_transposed_shadows() -> None:
+    global _tr_table
+    live = []
+    for key in list(_shadows_t):
+        p = _shadows_t[key][0]()
+        sh = _shadows_t[key][1]
+        if (p is None or sh.device != p.device or sh.numel() != p.numel() or p.dtype not in (torch.float32, torch.bfloat16)
+                or not p.is_contiguous()):
+            del _shadows_t[key]
+            _tr_table = None
+        else:
+            live.append((p, sh))
+            _shadows_t[key][2] = (_param_epoch, p._version)
+    if not live:
+        return
+    sig = tuple((p.data_ptr(), sh.data_ptr(), p.dtype) for p, sh in live)
+    if _tr_table is None or _tr_table[0] != sig:
+        rows, t0 = [], 0
+        for p, sh in live:
+            k_, n_ = sh.shape                  # the copy is (K, N); the parameter (N, K) or a reshaping view target of it
+            # { src, dst, rows | cols << 32, src_f32 | tile0 << 32 } as four little-endian 64-bit words = the 32-byte descriptor
+            rows.append([p.data_ptr(), sh.data_ptr(), n_ | (k_ << 32), int(p.dtype == torch.float32) | (t0 << 32)])
+            t0 += ((n_ + 63) // 64) * ((k_ + 63) // 64)
+        tab = torch.tensor(rows, dtype=torch.int64).to(live[0][0].device)
+        _tr_table = (sig, tab, len(live), t0)
+    L = _bind()
+    if not getattr(L, "_pafc_mtr_bound", False):
+        _lib._sig(L.pafc_multi_transpose_bf16, c_int, c_void_p, c_int, c_int, c_void_p)
+        L._pafc_mtr_bound = True
+    _, tab, n, tiles = _tr_table
+    _lib.check(L.pafc_multi_transpose_bf16(_lib.ptr(tab), n, tiles, _lib.stream_of(tab)), "pafc_multi_transpose_bf16")
+
+
 def refresh_train_shadows() -> None:
-    """Bring every registered bf16 weight copy up to date with its parameter in one multi-tensor copy."""
+    """Bring every registered bf16 weight copy up to date with its parameter in one multi-tensor copy (and the transposed
+    copies in one launch of their own)."""
+    _refresh_transposed_shadows()
     live, dead = [], []
     for key, ent in _shadows.items():
         p = ent[0]()
@@ -481,18 +561,29 @@ def train_shadows():
         _shadows_on = prev
 
 
+def _own_gemm_rows(t2: torch.Tensor) -> bool:
+    return t2.dtype == torch.bfloat16 and t2.dim() == 2 and t2.stride(1) == 1 and t2.stride(0) % 8 == 0 and t2.data_ptr() % 16 == 0
+
+
 class _LinearTrainBf16(torch.autograd.Function):
-    """nn.Linear for the bf16 training step: forward and input gradient through the library GEMM, the weight gradient
-    through gemm_tn (the library's pick for that layout runs at 5 % of the matrix peak), straight into the weight's
-    dtype -- fp32 master weights receive the fp32 sum."""
+    """nn.Linear for the bf16 training step, every product on hand-written kernels: forward y = x W^T + b and input gradient
+    dX = dY W on the tiled GEMMs (pafc_gemm_bf16; the latter against the bf16 copy of W^T that train_shadows() keeps, one
+    multi-tensor transpose per step), the weight gradient through gemm_tn, straight into the weight's dtype -- fp32 master
+    weights receive the fp32 sum.  Shapes the kernels do not take (K or N not a multiple of 64 / 8) keep the library."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         wb = _bf16_shadow(weight)
         bb = None if bias is None else _bf16_shadow(bias)
         ctx.save_for_backward(x, wb)
+        ctx.weight = weight if isinstance(_param_of(weight), torch.nn.Parameter) else None
         ctx.w_dtype = weight.dtype
         ctx.b_dtype = None if bias is None else bias.dtype
+        N, K = wb.shape
+        x2 = x.reshape(-1, K)
+        if (train_gemms_own() and K % 64 == 0 and N % 8 == 0 and _own_gemm_rows(x2) and wb.is_contiguous()
+                and (bb is None or bb.dtype == torch.bfloat16)):
+            return gemm_bf16(x2, wb.detach(), None if bb is None else bb.detach()).view(x.shape[:-1] + (N,))
         return torch.nn.functional.linear(x, wb, bb)
 
     @staticmethod
@@ -507,7 +598,10 @@ class _LinearTrainBf16(torch.autograd.Function):
             x2 = x2.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = (dy2 @ wb).view(x.shape)
+            if train_gemms_own() and N % 64 == 0 and K % 8 == 0 and ctx.weight is not None and _own_gemm_rows(dy2):
+                dx = gemm_bf16(dy2, _bf16_shadow_t(ctx.weight)).view(x.shape)      # dY (M, N) x (W^T)(K, N)^T
+            else:
+                dx = (dy2 @ wb).view(x.shape)
         want_b = ctx.b_dtype is not None and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             od = ctx.w_dtype if ctx.w_dtype in (torch.float32, torch.bfloat16) else torch.float32
@@ -915,9 +1009,11 @@ class _LinearPlans:
     (long-form shapes, where the heuristic's first pick was seen to lose 20 %), never while a graph is being captured,
     on a scratch output of the call's own shape.  PAFC_GEMM_TUNE=0 switches it off, PAFC_GEMM_TUNE_MIN_ROWS moves the
     threshold."""
-    CAP = 256
+    CAP = 1024
+    RETIRE_AT = 512
 
     def __init__(self, device):
+        self.device, self.retired = device, []
         import os
         from collections import OrderedDict
         from ctypes import POINTER, byref, c_float, c_long
@@ -959,12 +1055,22 @@ class _LinearPlans:
         while len(self.plans) > self.CAP:
             _, old = self.plans.popitem(last=False)
             if old is not None:
+                self.retired.append(old)
+        if len(self.retired) >= self.RETIRE_AT:
+            # An evicted plan may still have launches queued on ANY stream (decode batches in flight on side streams; the
+            # host runs batches ahead of the device): its library objects are destroyed only behind a device-wide synchronize,
+            # and that rarely -- every RETIRE_AT evictions.  (Round 5: a ragged fp32 pass of 630 distinct problems against a
+            # table of 256 -- plans created and destroyed under queued work all the time -- never finished its second pass in
+            # three runs out of four; nothing else in that path has a lifetime that ends while the device is behind.)
+            torch.cuda.synchronize(self.device)
+            for old in self.retired:
                 self.L.pafc_linear_plan_destroy(old)
+            self.retired.clear()
         return plan
 
     def __del__(self):
         try:
-            for plan in self.plans.values():
+            for plan in list(self.plans.values()) + self.retired:
                 if plan is not None:
                     self.L.pafc_linear_plan_destroy(plan)
             self.L.pafc_gemm_ctx_destroy(self.ctx)

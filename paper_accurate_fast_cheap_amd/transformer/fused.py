@@ -762,10 +762,12 @@ def encoder_layers_forward(plan: EncoderPlan, xs: torch.Tensor, masks: torch.Ten
     first = plan.layers[0].layer.norm_ff_macaron
     outs: List[torch.Tensor] = []
     n = len(plan.layers)
-    if (lens is not None and all(lnfold_eligible(lp, xs, None) for lp in plan.layers)
-            and not torch.cuda.is_current_stream_capturing() and int(lens.min()) == xs.shape[1]):
+    if (lens is not None and xs.numel() // xs.shape[-1] >= _LN_FOLD_MIN_ROWS and not torch.cuda.is_current_stream_capturing()
+            and (all(lnfold_eligible(lp, xs, None) for lp in plan.layers) or all(split_eligible(lp, xs) for lp in plan.layers))
+            and int(lens.min()) == xs.shape[1]):
         # a long input whose rows are all full length (the 30-minute file, B = 1): the padding masks are no-ops -- worth one
-        # host read of the lengths per pass to take the unmasked schedule
+        # host read of the lengths per pass to take the unmasked schedule (bf16: the folded LayerNorms; fp32 around the bf16
+        # slot: pointwise_conv2's residual add rides on the GEMM instead of a second operand of the LayerNorm pass)
         lens = None
     if all(lnfold_eligible(lp, xs, lens) for lp in plan.layers):
         st = torch.empty((xs.numel() // xs.shape[-1], 8, 2), dtype=torch.float32, device=xs.device)

@@ -512,6 +512,45 @@ def test_bf16slot_full_size_split_operand_path_vs_oracle(hip, monkeypatch):
     _token_parity(logp, ref_logp, valid, 0.08, "bf16slot full size, split-operand GEMMs")
 
 
+def test_bf16slot_unmasked_schedule_equals_masked_schedule(hip, monkeypatch):
+    """The headline's schedule (fp32 model + bf16 slot, every row full length: the 30-minute file) drops the padding masks --
+    pointwise_conv2's residual add rides on its GEMM, norm_conv zeroes nothing.  Forced here onto a short equal-length batch
+    (it starts at 24 576 rows) and compared with the masked schedule of the same batch and with the oracle."""
+    import bench
+    from paper_accurate_fast_cheap_amd.transformer import fused
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    conf = bench.encoder_conf()
+    torch.manual_seed(777)
+    enc = ConformerEncoder(80, **conf).eval()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.02)
+    lens = torch.tensor([2403, 2403])
+    xs = synth.randn((2, 2403, 80), 905, 2.0)
+    sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    ref, ref_masks = EO.encoder_forward(xs, lens, sd, conf, env={})
+    enc = enc.cuda()
+    calls = []
+    real = fused.layer_forward_split
+    monkeypatch.setattr(fused, "layer_forward_split", lambda plan, x, hp, lens_, *a: (calls.append(lens_ is None), real(plan, x, hp, lens_, *a))[1])
+    with torch.no_grad():
+        masked, m1 = enc(xs.cuda(), lens.cuda())
+        assert calls and not any(calls)
+        del calls[:]
+        monkeypatch.setattr(fused, "_LN_FOLD_MIN_ROWS", 0)
+        plain, m2 = enc(xs.cuda(), lens.cuda())
+        assert calls and all(calls)                              # every layer ran without masks
+    assert torch.equal(m1, m2) and torch.equal(m1.cpu(), ref_masks)
+    dm = (plain - masked).abs()
+    d = (plain.cpu() - ref).abs()
+    parity_log.record("bf16slot unmasked schedule", vs_masked_schedule_max=float(dm.max()), vs_masked_schedule_mean=float(dm.mean()),
+                      max_abs_err=float(d.max()), mean_abs_err=float(d.mean()))
+    # the two schedules differ in where fp32 sums are rounded (GEMM epilogue vs LayerNorm pass): bf16-slot noise downstream
+    assert float(dm.mean()) <= 1.6e-2 and float(dm.max()) <= 0.12
+    assert float(d.mean()) <= 1.6e-2 and float(d.max()) <= 0.12
+
+
 def test_bf16slot_token_lists_through_a_head_that_decides(hip):
     """Token LISTS in the reference's own precision (fp32 model + bf16 slot, the bench headline) through a head that decides.
     A c2-shaped ragged batch of 24 utterances (1-6 s) through the full-size 12-layer model; the CTC head reads the leading

@@ -5,7 +5,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R; export PYTHONPATH=$R
 O=gpurun_out/step_hbm_$1; rm -rf $O; mkdir -p $O
-CMD="python3 bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline"
+CMD="python3 bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline ${BENCH_ARGS:-}"
 timeout -k 10 300 rocprofv3 --kernel-trace -d $O/trace -o r --output-format csv -- $CMD > $O/trace.json 2> $O/trace.err
 echo trace >> $O/progress.log
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o r --output-format csv -- $CMD > $O/fetch.json 2> $O/fetch.err
