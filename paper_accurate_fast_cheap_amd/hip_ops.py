@@ -617,12 +617,18 @@ class _LinearTrainBf16(torch.autograd.Function):
 
 
 class _MatmulTrainBf16(torch.autograd.Function):
-    """y = x @ W for a parameter stored (K, N) -- the LoRA matrices of the time-mix (src/model.py:277,289) -- with the
-    weight gradient x^T dy through gemm_tn."""
+    """y = x @ W for a parameter stored (K, N) -- the LoRA matrices of the time-mix (src/model.py:277,289) -- on the hand-written
+    kernels: forward against the bf16 copy of W^T (N, K) that train_shadows() keeps, input gradient dx = dy W^T against W as
+    it lies, weight gradient x^T dy through gemm_tn."""
 
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
+        K, N = weight.shape
+        x2 = x.reshape(-1, K)
+        if (train_gemms_own() and K % 64 == 0 and N % 8 == 0 and _own_gemm_rows(x2)
+                and isinstance(_param_of(weight), torch.nn.Parameter)):
+            return gemm_bf16(x2, _bf16_shadow_t(weight)).view(x.shape[:-1] + (N,))       # (M, K) x (W^T)(N, K)^T
         return x @ weight
 
     @staticmethod
@@ -635,7 +641,12 @@ class _MatmulTrainBf16(torch.autograd.Function):
         x2 = x.reshape(-1, K)
         if x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
             x2 = x2.contiguous()
-        dx = (dy2 @ weight.t()).view(x.shape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if train_gemms_own() and N % 64 == 0 and K % 8 == 0 and weight.is_contiguous() and _own_gemm_rows(dy2):
+                dx = gemm_bf16(dy2, weight.detach()).view(x.shape)                       # (M, N) x W (K, N)^T
+            else:
+                dx = (dy2 @ weight.t()).view(x.shape)
         dw = gemm_tn(x2, dy2, torch.bfloat16) if ctx.needs_input_grad[1] else None
         return dx, dw
 
