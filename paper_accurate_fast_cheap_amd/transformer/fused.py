@@ -52,6 +52,8 @@ class LayerPlan:
         # (storage, in-place version, dtype) of every parameter the plan derives something from, and the parameter epoch
         # (hip_ops.param_epoch: fused optimizers move parameters without touching Tensor._version).  The parameter OBJECTS are
         # looked up once per epoch -- walking the modules on every forward cost 90 us per layer of a launch-bound decode batch.
+        # Contract: code that REPLACES a parameter object (`module.weight = nn.Parameter(...)`, pruning / re-parametrisation, weight
+        # tying) calls hip_ops.bump_param_epoch(); .to() / .cuda() / load_state_dict / train() / eval() / train_step do it themselves.
         ep = hip_ops.param_epoch()
         if getattr(self, "_stamp_params", None) is None or self._stamp_epoch != ep:
             L = self.layer

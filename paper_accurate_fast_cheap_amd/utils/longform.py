@@ -59,34 +59,6 @@ def _side_streams(device: torch.device, n: int):
     return have[:n]
 
 
-_POOLS = {}
-
-
-def _pool(n: int):
-    """One small pool of issuing threads per width, kept for the life of the process."""
-    from concurrent.futures import ThreadPoolExecutor
-    if n not in _POOLS:
-        _POOLS[n] = ThreadPoolExecutor(max_workers=n, thread_name_prefix="pafc-issue")
-    return _POOLS[n]
-
-
-def _warm_graphs(enc_mod, batches, side):
-    """The captured graph of every batch of the pass (its shape on the side stream it will be issued on), or None when any
-    of them is missing, the encoder is not in inference mode or its parameters have changed since the graphs were captured."""
-    if enc_mod is None or not getattr(enc_mod, "graph_cache_size", 0) or enc_mod.training or not hasattr(enc_mod, "_weights_token"):
-        return None
-    if enc_mod._weights_token() != enc_mod._graphs_token:
-        return None
-    ents = []
-    n_side = len(side)
-    for i, (fb, lens) in enumerate(batches):
-        ent = enc_mod._graphs.get((tuple(fb.shape), fb.dtype, lens.dtype, side[i % n_side].cuda_stream))
-        if not isinstance(ent, tuple):
-            return None
-        ents.append(ent)
-    return ents
-
-
 @torch.no_grad()
 def greedy_decode_batches(model, batches, streams: int = 2, blank_id: int = 0, want_tokens: bool = True):
     """One pass over decode batches [(feats (B, T, F), lengths (B,)), ...] already resident on the GPU: encoder + CTC
@@ -120,7 +92,7 @@ def greedy_decode_batches(model, batches, streams: int = 2, blank_id: int = 0, w
 @torch.no_grad()
 def decode_windows(model, feats: torch.Tensor, chunk_size: int, batch_size: int, mode: str = "ctc_greedy_search",
                    beam_size: int = 10, input_frame_ms: float = 10.0, output_frame_ms: float = 40.0, streams: int = 3,
-                   graph_cache: bool = True, merge_frames: int = 0, host_threads: bool = True, **decode_kw) -> Dict[str, object]:
+                   graph_cache: bool = True, merge_frames: int = 0, **decode_kw) -> Dict[str, object]:
     """Decode a long file window by window with `model.decode` and stitch the token sequences.
 
     Returns {"tokens": all token ids in order, "windows": per-window token lists, "window_start_ms": start time of each
@@ -149,32 +121,13 @@ def decode_windows(model, feats: torch.Tensor, chunk_size: int, batch_size: int,
             # setting is left in place for the next file (the graphs pin their activations: encoder.graph_cache_size = 0 and
             # encoder._graphs.clear() release them)
             enc_mod.graph_cache_size = max(enc_mod.graph_cache_size, 2 * n_side)    # (full batches, the last one) x streams
-        blank = decode_kw.get("blank_id", 0)
-        warm = _warm_graphs(enc_mod, batches, side) if (host_threads and side and graph_cache) else None
-        if warm is not None:
-            def issue(si: int):
-                out = []
-                torch.cuda.set_device(feats.device)          # current device and grad mode are per thread
-                with torch.no_grad(), torch.cuda.stream(side[si]):
-                    for i in range(si, len(batches), n_side):
-                        fb, lens = batches[i]
-                        graph, sx, sl, oy, om = warm[i]
-                        sx.copy_(fb)
-                        sl.copy_(lens)
-                        graph.replay()
-                        # (no copies of the graph's outputs: the consumers below are queued on this stream before its next replay)
-                        logp = model.ctc_logprobs(oy)
-                        out.append((i, ctc_greedy(logp.contiguous(), om.squeeze(1).sum(1), blank, want_frames=True)))
-                return out
-            done = [r for part in _pool(n_side).map(issue, range(n_side)) for r in part]
-            pending = [r for _, r in sorted(done, key=lambda t: t[0])]
-        else:
-            pending = []
-            for i, (fb, lens) in enumerate(batches):
-                with (torch.cuda.stream(side[i % n_side]) if side else contextlib.nullcontext()):
-                    enc, mask = model._forward_encoder(fb, lens)
-                    logp = model.ctc_logprobs(enc)
-                    pending.append(ctc_greedy(logp.contiguous(), mask.squeeze(1).sum(1), blank, want_frames=True))
+        pending = []
+        for i, (fb, lens) in enumerate(batches):
+            with (torch.cuda.stream(side[i % n_side]) if side else contextlib.nullcontext()):
+                enc, mask = model._forward_encoder(fb, lens)
+                logp = model.ctc_logprobs(enc)
+                pending.append(ctc_greedy(logp.contiguous(), mask.squeeze(1).sum(1), decode_kw.get("blank_id", 0),
+                                          want_frames=True))
         for s_ in side:
             main.wait_stream(s_)
         for tk, nt, fr in pending:

@@ -1000,42 +1000,6 @@ def test_graph_cache_follows_parameter_updates(hip):
     model.encoder._graphs.clear()
 
 
-def test_decode_windows_issuing_threads_equal_the_one_thread_pass(hip, monkeypatch):
-    """utils.longform.decode_windows in its steady state (every batch of the pass has its captured graph): the batches of each
-    side stream are issued by a host thread of their own.  Same graphs, same streams, same order per stream -- token lists and
-    token start times equal those of the one-thread pass, and the threaded path really ran."""
-    from paper_accurate_fast_cheap_amd.utils import longform
-    from paper_accurate_fast_cheap_amd.utils.init_model import init_model
-    g = load_golden("encoder_reduced_f32")
-    conf = dict(g["conf"], rwkv_do_bfloat16=True)
-    configs = dict(encoder="conformer", encoder_conf=conf, input_dim=80, output_dim=40, ctc="ctc",
-                   ctc_conf={"ctc_blank_id": 0}, model_conf={}, dataset_conf={})
-
-    class A:
-        checkpoint = None
-
-    torch.manual_seed(6)
-    model, _ = init_model(A(), configs)
-    model = model.eval().cuda()                                   # fp32 model + bf16 slot: the headline precision
-    with torch.no_grad():
-        for n, p in model.named_parameters():
-            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
-                p.normal_(0, 0.05)
-    feats = synth.randn((1, 9 * 2 * 203 + 77, 80), 78, 2.0).cuda()
-    for _ in range(3):                                            # seen, captured, replayed
-        one = longform.decode_windows(model, feats, 203, 2, streams=3, host_threads=False)
-    used = []
-    real = longform._warm_graphs
-    monkeypatch.setattr(longform, "_warm_graphs", lambda *a: (used.append(real(*a)), used[-1])[1])
-    for _ in range(2):
-        many = longform.decode_windows(model, feats, 203, 2, streams=3)
-    assert used and all(u is not None for u in used)              # the issuing threads ran both passes
-    assert many["windows"] == one["windows"] and many["token_start_ms"] == one["token_start_ms"]
-    assert sum(len(w) for w in one["windows"]) > 20
-    model.encoder.graph_cache_size = 0
-    model.encoder._graphs.clear()
-
-
 def test_graph_capture_errors_surface(hip, monkeypatch):
     """An error of the captured work itself (a failing launch, a PafcError from the C ABI) is raised to the caller, not turned
     into "eager from now on"; only a capture the runtime REFUSES (hipErrorStreamCapture*) falls back.  (That fallback is not

@@ -60,7 +60,6 @@ def main():
     ap.add_argument("--batches", default=",".join(map(str, BATCHES)))
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "rtf_sweep"))
     ap.add_argument("--no-eager-check", action="store_true", help="skip the eager one-stream pass behind the token checksum")
-    ap.add_argument("--no-host-threads", action="store_true", help="issue every stream's graphs from the one calling thread (A/B)")
     ap.add_argument("--merge-frames", type=int, default=0,
                     help="decode_windows(merge_frames=...): consecutive batches run as one launch of up to this many input frames "
                          "(0 = one forward per batch, the reference's literal schedule)")
@@ -88,7 +87,6 @@ def main():
     with open(args.out + ".jsonl", "w") as fj:
         head = {"one_sequence_ms": round(one_ms, 3), "one_sequence_audio_sec_per_sec": round(one_rate, 1), "dtype": args.dtype,
                 "precision": bench.PRECISION[args.dtype], "frames": frames, "streams": args.streams, "merge_frames": args.merge_frames,
-                "host_threads": not args.no_host_threads,
                 "device": torch.cuda.get_device_name(0)}
         fj.write(json.dumps(head) + "\n")
         fj.flush()
@@ -101,8 +99,7 @@ def main():
                 last = {}
 
                 def step():
-                    last["out"] = decode_windows(model, feats, c, b, streams=args.streams, merge_frames=args.merge_frames,
-                                                 host_threads=not args.no_host_threads)
+                    last["out"] = decode_windows(model, feats, c, b, streams=args.streams, merge_frames=args.merge_frames)
                 sec = bench.timed_passes(step, args.passes, args.warmup)
                 vram = torch.cuda.max_memory_allocated(device) / 1024 / 1024
                 checksum = bench.token_checksum([last["out"]["windows"]])
