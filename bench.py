@@ -293,16 +293,28 @@ def windows_leg(model, feats, device, chunk: int = 2000, batch: int = 8, nstream
 
     def step():           # the package's own window scheduler, token lists fetched and stitched inside the timed region
         last["out"] = decode_windows(model, feats, chunk, batch, streams=nstreams)
+
+    def step_merged():    # the same windows, consecutive batches merged into launches of up to the whole file
+        last["merged"] = decode_windows(model, feats, chunk, batch, streams=nstreams, merge_frames=feats.shape[1] + chunk)
     try:
         sec = timed_passes(step, 3, 2)
+        model.encoder._graphs.clear()
+        sec_m = timed_passes(step_merged, 3, 2)
     finally:
         model.encoder.graph_cache_size = old
         model.encoder._graphs.clear()
+    wl, wm = last["out"]["windows"], last["merged"]["windows"]
     return {"workload": f"the 30-minute file as windows of {chunk} frames x batch {batch} (encoder-rtf.py:354-385) through "
                         f"utils.longform.decode_windows: encoder + CTC + greedy tokens + stitching, hipGraph replay of the recurring "
                         f"batch shape, {nstreams} batches in flight, package-default dispatch, " + PRECISION[dtype],
             "batches": nb, "passes": 3, "ms_per_pass": round(sec * 1e3, 3),
-            "audio_sec_per_sec": round(feats.shape[1] / 100.0 / sec, 1), "token_checksum": token_checksum([last["out"]["windows"]])}
+            "audio_sec_per_sec": round(feats.shape[1] / 100.0 / sec, 1), "token_checksum": token_checksum([wl]),
+            # batch_size is the reference's memory knob for a 24 GB card; the windows are independent: decode_windows(merge_frames=...)
+            # runs them as one launch (same windows, same order).  Token lists follow the launch shape on a random-init head
+            # (scan chunking and GEMM tiles follow the rows per launch): the equal windows are counted, not assumed
+            "merged_launches": {"ms_per_pass": round(sec_m * 1e3, 3), "audio_sec_per_sec": round(feats.shape[1] / 100.0 / sec_m, 1),
+                                "windows": len(wl), "windows_with_the_same_token_list": sum(1 for a, b in zip(wl, wm) if a == b),
+                                "tokens": sum(len(w) for w in wm), "tokens_one_forward_per_batch": sum(len(w) for w in wl)}}
 
 
 def build_model(dtype: str, device):
