@@ -86,6 +86,7 @@ struct PhParams {
     // SPL: K-steps per tile (32 columns of both planes each), and the byte offset of the lo plane from the hi plane inside a
     // row of A / of W (pb_shift then counts in 32-column steps)
     int nsteps, a_lo, w_lo;
+    int w_step;                       // SPL: bytes a K-step advances inside a row of W (64: [hi | hi | lo] planes)
     long lo_off;                      // OUT 2: column offset of the lo plane inside an output row
     // LayerNorm folded into the GEMMs either side of it (LNF): row statistics as 8 partial (sum, sum of squares) pairs per
     // row, float2 [M][8] -- written by the GEMM that produces the row (LNF 2: one pair per 64-column wave slice of the
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const PhParams p) {
         }
     };
     auto w_soff = [&](int kt) -> unsigned {
-        if constexpr (!CONV) return kt * (SPL ? 64 : 128);
+        if constexpr (!CONV) return SPL ? kt * p.w_step : kt * 128;
         const int tap = (kt * p.inv_spt) >> 16, kc = kt - tap * p.spt;
         return (unsigned)(tap * p.N * p.CiW * 2 + kc * (SPL ? 64 : 128));
     };
@@ -864,6 +865,7 @@ extern "C" int pafc_gemm_ph_ex2(long M, int N, int K, int batch, const void *A, 
         p.nsteps = K / 32;
         p.a_lo = (int)p.pb_bytes;                 // [hi PB | lo PB]: lo follows hi inside a block (one block: PB = K)
         p.w_lo = 2 * K * 2;                       // W' = [hi | hi | lo]: the lo plane starts 2 K columns in
+        p.w_step = 64;
         p.pb_shift = p.pb_shift >= 30 ? 30 : p.pb_shift + 1;
         if (out_kind == 1) {
             if (glu) return pafc::launch_ph<true, 0, 0, 1, false, 0, true>(p, batch, s);

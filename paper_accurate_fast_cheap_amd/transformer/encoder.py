@@ -64,6 +64,7 @@ class BaseEncoder(torch.nn.Module):
         self.graph_cache_size = 0
         self._graphs = {}
         self._graphs_token = None              # the parameter state the cached graphs were captured on (_weights_token)
+        self._graph_all_full = None            # set while a graph is captured: the batch's rows are all full length (or not)
         self._wt_epoch, self._wt_tensors = None, []
         # a checkpoint load rewrites parameters in place (Tensor._version moves) and may be followed by anything: new epoch
         self.register_load_state_dict_post_hook(lambda module, incompatible: _bump_epoch())
@@ -134,7 +135,14 @@ class BaseEncoder(torch.nn.Module):
         if token != self._graphs_token:
             self._graphs.clear()
             self._graphs_token = token
-        key = (tuple(xs.shape), xs.dtype, xs_lens.dtype, torch.cuda.current_stream(xs.device).cuda_stream)
+        # Long batches whose rows are all full length run the schedule without padding masks (fused.encoder_layers_forward), a
+        # decision that takes a host read of the lengths -- not possible inside a capture.  It is taken HERE, before the capture,
+        # and is part of the key: a replay runs the schedule the eager pass of the same batch would run (equal-length windows: the
+        # unmasked one; the file's last, padded batch: another graph).
+        full = None
+        if self._long_batch(xs):
+            full = bool(int(xs_lens.min()) == xs.shape[1])
+        key = (tuple(xs.shape), xs.dtype, xs_lens.dtype, torch.cuda.current_stream(xs.device).cuda_stream, full)
         ent = self._graphs.get(key)
         if ent is None:
             self._graphs[key] = "seen"
@@ -144,8 +152,12 @@ class BaseEncoder(torch.nn.Module):
             try:
                 sx, sl = xs.clone(), xs_lens.clone()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    oy, om, _ = self.forward_return_layers(sx, sl)
+                self._graph_all_full = full
+                try:
+                    with torch.cuda.graph(graph):
+                        oy, om, _ = self.forward_return_layers(sx, sl)
+                finally:
+                    self._graph_all_full = None
                 ent = self._graphs[key] = (graph, sx, sl, oy, om)
                 self._graphs[key] = self._graphs.pop(key)     # newest last, then drop the oldest graphs beyond the bound
                 self._trim_graphs()
@@ -163,6 +175,13 @@ class BaseEncoder(torch.nn.Module):
         graph.replay()
         self._graphs[key] = self._graphs.pop(key)  # most recently used last
         return oy.clone(), om.clone()
+
+    def _long_batch(self, xs: torch.Tensor) -> bool:
+        """Is this input long enough for the unmasked schedule to be a possibility (rows after subsampling against the schedule's
+        threshold)?  Cheap and conservative: the exact eligibility is re-checked where the schedule is chosen."""
+        from . import fused
+        sub = getattr(self.embed, "subsampling_rate", 1)
+        return xs.size(0) * (xs.size(1) // max(1, sub)) >= fused._LN_FOLD_MIN_ROWS
 
     def _trim_graphs(self):
         live = [k for k, v in self._graphs.items() if isinstance(v, tuple)]
@@ -185,7 +204,8 @@ class BaseEncoder(torch.nn.Module):
         plan = self._fused(xs)
         if plan is not None:
             from . import fused
-            xs, layer_outs = fused.encoder_layers_forward(plan, xs, mask_pad, self.after_norm, want_layers)
+            xs, layer_outs = fused.encoder_layers_forward(plan, xs, mask_pad, self.after_norm, want_layers,
+                                                          all_full=self._graph_all_full)
             return xs, masks, layer_outs
         layer_outs: List[torch.Tensor] = []
         for layer in self.encoders:

@@ -754,19 +754,29 @@ class EncoderPlan:
             p.refresh()
 
 
+def unmasked_schedule_possible(plan: EncoderPlan, xs: torch.Tensor) -> bool:
+    """Could this (B, T', C) input take the schedule without padding masks if every row turned out to be full length?  (Long
+    inputs only: the decision costs one host read of the lengths.)"""
+    return (xs.numel() // xs.shape[-1] >= _LN_FOLD_MIN_ROWS
+            and (all(lnfold_eligible(lp, xs, None) for lp in plan.layers) or all(split_eligible(lp, xs) for lp in plan.layers)))
+
+
 def encoder_layers_forward(plan: EncoderPlan, xs: torch.Tensor, masks: torch.Tensor, after_norm: Optional[nn.LayerNorm],
-                           want_layers: bool = False) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+                           want_layers: bool = False, all_full: Optional[bool] = None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """The `for layer in self.encoders` loop of BaseEncoder.forward (+ after_norm), encoder.py:141-146.
-    masks: (B, 1, T') prefix masks from make_pad_mask, or a (0,0,0) fake mask (forward_chunk)."""
+    masks: (B, 1, T') prefix masks from make_pad_mask, or a (0,0,0) fake mask (forward_chunk).
+    all_full: the caller already knows whether every row is full length (the hipGraph cache reads the lengths BEFORE it captures
+    and keys the graph on the answer, so that a replay runs the schedule the eager pass of the same batch runs); None = find out
+    here, with one host read, when the unmasked schedule is possible at all (never while capturing)."""
     plan.refresh()
     lens = masks.squeeze(1).sum(1).to(torch.int32) if masks.numel() > 0 else None
     xs = xs.contiguous()
     first = plan.layers[0].layer.norm_ff_macaron
     outs: List[torch.Tensor] = []
     n = len(plan.layers)
-    if (lens is not None and xs.numel() // xs.shape[-1] >= _LN_FOLD_MIN_ROWS and not torch.cuda.is_current_stream_capturing()
-            and (all(lnfold_eligible(lp, xs, None) for lp in plan.layers) or all(split_eligible(lp, xs) for lp in plan.layers))
-            and int(lens.min()) == xs.shape[1]):
+    if lens is not None and unmasked_schedule_possible(plan, xs) and (
+            all_full if all_full is not None else
+            (not torch.cuda.is_current_stream_capturing() and int(lens.min()) == xs.shape[1])):
         # a long input whose rows are all full length (the 30-minute file, B = 1): the padding masks are no-ops -- worth one
         # host read of the lengths per pass to take the unmasked schedule (bf16: the folded LayerNorms; fp32 around the bf16
         # slot: pointwise_conv2's residual add rides on the GEMM instead of a second operand of the LayerNorm pass)

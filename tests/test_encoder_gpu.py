@@ -886,7 +886,7 @@ def test_graph_cache_replays_recurring_batch_shapes(hip):
         want = [enc(x, l) for x, l in zip(xs, lens)]
         enc.graph_cache_size = 1
         got = [enc(x, l) for x, l in zip(xs, lens)]
-        assert isinstance(enc._graphs[((3, 95, 80), torch.float32, torch.int64, torch.cuda.current_stream().cuda_stream)], tuple)
+        assert isinstance(enc._graphs[((3, 95, 80), torch.float32, torch.int64, torch.cuda.current_stream().cuda_stream, None)], tuple)
         other = enc(xs[0][:, :71], torch.tensor([71, 30, 9], device="cuda"))         # another shape: eager, then captured
         other2 = enc(xs[0][:, :71], torch.tensor([71, 30, 9], device="cuda"))
         assert sum(isinstance(v, tuple) for v in enc._graphs.values()) == 1            # bounded: the older graph is gone
@@ -934,6 +934,47 @@ def test_graph_cache_two_batches_in_flight(hip):
         assert sum(isinstance(v, tuple) for v in enc._graphs.values()) == 3       # the main stream's graph + one per side stream
     for a, b in zip(single, double):
         assert torch.equal(a, b)
+
+
+def test_graph_replay_runs_the_schedule_of_the_eager_pass(hip, monkeypatch):
+    """A long batch whose rows are all full length takes the schedule without padding masks, a decision that reads the lengths
+    on the host.  The hipGraph cache takes it BEFORE capturing and keys the graph on it: replays of equal-length batches equal
+    the eager pass bit for bit (whole-model bf16: the folded-LayerNorm schedule), and a batch of the same shape with a short row
+    gets a graph of its own (the masked schedule) instead of a wrong replay."""
+    from paper_accurate_fast_cheap_amd.transformer import fused
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    import bench
+    conf = dict(bench.encoder_conf(), num_blocks=2)
+    torch.manual_seed(9)
+    enc = ConformerEncoder(80, **conf).eval().to(torch.bfloat16).cuda()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.02)
+    monkeypatch.setattr(fused, "_LN_FOLD_MIN_ROWS", 256)          # the schedule's threshold (24 576 rows) brought down to this batch
+    xs = [synth.randn((2, 803, 80), 500 + i, 2.0).cuda().to(torch.bfloat16) for i in range(3)]
+    full = torch.tensor([803, 803], device="cuda")
+    ragged = torch.tensor([803, 411], device="cuda")
+    seen = []
+    real = fused.layer_forward_lnfold
+    monkeypatch.setattr(fused, "layer_forward_lnfold", lambda *a, **k: (seen.append(torch.cuda.is_current_stream_capturing()), real(*a, **k))[1])
+    with torch.no_grad():
+        want = [enc(x, full)[0] for x in xs]
+        want_r = enc(xs[0], ragged)[0]
+        assert seen and not any(seen)
+        del seen[:]
+        enc.graph_cache_size = 4
+        for _ in range(3):                                       # seen, captured, replayed
+            got = [enc(x, full)[0] for x in xs]
+            got_r = enc(xs[0], ragged)[0]
+        assert any(seen)                                         # the folded-LayerNorm schedule was CAPTURED
+        keys = [k for k, v in enc._graphs.items() if isinstance(v, tuple)]
+        assert sorted(k[-1] for k in keys) == [False, True]      # one graph per answer
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    assert torch.equal(want_r, got_r)
+    enc.graph_cache_size = 0
+    enc._graphs.clear()
 
 
 def test_graph_cache_follows_parameter_updates(hip):

@@ -502,6 +502,59 @@ def test_bf16_weight_shadows_follow_the_parameter():
 
 
 @pytest.mark.gpu
+def test_transposed_weight_shadows_and_the_training_linear_on_own_gemms(hip, monkeypatch):
+    """The training Linear's forward and input gradient on the hand-written GEMMs: dX = dY W runs against bf16 copies of W^T kept
+    beside the parameters -- made on first use, ALL refreshed by one launch of pafc_multi_transpose_bf16 when train_shadows() is
+    entered (fp32 and bf16 parameters, shapes that are not multiples of the 64 x 64 tile, a 1 x 1 convolution's weight seen
+    through `squeeze(-1)`), re-made on the spot when their stamp is stale.  Gradients equal the library path's to bf16 round-off."""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(512, 2048).cuda()
+    odd = torch.nn.Linear(200, 72, bias=False).cuda()
+    slot = torch.nn.Linear(512, 512, bias=False).cuda().to(torch.bfloat16)
+    conv = torch.nn.Conv1d(512, 1024, 1).cuda()
+    mats = [lin.weight, odd.weight, slot.weight, conv.weight.squeeze(-1)]
+    for m in mats:                                                     # first use: made from the parameter
+        t = hip_ops._bf16_shadow_t(m)
+        assert t.dtype == torch.bfloat16 and torch.equal(t, m.detach().to(torch.bfloat16).t())
+    with torch.no_grad():                                              # a fused-optimizer style update: versions untouched
+        for m in (lin.weight, odd.weight, conv.weight):
+            m.data.mul_(-1.5)
+        slot.weight.data.mul_(-0.5)
+    hip_ops.bump_param_epoch()                                         # (train_step does this after every update)
+    with hip_ops.train_shadows():                                      # entry: ONE launch refreshes all four copies
+        for m in mats:
+            p = hip_ops._param_of(m)
+            ent = hip_ops._shadows_t[id(p)]
+            assert torch.equal(ent[1], m.detach().to(torch.bfloat16).t()), tuple(m.shape)
+            assert hip_ops._bf16_shadow_t(m) is ent[1]
+    with torch.no_grad():
+        lin.weight.add_(1.0)                                           # in place outside train_step: the stamp is stale ...
+    assert torch.equal(hip_ops._bf16_shadow_t(lin.weight), lin.weight.detach().to(torch.bfloat16).t())   # ... re-made on use
+
+    def grads(own):
+        monkeypatch.setenv("PAFC_TRAIN_OWN_GEMMS", "1" if own else "0")
+        x = (torch.randn(3, 700, 512, device="cuda") * 0.5).requires_grad_()
+        torch.manual_seed(11)
+        for m in (lin, conv):
+            m.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = hip_ops.linear(x, lin.weight, lin.bias)
+            z = hip_ops.linear(x, conv.weight.squeeze(-1), conv.bias)
+        g1, g2 = torch.randn_like(y), torch.randn_like(z)
+        (y * g1).sum().backward(retain_graph=True)
+        (z * g2).sum().backward()
+        return y.detach().float(), z.detach().float(), x.grad.clone(), lin.weight.grad.clone(), conv.weight.grad.clone()
+    torch.manual_seed(5)
+    a = grads(True)
+    torch.manual_seed(5)
+    b = grads(False)
+    for u, v, name in zip(a, b, ("y", "z", "dx", "dW lin", "dW conv")):
+        scale = float(v.abs().max())
+        assert float((u - v).abs().max()) <= 2 ** -6 * scale, (name, float((u - v).abs().max()), scale)
+
+
+@pytest.mark.gpu
 def test_c4_full_size_training_step(hip):
     """Config c4 at FULL model size (12 layers, 512 d, 8 x 64 heads, CTC over 5000 tokens; 32 ragged utterances): one
     training step under bf16 autocast through the training kernels -- finite loss and gradients on every parameter, the

@@ -306,6 +306,64 @@ static int run_pmc(const Case &c) {
     return 0;
 }
 
+// Experiment (round 5): both operands with their planes INTERLEAVED in blocks of 32 columns, [hi 32 | lo 32] [hi 32 | lo 32] ...
+// (a K-step's 128-byte LDS row is then ONE contiguous 128-byte line of the source row instead of two 64-byte halves 2 K bytes
+// apart), against the shipped plane layout on the same fp32 operands.  `il <M> <N> <K>`.
+__global__ void interleave32(const float *x, u16 *out, long rows, int cols) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t n = (size_t)rows * cols;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const long r = i / cols; const int c = (int)(i % cols);
+        const u16 hi = f2bf(x[i]);
+        const size_t o = (size_t)r * 2 * cols + (size_t)(c >> 5) * 64 + (c & 31);
+        out[o] = hi;
+        out[o + 32] = f2bf(x[i] - bf2f(hi));
+    }
+}
+
+static int run_interleaved(long M, int N, int K) {
+    float *Af, *Wf, *bias, *out0, *out1;
+    u16 *A0, *W0, *A1, *W1;
+    CK(hipMalloc(&Af, (size_t)M * K * 4)); CK(hipMalloc(&Wf, (size_t)N * K * 4)); CK(hipMalloc(&bias, (size_t)N * 4));
+    CK(hipMalloc(&A0, (size_t)M * 2 * K * 2)); CK(hipMalloc(&W0, (size_t)N * 3 * K * 2));
+    CK(hipMalloc(&A1, (size_t)M * 2 * K * 2)); CK(hipMalloc(&W1, (size_t)N * 2 * K * 2));
+    CK(hipMalloc(&out0, (size_t)M * N * 4)); CK(hipMalloc(&out1, (size_t)M * N * 4));
+    fill_f32<<<2048, 256>>>(Af, (size_t)M * K, 11, 1.7f);
+    fill_f32<<<512, 256>>>(Wf, (size_t)N * K, 12, 1.7f / sqrtf((float)K));
+    fill_f32<<<8, 256>>>(bias, (size_t)N, 13, 0.5f);
+    split_planes<<<2048, 256>>>(Af, A0, M, K);
+    split_weight3<<<512, 256>>>(Wf, W0, N, K);
+    interleave32<<<2048, 256>>>(Af, A1, M, K);
+    interleave32<<<512, 256>>>(Wf, W1, N, K);
+    const int tm = N <= 512 ? 192 : 256;
+    auto run_planes = [&]() {
+        const int rc = pafc_gemm_ph_ex(M, N, K, 1, A0, 2 * K, 0, 1, W0, 3 * K, 0, bias, 0, nullptr, 0, 0, 0, out0, 1, N, 0, 0, 1.f, 0, tm, 0);
+        if (rc != PAFC_OK) { printf("planes: rc %d\n", rc); exit(1); }
+    };
+    auto run_il = [&]() {
+        pafc::PhParams p{};
+        p.A = (const pafc::bf16_t *)A1; p.W = (const pafc::bf16_t *)W1; p.bias = bias; p.out = out1;
+        p.M = M; p.N = N; p.K = 2 * K; p.lda = 2 * K; p.ldw = 2 * K; p.ldo = N; p.alpha = 1.f;
+        p.nk1 = K / 64; p.pb_shift = 0; p.pb_bytes = 64; p.nsteps = K / 32; p.a_lo = 64; p.w_lo = 64; p.w_step = 128;
+        p.tm = tm; p.mtiles = (int)((M + tm - 1) / tm); p.ntiles = (N + 255) / 256;
+        const int rc = pafc::launch_ph<false, 0, 0, 1, false, 0, true>(p, 1, 0);
+        if (rc != PAFC_OK) { printf("interleaved: rc %d\n", rc); exit(1); }
+    };
+    run_planes(); run_il();
+    CK(hipDeviceSynchronize());
+    std::vector<float> h0((size_t)1 << 20), h1((size_t)1 << 20);
+    const size_t n = std::min((size_t)M * N, h0.size());
+    CK(hipMemcpy(h0.data(), out0, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), out1, n * 4, hipMemcpyDeviceToHost));
+    double md = 0, mx = 0;
+    for (size_t i = 0; i < n; ++i) { md = std::max(md, (double)fabsf(h0[i] - h1[i])); mx = std::max(mx, (double)fabsf(h0[i])); }
+    std::vector<float> t0, t1;
+    for (int r = 0; r < 9; ++r) { t0.push_back(time_us(run_planes, 6)); t1.push_back(time_us(run_il, 6)); }
+    std::sort(t0.begin(), t0.end()); std::sort(t1.begin(), t1.end());
+    printf("M %ld N %d K %d: planes [hi K | lo K] x [hi | hi | lo] %.1f us (min %.1f) | interleaved blocks of 32 %.1f us (min %.1f) | %.3fx | max |diff| %.2e of %.2e\n",
+           M, N, K, t0[4], t0[0], t1[4], t1[0], t0[4] / t1[4], md, mx);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     const std::string mode = argc > 1 ? argv[1] : "all";
     const bool race = mode != "check";
@@ -346,6 +404,7 @@ int main(int argc, char **argv) {
         {"small f32 333x264x640 split res x2", 333, 264, 640, 2, 0, 2, 1, 1, 128, 0.5f},
     };
     if (mode == "pmc") return run_pmc(big[argc > 2 ? atoi(argv[2]) : 0]);
+    if (mode == "il") return run_interleaved(argc > 2 ? atol(argv[2]) : M, argc > 3 ? atoi(argv[3]) : 2048, argc > 4 ? atoi(argv[4]) : 512);
     if (mode != "race") for (const Case &c : small) run_case(c, false);
     for (const Case &c : big) run_case(c, race);
     printf(g_fail ? "FAILED: %d problem(s)\n" : "all checks passed\n", g_fail);
