@@ -243,6 +243,23 @@ __global__ __launch_bounds__(256) void wkv6_scan_kernel(const FwdParams p) {
     const size_t sidx = (((size_t)b * p.H + h) * N + i) * N + j;
     float run = D.s_in ? D.s_in[sidx] : 0.f;
     int c = 0;
+    // The recurrence itself is one FMA per chunk; what the kernel waits for is the round trip of its loads (4 waves per CU,
+    // the states of pass A still in L2 / the Infinity Cache).  PB chunks are fetched per round trip: with 4 (rounds 1-4) the
+    // 128 chunks of the 30-minute shape were 32 dependent round trips = 17.5 us; 16 leaves 8.
+    constexpr int PB = 16;
+    for (; c + PB <= p.nc_local; c += PB) {
+        float loc[PB], dec[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            loc[q] = ws[(size_t)(c + q) * (N * N)];
+            dec[q] = wd[(size_t)(c + q) * N];
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            ws[(size_t)(c + q) * (N * N)] = run;
+            run = fmaf(run, dec[q], loc[q]);
+        }
+    }
     for (; c + 4 <= p.nc_local; c += 4) {
         float loc[4], dec[4];
 #pragma unroll

@@ -1,0 +1,24 @@
+#!/bin/bash
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; export PYTHONPATH=$R
+O=gpurun_out/r05k; mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_fused_gpu.py tests/test_wkv6_gpu.py tests/test_encoder_gpu.py tests/test_streaming_gpu.py -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc=$?" > $O/progress.log
+tail -4 $O/pytest.log
+for rep in 1 2 3; do
+  timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-extra --no-cpu-baseline > $O/bench_$rep.json 2>> $O/bench.err
+done
+python3 - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r05k/bench_*.json')):
+    try:
+        d=json.load(open(f)); print(f, d['ms_per_step'], d['value'], d['roofline']['avg_launch_us'], d['roofline']['frac'])
+    except Exception as e: print(f, 'ERR', e)
+PY
+cd /tmp && export TMPDIR=/tmp; cd $R
+timeout -k 10 400 rocprofv3 --kernel-trace -d $O/rp2 -o run --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-extra --no-cpu-baseline > $O/rp2.json 2> $O/rp2.err
+python3 tools/prof_last_step.py $O/rp2/run_kernel_trace.csv 45 > $O/bench_last_step_kernels.txt; rm -rf $O/rp2
+head -30 $O/bench_last_step_kernels.txt | cut -c1-150
+bash tools/prof_wkv_traffic.sh r05k > $O/wkv_traffic.log 2>&1; echo "wkv traffic rc=$?" >> $O/progress.log
+grep -A3 "kernel_avg_duration" $O/wkv_traffic.log | head; grep "hbm_bytes_per_launch_corrected\|op_us" $O/wkv_traffic.log
+cat $O/progress.log
