@@ -513,25 +513,13 @@ __global__ __launch_bounds__(DL_WAVES * 64) void decay_lora_kernel(long rows, in
             s_d2[f * 64 + lane] = uint4{lo.x, lo.y, hi.x, hi.y};
         }
         __syncthreads();
-        // Round 5: the NEXT tile's row pieces are requested as soon as the first product has consumed this tile's (same
-        // registers), so that their round trip runs under tanh, the second product and the stores instead of in front of the
-        // next tile (a wave walks ~3 tiles: three exposed round trips in a 56 us kernel that moves 184 MB)
-        const long tstep = (long)gridDim.x * DL_WAVES;
-        auto row_of = [&](long tile) -> const bf16_t * {
+        for (long tile = (long)blockIdx.x * DL_WAVES + wave; tile < ntiles; tile += (long)gridDim.x * DL_WAVES) {
             const long row = tile * 16 + r16;
             const long rowc = row < rows ? row : rows - 1;     // clamp (every lane takes part in the MFMAs), skip the store
-            return zw + ((size_t)d * rows + rowc) * C + 8 * qq;
-        };
-        uint4 zf[16];
-        {
-            const long t0 = (long)blockIdx.x * DL_WAVES + wave;
-            if (t0 < ntiles) {
-                const bf16_t *zr = row_of(t0);
+            const bf16_t *zr = zw + ((size_t)d * rows + rowc) * C + 8 * qq;
+            uint4 zf[16];
 #pragma unroll
-                for (int ks = 0; ks < 16; ++ks) zf[ks] = *reinterpret_cast<const uint4 *>(zr + 32 * ks);
-            }
-        }
-        for (long tile = (long)blockIdx.x * DL_WAVES + wave; tile < ntiles; tile += tstep) {
+            for (int ks = 0; ks < 16; ++ks) zf[ks] = *reinterpret_cast<const uint4 *>(zr + 32 * ks);
             f32x4g acc1[4] = {zero, zero, zero, zero};
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks)
@@ -539,11 +527,6 @@ __global__ __launch_bounds__(DL_WAVES * 64) void decay_lora_kernel(long rows, in
                 for (int tau = 0; tau < 4; ++tau)
                     acc1[tau] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8g, s_d1[(ks * 4 + tau) * 64 + lane]),
                                                                          __builtin_bit_cast(bf16x8g, zf[ks]), acc1[tau], 0, 0, 0);
-            if (tile + tstep < ntiles) {
-                const bf16_t *zr = row_of(tile + tstep);
-#pragma unroll
-                for (int ks = 0; ks < 16; ++ks) zf[ks] = *reinterpret_cast<const uint4 *>(zr + 32 * ks);
-            }
             // tanh + rounding; k-step p of the second product takes n1 = 32 p + 4 qq + e (e < 4) | 32 p + 16 + 4 qq + e - 4
             u32x4g b2[2];
 #pragma unroll
@@ -622,90 +605,54 @@ __global__ __launch_bounds__(NW * 64) void tmix_lora_down_kernel(int T, long row
     }
     __syncthreads();
     const long ntiles = (rows + 15) / 16;
-    // Round 5: software-pipelined over groups of four K-steps ACROSS tiles.  A wave used to request a group's rows, wait, form the
-    // operands and multiply, 4 groups x ~3 tiles = 12 exposed round trips of 1-2 us in a 44 us kernel whose instructions take ~14.
-    // Now the x / neighbour rows of group g + 1 (the next tile's first group after a tile's last) are in flight while group g is
-    // multiplied: 8 more 16-byte registers.
-    const long tstep = (long)gridDim.x * NW;
-    struct RowPtr { const bf16_t *xr, *xnr; bool has_nb; long row; };
-    auto row_ptrs = [&](long tile) -> RowPtr {
+    for (long tile = (long)blockIdx.x * NW + wave; tile < ntiles; tile += (long)gridDim.x * NW) {
         const long row = tile * 16 + r16;
         const long rowc = row < rows ? row : rows - 1;     // clamp (every lane takes part in the MFMAs), skip the store
         const int tt = (int)(rowc % T);
         const bool in_seq = rev ? (tt < T - 1) : (tt > 0);
         const bool has_nb = in_seq || (prev != nullptr && !rev);       // prev: (B, C) the frame before each sequence, or null
         const bf16_t *nbrow = in_seq ? x + (rev ? rowc + 1 : rowc - 1) * C : (has_nb ? prev + (rowc / T) * C : x + rowc * C);
-        return RowPtr{x + rowc * C + 8 * qq, nbrow + 8 * qq, has_nb, row};
-    };
-    const bf16_t *mr = maa_x + (size_t)d * C + 8 * qq;
-    long tile = (long)blockIdx.x * NW + wave;
-    if (tile >= ntiles) return;
-    RowPtr cur = row_ptrs(tile);
-    uint4 gx[4], gn[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        gx[q] = *reinterpret_cast<const uint4 *>(cur.xr + 32 * q);
-        gn[q] = *reinterpret_cast<const uint4 *>(cur.xnr + 32 * q);
-    }
-    for (; tile < ntiles; tile += tstep) {
-        const bool more = tile + tstep < ntiles;
-        const RowPtr nxt = row_ptrs(more ? tile + tstep : tile);
+        const bf16_t *xr = x + rowc * C + 8 * qq, *xnr = nbrow + 8 * qq, *mr = maa_x + (size_t)d * C + 8 * qq;
         f32x4g acc[4][2];
 #pragma unroll
         for (int np = 0; np < 4; ++np) { acc[np][0] = zero; acc[np][1] = zero; }
 #pragma unroll 1
-        for (int kc = 0; kc < 16; kc += 4) {
-            // the next group's rows: this tile's next four K-steps, or the next tile's first four
-            uint4 nx[4], nn[4];
-            const bool last = kc == 12;
-            const bf16_t *pxr = last ? nxt.xr : cur.xr + 32 * (kc + 4), *pnr = last ? nxt.xnr : cur.xnr + 32 * (kc + 4);
-            if (!last || more) {
+        for (int kc = 0; kc < 16; kc += 4)   // four K-steps at a time: their 12 loads are in flight together, no more
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    nx[q] = *reinterpret_cast<const uint4 *>(pxr + 32 * q);
-                    nn[q] = *reinterpret_cast<const uint4 *>(pnr + 32 * q);
-                }
+        for (int ks = kc; ks < kc + 4; ++ks) {
+            float xc[VEC], xn[VEC], mm[VEC];
+            load8<bf16_t>(xr + 32 * ks, xc);
+            load8<bf16_t>(xnr + 32 * ks, xn);                // branch-free: select after the load
+            load8<bf16_t>(mr + 32 * ks, mm);
+            float o[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xx = round_bf16((has_nb ? xn[e] : 0.f) - xc[e]);
+                o[e] = xc[e] + round_bf16(xx * mm[e]);              // (rounded by the packing conversion below: one v_cvt_pk per pair)
             }
+            const u32x4g bq = {pack_bf16_rne(o[0], o[1]), pack_bf16_rne(o[2], o[3]), pack_bf16_rne(o[4], o[5]),
+                               pack_bf16_rne(o[6], o[7])};
+            // the K-step's products at raised wave priority: a wave that has formed its operand (115 VALU instructions per K-step)
+            // gets the matrix pipe ahead of the waves still forming theirs (8 waves per block: 49.0 -> 43.5 us; 16: 47.6 -> 45.3)
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ks = kc + q;
-                float xc[VEC], xn[VEC], mm[VEC];
-                Elem<bf16_t>::unpack(gx[q], xc);
-                Elem<bf16_t>::unpack(gn[q], xn);                 // branch-free: select after the load
-                load8<bf16_t>(mr + 32 * ks, mm);
-                float o[VEC];
+            for (int np = 0; np < 4; ++np)
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const float xx = round_bf16((cur.has_nb ? xn[e] : 0.f) - xc[e]);
-                    o[e] = xc[e] + round_bf16(xx * mm[e]);              // (rounded by the packing conversion below: one v_cvt_pk per pair)
-                }
-                const u32x4g bq = {pack_bf16_rne(o[0], o[1]), pack_bf16_rne(o[2], o[3]), pack_bf16_rne(o[4], o[5]),
-                                   pack_bf16_rne(o[6], o[7])};
-                // the K-step's products at raised wave priority: a wave that has formed its operand (115 VALU instructions per K-step)
-                // gets the matrix pipe ahead of the waves still forming theirs (8 waves per block: 49.0 -> 43.5 us; 16: 47.6 -> 45.3)
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int np = 0; np < 4; ++np)
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-                        acc[np][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8g, s_w1[((ks * 4 + np) * 2 + a) * 64 + lane]), __builtin_bit_cast(bf16x8g, bq),
-                            acc[np][a], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { gx[q] = nx[q]; gn[q] = nn[q]; }
+                for (int a = 0; a < 2; ++a)
+                    acc[np][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8g, s_w1[((ks * 4 + np) * 2 + a) * 64 + lane]), __builtin_bit_cast(bf16x8g, bq),
+                        acc[np][a], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
-        if (cur.row < rows) {
+        if (row < rows) {
 #pragma unroll
             for (int np = 0; np < 4; ++np) {
                 float o[VEC];
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) o[e] = tanh_as_gemm_epilogue(e < 4 ? acc[np][0][e] : acc[np][1][e - 4]);
-                store8<bf16_t>(tout + ((size_t)d * rows + cur.row) * LD_N + 32 * np + 8 * qq, o);
+                store8<bf16_t>(tout + ((size_t)d * rows + row) * LD_N + 32 * np + 8 * qq, o);
             }
         }
-        cur = nxt;
     }
 }
 
