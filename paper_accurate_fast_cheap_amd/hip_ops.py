@@ -1067,7 +1067,7 @@ class _LinearPlans:
             _, old = self.plans.popitem(last=False)
             if old is not None:
                 self.retired.append(old)
-        if len(self.retired) >= self.RETIRE_AT:
+        if len(self.retired) >= self.RETIRE_AT and not torch.cuda.is_current_stream_capturing():
             # An evicted plan may still have launches queued on ANY stream (decode batches in flight on side streams; the
             # host runs batches ahead of the device): its library objects are destroyed only behind a device-wide synchronize,
             # and that rarely -- every RETIRE_AT evictions.  (Round 5: a ragged fp32 pass of 630 distinct problems against a
