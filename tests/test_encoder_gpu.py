@@ -588,8 +588,8 @@ def test_bf16slot_full_size_five_minute_file_headline_schedule_vs_oracle(hip, mo
     parity_log.record("bf16slot 5-minute file, headline schedule", max_abs_err=float(d.max()), mean_abs_err=float(d.mean()),
                       frames=int(valid.sum()))
     print(f"[bf16slot 5-minute file] max {float(d.max()):.4g} mean {float(d.mean()):.4g}")
-    # 24 bf16 slots deep over 7 499 frames: the mean as on the short batches (recorded 0.0077 there), a longer tail for the max
-    assert float(d.mean()) <= 1.6e-2 and float(d.max()) <= 0.25
+    # 24 bf16 slots deep over 7 499 frames: recorded max 0.107 / mean 0.0074 (short batches: 0.075 / 0.0077); bounds = 2 x
+    assert float(d.mean()) <= 1.5e-2 and float(d.max()) <= 0.22
     _token_parity(logp, ref_logp, valid, 0.12, "bf16slot 5-minute file, headline schedule")
     # the deciding head: sign of the leading principal component of the oracle's output
     X = ref[valid]
@@ -608,7 +608,8 @@ def test_bf16slot_full_size_five_minute_file_headline_schedule_vs_oracle(hip, mo
     changes = int(((lp_ref.argmax(-1)[:, 1:] != lp_ref.argmax(-1)[:, :-1]) & valid[:, 1:]).sum())
     parity_log.record("bf16slot 5-minute file, headline schedule", deciding_head_frames_flipped=flipped, deciding_head_token_changes=changes)
     print(f"[bf16slot 5-minute file] deciding head: {flipped} of {int(valid.sum())} frames flipped, {changes} token changes")
-    assert changes > 100 and flipped <= 0.005 * float(valid.sum()), (flipped, changes)
+    # recorded: 27 of 7 499 frames flipped among 2 925 token changes (the component changes sign every 2-3 frames on this model)
+    assert changes > 100 and flipped <= 0.01 * float(valid.sum()), (flipped, changes)
 
 
 def test_bf16slot_token_lists_through_a_head_that_decides(hip):
