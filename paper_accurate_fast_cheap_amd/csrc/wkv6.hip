@@ -242,26 +242,42 @@ __global__ __launch_bounds__(256) void wkv6_scan_kernel(const FwdParams p) {
     const float *wd = p.ws_decay + seq * p.NC * (size_t)N + j;
     const size_t sidx = (((size_t)b * p.H + h) * N + i) * N + j;
     float run = D.s_in ? D.s_in[sidx] : 0.f;
+    int c = 0;
     // The recurrence itself is one FMA per chunk; what the kernel waits for is the round trip of its loads (4 waves per CU,
-    // the states of pass A still in L2 / the Infinity Cache).  PB chunks are fetched per round trip, the ragged last batch
-    // under a bounds check: with 4 per trip (rounds 1-4) the 127 chunks of the 30-minute shape were 32 dependent round trips =
-    // 17.5 us, with 16 eight (15.7 us in the model, 14.6 stand-alone), with 32 four.
-    constexpr int PB = 32;
-    for (int c = 0; c < p.nc_local; c += PB) {
+    // the states of pass A still in L2 / the Infinity Cache).  PB chunks are fetched per round trip: with 4 (rounds 1-4) the
+    // 128 chunks of the 30-minute shape were 32 dependent round trips = 17.5 us; 16 leaves 8.
+    constexpr int PB = 16;
+    for (; c + PB <= p.nc_local; c += PB) {
         float loc[PB], dec[PB];
 #pragma unroll
         for (int q = 0; q < PB; ++q) {
-            const bool in = c + q < p.nc_local;
-            loc[q] = in ? ws[(size_t)(c + q) * (N * N)] : 0.f;
-            dec[q] = in ? wd[(size_t)(c + q) * N] : 0.f;
+            loc[q] = ws[(size_t)(c + q) * (N * N)];
+            dec[q] = wd[(size_t)(c + q) * N];
         }
 #pragma unroll
         for (int q = 0; q < PB; ++q) {
-            if (c + q < p.nc_local) {
-                ws[(size_t)(c + q) * (N * N)] = run;
-                run = fmaf(run, dec[q], loc[q]);
-            }
+            ws[(size_t)(c + q) * (N * N)] = run;
+            run = fmaf(run, dec[q], loc[q]);
         }
+    }
+    for (; c + 4 <= p.nc_local; c += 4) {
+        float loc[4], dec[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            loc[q] = ws[(size_t)(c + q) * (N * N)];
+            dec[q] = wd[(size_t)(c + q) * N];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ws[(size_t)(c + q) * (N * N)] = run;
+            run = fmaf(run, dec[q], loc[q]);
+        }
+    }
+    for (; c < p.nc_local; ++c) {
+        const float loc = ws[(size_t)c * (N * N)];
+        const float dec = wd[(size_t)c * N];
+        ws[(size_t)c * (N * N)] = run;
+        run = fmaf(run, dec, loc);
     }
     if (p.nc_local < p.NC) ws[(size_t)(p.NC - 1) * (N * N)] = run;  // last chunk's incoming state
     if (D.s_out) D.s_out[sidx] = run;  // only reached with nc_local == NC
