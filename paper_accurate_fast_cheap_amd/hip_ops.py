@@ -835,37 +835,6 @@ def _ph_tile_m(M: int, N: int, batch: int = 1, min_tm: int = 64) -> int:
     return best[1]
 
 
-_PH_LAUNCH_COST = 30          # a second launch in the units of _ph_tile_m's cost model (a round of 256-row tiles = 320 ~ 42 us)
-
-
-def _ph_row_plan(M: int, N: int):
-    """Row segments [(first row, rows, rows per tile)] of a long GEMM on the phase-pipelined kernel.  One launch walks whole
-    rounds of one-tile-per-CU work and its LAST round is as long as a full one however few tiles it holds (w_1 at the 30-minute
-    shape: 1 408 tiles of 256 rows on 256 CUs = 5.5 rounds, paid as 6).  When the model of _ph_tile_m says so, the rows are cut
-    in two: k full rounds of 256-row tiles, then the remainder at the tile height that fits ONE round (w_1: 5 rounds + 32 x 8
-    tiles of 128 rows; the GLU GEMM: 2 rounds + 64 x 4 tiles of 192 rows).  PAFC_PH_ROW_PLAN=0 keeps one launch (A/B)."""
-    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    nt = (N + 255) // 256
-
-    def cost(rows, tm):
-        return -(-(-(-rows // tm) * nt) // cus) * (tm + 64)
-    one_tm = min((256, 192, 128, 64), key=lambda tm: (cost(M, tm), -tm))
-    best = (cost(M, one_tm), [(0, M, one_tm)])
-    if os.environ.get("PAFC_PH_ROW_PLAN", "1") == "0" or cus % nt:
-        return best[1]
-    per_round = (cus // nt) * 256
-    for k in range(1, M // per_round + 1):
-        r0 = k * per_round
-        rem = M - r0
-        if rem <= 0:
-            break
-        tm = min((256, 192, 128, 64), key=lambda t: (cost(rem, t), -t))
-        c = k * 320 + _PH_LAUNCH_COST + cost(rem, tm)
-        if c < best[0]:
-            best = (c, [(0, r0, 256), (r0, rem, tm)])
-    return best[1]
-
-
 def gemm_ph_ex(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none", alpha: float = 1.0,
                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, a_split: bool = False,
                out_kind: str = "bf16", tile_m: int = 0, a_plane_block: int = 0) -> torch.Tensor:
@@ -906,16 +875,13 @@ def gemm_ph_ex(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         _lib._sig(L.pafc_gemm_ph_ex2, I, G, I, I, I, P, G, G, I, I, P, G, G, P, G, P, I, G, G, P, I, G, G, G, c_float, I, I, P)
         L._pafc_gemmex_bound = True
     from .profiling import op_timer
-    segments = [(0, M, int(tile_m))] if tile_m else _ph_row_plan(M, N)
     with op_timer("gemm%s_%dx%d" % ("3" if a_split else "", K, N), sample=12, flops=2.0 * M * N * K * (3 if a_split else 1)):
-        for r0, nr, tm in segments:
-            a_, o_ = (a, out) if nr == M else (a[r0:r0 + nr], out[r0:r0 + nr])
-            r_ = residual if (residual is None or nr == M) else residual[r0:r0 + nr]
-            rc = L.pafc_gemm_ph_ex2(nr, N, K, 1, _lib.ptr(a_), a.stride(0), 0, int(a_split), int(a_plane_block), _lib.ptr(w), w.stride(0), 0,
-                                    _lib.ptr(bias), 0,
-                                    _lib.ptr(r_), rk, residual.stride(0) if residual is not None else 0, 0, _lib.ptr(o_), ok,
-                                    out.stride(0), No if ok == 2 else 0, 0, float(alpha), _ACTS[act], tm, _lib.stream_of(a))
-            _lib.check(rc, "pafc_gemm_ph_ex")
+        rc = L.pafc_gemm_ph_ex2(M, N, K, 1, _lib.ptr(a), a.stride(0), 0, int(a_split), int(a_plane_block), _lib.ptr(w), w.stride(0), 0,
+                                _lib.ptr(bias), 0,
+                               _lib.ptr(residual), rk, residual.stride(0) if residual is not None else 0, 0, _lib.ptr(out), ok,
+                               out.stride(0), No if ok == 2 else 0, 0, float(alpha), _ACTS[act], int(tile_m or _ph_tile_m(M, N)),
+                               _lib.stream_of(a))
+    _lib.check(rc, "pafc_gemm_ph_ex")
     return out
 
 
