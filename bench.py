@@ -317,10 +317,12 @@ def windows_leg(model, feats, device, chunk: int = 2000, batch: int = 8, nstream
                                 "tokens": sum(len(w) for w in wm), "tokens_one_forward_per_batch": sum(len(w) for w in wl)}}
 
 
-def build_model(dtype: str, device):
+def build_model(dtype: str, device, **conf_overrides):
+    """The bench's model; conf_overrides change encoder_conf keys (tools/rtf_sweep.py: the paper's other models -- num_blocks
+    18 / 24 / 30, the uni-directional slot)."""
     from paper_accurate_fast_cheap_amd.utils.init_model import init_model
     torch.manual_seed(777)  # the trainer's seed, wenet/bin/train.py:71
-    configs = dict(encoder="conformer", encoder_conf=encoder_conf(), input_dim=80, output_dim=VOCAB, ctc="ctc",
+    configs = dict(encoder="conformer", encoder_conf=dict(encoder_conf(), **conf_overrides), input_dim=80, output_dim=VOCAB, ctc="ctc",
                    ctc_conf={"ctc_blank_id": 0}, model_conf={}, dataset_conf={})
 
     class Args:

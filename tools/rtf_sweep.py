@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
+MODEL_NAME = "rwkv_bi_12L-GPU"
 CHUNKS = [2000, 4000, 9000, 15000, 20000, 40000, 60000, 100000, 200000]
 BATCHES = [1, 4, 8, 10, 12, 14]
 
@@ -38,7 +39,7 @@ def table(records, key, fmt, title):
     batches = sorted({r["batch_size"] for r in records})
     cell = {(r["chunk_size"], r["batch_size"]): r for r in records}
     w = 12
-    lines = [f"### rwkv_bi_12L-GPU - {title}", "",
+    lines = [f"### {MODEL_NAME} - {title}", "",
              "|" + "Chunk Size".center(w + 2) + "|" + "".join(f"BS {b}".center(w + 2) + "|" for b in batches),
              "|" + "-" * (w + 2) + "|" + "".join("-" * (w + 2) + "|" for _ in batches)]
     for c in chunks:
@@ -60,6 +61,8 @@ def main():
     ap.add_argument("--batches", default=",".join(map(str, BATCHES)))
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "rtf_sweep"))
     ap.add_argument("--no-eager-check", action="store_true", help="skip the eager one-stream pass behind the token checksum")
+    ap.add_argument("--num-blocks", type=int, default=12, help="encoder layers: the paper sweeps 12 / 18 / 24 / 30 (go-run-encoder-rtf...sh:63-70)")
+    ap.add_argument("--direction", default="bi", choices=["bi", "uni"], help="bidirectional slot (rwkv_tmix60_bidirectional) or uni (rwkv_tmix60)")
     ap.add_argument("--merge-frames", type=int, default=0,
                     help="decode_windows(merge_frames=...): consecutive batches run as one launch of up to this many input frames "
                          "(0 = one forward per batch, the reference's literal schedule)")
@@ -69,7 +72,12 @@ def main():
     _lib.lib()
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
-    model, _ = bench.build_model(args.dtype, device)
+    over = dict(num_blocks=args.num_blocks)
+    if args.direction == "uni":     # conf/rwkv/giga.rwkv_uni_ds4k31nc_12le.*.yaml: same layer, one direction, non-causal conv k = 31
+        over.update(selfattention_layer_type="rwkv_tmix60", rnn_att_direction="uni")
+    model, _ = bench.build_model(args.dtype, device, **over)
+    global MODEL_NAME
+    MODEL_NAME = f"rwkv_{args.direction}_{args.num_blocks}L-GPU"
     wave = bench.synthetic_waveform(bench.AUDIO_SECONDS, 777)
     feats, _ = bench.front_end(wave, device)
     if args.dtype == "bf16":
@@ -87,6 +95,7 @@ def main():
     with open(args.out + ".jsonl", "w") as fj:
         head = {"one_sequence_ms": round(one_ms, 3), "one_sequence_audio_sec_per_sec": round(one_rate, 1), "dtype": args.dtype,
                 "precision": bench.PRECISION[args.dtype], "frames": frames, "streams": args.streams, "merge_frames": args.merge_frames,
+                "model": MODEL_NAME,
                 "device": torch.cuda.get_device_name(0)}
         fj.write(json.dumps(head) + "\n")
         fj.flush()
@@ -135,7 +144,7 @@ def main():
     enc.graph_cache_size = 0
     enc._graphs.clear()
     with open(args.out + ".md", "w") as fm:
-        fm.write(f"# Encoder RTF sweep, one MI355X, {bench.PRECISION[args.dtype]}\n\n"
+        fm.write(f"# Encoder RTF sweep, {MODEL_NAME}, one MI355X, {bench.PRECISION[args.dtype]}\n\n"
                  f"One synthetic 30-minute file ({frames} frames), `utils.longform.decode_windows` (encoder + CTC log-softmax + greedy "
                  f"tokens + stitching inside the timing), {args.streams} window batches in flight, "
                  + (f"consecutive batches merged into launches of up to {args.merge_frames} frames, " if args.merge_frames else
