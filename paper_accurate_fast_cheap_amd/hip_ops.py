@@ -1021,10 +1021,14 @@ class _LinearPlans:
     on a scratch output of the call's own shape.  PAFC_GEMM_TUNE=0 switches it off, PAFC_GEMM_TUNE_MIN_ROWS moves the
     threshold."""
     CAP = 1024
-    RETIRE_AT = 512
 
     def __init__(self, device):
-        self.device, self.retired = device, []
+        self.device = device
+        # retirement queue, oldest first: [plan, {raw stream: torch stream} it was launched on, events or None].  An evicted
+        # plan is destroyed once an event recorded on EVERY stream it was launched on (at eviction time, or at the first
+        # call after it that is not under graph capture) has completed -- checked with Event.query(), never waited for.
+        self.retired = []
+        self.used = {}          # plan address -> {raw stream handle: torch stream object} the plan has been launched on
         import os
         from collections import OrderedDict
         from ctypes import POINTER, byref, c_float, c_long
@@ -1044,12 +1048,39 @@ class _LinearPlans:
         self.ctx = c_void_p()
         with torch.cuda.device(device):
             _lib.check(L.pafc_gemm_ctx_create(byref(self.ctx)), "pafc_gemm_ctx_create")
-        # a plan's descriptor carries the CALL's bias pointer between pafc_linear_plan_run's write and its launch, and ctypes
-        # releases the GIL: one thread at a time per device (include/pafc_encoder_ops.h: "a plan is used by one thread at a time")
+        # pafc_linear_plan_run hands the CALL's bias pointer to the library inside the call; ctypes releases the GIL, so the table
+        # and a plan are used by one thread at a time per device (include/pafc_encoder_ops.h)
         import threading
         self.lock = threading.Lock()
         self.tune = os.environ.get("PAFC_GEMM_TUNE", "1") != "0"
         self.tune_min_rows = DISPATCH["gemm_tune_min_rows"]
+
+    def note_launch(self, plan, raw_stream: int) -> None:
+        """`plan` is about to be launched on torch's current stream (raw handle given): remembered until the plan retires."""
+        on = self.used.setdefault(plan.value, {})
+        if raw_stream not in on:
+            on[raw_stream] = torch.cuda.current_stream(self.device)
+
+    def _reap(self) -> None:
+        """Destroy retired plans whose streams have all passed their events; stamp the ones retired under capture.  Never blocks."""
+        if not self.retired or torch.cuda.is_current_stream_capturing():
+            return
+        keep = []
+        for ent in self.retired:
+            plan, streams, events = ent
+            if events is None:
+                events = ent[2] = [self._mark(st) for st in streams.values()]
+            if all(e.query() for e in events):
+                self.L.pafc_linear_plan_destroy(plan)
+            else:
+                keep.append(ent)
+        self.retired = keep
+
+    @staticmethod
+    def _mark(stream):
+        e = torch.cuda.Event()
+        e.record(stream)
+        return e
 
     def get(self, key):
         plan = self.plans.get(key)
@@ -1063,25 +1094,20 @@ class _LinearPlans:
             return None
         _lib.check(rc, "pafc_linear_plan_create")
         self.plans[key] = plan
+        capturing = torch.cuda.is_current_stream_capturing()
         while len(self.plans) > self.CAP:
             _, old = self.plans.popitem(last=False)
-            if old is not None:
-                self.retired.append(old)
-        if len(self.retired) >= self.RETIRE_AT and not torch.cuda.is_current_stream_capturing():
-            # An evicted plan may still have launches queued on ANY stream (decode batches in flight on side streams; the
-            # host runs batches ahead of the device): its library objects are destroyed only behind a device-wide synchronize,
-            # and that rarely -- every RETIRE_AT evictions.  (Round 5: a ragged fp32 pass of 630 distinct problems against a
-            # table of 256 -- plans created and destroyed under queued work all the time -- never finished its second pass in
-            # three runs out of four; nothing else in that path has a lifetime that ends while the device is behind.)
-            torch.cuda.synchronize(self.device)
-            for old in self.retired:
-                self.L.pafc_linear_plan_destroy(old)
-            self.retired.clear()
+            if old is None:
+                continue
+            streams = self.used.pop(old.value, {})
+            # the launches of `old` that are still queued sit in front of these events on their streams
+            self.retired.append([old, streams, None if capturing else [self._mark(st) for st in streams.values()]])
+        self._reap()
         return plan
 
     def __del__(self):
         try:
-            for plan in list(self.plans.values()) + self.retired:
+            for plan in list(self.plans.values()) + [ent[0] for ent in self.retired]:
                 if plan is not None:
                     self.L.pafc_linear_plan_destroy(plan)
             self.L.pafc_gemm_ctx_destroy(self.ctx)
@@ -1140,6 +1166,7 @@ def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
             _lib.check(L.pafc_linear_plan_tune(plan, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(scratch),
                                                float(alpha), _lib.ptr(residual), 16, stream), "pafc_linear_plan_tune")
             del scratch
+        plans.note_launch(plan, stream.value or 0)
         with op_timer("linear_%dx%d" % (K, N), sample=12, flops=2.0 * rows * N * K):
             rc = L.pafc_linear_plan_run(plan, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out), float(alpha),
                                         _lib.ptr(residual), stream)

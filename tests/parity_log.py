@@ -1,6 +1,6 @@
 """Driver-visible record of what the GPU parity tests measured (pytest -q drops their prints): per test max / mean |err|,
 max |dlogp|, flipped frames and the largest reference margin among them.  Written at session end to
-profiles/parity_r05.json and, because only gpurun_out/ travels back from a GPU box, to gpurun_out/parity_r05.json as
+profiles/parity_r06.json and, because only gpurun_out/ travels back from a GPU box, to gpurun_out/parity_r06.json as
 well; entries of earlier (partial) runs are kept, same-named ones replaced."""
 import json
 import os
@@ -23,7 +23,7 @@ def flush():
     meta = {"written": time.strftime("%Y-%m-%d %H:%M:%S"),
             "device": torch.cuda.get_device_name(0) if torch.cuda.is_available() else "cpu"}
     for d in ("profiles", "gpurun_out"):
-        path = os.path.join(ROOT, d, "parity_r05.json")
+        path = os.path.join(ROOT, d, "parity_r06.json")
         try:
             os.makedirs(os.path.dirname(path), exist_ok=True)
             try:

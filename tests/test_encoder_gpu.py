@@ -612,6 +612,87 @@ def test_bf16slot_full_size_five_minute_file_headline_schedule_vs_oracle(hip, mo
     assert changes > 100 and flipped <= 0.01 * float(valid.sum()), (flipped, changes)
 
 
+def test_bf16slot_thirty_minute_file_vs_oracle(hip, monkeypatch):
+    """The headline itself: `bench.build_model("bf16slot")` (fp32 model, bf16 time-mix slot, the 5000-way CTC head), the bench's
+    own synthetic 30-minute file through the HIP fbank (T = 179 998 -> 44 998 frames) as ONE sequence, through
+    `_forward_encoder` + `ctc_logprobs` exactly as `bench.py`'s timed step calls them (encoder-rtf.py:499-509), on the package's
+    default dispatch -- nothing patched but a spy that records which schedule each layer took -- against the oracle on the WHOLE
+    file in the same precision (one pass of `EO.encoder_forward` + `ctc_log_softmax` over all 179 998 frames on the host: about
+    a minute on the GPU box's cores).  Element-wise at the 5-minute test's bounds, masks exact, tokens through the model's own
+    5000-way head by the margin rule and through the deciding one-component head by flipped frames (<= 1 %).  This is the only
+    place the split-operand GEMMs at 44 998 rows, conv2 over the 7.2 GB plane image (854 962 rows, ragged last tile) and the
+    fp32 log-softmax at 44 998 x 5000 are compared with anything inside the model."""
+    import time
+    import bench
+    from paper_accurate_fast_cheap_amd.transformer import fused
+    from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+    dev = torch.device("cuda")
+    model, configs = bench.build_model("bf16slot", dev)
+    conf = configs["encoder_conf"]
+    wave = bench.synthetic_waveform(bench.AUDIO_SECONDS, 777)
+    feats, _ = bench.front_end(wave, dev)
+    assert feats.shape == (1, bench.FRAMES, 80) and feats.dtype == torch.float32
+    lens = torch.tensor([bench.FRAMES], dtype=torch.int32, device=dev)
+    ran = []
+    real = fused.layer_forward_split
+    monkeypatch.setattr(fused, "layer_forward_split", lambda plan, x, hp, lens_, *a: (ran.append(lens_ is None), real(plan, x, hp, lens_, *a))[1])
+    with torch.no_grad():
+        out, masks = model._forward_encoder(feats, lens)
+        logp = model.ctc_logprobs(out)
+        torch.cuda.synchronize()
+        out2, _ = model._forward_encoder(feats, lens)              # a second pass on the warm plans: the timed steps' state
+        logp2 = model.ctc_logprobs(out2)
+    assert len(ran) == 24 and all(ran)                             # 12 layers x 2 passes, all on the unmasked split-operand schedule
+    assert torch.equal(out, out2) and torch.equal(logp, logp2)     # run-to-run deterministic
+    assert out.shape == (1, 44998, 512) and out.dtype == torch.float32 and logp.shape == (1, 44998, bench.VOCAB)
+    out, logp = out.cpu(), logp.float().cpu()
+    del out2, logp2
+    # the oracle over the whole file (same state dict handling as bench.cpu_baseline)
+    sd = {k: v.detach().float().cpu() for k, v in model.encoder.state_dict().items()}
+    for k in list(sd):
+        if ".tmix_block." in k and conf.get("rwkv_do_bfloat16", True):
+            sd[k] = sd[k].to(torch.bfloat16)
+    csd = {"ctc." + k: v.detach().float().cpu() for k, v in model.ctc.state_dict().items()}
+    xs = feats.cpu()
+    t0 = time.time()
+    with torch.no_grad():
+        ref, ref_masks = EO.encoder_forward(xs, torch.tensor([bench.FRAMES]), sd, conf, env={})
+        ref_logp = EO.ctc_log_softmax(ref, csd)
+    oracle_s = time.time() - t0
+    assert torch.equal(masks.cpu(), ref_masks) and int(ref_masks.sum()) == 44998
+    valid = ref_masks.squeeze(1)
+    d = (out[valid] - ref[valid]).abs()
+    what = "bf16slot 30-minute file (the headline), default schedule"
+    parity_log.record(what, max_abs_err=float(d.max()), mean_abs_err=float(d.mean()), frames=int(valid.sum()),
+                      ref_abs_max=float(ref.abs().max()), oracle_seconds=round(oracle_s, 1), oracle_threads=torch.get_num_threads())
+    print(f"[bf16slot 30-minute file] max {float(d.max()):.4g} mean {float(d.mean()):.4g} (oracle {oracle_s:.0f} s)")
+    # by quarter of the file: an indexing error late in the 7.2 GB image or in the last tiles would show as a jump
+    q = [float((out[0, a:b] - ref[0, a:b]).abs().mean()) for a, b in ((0, 11250), (11250, 22500), (22500, 33750), (33750, 44998))]
+    tail = float((out[0, -256:] - ref[0, -256:]).abs().max())
+    parity_log.record(what, mean_abs_err_by_quarter=[round(v, 6) for v in q], max_abs_err_last_256_frames=tail)
+    assert float(d.mean()) <= 1.5e-2 and float(d.max()) <= 0.22     # the 5-minute test's bounds
+    assert max(q) <= 2.0 * min(q) + 1e-3 and tail <= 0.22
+    _token_parity(logp, ref_logp, valid, 0.12, what)
+    # the deciding head: sign of the leading principal component of the oracle's output
+    X = ref[valid]
+    mu = X.mean(0)
+    _, _, V = torch.pca_lowrank(X - mu, q=8, center=False, niter=4)
+    W = torch.zeros(16, 512)
+    W[1], W[2] = V[:, 0], -V[:, 0]
+    b = -(W @ mu)
+    b[3:] = -60.0
+    head = CTC(16, 512)
+    head.load_state_dict({"ctc_lo.weight": W, "ctc_lo.bias": b})
+    with torch.no_grad():
+        lp_hip = head.cuda().eval().log_softmax(out.cuda()).float().cpu()
+    lp_ref = EO.ctc_log_softmax(ref, {"ctc.ctc_lo.weight": W, "ctc.ctc_lo.bias": b})
+    flipped = int(((lp_hip.argmax(-1) != lp_ref.argmax(-1)) & valid).sum())
+    changes = int(((lp_ref.argmax(-1)[:, 1:] != lp_ref.argmax(-1)[:, :-1]) & valid[:, 1:]).sum())
+    parity_log.record(what, deciding_head_frames_flipped=flipped, deciding_head_token_changes=changes)
+    print(f"[bf16slot 30-minute file] deciding head: {flipped} of {int(valid.sum())} frames flipped, {changes} token changes")
+    assert changes > 1000 and flipped <= 0.01 * float(valid.sum()), (flipped, changes)
+
+
 def test_bf16slot_token_lists_through_a_head_that_decides(hip):
     """Token LISTS in the reference's own precision (fp32 model + bf16 slot, the bench headline) through a head that decides.
     A c2-shaped ragged batch of 24 utterances (1-6 s) through the full-size 12-layer model; the CTC head reads the leading

@@ -160,6 +160,63 @@ def test_linear_plans_are_bounded_explicit_and_capture_safe(hip, monkeypatch):
     hip_ops._linear_plans.pop(dev, None)                          # plans and context are destroyed with their owner
 
 
+def test_linear_plan_churn_with_two_streams_in_flight(hip, monkeypatch):
+    """Plan churn under queued work (round 5's c2 stall was first blamed on it; tools/repro_plan_churn.py has the diagnosis):
+    far more distinct fp32 problems than the table holds, two side streams in flight, nothing waited for inside the passes --
+    every evicted plan retires behind events on the streams it was launched on and is destroyed by a later call once they have
+    completed.  Results of every pass equal those of a pass that never evicts; the retirement queue drains; every evicted plan
+    is destroyed exactly once."""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev).manual_seed(11)
+    x_all = torch.randn(4096, 512, device=dev, generator=g)
+    w1, b1 = torch.randn(1024, 512, device=dev, generator=g) / 23, torch.randn(1024, device=dev, generator=g)
+    w2, b2 = torch.randn(512, 1024, device=dev, generator=g) / 32, torch.randn(512, device=dev, generator=g)
+    rows = [64 * t for t in range(3, 63)]                          # 60 row counts x 2 problems = 120 distinct plans
+    side = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def one_pass():
+        main = torch.cuda.current_stream()
+        for s_ in side:
+            s_.wait_stream(main)
+        outs = []
+        for i, m in enumerate(rows):
+            with torch.cuda.stream(side[i % 2]):
+                h = hip_ops.linear_bias_act(x_all[:m], w1, b1, "silu")
+                outs.append(hip_ops.linear_bias_act(h, w2, b2, "none", alpha=0.5, residual=x_all[:m]))
+        for s_ in side:
+            main.wait_stream(s_)
+        return outs
+
+    hip_ops._linear_plans.pop(dev, None)
+    monkeypatch.setattr(hip_ops._LinearPlans, "CAP", 1 << 20)
+    want = one_pass()                                              # never evicts
+    torch.cuda.synchronize()
+    assert not hip_ops._linear_plans[dev].retired
+    hip_ops._linear_plans.pop(dev, None)
+    monkeypatch.setattr(hip_ops._LinearPlans, "CAP", 16)
+    plans = hip_ops._linear_plans[dev] = hip_ops._LinearPlans(dev)
+    created, destroyed = [], []
+    real_create, real_destroy = plans.L.pafc_linear_plan_create, plans.L.pafc_linear_plan_destroy
+    counted = type("L", (), {})()
+    for name in dir(plans.L):
+        if name.startswith("pafc_"):
+            setattr(counted, name, getattr(plans.L, name))
+    counted.pafc_linear_plan_create = lambda *a: (created.append(1), real_create(*a))[1]
+    counted.pafc_linear_plan_destroy = lambda q: (destroyed.append(1), real_destroy(q))[1]
+    plans.L = counted
+    for p in range(3):
+        got = one_pass()                                           # (the host runs ahead of the device inside a pass)
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    assert len(plans.plans) == 16 and len(created) == 3 * 120     # a cyclic workload misses every time in an LRU table
+    hip_ops.linear_bias_act(x_all[:7], w1, b1, "silu")            # a miss after the synchronize: reaps everything that was queued
+    assert len(created) - 16 == len(destroyed) + len(plans.retired)
+    assert len(plans.retired) <= 1, len(plans.retired)             # (at most the plan this very call evicted)
+    hip_ops._linear_plans.pop(dev, None)
+
+
 @pytest.mark.parametrize("B,T,C,nd", [(2, 37, 128, 2), (2, 2101, 128, 2), (1, 4099, 64, 1)])
 def test_lora_mix4_fused_equals_two_step(hip, B, T, C, nd):
     """pafc_tmix_lora_mix4_bf16 (LoRA up-projection on MFMA inside the lerp pass) vs bmm + pafc_tmix_mix4; from 256 row tiles
@@ -986,6 +1043,119 @@ def test_gemm_split_operand_forms(hip, M, N, K):
     ab, wb = a.bfloat16(), w.bfloat16()
     got = gemm_ph_ex(ab, wb, None, residual=r, out_kind="f32")
     torch.testing.assert_close(got.double(), ab.double() @ wb.double().t() + r.double(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("form", ["w_1 planes+SiLU", "w_2 residual", "w_2 residual in place", "pointwise_conv1 GLU",
+                                  "pointwise_conv2 residual in place", "slot output bf16 operands", "CTC head",
+                                  "Linear(9728,512) plane blocks"])
+def test_gemm_split_forms_at_the_production_shape(hip, form):
+    """Every split-operand form the headline (fp32 model + bf16 slot, fused.layer_forward_split / the subsampling Linear / the
+    CTC head) launches, at ITS row count M = 44 998 (175 full 256-row tiles + a ragged one of 198 rows) -- through the same
+    entry point with the same arguments -- against a float64 product of the same fp32 operands on the GPU.  Error of 16-bit
+    significands (three bf16 products per fp32 product), not of bf16; 64 guard rows behind every output stay untouched."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_ph_ex, glu_interleave, split_planes
+    from tests import parity_log
+    M, dev = 44998, "cuda"
+    g = torch.Generator(device=dev).manual_seed(4321)
+    rnd = lambda *s, scale=1.0: torch.randn(*s, device=dev, generator=g) * scale
+    tol = dict(rtol=1e-4, atol=1e-4)
+
+    def guarded(cols, dtype, fill=None):
+        buf = torch.full((M + 64, cols), 7.0, device=dev, dtype=dtype)
+        if fill is not None:
+            buf[:M] = fill
+        return buf
+
+    def check(got, want, buf, name=form, **kw):
+        d = (got.double() - want).abs()
+        parity_log.record(f"split gemm M=44998/{name}", max_abs_err=float(d.max()), mean_abs_err=float(d.mean()),
+                          want_abs_max=float(want.abs().max()), last_tile_max_abs_err=float(d[175 * 256:].max()))
+        torch.testing.assert_close(got.double(), want, **(kw or tol))
+        assert bool((buf[M:] == 7.0).all()), "rows behind the matrix were written"
+
+    if form == "w_1 planes+SiLU":
+        a, w, b = rnd(M, 512), rnd(2048, 512, scale=512 ** -0.5), rnd(2048, scale=0.3)
+        buf = guarded(4096, torch.bfloat16)
+        got = gemm_ph_ex(split_planes(a), split_planes(w, triple=True), b, "silu", out=buf[:M], a_split=True, out_kind="planes")
+        check(_planes_value(got), F.silu(a.double() @ w.double().t() + b.double()), buf)
+    elif form.startswith("w_2 residual"):
+        a, w, b, r = rnd(M, 2048), rnd(512, 2048, scale=2048 ** -0.5), rnd(512, scale=0.3), rnd(M, 512)
+        want = 0.5 * (a.double() @ w.double().t()) + b.double() + r.double()
+        if form.endswith("in place"):
+            buf = guarded(512, torch.float32, r)
+            got = gemm_ph_ex(split_planes(a), split_planes(w, triple=True), b, alpha=0.5, residual=buf[:M], out=buf[:M], a_split=True, out_kind="f32")
+        else:
+            buf = guarded(512, torch.float32)
+            got = gemm_ph_ex(split_planes(a), split_planes(w, triple=True), b, alpha=0.5, residual=r, out=buf[:M], a_split=True, out_kind="f32")
+        check(got, want, buf)
+    elif form == "pointwise_conv1 GLU":
+        a, w, b = rnd(M, 512), rnd(1024, 512, scale=512 ** -0.5), rnd(1024, scale=0.3)
+        buf = guarded(512, torch.float32)
+        got = gemm_ph_ex(split_planes(a), split_planes(glu_interleave(w, 32), triple=True), glu_interleave(b, 32), "glu", out=buf[:M],
+                         a_split=True, out_kind="f32")
+        check(got, F.glu(a.double() @ w.double().t() + b.double(), dim=-1), buf)
+    elif form == "pointwise_conv2 residual in place":
+        a, w, b, r = rnd(M, 512), rnd(512, 512, scale=512 ** -0.5), rnd(512, scale=0.3), rnd(M, 512)
+        buf = guarded(512, torch.float32, r)
+        got = gemm_ph_ex(split_planes(a), split_planes(w, triple=True), b, residual=buf[:M], out=buf[:M], a_split=True, out_kind="f32")
+        check(got, a.double() @ w.double().t() + b.double() + r.double(), buf)
+    elif form == "slot output bf16 operands":
+        a, w, r = rnd(M, 1024).bfloat16(), rnd(512, 1024, scale=1024 ** -0.5).bfloat16(), rnd(M, 512)
+        buf = guarded(512, torch.float32, r)
+        got = gemm_ph_ex(a, w, None, residual=buf[:M], out=buf[:M], out_kind="f32")
+        check(got, a.double() @ w.double().t() + r.double(), buf, rtol=1e-5, atol=1e-5)
+    elif form == "CTC head":
+        a, w, b = rnd(M, 512), rnd(5000, 512, scale=512 ** -0.5), rnd(5000, scale=0.3)
+        buf = guarded(5000, torch.float32)
+        got = gemm_ph_ex(split_planes(a), split_planes(w, triple=True), b, out=buf[:M], a_split=True, out_kind="f32")
+        check(got, a.double() @ w.double().t() + b.double(), buf)
+    else:
+        Fp, C = 19, 512       # conv2's output pixels as [hi C | lo C] blocks: the A operand of the subsampling Linear (K = 9 728)
+        a, w, b = rnd(M, Fp * C, scale=0.5), rnd(512, Fp * C, scale=(Fp * C) ** -0.5), rnd(512, scale=0.3)
+        ap = split_planes(a.view(M * Fp, C)).view(M, Fp * 2 * C)
+        buf = guarded(512, torch.float32)
+        got = gemm_ph_ex(ap, split_planes(w, triple=True), b, out=buf[:M], a_split=True, out_kind="f32", a_plane_block=C)
+        check(got, a.double() @ w.double().t() + b.double(), buf, rtol=2e-4, atol=2e-4)
+
+
+def test_conv_sub_split_at_the_thirty_minute_image(hip):
+    """The subsampling convolutions of the headline at the 30-minute file's size: x (1, 179 998, 80) -> conv1 planes (89 998 x 39
+    pixels x 1 024 bf16 = the 7.2 GB image) -> conv2 as the split-operand implicit GEMM over 44 998 x 19 = 854 962 output rows
+    (3 339 full 256-row tiles + a ragged one; 64-bit per-tile rebased descriptors) -- against float64 torch convolutions of the
+    same fp32 operands on WINDOWS of output frames: the first ones, the ones on either side of 2^31 and 2^32 bytes into the image,
+    random ones, and the last 300 frames (the ragged tile and the frames before it)."""
+    from paper_accurate_fast_cheap_amd.hip_ops import conv_sub_f32split_planes, split_planes
+    from tests import parity_log
+    C, T, dev = 512, 179998, "cuda"
+    g = torch.Generator(device=dev).manual_seed(77)
+    x = torch.randn(1, T, 80, device=dev, generator=g) * 2.0
+    w1 = torch.randn(C, 1, 3, 3, device=dev, generator=g) / 3
+    b1 = torch.randn(C, device=dev, generator=g) * 0.1
+    w2 = torch.randn(C, C, 3, 3, device=dev, generator=g) / (3 * C ** 0.5)
+    b2 = torch.randn(C, device=dev, generator=g) * 0.1
+    taps3 = split_planes(w2.permute(2, 3, 0, 1).reshape(9, C, C).contiguous(), triple=True)
+    y = conv_sub_f32split_planes(x, w1, b1, taps3, b2)
+    T2 = ((T - 3) // 2 + 1 - 3) // 2 + 1
+    assert T2 == 44998 and y.shape == (1, T2, 19, 2 * C) and y.dtype == torch.bfloat16
+    row_bytes1 = 39 * 2 * C * 2                                     # one conv1 frame of the plane image
+    starts = {0, T2 - 300}
+    for edge in (2 ** 31, 2 ** 32, 3 * 2 ** 31):                    # output frames whose inputs straddle these image offsets
+        starts.add(max(0, edge // row_bytes1 // 2 - 20))
+    gen = torch.Generator().manual_seed(5)
+    starts |= {int(s) for s in torch.randint(0, T2 - 300, (5,), generator=gen)}
+    worst = 0.0
+    w1d, b1d, w2d, b2d = w1.double().cpu(), b1.double().cpu(), w2.double().cpu(), b2.double().cpu()   # float64 on the host
+    for a in sorted(starts):
+        n = 300 if a == T2 - 300 else 64
+        xin = x[:, 4 * a:4 * (a + n - 1) + 7].double().unsqueeze(1).cpu()            # frames the window's outputs read
+        ref = F.relu(F.conv2d(F.relu(F.conv2d(xin, w1d, b1d, stride=2)), w2d, b2d, stride=2)).permute(0, 2, 3, 1)
+        assert ref.shape == (1, n, 19, C)
+        got = (y[:, a:a + n, :, :C].double() + y[:, a:a + n, :, C:].double()).cpu()
+        d = float((got - ref).abs().max())
+        worst = max(worst, d)
+        torch.testing.assert_close(got, ref, rtol=2e-4, atol=2e-4, msg=lambda m, a=a: f"output frames from {a}: {m}")
+    parity_log.record("conv2 split at the 30-minute image", windows=len(starts), max_abs_err=worst, output_rows=T2 * 19)
+    assert bool(torch.isfinite(y.float()).all())
 
 
 @pytest.mark.parametrize("B,T,C", [(2, 203, 256), (1, 1203, 512)])
