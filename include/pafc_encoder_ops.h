@@ -292,6 +292,9 @@ int pafc_linear_plan_run(pafc_linear_plan *plan, const void *x, const void *weig
 int pafc_linear_plan_tune(pafc_linear_plan *plan, const void *x, const void *weight, const void *bias, void *scratch_out,
                           float alpha, const void *residual, int max_candidates, pafc_stream_t stream);
 int pafc_linear_plan_is_tuned(const pafc_linear_plan *plan);
+/* Diagnostics: the library's name of the kernel the plan launches, NUL-terminated into buf (truncated to cap - 1 characters);
+ * returns the library's solution index, or a negative error code. */
+int pafc_linear_plan_kernel_name(pafc_linear_plan *plan, char *buf, int cap);
 
 /* Glue of the Mamba-2 block around the chunked scan (restated from the published block -- the reference only wraps the
  * third-party mamba_ssm Mamba2: mamba_att_wrapper.py:24-35, mamba2_bidirectional.py:12-36; PARITY UNPINNED; headdim 64,

@@ -32,8 +32,11 @@
 // workspace candidates, ever.
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
+#include <hipblaslt/hipblaslt-ext.hpp>
 
+#include <cstring>
 #include <new>
+#include <string>
 
 #include "../../include/pafc_encoder_ops.h"
 
@@ -204,5 +207,13 @@ int pafc_linear_plan_tune(pafc_linear_plan *p, const void *x, const void *weight
 }
 
 int pafc_linear_plan_is_tuned(const pafc_linear_plan *p) { return p ? p->tuned : 0; }
+
+int pafc_linear_plan_kernel_name(pafc_linear_plan *p, char *buf, int cap) {
+    if (!p || !buf || cap < 1) return PAFC_ERR_NULL_POINTER;
+    const std::string name = hipblaslt_ext::getKernelNameFromAlgo(p->ctx->handle, p->algo);
+    std::strncpy(buf, name.c_str(), (size_t)cap - 1);
+    buf[cap - 1] = 0;
+    return hipblaslt_ext::getIndexFromAlgo(p->algo);
+}
 
 }  // extern "C"

@@ -471,7 +471,7 @@ def _param_as(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 _shadows_t = {}    # id(parameter) -> [weak reference, bf16 copy of the TRANSPOSED matrix (K, N), (param epoch, version) of the copy]
-_tr_table = None   # (signature, device table of pafc_multi_transpose_bf16 descriptors, n, total tiles)
+_tr_table = None   # {device: (signature, device table of pafc_multi_transpose_bf16 descriptors, n, total tiles)}
 
 
 def _bf16_shadow_t(w: torch.Tensor) -> torch.Tensor:
@@ -499,8 +499,10 @@ def _bf16_shadow_t(w: torch.Tensor) -> torch.Tensor:
 
 
 def _refresh_transposed_shadows() -> None:
+    """One pafc_multi_transpose_bf16 launch per DEVICE that holds registered parameters (descriptor table and launch on that
+    device, on its current stream)."""
     global _tr_table
-    live = []
+    by_dev = {}
     for key in list(_shadows_t):
         p = _shadows_t[key][0]()
         sh = _shadows_t[key][1]
@@ -509,26 +511,30 @@ def _refresh_transposed_shadows() -> None:
             del _shadows_t[key]
             _tr_table = None
         else:
-            live.append((p, sh))
+            by_dev.setdefault(p.device, []).append((p, sh))
             _shadows_t[key][2] = (_param_epoch, p._version)
-    if not live:
+    if not by_dev:
         return
-    sig = tuple((p.data_ptr(), sh.data_ptr(), p.dtype) for p, sh in live)
-    if _tr_table is None or _tr_table[0] != sig:
-        rows, t0 = [], 0
-        for p, sh in live:
-            k_, n_ = sh.shape                  # the copy is (K, N); the parameter (N, K) or a reshaping view target of it
-            # { src, dst, rows | cols << 32, src_f32 | tile0 << 32 } as four little-endian 64-bit words = the 32-byte descriptor
-            rows.append([p.data_ptr(), sh.data_ptr(), n_ | (k_ << 32), int(p.dtype == torch.float32) | (t0 << 32)])
-            t0 += ((n_ + 63) // 64) * ((k_ + 63) // 64)
-        tab = torch.tensor(rows, dtype=torch.int64).to(live[0][0].device)
-        _tr_table = (sig, tab, len(live), t0)
+    if _tr_table is None:
+        _tr_table = {}
     L = _bind()
     if not getattr(L, "_pafc_mtr_bound", False):
         _lib._sig(L.pafc_multi_transpose_bf16, c_int, c_void_p, c_int, c_int, c_void_p)
         L._pafc_mtr_bound = True
-    _, tab, n, tiles = _tr_table
-    _lib.check(L.pafc_multi_transpose_bf16(_lib.ptr(tab), n, tiles, _lib.stream_of(tab)), "pafc_multi_transpose_bf16")
+    for dev, live in by_dev.items():
+        sig = tuple((p.data_ptr(), sh.data_ptr(), p.dtype) for p, sh in live)
+        ent = _tr_table.get(dev)
+        if ent is None or ent[0] != sig:
+            rows, t0 = [], 0
+            for p, sh in live:
+                k_, n_ = sh.shape                  # the copy is (K, N); the parameter (N, K) or a reshaping view target of it
+                # { src, dst, rows | cols << 32, src_f32 | tile0 << 32 } as four little-endian 64-bit words = the 32-byte descriptor
+                rows.append([p.data_ptr(), sh.data_ptr(), n_ | (k_ << 32), int(p.dtype == torch.float32) | (t0 << 32)])
+                t0 += ((n_ + 63) // 64) * ((k_ + 63) // 64)
+            ent = _tr_table[dev] = (sig, torch.tensor(rows, dtype=torch.int64).to(dev), len(live), t0)
+        _, tab, n, tiles = ent
+        with torch.cuda.device(dev):
+            _lib.check(L.pafc_multi_transpose_bf16(_lib.ptr(tab), n, tiles, _lib.stream_of(tab)), "pafc_multi_transpose_bf16")
 
 
 def refresh_train_shadows() -> None:
@@ -576,7 +582,9 @@ class _LinearTrainBf16(torch.autograd.Function):
         wb = _bf16_shadow(weight)
         bb = None if bias is None else _bf16_shadow(bias)
         ctx.save_for_backward(x, wb)
-        ctx.weight = weight if isinstance(_param_of(weight), torch.nn.Parameter) else None
+        # the kept W^T copies are only known to be current inside train_shadows() (refreshed on entry, whatever the optimizer did
+        # to Tensor._version); a forward pass outside it cast the weight fresh, so its backward transposes THAT copy
+        ctx.weight = weight if (_shadows_on and isinstance(_param_of(weight), torch.nn.Parameter)) else None
         ctx.w_dtype = weight.dtype
         ctx.b_dtype = None if bias is None else bias.dtype
         N, K = wb.shape
@@ -600,6 +608,8 @@ class _LinearTrainBf16(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if train_gemms_own() and N % 64 == 0 and K % 8 == 0 and ctx.weight is not None and _own_gemm_rows(dy2):
                 dx = gemm_bf16(dy2, _bf16_shadow_t(ctx.weight)).view(x.shape)      # dY (M, N) x (W^T)(K, N)^T
+            elif train_gemms_own() and N % 64 == 0 and K % 8 == 0 and _own_gemm_rows(dy2) and wb.dtype == torch.bfloat16:
+                dx = gemm_bf16(dy2, wb.detach().t().contiguous()).view(x.shape)    # the forward's own copy, transposed now
             else:
                 dx = (dy2 @ wb).view(x.shape)
         want_b = ctx.b_dtype is not None and ctx.needs_input_grad[2]
@@ -626,9 +636,12 @@ class _MatmulTrainBf16(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         K, N = weight.shape
         x2 = x.reshape(-1, K)
-        if (train_gemms_own() and K % 64 == 0 and N % 8 == 0 and _own_gemm_rows(x2)
-                and isinstance(_param_of(weight), torch.nn.Parameter)):
-            return gemm_bf16(x2, _bf16_shadow_t(weight)).view(x.shape[:-1] + (N,))       # (M, K) x (W^T)(N, K)^T
+        if train_gemms_own() and K % 64 == 0 and N % 8 == 0 and _own_gemm_rows(x2):
+            if _shadows_on and isinstance(_param_of(weight), torch.nn.Parameter):
+                wt = _bf16_shadow_t(weight)                 # kept beside the parameter, refreshed when train_shadows() was entered
+            else:
+                wt = weight.detach().t().contiguous()       # outside the step's context nothing vouches for a kept copy
+            return gemm_bf16(x2, wt).view(x.shape[:-1] + (N,))                           # (M, K) x (W^T)(N, K)^T
         return x @ weight
 
     @staticmethod
@@ -1213,6 +1226,14 @@ class DerivedFill:
             self.event.record(st)
             self.seen.add(st.cuda_stream)
 
+    # an event belongs to the process and stream that recorded it: a copy (copy.deepcopy of a model for EMA / averaging,
+    # pickling for spawn / torch.save) starts empty -- its tensors are copies that nobody is still filling
+    def __deepcopy__(self, memo):
+        return _empty_fill()
+
+    def __reduce__(self):
+        return (_empty_fill, ())
+
     def use(self, device=None) -> None:
         if self.event is None:
             return
@@ -1223,6 +1244,12 @@ class DerivedFill:
         torch.cuda.current_stream(device).wait_event(self.event)
         self.seen.add(raw)
 
+
+
+def _empty_fill() -> DerivedFill:
+    f = DerivedFill.__new__(DerivedFill)
+    f.event, f.seen = None, set()
+    return f
 
 
 def split_weight_cached(weight: torch.Tensor) -> torch.Tensor:
@@ -1242,9 +1269,11 @@ def split_weight_cached(weight: torch.Tensor) -> torch.Tensor:
     return ent[1]
 
 
-def linear_fused(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: str = "none") -> torch.Tensor:
+def linear_fused(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: str = "none",
+                 split_ok: bool = True) -> torch.Tensor:
     """act(x @ weight.T + bias) with the epilogue fused: bf16 operands on the hand-written GEMM (K % 64 == 0, N % 8 == 0),
-    long fp32 inputs on the same kernel with split operands, anything else on the library GEMM."""
+    long fp32 inputs on the same kernel with split operands (unless split_ok is False: a pure-fp32 model's exact products),
+    anything else on the library GEMM."""
     N, K = weight.shape
     rows = x.numel() // K
     if (x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_cuda and weight.is_contiguous()
@@ -1253,7 +1282,7 @@ def linear_fused(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     if x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and K % 64 == 0 and N % 8 == 0:
         return gemm_bf16(x.reshape(-1, K), weight, bias, act).view(x.shape[:-1] + (N,))
     if (x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_cuda and K % 128 == 0 and N % 8 == 0 and N >= 256
-            and rows >= _SPLIT_GEMM_MIN_ROWS and act == "none" and not torch.is_grad_enabled()
+            and rows >= _SPLIT_GEMM_MIN_ROWS and split_ok and act == "none" and not torch.is_grad_enabled()
             and (bias is None or bias.dtype == torch.float32)):
         planes = split_planes(x.reshape(rows, K) if x.is_contiguous() else x.reshape(rows, K).contiguous())
         return gemm_ph_ex(planes, split_weight_cached(weight), bias, a_split=True, out_kind="f32").view(x.shape[:-1] + (N,))

@@ -12,6 +12,9 @@ class CTC(torch.nn.Module):
         self.dropout_rate = dropout_rate
         self.ctc_lo = torch.nn.Linear(encoder_output_size, odim)
         self.ctc_loss = torch.nn.CTCLoss(blank=blank_id, reduction="sum" if reduce else "none", zero_infinity=True)
+        # long fp32 inputs: the head's product as split operands on the bf16 matrix cores (~2^-16 relative); init_model clears
+        # this for a pure-fp32 model (encoder.fp32_split_operands), which keeps exact fp32 products
+        self.fp32_split_operands = True
 
     def forward(self, hs_pad: torch.Tensor, hlens: torch.Tensor, ys_pad: torch.Tensor, ys_lens: torch.Tensor
                 ) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -27,7 +30,8 @@ class CTC(torch.nn.Module):
         if hs_pad.is_cuda and not torch.is_grad_enabled() and hs_pad.dtype in (torch.float32, torch.bfloat16) \
                 and hs_pad.dtype == self.ctc_lo.weight.dtype:
             from ..hip_ops import linear_fused, log_softmax_rows
-            logits = linear_fused(hs_pad.contiguous(), self.ctc_lo.weight, self.ctc_lo.bias, "none")
+            logits = linear_fused(hs_pad.contiguous(), self.ctc_lo.weight, self.ctc_lo.bias, "none",
+                                  split_ok=self.fp32_split_operands)
             return log_softmax_rows(logits, inplace=True)
         return F.log_softmax(self.ctc_lo(hs_pad), dim=2)
 

@@ -25,6 +25,11 @@ def _bump_epoch():
     hip_ops.bump_param_epoch()
 
 
+def _post_load_bump(module, incompatible_keys):
+    """load_state_dict post-hook (a module-level function: a lambda would make the module unpicklable)."""
+    _bump_epoch()
+
+
 def _capture_refused(e: BaseException) -> bool:
     """Is this the runtime refusing an operation under stream capture (hipErrorStreamCapture* -- a synchronising call, an
     allocation the graph pool cannot serve, a capture-unsafe library call), as opposed to an error of the work itself?"""
@@ -64,10 +69,20 @@ class BaseEncoder(torch.nn.Module):
         self.graph_cache_size = 0
         self._graphs = {}
         self._graphs_token = None              # the parameter state the cached graphs were captured on (_weights_token)
-        self._graph_all_full = None            # set while a graph is captured: the batch's rows are all full length (or not)
         self._wt_epoch, self._wt_tensors = None, []
         # a checkpoint load rewrites parameters in place (Tensor._version moves) and may be followed by anything: new epoch
-        self.register_load_state_dict_post_hook(lambda module, incompatible: _bump_epoch())
+        self.register_load_state_dict_post_hook(_post_load_bump)
+
+    # runtime state that is rebuilt on demand and must not travel with copy.deepcopy / pickle / torch.save of the module
+    # (captured hipGraphs, the fused executor's plans with their events and derived weight copies)
+    _TRANSIENT = dict(_fused_plan=None, _graphs=None, _graphs_token=None, _wt_epoch=None, _wt_tensors=None, _carry_last_fused=False)
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        for k, v in self._TRANSIENT.items():
+            if k in st:
+                st[k] = {} if k == "_graphs" else [] if k == "_wt_tensors" else v
+        return st
 
     def _fused(self, xs: torch.Tensor):
         """The fused executor's plan when this call may use it (no autograd, GPU, eligible layers), else None."""
@@ -141,7 +156,10 @@ class BaseEncoder(torch.nn.Module):
         # unmasked one; the file's last, padded batch: another graph).
         full = None
         if self._long_batch(xs):
-            full = bool(int(xs_lens.min()) == xs.shape[1])
+            # in SUBSAMPLED frames, as the eager pass decides it (fused.encoder_layers_forward compares the subsampled mask's sums
+            # with T'): an input 1-3 frames short of T has as many output frames as a full one
+            sub_len = getattr(self.embed, "subsampled_length", lambda n: n)
+            full = bool(sub_len(int(xs_lens.min())) == sub_len(xs.shape[1]))
         key = (tuple(xs.shape), xs.dtype, xs_lens.dtype, torch.cuda.current_stream(xs.device).cuda_stream, full)
         ent = self._graphs.get(key)
         if ent is None:
@@ -152,12 +170,8 @@ class BaseEncoder(torch.nn.Module):
             try:
                 sx, sl = xs.clone(), xs_lens.clone()
                 graph = torch.cuda.CUDAGraph()
-                self._graph_all_full = full
-                try:
-                    with torch.cuda.graph(graph):
-                        oy, om, _ = self.forward_return_layers(sx, sl)
-                finally:
-                    self._graph_all_full = None
+                with torch.cuda.graph(graph):
+                    oy, om, _ = self.forward_return_layers(sx, sl, all_full=full)
                 ent = self._graphs[key] = (graph, sx, sl, oy, om)
                 self._graphs[key] = self._graphs.pop(key)     # newest last, then drop the oldest graphs beyond the bound
                 self._trim_graphs()
@@ -192,7 +206,9 @@ class BaseEncoder(torch.nn.Module):
                 self._graphs.pop(k)
 
     def forward_return_layers(self, xs, xs_lens, decoding_chunk_size: int = 0, num_decoding_left_chunks: int = -1,
-                              cat_embs=None, want_layers: bool = False):
+                              cat_embs=None, want_layers: bool = False, all_full: Optional[bool] = None):
+        """all_full: the caller has read the lengths and knows whether every row is full length after subsampling (the hipGraph
+        cache, before it captures); None: the fused executor finds out itself."""
         T = xs.size(1)
         masks = ~make_pad_mask(xs_lens, T).unsqueeze(1)
         if self.global_cmvn is not None:
@@ -205,7 +221,7 @@ class BaseEncoder(torch.nn.Module):
         if plan is not None:
             from . import fused
             xs, layer_outs = fused.encoder_layers_forward(plan, xs, mask_pad, self.after_norm, want_layers,
-                                                          all_full=self._graph_all_full)
+                                                          all_full=all_full)
             return xs, masks, layer_outs
         layer_outs: List[torch.Tensor] = []
         for layer in self.encoders:
@@ -613,3 +629,8 @@ class ConformerEncoder(BaseEncoder):
                 dropout_rate, normalize_before,
             ) for layer_id in range(num_blocks)
         ])
+        # fp32 products outside the layers (the subsampling Linear; the CTC head via init_model): split operands on the bf16 matrix
+        # cores (~2^-16 relative) only in a model whose slot rounds to bf16 anyway -- a pure-fp32 model (rwkv_do_bfloat16: False,
+        # the 1e-3 parity configuration) keeps exact fp32 products everywhere (hip_ops.DISPATCH: split_gemm_min_rows)
+        self.fp32_split_operands = bool(selfattention_layer_type != "mamba_att" and rwkv_do_bfloat16)
+        self.embed.fp32_split_operands = self.fp32_split_operands

@@ -25,7 +25,13 @@ from torch import nn
 from .. import hip_ops
 from ..rwkv_v6.rwkv_wrapper import RWKV_TmixWrapper
 from ..rwkv_v6.rwkv_wrapper_bidirectional import RWKV_TmixWrapper_bidirectional
+from ..rwkv_v6.rwkv_wrapper_bidirectional_direction_dropout import (RWKV_TmixWrapper_bidirectional_direction_dropout,
+                                                                     RWKV_TmixWrapper_bidirectional_direction_dropout_both)
 from ..rwkv_v6.wkv6_op import wkv6_forward, wkv6_forward_bidir
+
+
+_DIR_DROP_SLOTS = (RWKV_TmixWrapper_bidirectional_direction_dropout, RWKV_TmixWrapper_bidirectional_direction_dropout_both)
+_RWKV_SLOTS = (RWKV_TmixWrapper, RWKV_TmixWrapper_bidirectional) + _DIR_DROP_SLOTS
 
 
 class LayerPlan:
@@ -36,15 +42,30 @@ class LayerPlan:
         slot = layer.self_attn
         # the slot is either the RWKV time-mix (fused here too) or any other registry slot with the MHA-shaped forward
         # (Mamba-2): then only the rest of the layer is re-scheduled and the slot module is called as is
-        self.rwkv = type(slot) in (RWKV_TmixWrapper, RWKV_TmixWrapper_bidirectional)
-        if isinstance(slot, RWKV_TmixWrapper_bidirectional):
+        self.rwkv = type(slot) in _RWKV_SLOTS
+        self.reverse0 = False                  # direction of blocks[0]: left-to-right unless an eval-time variant says otherwise
+        if type(slot) in _DIR_DROP_SLOTS:
+            # the EVAL branches of the direction-dropout wrappers (rwkv_wrapper_bidirectional_direction_dropout{,_both}.py:70-92;
+            # the executor only runs in eval mode): both directions averaged in the layers RWKV_BIDIRECTIONAL_LAYERS keeps
+            # bidirectional, else one direction -- right-to-left in odd layers under RWKV_ALT_DECODING, left-to-right otherwise.
+            # Both are fixed at construction, as in the reference (:25-33).
+            fwd, bwd = slot.rwkv_wrapper_forward, slot.rwkv_wrapper_backward
+            if slot.bi_active:
+                self.blocks = [fwd.tmix_block, bwd.tmix_block]
+            elif slot.alt_decoding and slot.layer_id % 2 == 1:
+                self.blocks, self.reverse0 = [bwd.tmix_block], True
+            else:
+                self.blocks = [fwd.tmix_block]
+            self.slot_bf16 = bool(fwd.do_bfloat16)
+        elif isinstance(slot, RWKV_TmixWrapper_bidirectional):
             self.blocks = [slot.rwkv_wrapper_forward.tmix_block, slot.rwkv_wrapper_backward.tmix_block]
         elif self.rwkv:
             self.blocks = [slot.tmix_block]
         else:
             self.blocks = []
         self.ndir = len(self.blocks)
-        self.slot_bf16 = bool(getattr(slot, "do_bfloat16", False))
+        if type(slot) not in _DIR_DROP_SLOTS:
+            self.slot_bf16 = bool(getattr(slot, "do_bfloat16", False))
         self._stamp = None
         self.refresh()
 
@@ -192,7 +213,7 @@ class LayerPlan:
 def eligible(layer: nn.Module) -> bool:
     from .mamba2 import MambaAttWrapper
     slot = layer.self_attn
-    if type(slot) not in (RWKV_TmixWrapper, RWKV_TmixWrapper_bidirectional, MambaAttWrapper):
+    if type(slot) not in _RWKV_SLOTS + (MambaAttWrapper,):
         return False
     cm = layer.conv_module
     return (layer.normalize_before and layer.feed_forward_macaron is not None and cm is not None
@@ -264,19 +285,20 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
     then also receives the new rows' statistics (the LayerNorm that follows is folded into its consumer)."""
     B, T, C = h.shape
     M, nd = B * T, plan.ndir
+    rev = plan.reverse0                       # (two directions: always left-to-right first)
     own_gemm = h.dtype == torch.bfloat16 and C % 64 == 0
     if own_gemm:   # token shift, first lerp, down-projection and tanh in one pass (one rounding of the product, then tanh)
-        t = hip_ops.tmix_lora_down(h, plan.maa_x_n, plan.W1n)                               # (nd, M, 128)
+        t = hip_ops.tmix_lora_down(h, plan.maa_x_n, plan.W1n, reverse0=rev)                  # (nd, M, 128)
     else:
-        xxx = hip_ops.tmix_shift_mix(h, plan.maa_x[0], plan.maa_x[1] if nd == 2 else None)
+        xxx = hip_ops.tmix_shift_mix(h, plan.maa_x[0], plan.maa_x[1] if nd == 2 else None, reverse0=rev)
         t = torch.tanh(torch.bmm(xxx.view(nd, M, C), plan.W1))
     if h.dtype == torch.bfloat16 and t.shape[-1] == 128 and C % 64 == 0:
-        z = hip_ops.tmix_lora_mix4(h, t, plan.W2t, plan.maa4)      # LoRA up-projection on MFMA inside the lerp pass
+        z = hip_ops.tmix_lora_mix4(h, t, plan.W2t, plan.maa4, reverse0=rev)   # LoRA up-projection on MFMA inside the lerp pass
     else:
         m = torch.empty((nd, 4, M, C), dtype=h.dtype, device=h.device)
         for d in range(nd):
             torch.bmm(t[d].view(M, 4, -1).transpose(0, 1), plan.W2[d], out=m[d])
-        z = hip_ops.tmix_mix4(h, m, plan.maa4)                                              # (4, nd, M, C)
+        z = hip_ops.tmix_mix4(h, m, plan.maa4, reverse0=rev)                                # (4, nd, M, C)
     if own_gemm and hip_ops.skinny_ok(M, C, C):  # a chunk step: the few-rows kernel
         rkv = hip_ops.gemm_skinny(z[:3].view(3 * nd, M, C), plan.Wrkv_n)
     elif own_gemm and M >= _OWN_GEMM_MIN_ROWS:
@@ -302,7 +324,7 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
             w_bias=None if own_gemm and bias_in_lora else (plan.time_decay[0].view(-1), plan.time_decay[1].view(-1)))
     else:
         ys = (wkv6_forward(rkv[0].view(B, T, C), rkv[1].view(B, T, C), rkv[2].view(B, T, C), w[0].view(B, T, C),
-                           plan.u[0]),)
+                           plan.u[0], reverse=rev),)
     for d, y in enumerate(ys):
         ln = plan.blocks[d].ln_x
         hip_ops.add_layernorm(y.view(M, C), None, 1.0, ln.weight, ln.bias, out1=ycat[:, d * C:(d + 1) * C], eps=ln.eps)

@@ -15,6 +15,10 @@ class BaseSubsampling(torch.nn.Module):
     def position_encoding(self, offset: Union[int, torch.Tensor], size: int) -> torch.Tensor:
         return self.pos_enc.position_encoding(offset, size)
 
+    def subsampled_length(self, n: int) -> int:
+        """Valid output frames for n valid input frames, as the module's mask slicing counts them."""
+        return n
+
 
 class Conv2dSubsampling4(BaseSubsampling):
     def __init__(self, idim: int, odim: int, dropout_rate: float, pos_enc_class: torch.nn.Module):
@@ -30,6 +34,14 @@ class Conv2dSubsampling4(BaseSubsampling):
         self.subsampling_rate = 4
         self.right_context = 6  # (3-1)*1 + (3-1)*2, subsampling.py:197-199
 
+    def subsampled_length(self, n: int) -> int:
+        """x_mask[:, :, 2::2][:, :, 2::2] keeps input positions 6, 10, 14, ...: (n - 7) // 4 + 1 of the first n (0 below 7)."""
+        return (n - 7) // 4 + 1 if n >= 7 else 0
+
+    # derived weight copies of the inference schedule (_forward_nhwc): rebuilt on demand, never copied or pickled with the module
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if not (k.startswith("_w_") or k.startswith("_nhwc_"))}
+
     def _forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
         """Inference schedule of the same arithmetic, kept channels-last end to end (measured on MI355X at the
         30-minute shape: 8.1 ms vs 18.0 ms for the NCHW module chain, whose conv2 is wrapped in two layout
@@ -40,6 +52,7 @@ class Conv2dSubsampling4(BaseSubsampling):
         c1, c2, lin = self.conv[0], self.conv[2], self.out[0]
         B, T, Fd = x.shape
         C = c1.out_channels
+        split_ok = getattr(self, "fp32_split_operands", True)     # the encoder clears it for a pure-fp32 model
         T1, F1 = (T - 3) // 2 + 1, (Fd - 3) // 2 + 1
         from ..hip_ops import param_epoch
         stamp = (lin.weight.data_ptr(), lin.weight._version, c2.weight.data_ptr(), c2.weight._version, x.dtype, param_epoch())
@@ -78,7 +91,7 @@ class Conv2dSubsampling4(BaseSubsampling):
             from .. import hip_ops
             T2 = ((T - 3) // 2 + 1 - 3) // 2 + 1
             F2 = ((Fd - 3) // 2 + 1 - 3) // 2 + 1
-            if (B * T2 >= hip_ops._SPLIT_GEMM_MIN_ROWS and lin.out_features >= 256 and lin.out_features % 8 == 0
+            if (B * T2 >= hip_ops._SPLIT_GEMM_MIN_ROWS and split_ok and lin.out_features >= 256 and lin.out_features % 8 == 0
                     and self._w_lin_3 is not None):
                 y = hip_ops.conv_sub_f32split_planes(x.contiguous(), c1.weight, c1.bias, self._w_c2_3, c2.bias)
                 return hip_ops.gemm_ph_ex(y.view(B * T2, F2 * 2 * C), self._w_lin_3, lin.bias, a_split=True,
@@ -90,7 +103,7 @@ class Conv2dSubsampling4(BaseSubsampling):
             y = conv_sub_f32split(x.contiguous(), c1.weight, c1.bias, self._w_c2_split[0], self._w_c2_split[1], c2.bias)
             b, t, f, c = y.shape
             from ..hip_ops import linear_fused
-            return linear_fused(y.view(b, t, f * c), self._w_lin, lin.bias, "none")     # (long inputs: split operands too)
+            return linear_fused(y.view(b, t, f * c), self._w_lin, lin.bias, "none", split_ok=split_ok)   # (long inputs of a model with the bf16 slot: split operands too)
         p = x.unsqueeze(1).unfold(2, 3, 2).unfold(3, 3, 2).reshape(B, T1 * F1, 9)
         # relu(bias + p W^T) in one GEMM epilogue
         y = torch._addmm_activation(c1.bias, p.view(B * T1 * F1, 9), c1.weight.view(C, 9).t(), use_gelu=False)

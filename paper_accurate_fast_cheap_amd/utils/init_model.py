@@ -43,6 +43,7 @@ def init_model(args, configs):
     ctc = WENET_CTC_CLASSES[configs.get("ctc", "ctc")](
         vocab_size, encoder.output_size(),
         blank_id=configs["ctc_conf"]["ctc_blank_id"] if "ctc_conf" in configs else 0)
+    ctc.fp32_split_operands = bool(getattr(encoder, "fp32_split_operands", True))   # a pure-fp32 model keeps exact fp32 products
     model_conf = dict(configs.get("model_conf", {}))
     special = configs.get("tokenizer_conf", {}).get("special_tokens", None)
     if configs.get("model", "asr_model") == "transducer" and "predictor_conf" in configs and "joint_conf" in configs:

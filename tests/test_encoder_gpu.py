@@ -192,7 +192,7 @@ def test_encoder_matches_oracle_on_fresh_inputs(hip):
     _assert_close(out, ref, False, "fresh")
 
 
-def test_config_c1_full_size_fp32_vs_oracle(hip):
+def test_config_c1_full_size_fp32_vs_oracle(hip, monkeypatch):
     """BASELINE configs[0] on the GPU: 10 utterances with the config's own length filter (100..2000 frames, conf yaml
     :113; the longest is exactly 2000), the FULL 12-layer 512-d bidirectional encoder in fp32 + CTC head: HIP path vs
     the CPU restatement ELEMENT-wise: |err| <= 1e-3 * |ref| + 2.5e-4 (outputs are LayerNorm rows of unit RMS: the
@@ -219,10 +219,19 @@ def test_config_c1_full_size_fp32_vs_oracle(hip):
     ref_logp = EO.ctc_log_softmax(ref, {"ctc." + k: v for k, v in ctc.state_dict().items()})
     ref_lens = ref_masks.squeeze(1).sum(1)
     enc, ctc = enc.cuda(), ctc.cuda()
+    # a pure-fp32 model takes exact fp32 products everywhere -- also outside the layers, at 4 990 rows (>= split_gemm_min_rows):
+    # the encoder tells its front end, init_model tells the CTC head (set by hand here: the head is built stand-alone)
+    from paper_accurate_fast_cheap_amd import hip_ops
+    assert enc.fp32_split_operands is False and enc.embed.fp32_split_operands is False
+    ctc.fp32_split_operands = enc.fp32_split_operands
+    split_calls = []
+    real_ex = hip_ops.gemm_ph_ex
+    monkeypatch.setattr(hip_ops, "gemm_ph_ex", lambda *a, **k: (split_calls.append(k.get("a_split", False)), real_ex(*a, **k))[1])
     with torch.no_grad():
         out, masks = enc(xs.cuda(), lens.cuda())
         logp = ctc.log_softmax(out)
         toks = [r.tokens for r in ctc_greedy_search(logp, masks.squeeze(1).sum(1), 0)]
+    assert not any(split_calls), "a pure-fp32 model launched a split-operand GEMM"
     assert out.shape == (10, 499, 512) and torch.equal(masks.cpu(), ref_masks)
     valid = ref_masks.squeeze(1)
     got = out.cpu()[valid]
@@ -690,7 +699,16 @@ def test_bf16slot_thirty_minute_file_vs_oracle(hip, monkeypatch):
     changes = int(((lp_ref.argmax(-1)[:, 1:] != lp_ref.argmax(-1)[:, :-1]) & valid[:, 1:]).sum())
     parity_log.record(what, deciding_head_frames_flipped=flipped, deciding_head_token_changes=changes)
     print(f"[bf16slot 30-minute file] deciding head: {flipped} of {int(valid.sum())} frames flipped, {changes} token changes")
-    assert changes > 1000 and flipped <= 0.01 * float(valid.sum()), (flipped, changes)
+    # recorded: 21 of 44 998 frames flipped among 208 token changes (on the bench's own weights -- zero-initialised LoRA matrices,
+    # src/model.py:232-260 -- the leading component moves slowly; the 5-minute test above randomises them: 2 925 changes)
+    assert changes > 100 and flipped <= 0.01 * float(valid.sum()), (flipped, changes)
+
+
+@pytest.fixture(autouse=True)
+def _restore_host_threads():
+    n = torch.get_num_threads()
+    yield
+    torch.set_num_threads(n)
 
 
 def test_bf16slot_token_lists_through_a_head_that_decides(hip):
@@ -700,9 +718,9 @@ def test_bf16slot_token_lists_through_a_head_that_decides(hip):
     to 16), through the product's CTC module and GPU greedy search (search.py:106-121) for the HIP output and the oracle's own
     restatement for the reference.  With e_t = that frame's max |dlogp| (HIP vs oracle), a frame is DECIDED when the oracle's
     top-2 margin exceeds 2 e_t.  Asserted: (i) every utterance all of whose frames are decided yields the oracle's token list
-    (collapsed, blanks removed); (ii) at most 0.5 % of the frames flip and >= 80 % of ALL utterances yield the oracle's list (a
+    (collapsed, blanks removed); (ii) at most 0.5 % of the frames flip and >= 90 % of ALL utterances yield the oracle's list (a
     flip at a sign change moves the change by a frame, which the collapse absorbs -- lists differ only where the projection
-    grazes zero; recorded: 21-24 of 24).  Recorded in profiles/parity_r05.json."""
+    grazes zero).  The oracle runs on 16 host threads whatever the box has.  Recorded in profiles/parity_r06.json."""
     import itertools
     import bench
     from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
@@ -721,6 +739,9 @@ def test_bf16slot_token_lists_through_a_head_that_decides(hip):
     for b, n in enumerate(lens.tolist()):
         xs[b, n:] = 0
     sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    # the oracle's fp32 sums follow the host's thread count (GEMM blocking, reduction splits): pinned, so that the reference
+    # side of this comparison is the same computation on every box and what moves between boxes, if anything, is the HIP path
+    torch.set_num_threads(16)                                     # (restored by the autouse fixture below, whatever happens)
     ref, ref_masks = EO.encoder_forward(xs, lens, sd, conf, env={})
     valid = ref_masks.squeeze(1)
     enc = enc.cuda()
@@ -762,7 +783,7 @@ def test_bf16slot_token_lists_through_a_head_that_decides(hip):
                           token_lists_equal_among_fully_decided=int((equal & full).sum()),
                           frames=int(valid.sum()), frames_flipped=int((~same_frame).sum()),
                           frames_undecided=int((~decided).sum()), tokens_reference=int(sum(len(t) for t in toks_ref)),
-                          max_abs_dlogp=float((e_t * valid).max()))
+                          max_abs_dlogp=float((e_t * valid).max()), oracle_threads=16)
         print(f"[bf16slot token lists n={npc}] {int(equal.sum())} of {n_utt} utterances decode to the oracle's token list "
               f"({int(full.sum())} fully decided, all of them equal: {bool((equal | ~full).all())}); "
               f"{int((~same_frame).sum())} of {int(valid.sum())} frames flipped, {int((~decided).sum())} undecided; "
@@ -774,7 +795,7 @@ def test_bf16slot_token_lists_through_a_head_that_decides(hip):
             # moves by two tokens between boxes: its fp32 sums follow the host's thread count) -- a flipped frame at a sign change
             # that the collapse does not absorb costs one utterance, so the bar on the lists leaves room for four such frames
             assert int((~same_frame).sum()) <= 0.005 * float(valid.sum()), int((~same_frame).sum())
-            assert int(equal.sum()) >= 0.8 * n_utt, (int(equal.sum()), n_utt)
+            assert int(equal.sum()) >= 0.9 * n_utt, (int(equal.sum()), n_utt)
 
 
 @pytest.mark.parametrize("variant", ["bf16slot", "f32", "uni_bf16slot"])
@@ -1087,7 +1108,9 @@ def test_graph_replay_runs_the_schedule_of_the_eager_pass(hip, monkeypatch):
     """A long batch whose rows are all full length takes the schedule without padding masks, a decision that reads the lengths
     on the host.  The hipGraph cache takes it BEFORE capturing and keys the graph on it: replays of equal-length batches equal
     the eager pass bit for bit (whole-model bf16: the folded-LayerNorm schedule), and a batch of the same shape with a short row
-    gets a graph of its own (the masked schedule) instead of a wrong replay."""
+    gets a graph of its own (the masked schedule) instead of a wrong replay.  "Full length" is counted in SUBSAMPLED frames, as the
+    eager pass counts it: a row two input frames short of T that still yields all T' output frames takes the unmasked schedule
+    eagerly and must replay that same schedule (the graph of the all-full batch)."""
     from paper_accurate_fast_cheap_amd.transformer import fused
     from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
     import bench
@@ -1099,27 +1122,32 @@ def test_graph_replay_runs_the_schedule_of_the_eager_pass(hip, monkeypatch):
             if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
                 p.normal_(0, 0.02)
     monkeypatch.setattr(fused, "_LN_FOLD_MIN_ROWS", 256)          # the schedule's threshold (24 576 rows) brought down to this batch
-    xs = [synth.randn((2, 803, 80), 500 + i, 2.0).cuda().to(torch.bfloat16) for i in range(3)]
-    full = torch.tensor([803, 803], device="cuda")
-    ragged = torch.tensor([803, 411], device="cuda")
+    xs = [synth.randn((2, 805, 80), 500 + i, 2.0).cuda().to(torch.bfloat16) for i in range(3)]
+    full = torch.tensor([805, 805], device="cuda")
+    ragged = torch.tensor([805, 411], device="cuda")
+    almost = torch.tensor([805, 803], device="cuda")             # (803 - 7) // 4 + 1 = 200 = T': every output frame is valid
     seen = []
     real = fused.layer_forward_lnfold
     monkeypatch.setattr(fused, "layer_forward_lnfold", lambda *a, **k: (seen.append(torch.cuda.is_current_stream_capturing()), real(*a, **k))[1])
     with torch.no_grad():
         want = [enc(x, full)[0] for x in xs]
         want_r = enc(xs[0], ragged)[0]
-        assert seen and not any(seen)
+        n_unmasked = len(seen)
+        want_a = enc(xs[1], almost)[0]
+        assert len(seen) == n_unmasked + 2 and not any(seen)     # eager: the almost-full batch took the unmasked schedule too
         del seen[:]
         enc.graph_cache_size = 4
         for _ in range(3):                                       # seen, captured, replayed
             got = [enc(x, full)[0] for x in xs]
             got_r = enc(xs[0], ragged)[0]
+            got_a = enc(xs[1], almost)[0]
         assert any(seen)                                         # the folded-LayerNorm schedule was CAPTURED
         keys = [k for k, v in enc._graphs.items() if isinstance(v, tuple)]
         assert sorted(k[-1] for k in keys) == [False, True]      # one graph per answer
     for a, b in zip(want, got):
         assert torch.equal(a, b)
     assert torch.equal(want_r, got_r)
+    assert torch.equal(want_a, got_a) and torch.equal(want_a, want[1])   # (frames 803, 804 are read by no valid output frame)
     enc.graph_cache_size = 0
     enc._graphs.clear()
 

@@ -278,3 +278,44 @@ def test_derived_fill_is_a_no_op_without_a_gpu():
     f.use()
     if not torch.cuda.is_available():
         assert f.event is None
+
+
+def test_encoder_copies_and_pickles_without_its_runtime_state():
+    """copy.deepcopy (EMA copies, model averaging), pickle (spawn) and torch.save of a model keep parameters and configuration and
+    drop what is rebuilt on demand: captured graphs, the fused executor's plans (their DerivedFill events cannot be copied), the
+    subsampling module's derived weight copies.  The load_state_dict post-hook is a module-level function."""
+    import copy
+    import io
+    import pickle
+    from paper_accurate_fast_cheap_amd import hip_ops
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_reduced_f32")
+    enc = ConformerEncoder(80, **g["conf"]).eval()
+    enc._graphs = {"a shape": "seen"}
+    enc._fused_plan = object()
+    enc.embed._nhwc_fill = hip_ops.DerivedFill()
+    enc.embed._w_lin = torch.zeros(3)
+    for other in (copy.deepcopy(enc), pickle.loads(pickle.dumps(enc))):
+        assert other._graphs == {} and other._fused_plan is None
+        assert not hasattr(other.embed, "_w_lin") and not hasattr(other.embed, "_nhwc_fill")
+        assert other.graph_cache_size == enc.graph_cache_size and other.fp32_split_operands == enc.fp32_split_operands
+        for (ka, a), (kb, b) in zip(enc.state_dict().items(), other.state_dict().items()):
+            assert ka == kb and torch.equal(a, b)
+    buf = io.BytesIO()
+    torch.save(enc, buf)
+    assert enc._graphs == {"a shape": "seen"}                    # the original keeps its state
+    f = hip_ops.DerivedFill()
+    assert copy.deepcopy(f).event is None and pickle.loads(pickle.dumps(f)).seen == set()
+
+
+def test_subsampled_length_is_the_mask_slicing():
+    """Conv2dSubsampling4.subsampled_length (what the hipGraph cache keys its all-rows-full decision on) counts exactly what
+    x_mask[:, :, 2::2][:, :, 2::2] keeps (subsampling.py:201-226), for every input length."""
+    from paper_accurate_fast_cheap_amd.transformer.embedding import RelPositionalEncoding
+    from paper_accurate_fast_cheap_amd.transformer.subsampling import Conv2dSubsampling4
+    from paper_accurate_fast_cheap_amd.utils.mask import make_pad_mask
+    sub = Conv2dSubsampling4(80, 16, 0.0, RelPositionalEncoding(16, 0.0))
+    for n in range(0, 70):
+        m = ~make_pad_mask(torch.tensor([n]), 70).unsqueeze(1)
+        assert int(m[:, :, 2::2][:, :, 2::2].sum()) == sub.subsampled_length(n), n
+    assert sub.subsampled_length(179998) == 44998 and sub.subsampled_length(179995) == 44998 and sub.subsampled_length(179994) == 44997

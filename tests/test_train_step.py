@@ -555,6 +555,45 @@ def test_transposed_weight_shadows_and_the_training_linear_on_own_gemms(hip, mon
 
 
 @pytest.mark.gpu
+def test_training_linear_in_a_manual_loop_never_reads_a_stale_transposed_copy(hip):
+    """A training loop that does NOT go through train_step: forward + backward outside train_shadows(), the weights updated
+    through `.data` (Tensor._version untouched, as fused optimizers do) and no parameter-epoch bump.  The input gradient must be
+    dY W for the weights the forward pass used -- the kept W^T copies are only trusted inside train_shadows(), whose entry
+    refreshes them; outside it the backward pass transposes the forward's own bf16 copy.  Same for the (K, N) LoRA matrices
+    of matmul_param, whose FORWARD reads the transposed copy."""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    torch.manual_seed(9)
+    lin = torch.nn.Linear(512, 512).cuda()
+    lora = torch.nn.Parameter((torch.randn(512, 128, device="cuda") * 0.05).bfloat16())
+    x0 = torch.randn(2, 300, 512, device="cuda") * 0.5
+    dy = torch.randn(2, 300, 512, device="cuda").bfloat16()
+    with hip_ops.train_shadows():                                     # a train_step-style pass first: registers kept W^T copies
+        x = x0.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = hip_ops.linear(x, lin.weight, lin.bias)
+        xb = x0.bfloat16().requires_grad_()
+        z = hip_ops.matmul_param(xb, lora)
+    y.backward(dy)
+    z.sum().backward()
+    assert id(lin.weight) in hip_ops._shadows_t and id(lora) in hip_ops._shadows_t
+    with torch.no_grad():
+        lin.weight.data.mul_(-2.0)                                    # behind torch's back: no version change, no epoch bump
+        lora.data.mul_(-3.0)
+    for _ in range(2):                                                # the manual loop, outside train_shadows()
+        x = x0.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = hip_ops.linear(x, lin.weight, lin.bias)
+        y.backward(dy)
+        wb = lin.weight.detach().bfloat16()
+        want_dx = (dy.reshape(-1, 512).float() @ wb.float()).view_as(x0)
+        assert float((x.grad - want_dx).abs().max()) <= 2 ** -6 * float(want_dx.abs().max())
+        xb = x0.bfloat16().requires_grad_()
+        z = hip_ops.matmul_param(xb, lora)
+        want_z = xb.detach().float() @ lora.detach().float()
+        assert float((z.detach().float() - want_z).abs().max()) <= 2 ** -6 * float(want_z.abs().max())
+
+
+@pytest.mark.gpu
 def test_c4_full_size_training_step(hip):
     """Config c4 at FULL model size (12 layers, 512 d, 8 x 64 heads, CTC over 5000 tokens; 32 ragged utterances): one
     training step under bf16 autocast through the training kernels -- finite loss and gradients on every parameter, the
