@@ -317,6 +317,38 @@ def windows_leg(model, feats, device, chunk: int = 2000, batch: int = 8, nstream
                                 "tokens": sum(len(w) for w in wm), "tokens_one_forward_per_batch": sum(len(w) for w in wl)}}
 
 
+def two_files_leg(model, feats, device, dtype: str = "bf16slot", passes: int = 3):
+    """Two 30-minute files in flight on two HIP streams (utils.longform.greedy_decode_batches with one file per "batch": the decode
+    loop of recognize_wav2.py:323-351 over a list of files), against the same two files one after the other in the same run.  One
+    file's step keeps the matrix cores ~38 % and HBM ~41 % busy: the memory-bound passes of one file can run under the GEMMs of the
+    other.  Token lists of each file must be the ones the one-file-at-a-time pass decodes."""
+    from paper_accurate_fast_cheap_amd.utils.longform import greedy_decode_batches
+    wave_b = synthetic_waveform(AUDIO_SECONDS, 778)
+    feats_b, _ = front_end(wave_b, device)
+    feats_b = feats_b.to(feats.dtype)
+    lens = torch.tensor([FRAMES], dtype=torch.int32, device=device)
+    files = [(feats, lens), (feats_b, lens)]
+    last = {}
+
+    def run(streams):
+        def step():
+            toks, _ = greedy_decode_batches(model, files, streams=streams, want_tokens=True)
+            last[streams] = toks
+        return timed_passes(step, passes, 1)
+    sec1 = run(1)
+    sec2 = run(2)
+    sums1 = [token_checksum([t]) for t in last[1]]
+    sums2 = [token_checksum([t]) for t in last[2]]
+    audio = 2 * FRAMES / 100.0
+    return {"workload": "two 30-minute files per pass (seeds 777 / 778), each ONE sequence, encoder + CTC log-softmax + greedy tokens, "
+                        "utils.longform.greedy_decode_batches, " + PRECISION[dtype],
+            "passes": passes,
+            "one_file_at_a_time": {"ms_per_pass": round(sec1 * 1e3, 3), "audio_sec_per_sec": round(audio / sec1, 1)},
+            "two_files_in_flight": {"ms_per_pass": round(sec2 * 1e3, 3), "audio_sec_per_sec": round(audio / sec2, 1)},
+            "speedup": round(sec1 / sec2, 4), "token_checksums_per_file": sums2,
+            "token_checksums_equal_one_at_a_time": sums1 == sums2}
+
+
 def build_model(dtype: str, device, **conf_overrides):
     """The bench's model; conf_overrides change encoder_conf keys (tools/rtf_sweep.py: the paper's other models -- num_blocks
     18 / 24 / 30, the uni-directional slot)."""
@@ -710,6 +742,7 @@ def main():
         leg("c2", c2_leg, model, device, args.dtype)
         wfeats = feats32.to(device=device, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
         leg("windows_2000x8", windows_leg, model, wfeats, device, dtype=args.dtype)
+        leg("two_files_in_flight", two_files_leg, model, wfeats, device, dtype=args.dtype)
         del wfeats
         leg("streaming", streaming_leg, feats32, device)
         leg("streaming_lookahead", streaming_lookahead_leg, feats32, device)

@@ -265,6 +265,19 @@ size_t pafc_gemm_tn_workspace_bytes(long R, int M, int N);
 int pafc_gemm_tn_bf16(long R, int M, int N, const void *dy, long lda, const void *x, long ldb, void *dw, void *dbias,
                       int dw_dtype, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
 
+/* ---- fp32 GEMM with a fused epilogue on the fp32 matrix cores (csrc/gemm_f32.hip) --------------------------------------
+ * out (M, N) = act(alpha * A (M, K) . W (N, K)^T + bias (N) + residual (M, N)), batch entries strideX elements apart (0 = shared;
+ * bias may be null, residual may be null or alias out).  Exact fp32 products with fp32 accumulation: the arithmetic of the
+ * reference's fp32 nn.Linear / 1 x 1 Conv1d / torch.bmm call sites (positionwise_feed_forward.py:47-55, convolution.py:118-141,
+ * rwkv_v6/src/model.py:277-324, subsampling.py:218-224, ctc.py:106-114, encoder_layer.py:201-259) for a model without the bf16
+ * slot, and of the few-rows fp32 products of the other precision modes.  act: 0 none, 1 SiLU, 2 tanh, 3 ReLU.  bias is added as
+ * given (not scaled by alpha); everything is applied to the fp32 accumulator.  K, lda, ldw and the batch strides of A and W
+ * multiples of 4, A and W 16-byte aligned (else PAFC_ERR_UNSUPPORTED / PAFC_ERR_ALIGNMENT); any M, N.  Asynchronous on
+ * `stream`, no workspace, no global state, safe to issue from several streams at once. */
+int pafc_gemm_f32(long M, int N, int K, int batch, const float *A, long lda, long strideA, const float *W, long ldw, long strideW,
+                  const float *bias, long strideBias, const float *residual, long ldr, long strideR, float *out, long ldo,
+                  long strideO, float alpha, int act, pafc_stream_t stream);
+
 /* ---- library GEMM with a fused epilogue, behind explicit objects --------------------------------------------------
  * out (rows, N) = act(alpha * x (rows, K) . weight (N, K)^T + residual (rows, N) + bias (N)) as one hipBLASLt GEMM;
  * act 0 = identity, 1 = SiLU; residual may alias out; bias is added as given (not scaled by alpha).  Replaces

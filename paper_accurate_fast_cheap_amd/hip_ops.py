@@ -1025,116 +1025,66 @@ def mix4_train(x: torch.Tensor, m: torch.Tensor, maa4: torch.Tensor, reverse: bo
     return _Mix4Train.apply(x.contiguous(), m, maa4, reverse)
 
 
-class _LinearPlans:
-    """Host-side owner of the library-GEMM objects of one device (include/pafc_encoder_ops.h: pafc_gemm_ctx,
-    pafc_linear_plan): one context, and a BOUNDED least-recently-used table of plans keyed by the exact problem -- a
-    ragged workload (c2: a new row count per batch) recycles plans instead of growing without limit; evicted plans are
-    destroyed.  Measuring the library's candidates (pafc_linear_plan_tune) is explicit: `tune_min_rows` rows and more
-    (long-form shapes, where the heuristic's first pick was seen to lose 20 %), never while a graph is being captured,
-    on a scratch output of the call's own shape.  PAFC_GEMM_TUNE=0 switches it off, PAFC_GEMM_TUNE_MIN_ROWS moves the
-    threshold."""
-    CAP = 1024
-
-    def __init__(self, device):
-        self.device = device
-        # retirement queue, oldest first: [plan, {raw stream: torch stream} it was launched on, events or None].  An evicted
-        # plan is destroyed once an event recorded on EVERY stream it was launched on (at eviction time, or at the first
-        # call after it that is not under graph capture) has completed -- checked with Event.query(), never waited for.
-        self.retired = []
-        self.used = {}          # plan address -> {raw stream handle: torch stream object} the plan has been launched on
-        import os
-        from collections import OrderedDict
-        from ctypes import POINTER, byref, c_float, c_long
-        L = _bind2()
-        if not getattr(L, "_pafc_plan_bound", False):
-            P, I = c_void_p, c_int
-            _lib._sig(L.pafc_gemm_ctx_create, I, POINTER(P))
-            _lib._sig(L.pafc_gemm_ctx_destroy, None, P)
-            _lib._sig(L.pafc_linear_plan_create, I, P, POINTER(P), I, c_long, I, I, I, I, I)
-            _lib._sig(L.pafc_linear_plan_destroy, None, P)
-            _lib._sig(L.pafc_linear_plan_run, I, P, P, P, P, P, c_float, P, P)
-            _lib._sig(L.pafc_linear_plan_tune, I, P, P, P, P, P, c_float, P, I, P)
-            _lib._sig(L.pafc_linear_plan_is_tuned, I, P)
-            L._pafc_plan_bound = True
-        self.L, self.byref = L, byref
-        self.plans = OrderedDict()
-        self.ctx = c_void_p()
-        with torch.cuda.device(device):
-            _lib.check(L.pafc_gemm_ctx_create(byref(self.ctx)), "pafc_gemm_ctx_create")
-        # pafc_linear_plan_run hands the CALL's bias pointer to the library inside the call; ctypes releases the GIL, so the table
-        # and a plan are used by one thread at a time per device (include/pafc_encoder_ops.h)
-        import threading
-        self.lock = threading.Lock()
-        self.tune = os.environ.get("PAFC_GEMM_TUNE", "1") != "0"
-        self.tune_min_rows = DISPATCH["gemm_tune_min_rows"]
-
-    def note_launch(self, plan, raw_stream: int) -> None:
-        """`plan` is about to be launched on torch's current stream (raw handle given): remembered until the plan retires."""
-        on = self.used.setdefault(plan.value, {})
-        if raw_stream not in on:
-            on[raw_stream] = torch.cuda.current_stream(self.device)
-
-    def _reap(self) -> None:
-        """Destroy retired plans whose streams have all passed their events; stamp the ones retired under capture.  Never blocks."""
-        if not self.retired or torch.cuda.is_current_stream_capturing():
-            return
-        keep = []
-        for ent in self.retired:
-            plan, streams, events = ent
-            if events is None:
-                events = ent[2] = [self._mark(st) for st in streams.values()]
-            if all(e.query() for e in events):
-                self.L.pafc_linear_plan_destroy(plan)
-            else:
-                keep.append(ent)
-        self.retired = keep
-
-    @staticmethod
-    def _mark(stream):
-        e = torch.cuda.Event()
-        e.record(stream)
-        return e
-
-    def get(self, key):
-        plan = self.plans.get(key)
-        if plan is not None:
-            self.plans.move_to_end(key)
-            return plan
-        plan = c_void_p()
-        rc = self.L.pafc_linear_plan_create(self.ctx, self.byref(plan), *key)
-        if rc == -7:      # PAFC_ERR_UNSUPPORTED: the library has no workspace-free kernel for this problem
-            self.plans[key] = None
-            return None
-        _lib.check(rc, "pafc_linear_plan_create")
-        self.plans[key] = plan
-        capturing = torch.cuda.is_current_stream_capturing()
-        while len(self.plans) > self.CAP:
-            _, old = self.plans.popitem(last=False)
-            if old is None:
-                continue
-            streams = self.used.pop(old.value, {})
-            # the launches of `old` that are still queued sit in front of these events on their streams
-            self.retired.append([old, streams, None if capturing else [self._mark(st) for st in streams.values()]])
-        self._reap()
-        return plan
-
-    def __del__(self):
-        try:
-            for plan in list(self.plans.values()) + [ent[0] for ent in self.retired]:
-                if plan is not None:
-                    self.L.pafc_linear_plan_destroy(plan)
-            self.L.pafc_gemm_ctx_destroy(self.ctx)
-        except Exception:
-            pass
+def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none", alpha: float = 1.0,
+             residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Hand-written fp32 GEMM with a fused epilogue on the fp32 matrix cores (include/pafc_encoder_ops.h: pafc_gemm_f32; exact
+    fp32 products, fp32 accumulation): act(alpha * a w^T + bias + residual).  a: (M, K) or (Z, M, K); w: (N, K) or (Z, N, K) in
+    nn.Linear layout; bias (N) or (Z, N); residual / out (M, N) or (Z, M, N), `out` may be `residual`.  Rows and batch entries
+    may be strided views (unit stride in the last dimension; K and the strides of a and w multiples of 4).  act: none / silu /
+    tanh / relu.  No workspace, no plan objects: safe to issue from several streams at once."""
+    _lib.require_gpu(bias)
+    for t in (a, w, bias, residual, out):
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32 or t.stride(-1) != 1):
+            raise _lib.PafcError("gemm_f32: fp32 GPU tensors with unit stride in the last dimension")
+    L = _bind2()
+    if not getattr(L, "_pafc_gemmf32_bound", False):
+        from ctypes import c_float, c_long
+        P, I, G = c_void_p, c_int, c_long
+        _lib._sig(L.pafc_gemm_f32, I, G, I, I, I, P, G, G, P, G, G, P, G, P, G, G, P, G, G, c_float, I, P)
+        L._pafc_gemmf32_bound = True
+    batched = a.dim() == 3
+    Z = a.shape[0] if batched else 1
+    M, K = a.shape[-2], a.shape[-1]
+    N = w.shape[-2]
+    if w.shape[-1] != K or (batched and (w.dim() != 3 or w.shape[0] != Z)) or (not batched and (a.dim() != 2 or w.dim() != 2)):
+        raise _lib.PafcError("gemm_f32: a (M, K) x w (N, K), or both with a leading batch")
+    if act not in ("none", "silu", "tanh", "relu"):
+        raise _lib.PafcError("gemm_f32: act is none / silu / tanh / relu")
+    if out is None:
+        out = torch.empty((Z, M, N) if batched else (M, N), dtype=a.dtype, device=a.device)
+    for t in (residual, out):
+        if t is not None and tuple(t.shape) != ((Z, M, N) if batched else (M, N)):
+            raise _lib.PafcError("gemm_f32: residual / out must be (M, N) per batch entry")
+    if bias is not None and bias.shape[-1] != N:
+        raise _lib.PafcError("gemm_f32: bias must be (N) or (Z, N)")
+    sb = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
+    bs = lambda t: t.stride(0) if batched else 0
+    from .profiling import op_timer
+    with op_timer("gemmf32_%dx%d%s" % (K, N, "x%d" % Z if batched else ""), sample=12, flops=2.0 * Z * M * N * K):
+        rc = L.pafc_gemm_f32(M, N, K, Z, _lib.ptr(a), a.stride(-2), bs(a), _lib.ptr(w), w.stride(-2), bs(w),
+                             _lib.ptr(bias), sb, _lib.ptr(residual), residual.stride(-2) if residual is not None else 0,
+                             bs(residual) if residual is not None else 0, _lib.ptr(out), out.stride(-2), bs(out),
+                             float(alpha), _ACTS[act], _lib.stream_of(a))
+    _lib.check(rc, "pafc_gemm_f32")
+    return out
 
 
-_linear_plans = {}
+def gemm_f32_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
+    """Operand forms pafc_gemm_f32 takes: fp32, unit stride along K, K and the row / batch strides multiples of 4, 16-byte bases."""
+    return (a.is_cuda and a.dtype == torch.float32 and w.dtype == torch.float32 and a.shape[-1] % 4 == 0
+            and all(t.stride(-1) == 1 and all(st % 4 == 0 for st in t.stride()[:-1]) and t.data_ptr() % 16 == 0 for t in (a, w)))
 
 
 def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: str = "silu",
                     alpha: float = 1.0, residual: Optional[torch.Tensor] = None, inplace: bool = False):
-    """act(alpha * x @ weight.T + residual + bias) as one hipBLASLt GEMM with fused epilogue (act: 'silu' or 'none').
-    bias is added as given (not scaled by alpha).  inplace: write the result over ``residual``."""
+    """act(alpha * x @ weight.T + residual + bias) as ONE GEMM with a fused epilogue (act: 'silu' or 'none'), for the operands
+    the tiled bf16 kernels do not take: fp32 (exact fp32 products on the fp32 matrix cores, pafc_gemm_f32) and bf16 shapes off the
+    bf16 kernels' grid (K % 64 or N % 8: through the same kernel in fp32, one rounding at the end).  bias is added as given
+    (not scaled by alpha).  inplace: write the result over ``residual``.
+
+    Until round 6 this was a hipBLASLt plan per problem, falling back to the framework's F.linear where the library offered no
+    workspace-free kernel.  Both are gone from the inference paths: the framework's fp32 GEMM stalls when two HIP streams issue
+    it at once (DESIGN.md section 4 "the c2 stall"), and decode batches are issued two or three streams deep."""
     _lib.require_gpu(x, weight, bias, residual)
     N, K = weight.shape
     rows = x.numel() // K
@@ -1144,47 +1094,32 @@ def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
         raise _lib.PafcError("linear_bias_act: residual must be (rows, N) in the activation dtype")
     if act not in ("silu", "none"):
         raise _lib.PafcError("linear_bias_act: act is 'silu' or 'none'")
-    plans = _linear_plans.get(x.device)
-    if plans is None:
-        plans = _linear_plans[x.device] = _LinearPlans(x.device)
-    L = plans.L
-    with plans.lock:
-        plan = plans.get((_lib.dtype_code(x.dtype), rows, N, K, int(bias is not None), int(act == "silu"), int(residual is not None)))
-    if plan is None:
-        # no workspace-free library kernel for this problem (seen for some row counts at N = 5000): the framework's own
-        # GEMM + separate epilogue ops -- still on the GPU, just not fused
-        y = torch.nn.functional.linear(x, weight)
-        if alpha != 1.0:
-            y = y * alpha
-        if bias is not None:
-            y = y + bias
-        if residual is not None:           # act(alpha * x W^T + residual + bias), as the fused kernels compute it
-            y = y + residual.view(y.shape)
-        if act == "silu":
-            y = torch.nn.functional.silu(y)
-        if residual is not None and inplace:
-            residual.view(y.shape).copy_(y)
+    x2 = x.reshape(rows, K)
+    r2 = residual.reshape(rows, N) if residual is not None else None
+    if x.dtype == torch.float32 and gemm_f32_ok(x2, weight):
+        out = gemm_f32(x2, weight, bias, act, alpha=alpha, residual=r2, out=r2 if (inplace and r2 is not None) else None)
+        return residual if (inplace and residual is not None) else out.view(x.shape[:-1] + (N,))
+    if x.dtype == torch.bfloat16 and K % 4 == 0:
+        y = gemm_f32(x2.float(), weight.float(), None if bias is None else bias.float(), act, alpha=alpha,
+                     residual=None if r2 is None else r2.float())
+        if inplace and residual is not None:
+            r2.copy_(y)
             return residual
-        return y
-    if inplace and residual is not None:
-        out = residual
-    else:
-        out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
-    stream = _lib.stream_of(x)
-    from .profiling import op_timer
-    with plans.lock:
-        if (plans.tune and rows >= plans.tune_min_rows and not L.pafc_linear_plan_is_tuned(plan)
-                and not torch.cuda.is_current_stream_capturing()):
-            scratch = torch.empty(rows, N, dtype=x.dtype, device=x.device)
-            _lib.check(L.pafc_linear_plan_tune(plan, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(scratch),
-                                               float(alpha), _lib.ptr(residual), 16, stream), "pafc_linear_plan_tune")
-            del scratch
-        plans.note_launch(plan, stream.value or 0)
-        with op_timer("linear_%dx%d" % (K, N), sample=12, flops=2.0 * rows * N * K):
-            rc = L.pafc_linear_plan_run(plan, _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out), float(alpha),
-                                        _lib.ptr(residual), stream)
-    _lib.check(rc, "pafc_linear_plan_run")
-    return out
+        return y.to(torch.bfloat16).view(x.shape[:-1] + (N,))
+    # K not a multiple of 4 (no layer of this package has one): the framework's operators, still on the GPU
+    y = torch.nn.functional.linear(x, weight)
+    if alpha != 1.0:
+        y = y * alpha
+    if bias is not None:
+        y = y + bias
+    if residual is not None:           # act(alpha * x W^T + residual + bias), as the fused kernels compute it
+        y = y + residual.view(y.shape)
+    if act == "silu":
+        y = torch.nn.functional.silu(y)
+    if residual is not None and inplace:
+        residual.view(y.shape).copy_(y)
+        return residual
+    return y
 
 
 # fp32 GEMMs of long inputs run on the bf16 matrix cores with split operands (csrc/gemm_ph.hip: three bf16 products per fp32

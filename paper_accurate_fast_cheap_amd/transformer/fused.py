@@ -287,22 +287,31 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
     M, nd = B * T, plan.ndir
     rev = plan.reverse0                       # (two directions: always left-to-right first)
     own_gemm = h.dtype == torch.bfloat16 and C % 64 == 0
+    f32_own = h.dtype == torch.float32 and C % 4 == 0         # (anything else: a bf16 slot with C % 64 != 0 -- the framework's bmm)
     if own_gemm:   # token shift, first lerp, down-projection and tanh in one pass (one rounding of the product, then tanh)
         t = hip_ops.tmix_lora_down(h, plan.maa_x_n, plan.W1n, reverse0=rev)                  # (nd, M, 128)
     else:
         xxx = hip_ops.tmix_shift_mix(h, plan.maa_x[0], plan.maa_x[1] if nd == 2 else None, reverse0=rev)
-        t = torch.tanh(torch.bmm(xxx.view(nd, M, C), plan.W1))
+        if f32_own:     # fp32 slot (rwkv_do_bfloat16: False): exact fp32 products on the hand-written fp32 GEMM, tanh in its epilogue
+            t = hip_ops.gemm_f32(xxx.view(nd, M, C), plan.W1n, None, "tanh")
+        else:
+            t = torch.tanh(torch.bmm(xxx.view(nd, M, C), plan.W1))
     if h.dtype == torch.bfloat16 and t.shape[-1] == 128 and C % 64 == 0:
         z = hip_ops.tmix_lora_mix4(h, t, plan.W2t, plan.maa4, reverse0=rev)   # LoRA up-projection on MFMA inside the lerp pass
     else:
         m = torch.empty((nd, 4, M, C), dtype=h.dtype, device=h.device)
         for d in range(nd):
-            torch.bmm(t[d].view(M, 4, -1).transpose(0, 1), plan.W2[d], out=m[d])
+            if f32_own:     # four (M, 32) x (32, C) products per direction: one batched launch over strided views of t
+                hip_ops.gemm_f32(t[d].view(M, 4, -1).transpose(0, 1), plan.W2t[d], out=m[d])
+            else:
+                torch.bmm(t[d].view(M, 4, -1).transpose(0, 1), plan.W2[d], out=m[d])
         z = hip_ops.tmix_mix4(h, m, plan.maa4, reverse0=rev)                                # (4, nd, M, C)
     if own_gemm and hip_ops.skinny_ok(M, C, C):  # a chunk step: the few-rows kernel
         rkv = hip_ops.gemm_skinny(z[:3].view(3 * nd, M, C), plan.Wrkv_n)
     elif own_gemm and M >= _OWN_GEMM_MIN_ROWS:
         rkv = hip_ops.gemm_bf16(z[:3].view(3 * nd, M, C), plan.Wrkv_n)                      # (3nd, M, C), one launch
+    elif f32_own:
+        rkv = hip_ops.gemm_f32(z[:3].view(3 * nd, M, C), plan.Wrkv_n)                       # (3nd, M, C), one launch
     else:
         rkv = torch.bmm(z[:3].view(3 * nd, M, C), plan.Wrkv)
     if own_gemm:
@@ -312,6 +321,8 @@ def slot_forward(plan: LayerPlan, h: torch.Tensor, residual: Optional[torch.Tens
         # an extra pass over w: the bidirectional scan adds it itself.
         bias_in_lora = nd == 1 or hip_ops.decay_lora_one_pass(M, C, plan.D1n.shape[1])
         w = hip_ops.decay_lora(z[3], plan.D1n, plan.D2n, plan.time_decay.view(nd, C) if bias_in_lora else None)
+    elif f32_own:
+        w = hip_ops.gemm_f32(hip_ops.gemm_f32(z[3], plan.D1n, None, "tanh"), plan.D2n)
     else:
         w = torch.bmm(torch.tanh(torch.bmm(z[3], plan.D1)), plan.D2)
     if nd == 1 and not own_gemm:
@@ -388,7 +399,7 @@ def layer_forward(plan: LayerPlan, x: torch.Tensor, h: torch.Tensor, lens: Optio
         p = _pw1_glu(plan, h.view(B * Tc, C)).view(B, Tc, C)
         g = _dwconv_norm_silu(cm, p, left_pad, T)
     else:
-        p = F.linear(h, cm.pointwise_conv1.weight.squeeze(-1), cm.pointwise_conv1.bias)
+        p = hip_ops.linear_bias_act(h, cm.pointwise_conv1.weight.squeeze(-1), cm.pointwise_conv1.bias, "none")
         dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, left_pad, T, glu=True)
         _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps)
     if not masked:

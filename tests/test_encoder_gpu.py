@@ -93,6 +93,51 @@ def test_dir_dropout_eval(hip, monkeypatch):
         _assert_close(y, c["y"], True, f"{c['kind']} {c['env']} layer {c['layer_id']}")
 
 
+@pytest.mark.parametrize("kind", ["rwkv_tmix60_dir_layer_drop", "rwkv_tmix60_dir_layer_drop_both"])
+@pytest.mark.parametrize("env,want", [
+    ({}, [(2, False)] * 4),                                                         # no variable set: every layer bidirectional
+    ({"RWKV_BIDIRECTIONAL_LAYERS": "-1"}, [(1, False)] * 4),                         # "alt-only" as the sweep script RAN it: l2r only
+    ({"RWKV_BIDIRECTIONAL_LAYERS": "-1", "RWKV_ALT_DECODING": "1"}, [(1, False), (1, True), (1, False), (1, True)]),
+    ({"RWKV_BIDIRECTIONAL_LAYERS": "3", "RWKV_ALT_DECODING": "1"}, [(1, False), (1, True), (1, False), (2, False)]),
+    ({"RWKV_BIDIRECTIONAL_LAYERS": "0,1"}, [(2, False), (2, False), (1, False), (1, False)])])
+def test_dir_dropout_eval_variants_on_the_fused_executor(hip, monkeypatch, kind, env, want):
+    """The eval-time variants of the direction-dropout models the paper's RTF sweep runs (go-run-encoder-rtf.single-gpu-3x3-g5.sh:
+    83-103: RWKV_BIDIRECTIONAL_LAYERS = -1 / 11 / 9,10,11 / 0 / 6..11, RWKV_ALT_DECODING) through the fused executor: each layer
+    runs both directions, left-to-right only or right-to-left only as the wrapper's eval branches say
+    (rwkv_wrapper_bidirectional_direction_dropout_both.py:72-92), and the result equals the module path, whose wrappers are
+    pinned by the reference's golden (test_dir_dropout_eval).  fp32 model + bf16 slot and whole-model bf16, ragged batch."""
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    g = load_golden("encoder_reduced_f32")
+    for k in ("RWKV_BIDIRECTIONAL_LAYERS", "RWKV_ALT_DECODING"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    conf = dict(g["conf"], selfattention_layer_type=kind, rnn_att_direction="bi", num_blocks=4, rwkv_do_bfloat16=True)
+    torch.manual_seed(21)
+    enc = ConformerEncoder(80, **conf).eval()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.05)
+    xs = synth.randn((3, 211, 80), 77, 2.0)
+    lens = torch.tensor([211, 150, 64])
+    for whole_bf16 in (False, True):
+        m = (enc.to(torch.bfloat16) if whole_bf16 else enc).cuda()
+        x = xs.cuda().to(torch.bfloat16 if whole_bf16 else torch.float32)
+        with torch.no_grad():
+            m.fused_inference = True
+            got, masks = m(x, lens.cuda())
+            plan = m._fused_plan
+            assert plan and [(lp.ndir, lp.reverse0) for lp in plan.layers] == want
+            m.fused_inference = False
+            ref, masks2 = m(x, lens.cuda())
+            m.fused_inference = True
+        assert torch.equal(masks, masks2)
+        valid = masks.squeeze(1)
+        _assert_close(got[valid], ref[valid], True, f"fused dir-drop {kind} {env} {'bf16' if whole_bf16 else 'bf16slot'}",
+                      whole_model_bf16=whole_bf16)
+
+
 @pytest.mark.parametrize("variant", ["bf16slot", "f32", "uni_bf16slot", "uni_bf16model"])
 def test_encoder_reduced(hip, variant):
     from paper_accurate_fast_cheap_amd.transformer.cmvn import GlobalCMVN
@@ -796,6 +841,59 @@ def test_bf16slot_token_lists_through_a_head_that_decides(hip):
             # that the collapse does not absorb costs one utterance, so the bar on the lists leaves room for four such frames
             assert int((~same_frame).sum()) <= 0.005 * float(valid.sum()), int((~same_frame).sum())
             assert int(equal.sum()) >= 0.9 * n_utt, (int(equal.sum()), n_utt)
+
+
+def test_merged_window_launches_decode_the_same_token_lists(hip):
+    """decode_windows(merge_frames=...) runs consecutive window batches as one launch -- the windows are independent, but kernel
+    choice follows the rows per launch (below 1 024 rows the fp32 projections take exact fp32 products, above it split operands;
+    the scan's chunking and the GEMM tiles differ too), so on a random-init 5000-way head, where most frames are near-ties, a few
+    windows decode differently (bench.py counts them).  Through a head that DECIDES -- token = sign of the leading principal
+    component of the encoder output, built from the literal schedule's own output -- the merged schedule must give the literal
+    schedule's token list for (nearly) every window: full-size model in the headline precision, 24 windows of 1 000 frames in
+    batches of 4 (996 rows per launch) against ONE launch of 24 windows (5 976 rows), both through the product's decode_windows."""
+    import bench
+    from paper_accurate_fast_cheap_amd.utils.init_model import init_model
+    from paper_accurate_fast_cheap_amd.utils.longform import decode_windows, feats_batcher
+    torch.manual_seed(777)
+    configs = dict(encoder="conformer", encoder_conf=bench.encoder_conf(), input_dim=80, output_dim=16, ctc="ctc",
+                   ctc_conf={"ctc_blank_id": 0}, model_conf={}, dataset_conf={})
+
+    class A:
+        checkpoint = None
+
+    model, _ = init_model(A(), configs)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("time_maa_rkvw_w1") or n.endswith("time_decay_w1"):
+                p.normal_(0, 0.02)
+    model = model.eval().cuda()
+    chunk, batch, nwin = 1000, 4, 24
+    feats = synth.randn((1, chunk * nwin, 80), 913, 2.0).cuda()
+    with torch.no_grad():
+        outs = [model._forward_encoder(fb, lens)[0] for fb, lens in feats_batcher(feats, chunk, batch, feats.device)]
+    X = torch.cat([o.reshape(-1, 512) for o in outs]).float().cpu()
+    mu = X.mean(0)
+    _, _, V = torch.pca_lowrank(X - mu, q=8, center=False, niter=4)
+    W = torch.zeros(16, 512)
+    W[1], W[2] = V[:, 0], -V[:, 0]
+    b = -(W @ mu)
+    b[3:] = -60.0
+    model.ctc.load_state_dict({"ctc_lo.weight": W, "ctc_lo.bias": b}, strict=False)
+    model = model.cuda()
+    with torch.no_grad():
+        lit = decode_windows(model, feats, chunk, batch, streams=1, graph_cache=False)
+        mer = decode_windows(model, feats, chunk, batch, streams=1, graph_cache=False, merge_frames=chunk * nwin)
+        two = decode_windows(model, feats, chunk, batch, streams=2, merge_frames=2 * chunk * batch)     # 8 windows per launch, 2 in flight
+    assert len(lit["windows"]) == nwin == len(mer["windows"]) == len(two["windows"])
+    same = sum(1 for x, y in zip(lit["windows"], mer["windows"]) if x == y)
+    same2 = sum(1 for x, y in zip(lit["windows"], two["windows"]) if x == y)
+    ntok = sum(len(w) for w in lit["windows"])
+    parity_log.record("merged window launches, decisive head", windows=nwin, tokens_literal_schedule=ntok,
+                      windows_equal_one_launch=same, windows_equal_8_per_launch=same2,
+                      tokens_one_launch=sum(len(w) for w in mer["windows"]))
+    print(f"[merged windows] {same} / {same2} of {nwin} windows decode to the literal schedule's list ({ntok} tokens)")
+    assert ntok > 10 * nwin                                       # a real token sequence per window
+    assert same >= 0.9 * nwin and same2 >= 0.9 * nwin, (same, same2, nwin)
 
 
 @pytest.mark.parametrize("variant", ["bf16slot", "f32", "uni_bf16slot"])

@@ -1,5 +1,7 @@
 """Fused inference executor (transformer/fused.py) and its glue kernels vs the op-by-op module path and fp32
 PyTorch references of the same ops.  GPU only."""
+import contextlib
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -124,97 +126,101 @@ def test_linear_bias_silu_epilogue(hip, dtype):
     torch.testing.assert_close(buf.cpu().float(), res.float() + F.linear(x.float(), w.float()), **tol)
 
 
-def test_linear_plans_are_bounded_explicit_and_capture_safe(hip, monkeypatch):
-    """The library-GEMM objects (pafc_gemm_ctx / pafc_linear_plan): a ragged workload recycles a bounded table of plans;
-    candidates are measured only by the explicit tune call, never while a graph is being captured (a first sight of a
-    shape inside a capture keeps the heuristic's pick and the capture stays valid); results are the same either way."""
+@pytest.mark.parametrize("M,N,K,act,res,bias", [
+    (1, 1, 4, "none", False, False), (37, 5, 12, "tanh", False, True), (499, 512, 512, "silu", False, True),
+    (4990, 512, 2048, "none", True, True), (700, 5000, 512, "none", False, True), (130, 130, 36, "relu", True, False),
+    (31936, 2048, 512, "silu", False, True), (44998, 512, 9728, "none", False, True)])
+def test_gemm_f32_own_kernel(hip, M, N, K, act, res, bias):
+    """pafc_gemm_f32 (csrc/gemm_f32.hip: exact fp32 products on the fp32 matrix cores, fused epilogue) against a float64 product:
+    ragged M / N / K tails (rows clamped, quads beyond K zero), both tile sizes, every activation, residual in place with
+    alpha, the shapes of a pure-fp32 model (FFN, Linear(9728, 512), CTC head) -- to fp32 round-off of a K-term sum."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_f32
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g) * 0.3 if bias else None
+    r = torch.randn(M, N, device="cuda", generator=g) if res else None
+    alpha = 0.5 if res else 1.0
+    want = alpha * (a.double() @ w.double().t())
+    if b is not None:
+        want = want + b.double()
+    if r is not None:
+        want = want + r.double()
+    want = {"none": lambda t: t, "silu": F.silu, "tanh": torch.tanh, "relu": F.relu}[act](want)
+    if res:
+        buf = torch.full((M + 8, N), 7.0, device="cuda")
+        buf[:M] = r
+        got = gemm_f32(a, w, b, act, alpha=alpha, residual=buf[:M], out=buf[:M])
+        assert got.data_ptr() == buf.data_ptr() and bool((buf[M:] == 7.0).all())
+    else:
+        got = gemm_f32(a, w, b, act, alpha=alpha)
+    torch.testing.assert_close(got.double(), want, rtol=2e-5, atol=2e-5 * max(1.0, K ** 0.5 / 16))
+
+
+def test_gemm_f32_batched_strided_views(hip):
+    """The batched forms the fp32 time-mix uses (fused.slot_forward without the bf16 slot): stacked projections (Z, M, K) x
+    (Z, N, K), and the LoRA up-projection whose A operand is a strided view -- four (M, 32) slices of one (M, 128) tensor,
+    batch stride 32, row stride 128 -- each against torch.bmm in float64."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_f32
+    g = torch.Generator(device="cuda").manual_seed(3)
+    z = torch.randn(6, 1203, 128, device="cuda", generator=g)
+    wz = torch.randn(6, 128, 128, device="cuda", generator=g) / 11
+    torch.testing.assert_close(gemm_f32(z, wz).double(), torch.bmm(z.double(), wz.double().transpose(1, 2)), rtol=2e-5, atol=2e-5)
+    t = torch.tanh(torch.randn(1203, 128, device="cuda", generator=g))
+    w2t = torch.randn(4, 512, 32, device="cuda", generator=g) / 6          # Linear layout (N, K) per slice
+    m = torch.empty(4, 1203, 512, device="cuda")
+    gemm_f32(t.view(1203, 4, 32).transpose(0, 1), w2t, out=m)
+    want = torch.bmm(t.double().view(1203, 4, 32).transpose(0, 1), w2t.double().transpose(1, 2))
+    torch.testing.assert_close(m.double(), want, rtol=2e-5, atol=2e-5)
+    bias = torch.randn(6, 128, device="cuda", generator=g)
+    got = gemm_f32(z, wz, bias, "tanh")
+    torch.testing.assert_close(got.double(), torch.tanh(torch.bmm(z.double(), wz.double().transpose(1, 2)) + bias.double()[:, None]),
+                               rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.timeout(180)
+def test_fp32_products_with_two_streams_in_flight(hip):
+    """The round-5 c2 stall, as a regression test.  Its cause (tools/micro/two_stream_linear.py, profiles/r06_c2_stall_*): the
+    framework's fp32 GEMM -- what the fp32 projections of a ragged decode batch fell back to -- never finishes when two HIP
+    streams issue it concurrently; with one stream the same pass takes a second.  The fp32 products of the inference paths now run
+    on pafc_gemm_f32 (no workspace, no plan objects, no library call): the library-bound part of a c2 pass (24 decode batches
+    x 12 layers x 4 fp32 projections + the CTC head, two batches in flight, the host running ahead of the device) finishes, twice,
+    with the results of the same pass on ONE stream, bit for bit."""
     from paper_accurate_fast_cheap_amd import hip_ops
     dev = torch.device("cuda", torch.cuda.current_device())
-    hip_ops._linear_plans.pop(dev, None)
-    monkeypatch.setattr(hip_ops._LinearPlans, "CAP", 8)
-    monkeypatch.setitem(hip_ops.DISPATCH, "gemm_tune_min_rows", 64)      # (the table is read when a plan owner is created)
-    w = synth.randn((128, 64), 2, 0.1).to(torch.bfloat16).cuda()
-    b = synth.randn((128,), 3, 0.2).to(torch.bfloat16).cuda()
-    for rows in range(40, 72):                                   # 32 distinct problems through an 8-entry table
-        x = synth.randn((rows, 64), rows).to(torch.bfloat16).cuda()
-        got = hip_ops.linear_bias_act(x, w, b, "silu")
-        torch.testing.assert_close(got.float(), F.silu(F.linear(x.float(), w.float(), b.float())), rtol=2 ** -7, atol=1e-2)
-    plans = hip_ops._linear_plans[dev]
-    assert len(plans.plans) == 8
-    L = plans.L
-    tuned = {k[1]: bool(L.pafc_linear_plan_is_tuned(p)) for k, p in plans.plans.items()}
-    assert all(tuned[r] for r in tuned) and min(tuned) >= 64      # rows >= 64 were measured, by the explicit call
-    # first sight of a shape inside a capture: no measuring, the capture survives, the replay is right
-    x = synth.randn((300, 64), 7).to(torch.bfloat16).cuda()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
-            y = hip_ops.linear_bias_act(x, w, b, "none")
-    key = next(k for k in plans.plans if k[1] == 300)
-    assert not L.pafc_linear_plan_is_tuned(plans.plans[key])
-    graph.replay()
-    torch.cuda.synchronize()
-    torch.testing.assert_close(y.float(), F.linear(x.float(), w.float(), b.float()), rtol=2 ** -7, atol=1e-2)
-    hip_ops._linear_plans.pop(dev, None)                          # plans and context are destroyed with their owner
+    g = torch.Generator(device=dev).manual_seed(1)
+    rows = [64 * t for t in range(499, 20, -20)]                    # 24 batches, 31 936 ... 2 496 rows
+    x512 = torch.randn(rows[0], 512, device=dev, generator=g)
+    w1, b1 = torch.randn(2048, 512, device=dev, generator=g) / 23, torch.randn(2048, device=dev, generator=g) * 0.1
+    w2, b2 = torch.randn(512, 2048, device=dev, generator=g) / 45, torch.randn(512, device=dev, generator=g) * 0.1
+    wp, bp = torch.randn(512, 512, device=dev, generator=g) / 23, torch.randn(512, device=dev, generator=g) * 0.1
+    wc, bc = torch.randn(5000, 512, device=dev, generator=g) / 23, torch.randn(5000, device=dev, generator=g) * 0.1
+    L = hip_ops.linear_bias_act
 
-
-def test_linear_plan_churn_with_two_streams_in_flight(hip, monkeypatch):
-    """Plan churn under queued work (round 5's c2 stall was first blamed on it; tools/repro_plan_churn.py has the diagnosis):
-    far more distinct fp32 problems than the table holds, two side streams in flight, nothing waited for inside the passes --
-    every evicted plan retires behind events on the streams it was launched on and is destroyed by a later call once they have
-    completed.  Results of every pass equal those of a pass that never evicts; the retirement queue drains; every evicted plan
-    is destroyed exactly once."""
-    from paper_accurate_fast_cheap_amd import hip_ops
-    dev = torch.device("cuda", torch.cuda.current_device())
-    g = torch.Generator(device=dev).manual_seed(11)
-    x_all = torch.randn(4096, 512, device=dev, generator=g)
-    w1, b1 = torch.randn(1024, 512, device=dev, generator=g) / 23, torch.randn(1024, device=dev, generator=g)
-    w2, b2 = torch.randn(512, 1024, device=dev, generator=g) / 32, torch.randn(512, device=dev, generator=g)
-    rows = [64 * t for t in range(3, 63)]                          # 60 row counts x 2 problems = 120 distinct plans
-    side = [torch.cuda.Stream(), torch.cuda.Stream()]
-
-    def one_pass():
+    def one_pass(streams):
         main = torch.cuda.current_stream()
-        for s_ in side:
+        for s_ in streams:
             s_.wait_stream(main)
         outs = []
         for i, m in enumerate(rows):
-            with torch.cuda.stream(side[i % 2]):
-                h = hip_ops.linear_bias_act(x_all[:m], w1, b1, "silu")
-                outs.append(hip_ops.linear_bias_act(h, w2, b2, "none", alpha=0.5, residual=x_all[:m]))
-        for s_ in side:
+            with (torch.cuda.stream(streams[i % len(streams)]) if streams else contextlib.nullcontext()):
+                x = x512[:m]
+                for _ in range(12):
+                    h = L(x, w1, b1, "silu")
+                    x = L(h, w2, b2, "none", alpha=0.5, residual=x)
+                    c = L(x, wp, bp, "none")
+                    x = L(c, wp, bp, "none", residual=x)
+                    x = x * 0.25                                   # keeps twelve layers of random weights in range
+                outs.append(L(x, wc, bc, "none").abs().mean())
+        for s_ in streams:
             main.wait_stream(s_)
-        return outs
+        return torch.stack(outs).cpu()                             # the pass's only host wait
 
-    hip_ops._linear_plans.pop(dev, None)
-    monkeypatch.setattr(hip_ops._LinearPlans, "CAP", 1 << 20)
-    want = one_pass()                                              # never evicts
-    torch.cuda.synchronize()
-    assert not hip_ops._linear_plans[dev].retired
-    hip_ops._linear_plans.pop(dev, None)
-    monkeypatch.setattr(hip_ops._LinearPlans, "CAP", 16)
-    plans = hip_ops._linear_plans[dev] = hip_ops._LinearPlans(dev)
-    created, destroyed = [], []
-    real_create, real_destroy = plans.L.pafc_linear_plan_create, plans.L.pafc_linear_plan_destroy
-    counted = type("L", (), {})()
-    for name in dir(plans.L):
-        if name.startswith("pafc_"):
-            setattr(counted, name, getattr(plans.L, name))
-    counted.pafc_linear_plan_create = lambda *a: (created.append(1), real_create(*a))[1]
-    counted.pafc_linear_plan_destroy = lambda q: (destroyed.append(1), real_destroy(q))[1]
-    plans.L = counted
-    for p in range(3):
-        got = one_pass()                                           # (the host runs ahead of the device inside a pass)
-        torch.cuda.synchronize()
-        for a, b in zip(got, want):
-            assert torch.equal(a, b)
-    assert len(plans.plans) == 16 and len(created) == 3 * 120     # a cyclic workload misses every time in an LRU table
-    hip_ops.linear_bias_act(x_all[:7], w1, b1, "silu")            # a miss after the synchronize: reaps everything that was queued
-    assert len(created) - 16 == len(destroyed) + len(plans.retired)
-    assert len(plans.retired) <= 1, len(plans.retired)             # (at most the plan this very call evicted)
-    hip_ops._linear_plans.pop(dev, None)
+    want = one_pass([])
+    side = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for _ in range(2):
+        got = one_pass(side)
+        assert torch.equal(got, want) and bool(torch.isfinite(got).all())
 
 
 @pytest.mark.parametrize("B,T,C,nd", [(2, 37, 128, 2), (2, 2101, 128, 2), (1, 4099, 64, 1)])

@@ -15,7 +15,20 @@ batches in flight, hipGraph replay of the recurring batch shape), in the headlin
                 eager one-stream pass over the same windows (no graph, no side stream)
   <out>.md      the tables, chunk sizes as rows and batch sizes as columns (the layout of get-rtf-tables.py's per-model tables)
 
-Usage (GPU box):  python tools/rtf_sweep.py [--dtype bf16slot|bf16] [--streams 3] [--passes 3] [--out profiles/r05_rtf_sweep]
+The reference's sweep list (go-run-encoder-rtf.single-gpu-3x3-g5.sh:63-103) and how to name each model here:
+  rwkv_uni_12L / 18L                 --direction uni [--num-blocks 18]
+  rwkv_bi_12L / 18L / 24L / 30L      [--num-blocks N]
+  mamba2bi_12L, mamba2_uni_12L       --slot mamba_att --direction bi|uni   (conf/mamba/giga.mamba{bi,}_ds4k31nc_12le.*.yaml: fp32
+                                     parameters, no rwkv_do_bfloat16 key -- `--dtype bf16slot` runs them as the YAML ships, fp32)
+  rwkvbi_12L_alt-only / -bi11 / -bi9-11 / -BiFirst / -BiLast6
+                                     --slot dir_drop_both --dir-dropout-layers "-1" | "11" | "9,10,11" | "0" | "6,7,8,9,10,11"
+                                     (conf/rwkv/giga.rwkvbi_dldb_*.yaml; RWKV_BIDIRECTIONAL_LAYERS, read by the wrapper at
+                                     construction: rwkv_wrapper_bidirectional_direction_dropout_both.py:25-35).  The script exports
+                                     RRWKV_ALT_DECODING=1 -- a name the wrapper does not read (it reads RWKV_ALT_DECODING), so as
+                                     RUN the other layers were left-to-right only; `--alt-decoding` gives the intended alternation.
+  (mha_* and the LA256-GT / LFXL checkpoints: the MHA baseline is out of scope; LFXL is rwkv_bi_12L's architecture.)
+
+Usage (GPU box):  python tools/rtf_sweep.py [--dtype bf16slot|bf16] [--streams 3] [--passes 3] [--out profiles/r06_rtf_sweep]
 """
 import argparse
 import json
@@ -63,6 +76,12 @@ def main():
     ap.add_argument("--no-eager-check", action="store_true", help="skip the eager one-stream pass behind the token checksum")
     ap.add_argument("--num-blocks", type=int, default=12, help="encoder layers: the paper sweeps 12 / 18 / 24 / 30 (go-run-encoder-rtf...sh:63-70)")
     ap.add_argument("--direction", default="bi", choices=["bi", "uni"], help="bidirectional slot (rwkv_tmix60_bidirectional) or uni (rwkv_tmix60)")
+    ap.add_argument("--slot", default="rwkv", choices=["rwkv", "mamba_att", "dir_drop", "dir_drop_both"],
+                    help="attention slot: RWKV-v6 time-mix (default), Mamba-2 (mamba_att), or the direction-dropout wrappers' eval branches")
+    ap.add_argument("--dir-dropout-layers", default=None,
+                    help='RWKV_BIDIRECTIONAL_LAYERS for --slot dir_drop*: comma list of the layers that stay bidirectional ("-1": none)')
+    ap.add_argument("--alt-decoding", action="store_true", help="RWKV_ALT_DECODING=1 for --slot dir_drop*: the other layers alternate l2r / r2l")
+    ap.add_argument("--name", default=None, help="model name in the tables (default: derived from the options)")
     ap.add_argument("--merge-frames", type=int, default=0,
                     help="decode_windows(merge_frames=...): consecutive batches run as one launch of up to this many input frames "
                          "(0 = one forward per batch, the reference's literal schedule)")
@@ -73,11 +92,23 @@ def main():
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
     over = dict(num_blocks=args.num_blocks)
-    if args.direction == "uni":     # conf/rwkv/giga.rwkv_uni_ds4k31nc_12le.*.yaml: same layer, one direction, non-causal conv k = 31
-        over.update(selfattention_layer_type="rwkv_tmix60", rnn_att_direction="uni")
-    model, _ = bench.build_model(args.dtype, device, **over)
     global MODEL_NAME
     MODEL_NAME = f"rwkv_{args.direction}_{args.num_blocks}L-GPU"
+    if args.slot == "mamba_att":    # conf/mamba/giga.mamba{bi,}_ds4k31nc_12le.trans.shortform.yaml:21-23
+        over.update(selfattention_layer_type="mamba_att", rnn_att_version="mamba2", rnn_att_direction=args.direction)
+        MODEL_NAME = f"mamba2{'bi' if args.direction == 'bi' else '_uni'}_{args.num_blocks}L-GPU"
+    elif args.slot.startswith("dir_drop"):   # conf/rwkv/giga.rwkvbi_dldb_ds4k31nc_12le.trans.shortform.yaml:21-25
+        over.update(selfattention_layer_type="rwkv_tmix60_dir_layer_drop" + ("_both" if args.slot.endswith("both") else ""),
+                    rnn_att_direction="bi")
+        if args.dir_dropout_layers is not None:      # read by the wrappers when they are constructed
+            os.environ["RWKV_BIDIRECTIONAL_LAYERS"] = args.dir_dropout_layers
+        os.environ["RWKV_ALT_DECODING"] = "1" if args.alt_decoding else "0"
+        MODEL_NAME = f"rwkvbi_{args.num_blocks}L_bi[{args.dir_dropout_layers or 'all'}]{'_alt' if args.alt_decoding else ''}-GPU"
+    elif args.direction == "uni":   # conf/rwkv/giga.rwkv_uni_ds4k31nc_12le.*.yaml: same layer, one direction, non-causal conv k = 31
+        over.update(selfattention_layer_type="rwkv_tmix60", rnn_att_direction="uni")
+    if args.name:
+        MODEL_NAME = args.name
+    model, _ = bench.build_model(args.dtype, device, **over)
     wave = bench.synthetic_waveform(bench.AUDIO_SECONDS, 777)
     feats, _ = bench.front_end(wave, device)
     if args.dtype == "bf16":
