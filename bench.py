@@ -455,7 +455,8 @@ def mfma_object(prof, dtype: str, one_sequence: bool, copy_gbs):
                  else "subsampling conv2, split operands (hand-written implicit GEMM, 3 MFMAs per product)" if name == "conv3x3s2_split"
                  else "hand-written GEMM K x N [x batch] = " + name.split("_", 1)[1] if name.startswith("gemm_")
                  else "hand-written split-operand GEMM (3 MFMAs per fp32 product) K x N = " + name.split("_", 1)[1]
-                 if name.startswith("gemm3_") else "library GEMM K x N = " + name.split("_", 1)[1])
+                 if name.startswith("gemm3_") else "hand-written fp32 GEMM (fp32 matrix cores: priced against the bf16 peak here) K x N = "
+                 + name.split("_", 1)[1])
         ent = {"achieved": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
                "avg_us": round(rec["avg_ms"] * 1e3, 1), "launches": rec["n"]}
         # the other side of the roofline for the projections of ONE long sequence (c3): the activations cross HBM once

@@ -278,37 +278,6 @@ int pafc_gemm_f32(long M, int N, int K, int batch, const float *A, long lda, lon
                   const float *bias, long strideBias, const float *residual, long ldr, long strideR, float *out, long ldo,
                   long strideO, float alpha, int act, pafc_stream_t stream);
 
-/* ---- library GEMM with a fused epilogue, behind explicit objects --------------------------------------------------
- * out (rows, N) = act(alpha * x (rows, K) . weight (N, K)^T + residual (rows, N) + bias (N)) as one hipBLASLt GEMM;
- * act 0 = identity, 1 = SiLU; residual may alias out; bias is added as given (not scaled by alpha).  Replaces
- * `activation(w_1(x))` of PositionwiseFeedForward.forward (wenet/transformer/positionwise_feed_forward.py:47-55) and the
- * `x = residual + ff_scale * ff(x)` / `x = residual + branch(x)` adds of ConformerEncoderLayer.forward
- * (wenet/transformer/encoder_layer.py:201-259); bias, activation and residual see the fp32 accumulator (one rounding).
- * Used for fp32 models, the subsampling Linear(9728, 512) and the CTC head; the bf16 layer loop runs on pafc_gemm_bf16.
- *
- * No global state: a pafc_gemm_ctx owns the library handle of the current device, a pafc_linear_plan the descriptors and
- * the algorithm of one problem; the caller creates and destroys both.  pafc_linear_plan_run is asynchronous on `stream`,
- * allocates nothing, takes no lock and never synchronises.  pafc_linear_plan_tune is the only place library candidates
- * are measured: it runs up to max_candidates (<= 16) of them six times each on the given operands, writing to
- * scratch_out ((rows, N), must not alias residual), blocks until done, and is refused (PAFC_ERR_UNSUPPORTED) while the
- * stream is being captured into a graph.  Only candidates that need no workspace are ever considered -- see
- * csrc/gemm_epilogue.cpp for the library defect behind that rule.  A plan is used by one thread at a time. */
-typedef struct pafc_gemm_ctx pafc_gemm_ctx;
-typedef struct pafc_linear_plan pafc_linear_plan;
-int pafc_gemm_ctx_create(pafc_gemm_ctx **ctx);
-void pafc_gemm_ctx_destroy(pafc_gemm_ctx *ctx);
-int pafc_linear_plan_create(pafc_gemm_ctx *ctx, pafc_linear_plan **plan, int dtype, long rows, int N, int K, int has_bias,
-                            int act, int has_residual);
-void pafc_linear_plan_destroy(pafc_linear_plan *plan);
-int pafc_linear_plan_run(pafc_linear_plan *plan, const void *x, const void *weight, const void *bias, void *out, float alpha,
-                         const void *residual, pafc_stream_t stream);
-int pafc_linear_plan_tune(pafc_linear_plan *plan, const void *x, const void *weight, const void *bias, void *scratch_out,
-                          float alpha, const void *residual, int max_candidates, pafc_stream_t stream);
-int pafc_linear_plan_is_tuned(const pafc_linear_plan *plan);
-/* Diagnostics: the library's name of the kernel the plan launches, NUL-terminated into buf (truncated to cap - 1 characters);
- * returns the library's solution index, or a negative error code. */
-int pafc_linear_plan_kernel_name(pafc_linear_plan *plan, char *buf, int cap);
-
 /* Glue of the Mamba-2 block around the chunked scan (restated from the published block -- the reference only wraps the
  * third-party mamba_ssm Mamba2: mamba_att_wrapper.py:24-35, mamba2_bidirectional.py:12-36; PARITY UNPINNED; headdim 64,
  * d_state 128, ngroups 1).  xbc: (B, L, d_inner + 256) = [x | B | C] after conv1d + SiLU; dt_raw: the dt columns of

@@ -15,8 +15,8 @@ from ._lib import c_int, c_void_p
 # ---- dispatch thresholds: ONE table ---------------------------------------------------------------------------------------
 # Which kernel family serves a projection depends on how many rows it has.  Every threshold lives here, with the record that
 # justifies it; `PAFC_DISPATCH="name=value,name=value"` overrides any of them for A/B runs (the per-name variables of earlier
-# rounds -- PAFC_OWN_GEMM_MIN_ROWS, PAFC_LDS_RESIDENT_MIN_ROWS, PAFC_SPLIT_GEMM_MIN_ROWS, PAFC_SKINNY_MAX_ROWS,
-# PAFC_GEMM_TUNE_MIN_ROWS -- are still read).  bench.py sets none of them: what it measures is this table.
+# rounds -- PAFC_OWN_GEMM_MIN_ROWS, PAFC_LDS_RESIDENT_MIN_ROWS, PAFC_SPLIT_GEMM_MIN_ROWS, PAFC_SKINNY_MAX_ROWS -- are still
+# read).  bench.py sets none of them: what it measures is this table.
 #
 #   name                   default  meaning, and where the number comes from
 #   skinny_max_rows            640  bf16 projections of a streaming chunk step with at most this many rows run on
@@ -35,9 +35,9 @@ from ._lib import c_int, c_void_p
 #                                   against 6.0 + 6.5 for the two small kernels (profiles/r04e_windows_2000x8_kernels_*.txt);
 #                                   a c2 pass measured 2048 / 4096 / 8192 within 1 % (profiles/r03c_bench_c2_knobs.txt)
 #   split_gemm_min_rows       1024  fp32 activations of a model with the bf16 slot on the bf16 matrix cores as hi + lo planes
-#                                   (3 MFMAs per product, ~2^-16 relative) from this many rows on; below it the library's exact
-#                                   fp32 products (pure-fp32 models -- rwkv_do_bfloat16: False, the 1e-3 parity bar -- always
-#                                   take those).  Was 16384 until round 5: at 1 536 - 24 000 rows the split kernel at its best
+#                                   (3 MFMAs per product, ~2^-16 relative) from this many rows on; below it exact fp32
+#                                   products on the fp32 matrix cores (csrc/gemm_f32.hip; pure-fp32 models -- rwkv_do_bfloat16:
+#                                   False, the 1e-3 parity bar -- always take those; until round 6 these were library GEMMs).  Was 16384 until round 5: at 1 536 - 24 000 rows the split kernel at its best
 #                                   tile height takes 28 / 35 / 48 / 78 / 90 / 138 us for w_1 where the library takes 37 / 76 /
 #                                   137 / 256 / 273 / 507 (profiles/r05_split_mid_rows.txt; only w_2 below 4 000 rows is faster
 #                                   on the library, 32-74 vs 72-74 us): 2 000-frame windows x 8 20 600 -> 33 200 audio-sec/sec,
@@ -50,20 +50,17 @@ from ._lib import c_int, c_void_p
 #                                   the 30-minute sequence measured the same or 0.2 ms slower with it (the convolution kernel is
 #                                   latency-bound at two waves per SIMD and the epilogue's two block reductions add to that), so
 #                                   long inputs keep the two kernels
-#   gemm_tune_min_rows       32768  library (fp32) GEMMs of at least this many rows measure the library's candidates once
-#                                   (explicit plan objects; never under graph capture): DESIGN section 4, round-1 fault
 # C side (csrc/gemm_bf16.hip): which GEMM family takes a problem is decided by rounds -- the 128-wide kernel while its 128 x 128
 # tiles fit one round of two per CU, the 256-wide phase-pipelined kernel beyond (profiles/r04s_gemm_tile_choice_by_rows.txt);
 # PAFC_PH_MIN_FILL=<percent> (round 3's rule: 256-wide tiles must cover that share of the CUs) and PAFC_GEMM_TILE (force a tile
 # of the small kernel) are A/B switches of the kernels themselves.
 DISPATCH = dict(skinny_max_rows=640, own_gemm_min_rows=1, lds_resident_min_rows=8192, split_gemm_min_rows=1024,
-                ln_fold_min_rows=24576, gemm_tune_min_rows=32768, dwconv_ln_silu_max_rows=24575)
+                ln_fold_min_rows=24576, dwconv_ln_silu_max_rows=24575)
 
 
 def _load_dispatch():
     legacy = dict(skinny_max_rows="PAFC_SKINNY_MAX_ROWS", own_gemm_min_rows="PAFC_OWN_GEMM_MIN_ROWS",
-                  lds_resident_min_rows="PAFC_LDS_RESIDENT_MIN_ROWS", split_gemm_min_rows="PAFC_SPLIT_GEMM_MIN_ROWS",
-                  gemm_tune_min_rows="PAFC_GEMM_TUNE_MIN_ROWS")
+                  lds_resident_min_rows="PAFC_LDS_RESIDENT_MIN_ROWS", split_gemm_min_rows="PAFC_SPLIT_GEMM_MIN_ROWS")
     for name, env in legacy.items():
         if os.environ.get(env):
             DISPATCH[name] = int(os.environ[env])
@@ -1123,7 +1120,7 @@ def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
 
 
 # fp32 GEMMs of long inputs run on the bf16 matrix cores with split operands (csrc/gemm_ph.hip: three bf16 products per fp32
-# product, fp32 accumulation, ~2^-16 relative); shorter ones keep the library's exact fp32 kernels.
+# product, fp32 accumulation, ~2^-16 relative); shorter ones take exact fp32 products on the fp32 matrix cores (gemm_f32).
 _SPLIT_GEMM_MIN_ROWS = DISPATCH["split_gemm_min_rows"]
 _split_weights = {}      # id(weight) -> (stamp, [hi | hi | lo] planes, weakref to the weight); bounded
 
@@ -1208,7 +1205,7 @@ def linear_fused(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                  split_ok: bool = True) -> torch.Tensor:
     """act(x @ weight.T + bias) with the epilogue fused: bf16 operands on the hand-written GEMM (K % 64 == 0, N % 8 == 0),
     long fp32 inputs on the same kernel with split operands (unless split_ok is False: a pure-fp32 model's exact products),
-    anything else on the library GEMM."""
+    anything else through linear_bias_act (the hand-written fp32 GEMM)."""
     N, K = weight.shape
     rows = x.numel() // K
     if (x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_cuda and weight.is_contiguous()

@@ -11,8 +11,9 @@ arithmetic as ConformerEncoderLayer.forward / RWKV_Tmix_x060c.forward (reference
   * GLU is fused into the channels-last depthwise convolution.
 
 Every bf16 projection of the layer runs on the hand-written GEMM (csrc/gemm_ph.hip for the long-form shapes,
-csrc/gemm_bf16.hip otherwise) with its bias / activation / GLU / residual as the epilogue; fp32 projections go to the
-library GEMM (hip_ops.linear_bias_act).  Used only under torch.no_grad() on GPU tensors; training goes through the plain
+csrc/gemm_bf16.hip otherwise) with its bias / activation / GLU / residual as the epilogue; fp32 projections run as split
+operands on the same kernels (long inputs of a model with the bf16 slot) or on the hand-written fp32 GEMM (csrc/gemm_f32.hip,
+through hip_ops.linear_bias_act / gemm_f32) -- no library GEMM on any inference path.  Used only under torch.no_grad() on GPU tensors; training goes through the plain
 module path (autograd)."""
 from typing import List, Optional, Tuple
 
@@ -232,7 +233,7 @@ _LN_FOLD_MIN_ROWS = hip_ops.DISPATCH["ln_fold_min_rows"]
 
 def _own_gemm(x: torch.Tensor, w: torch.Tensor) -> bool:
     """bf16 projections run on the hand-written GEMMs (csrc/gemm_ph.hip / gemm_bf16.hip) -- except the few rows of a
-    streaming chunk step (csrc/gemm_skinny.hip, asked first); fp32 ones on the library or as split operands."""
+    streaming chunk step (csrc/gemm_skinny.hip, asked first); fp32 ones on the fp32 GEMM or as split operands."""
     rows = x.numel() // w.shape[-1]
     return (x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.shape[-1] % 64 == 0 and w.shape[-2] % 8 == 0
             and rows >= _OWN_GEMM_MIN_ROWS and not hip_ops.skinny_ok(rows, w.shape[-2], w.shape[-1]))
@@ -490,7 +491,7 @@ def layer_forward_lnfold(plan: LayerPlan, x: torch.Tensor, st: torch.Tensor, nex
 _FFN_ROW_BLOCK = int(os.environ.get("PAFC_FFN_ROW_BLOCK", "0"))
 
 
-# fp32 streams shorter than this keep the library's fp32 GEMMs (exact fp32 products; small problems do not fill 256-wide tiles)
+# fp32 streams shorter than this take exact fp32 products (csrc/gemm_f32.hip; small problems do not fill 256-wide tiles)
 _SPLIT_GEMM_MIN_ROWS = hip_ops.DISPATCH["split_gemm_min_rows"]
 
 

@@ -97,18 +97,13 @@ def test_argument_validation_returns_error_codes_without_a_gpu(so_path):
     assert L.pafc_rnnt_beam_workspace_bytes(8, 250, 8) > 0 and L.pafc_rnnt_beam_workspace_bytes(0, 250, 8) == 0
     L.pafc_log_softmax_rows.argtypes = [I, G, I, P, P, P]
     assert L.pafc_log_softmax_rows(1, 0, 5, one, one, NULL) == ERR_DIMS
-    # library-GEMM objects: a plan needs a context, a context needs a device
-    plan, ctx = P(0), P(0)
-    L.pafc_linear_plan_create.argtypes = [P, ctypes.POINTER(P), I, G, I, I, I, I, I]
-    assert L.pafc_linear_plan_create(NULL, ctypes.byref(plan), 1, 8, 8, 8, 0, 0, 0) == ERR_NULL and not plan.value
-    L.pafc_linear_plan_run.argtypes = [P, P, P, P, P, F, P, P]
-    assert L.pafc_linear_plan_run(NULL, one, one, NULL, one, 1.0, NULL, NULL) == ERR_NULL
-    L.pafc_linear_plan_is_tuned.argtypes = [P]
-    assert L.pafc_linear_plan_is_tuned(NULL) == 0
-    import torch
-    if not torch.cuda.is_available():
-        L.pafc_gemm_ctx_create.argtypes = [ctypes.POINTER(P)]
-        assert L.pafc_gemm_ctx_create(ctypes.byref(ctx)) == -5 and not ctx.value        # no device: reported, not fatal
+    # the fp32 GEMM: argument checks answer before anything is launched
+    L.pafc_gemm_f32.argtypes = [G, I, I, I, P, G, G, P, G, G, P, G, P, G, G, P, G, G, F, I, P]
+    assert L.pafc_gemm_f32(8, 8, 8, 1, NULL, 8, 0, one, 8, 0, NULL, 0, NULL, 0, 0, one, 8, 0, 1.0, 0, NULL) == ERR_NULL
+    assert L.pafc_gemm_f32(0, 8, 8, 1, one, 8, 0, one, 8, 0, NULL, 0, NULL, 0, 0, one, 8, 0, 1.0, 0, NULL) == ERR_DIMS
+    assert L.pafc_gemm_f32(8, 8, 6, 1, one, 8, 0, one, 8, 0, NULL, 0, NULL, 0, 0, one, 8, 0, 1.0, 0, NULL) == -7    # K % 4
+    assert L.pafc_gemm_f32(8, 8, 8, 1, P(8), 8, 0, one, 8, 0, NULL, 0, NULL, 0, 0, one, 8, 0, 1.0, 0, NULL) == -8   # alignment
+    assert L.pafc_gemm_f32(8, 8, 8, 1, one, 8, 0, one, 8, 0, NULL, 0, NULL, 0, 0, one, 8, 0, 1.0, 4, NULL) == -7    # no GLU here
     L.pafc_wkv6_forward_bf16.argtypes = [I, I, I, I, P, P, P, P, P, P, I, P, ctypes.c_size_t, P]
     assert L.pafc_wkv6_forward_bf16(1, 8, 128, 2, one, one, one, one, one, NULL, 0, NULL, 0, NULL) == ERR_NULL
     assert L.pafc_wkv6_forward_bf16(1, 8, 100, 2, one, one, one, one, one, one, 0, NULL, 0, NULL) == -3    # head size
