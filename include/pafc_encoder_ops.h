@@ -265,6 +265,25 @@ size_t pafc_gemm_tn_workspace_bytes(long R, int M, int N);
 int pafc_gemm_tn_bf16(long R, int M, int N, const void *dy, long lda, const void *x, long ldb, void *dw, void *dbias,
                       int dw_dtype, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
 
+/* ---- CTC loss of the training step, from the logits (csrc/ctc_loss.hip) -------------------------------------------------------
+ * `ys_hat.log_softmax(2)` + `torch.nn.CTCLoss(reduction="sum", zero_infinity=True)` of CTC.forward (wenet/transformer/ctc.py:
+ * 53-82) and their autograd, without the (B, T, V) log-probability tensor and without a host round trip.
+ * logits (B, T, V) bf16 or fp32, rows ldl elements apart; hlens (B) int32 valid frames; ys (B, ldy) int64 targets (entries beyond
+ * ylens[b] are not read); ylens (B) int32; max_target_len >= every ylens[b] sizes the workspace.
+ * forward:  nll[b] = -log p(y_b | logits_b), 0 for an utterance without an alignment (zero_infinity); leaves the row
+ *           statistics and label occupancies in `workspace` for backward.
+ * backward: dlogits (B, T, ldg >= V) in the logits' dtype = grad_out[0] * scale * d(sum_b nll[b]) / d logits -- the gradient
+ *           through the log-softmax; columns V .. ldg - 1 and rows t >= hlens[b] are written as zeros.  grad_out: one float on
+ *           the device.  Same workspace, unmodified since forward. */
+size_t pafc_ctc_loss_workspace_bytes(int B, int T, int max_target_len);
+int pafc_ctc_loss_forward(int dtype, int B, int T, int V, const void *logits, long ldl, const int32_t *hlens, const int64_t *ys,
+                          int ldy, const int32_t *ylens, int max_target_len, int blank, float *nll, void *workspace,
+                          size_t workspace_bytes, pafc_stream_t stream);
+int pafc_ctc_loss_backward(int dtype, int B, int T, int V, const void *logits, long ldl, const int32_t *hlens, const int64_t *ys,
+                           int ldy, const int32_t *ylens, int max_target_len, int blank, const float *nll, const float *grad_out,
+                           float scale, void *dlogits, long ldg, const void *workspace, size_t workspace_bytes,
+                           pafc_stream_t stream);
+
 /* ---- fp32 GEMM with a fused epilogue on the fp32 matrix cores (csrc/gemm_f32.hip) --------------------------------------
  * out (M, N) = act(alpha * A (M, K) . W (N, K)^T + bias (N) + residual (M, N)), batch entries strideX elements apart (0 = shared;
  * bias may be null, residual may be null or alias out).  Exact fp32 products with fp32 accumulation: the arithmetic of the

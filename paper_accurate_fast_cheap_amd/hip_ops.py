@@ -701,6 +701,101 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) 
     return torch.nn.functional.linear(x, weight, bias)
 
 
+class _CtcHeadLoss(torch.autograd.Function):
+    """CTC head + loss of the training step on hand-written kernels only: logits = x W^T + b (pafc_gemm_bf16), the loss from the
+    logits (pafc_ctc_loss_forward: row statistics, the alpha / beta lattice over the label columns), and backwards the gradient
+    through the log-softmax written once, bf16, into rows padded to a multiple of 64 columns (pafc_ctc_loss_backward), dX = dlogits W
+    on pafc_gemm_bf16 against a zero-padded W^T, dW / db through gemm_tn.  The (B, T, V) log-probabilities never exist; no call
+    waits for the host (torch's ctc_loss copies its length tensors back: five synchronising calls per step)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, hlens, ys, ylens, blank):
+        B, T, C = x.shape
+        V = weight.shape[0]
+        Vp = (V + 63) // 64 * 64
+        M = B * T
+        xb = x.reshape(M, C).to(torch.bfloat16)
+        wb = _bf16_shadow(weight).detach()
+        bb = None if bias is None else _bf16_shadow(bias).detach()
+        logits = torch.empty((M, Vp), dtype=torch.bfloat16, device=x.device)
+        gemm_bf16(xb, wb, bb, out=logits[:, :V])
+        hl = hlens.to(torch.int32).contiguous()
+        yl = ylens.to(torch.int32).contiguous()
+        ysc = ys.to(torch.int64).contiguous()
+        Lmax = ysc.shape[1]
+        L = _bind_ctc_loss()
+        nbytes = L.pafc_ctc_loss_workspace_bytes(B, T, Lmax)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        nll = torch.empty(B, dtype=torch.float32, device=x.device)
+        st = _lib.stream_of(x)
+        _lib.check(L.pafc_ctc_loss_forward(_lib.PAFC_BF16, B, T, V, _lib.ptr(logits), Vp, _lib.ptr(hl), _lib.ptr(ysc), Lmax, _lib.ptr(yl),
+                                           Lmax, int(blank), _lib.ptr(nll), _lib.ptr(ws), nbytes, st), "pafc_ctc_loss_forward")
+        ctx.save_for_backward(xb, wb, logits, ws, nll, hl, ysc, yl)
+        ctx.dims = (B, T, C, V, Vp, Lmax, int(blank))
+        ctx.w_dtype, ctx.b_dtype, ctx.x_dtype = weight.dtype, None if bias is None else bias.dtype, x.dtype
+        return nll.sum() / B                          # reduction="sum", then the batch-size average of ctc.py:77
+
+    @staticmethod
+    def backward(ctx, g):
+        xb, wb, logits, ws, nll, hl, ysc, yl = ctx.saved_tensors
+        B, T, C, V, Vp, Lmax, blank = ctx.dims
+        M = B * T
+        L = _bind_ctc_loss()
+        dl = torch.empty((M, Vp), dtype=torch.bfloat16, device=xb.device)
+        gf = g.detach().to(torch.float32).reshape(1).contiguous()
+        _lib.check(L.pafc_ctc_loss_backward(_lib.PAFC_BF16, B, T, V, _lib.ptr(logits), Vp, _lib.ptr(hl), _lib.ptr(ysc), Lmax, _lib.ptr(yl),
+                                            Lmax, blank, _lib.ptr(nll), _lib.ptr(gf), 1.0 / B, _lib.ptr(dl), Vp, _lib.ptr(ws), ws.numel(),
+                                            _lib.stream_of(xb)), "pafc_ctc_loss_backward")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.zeros((C, Vp), dtype=torch.bfloat16, device=xb.device)       # W^T, zero beyond V: K = Vp is a multiple of 64
+            wt[:, :V].copy_(wb.t())
+            dx = gemm_bf16(dl, wt).view(B, T, C).to(ctx.x_dtype)
+        want_b = ctx.b_dtype is not None and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            od = ctx.w_dtype if ctx.w_dtype in (torch.float32, torch.bfloat16) else torch.float32
+            if want_b:
+                dw, db = gemm_tn(dl[:, :V], xb, od, want_bias=True)
+                db = db.to(ctx.b_dtype)
+            else:
+                dw = gemm_tn(dl[:, :V], xb, od)
+            dw = dw.to(ctx.w_dtype)
+        elif want_b:
+            db = dl[:, :V].sum(0, dtype=torch.float32).to(ctx.b_dtype)
+        return dx, dw, db, None, None, None, None
+
+
+def _bind_ctc_loss():
+    L = _bind2()
+    if not getattr(L, "_pafc_ctcloss_bound", False):
+        from ctypes import c_float, c_long, c_size_t
+        P, I, G, Z = c_void_p, c_int, c_long, c_size_t
+        _lib._sig(L.pafc_ctc_loss_workspace_bytes, Z, I, I, I)
+        _lib._sig(L.pafc_ctc_loss_forward, I, I, I, I, I, P, G, P, P, I, P, I, I, P, P, Z, P)
+        _lib._sig(L.pafc_ctc_loss_backward, I, I, I, I, I, P, G, P, P, I, P, I, I, P, P, c_float, P, G, P, Z, P)
+        L._pafc_ctcloss_bound = True
+    return L
+
+
+def ctc_head_loss_eligible(x: torch.Tensor, weight: torch.Tensor, ys: torch.Tensor) -> bool:
+    """The GPU training step under bf16 autocast (or a bf16 model): dims the kernels take."""
+    if not (x.is_cuda and torch.is_grad_enabled() and train_kernels_enabled() and x.dim() == 3 and ys.dim() == 2):
+        return False
+    V, C = weight.shape
+    if C % 64 or V % 8 or V * 4 > 150 * 1024 or x.shape[0] > 65535 or ys.shape[1] > 3000 or os.environ.get("PAFC_TRAIN_CTC", "1") == "0":
+        return False
+    if x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16:
+        return True
+    return (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            and x.dtype in (torch.bfloat16, torch.float32) and weight.dtype in (torch.float32, torch.bfloat16))
+
+
+def ctc_head_loss(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], hlens: torch.Tensor, ys: torch.Tensor,
+                  ylens: torch.Tensor, blank: int = 0) -> torch.Tensor:
+    """sum_b CTC(log_softmax(x_b W^T + b), y_b) / B with zero_infinity (ctc.py:53-82), see _CtcHeadLoss."""
+    return _CtcHeadLoss.apply(x, weight, bias, hlens, ys, ylens, blank)
+
+
 def _bind2():
     L = _bind()
     if getattr(L, "_pafc_glue_bound", False):

@@ -51,7 +51,7 @@ class Transducer(ASRModel):
         loss = self.transducer_weight * loss_rnnt
         loss_ctc = None
         if self.ctc_weight != 0.0 and self.ctc is not None:
-            loss_ctc, _ = self.ctc(encoder_out.float(), encoder_out_lens, text, text_lengths)
+            loss_ctc = self.ctc.loss(encoder_out.float(), encoder_out_lens, text, text_lengths)
             loss = loss + self.ctc_weight * loss_ctc.sum()
         return {"loss": loss, "loss_att": None, "loss_ctc": loss_ctc, "loss_rnnt": loss_rnnt, "th_accuracy": -1.0}
 

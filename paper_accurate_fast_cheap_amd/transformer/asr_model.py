@@ -30,7 +30,7 @@ class ASRModel(torch.nn.Module):
         text_lengths = batch["target_lengths"].to(device)
         encoder_out, encoder_mask = self.encoder(speech, speech_lengths)
         encoder_out_lens = encoder_mask.squeeze(1).sum(1)
-        loss_ctc, _ = self.ctc(encoder_out.float(), encoder_out_lens, text, text_lengths)
+        loss_ctc = self.ctc.loss(encoder_out.float(), encoder_out_lens, text, text_lengths)
         return {"loss": loss_ctc, "loss_ctc": loss_ctc}
 
     def _forward_encoder(self, speech: torch.Tensor, speech_lengths: torch.Tensor, decoding_chunk_size: int = -1,

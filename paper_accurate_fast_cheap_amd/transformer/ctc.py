@@ -24,6 +24,16 @@ class CTC(torch.nn.Module):
         loss = self.ctc_loss(ys_hat, ys_pad, hlens, ys_lens) / ys_hat.size(1)
         return loss, ys_hat.transpose(0, 1)
 
+    def loss(self, hs_pad: torch.Tensor, hlens: torch.Tensor, ys_pad: torch.Tensor, ys_lens: torch.Tensor) -> torch.Tensor:
+        """forward()[0] for callers that drop the log-probabilities (the training objectives): in the GPU training step under
+        bf16 autocast the head, the loss and their gradients run on the hand-written kernels (hip_ops.ctc_head_loss), which never
+        form the (B, L, V) log-probabilities; otherwise forward()."""
+        if self.dropout_rate == 0.0 and self.ctc_loss.reduction == "sum" and self.ctc_loss.zero_infinity:
+            from ..hip_ops import ctc_head_loss, ctc_head_loss_eligible
+            if ctc_head_loss_eligible(hs_pad, self.ctc_lo.weight, ys_pad):
+                return ctc_head_loss(hs_pad, self.ctc_lo.weight, self.ctc_lo.bias, hlens, ys_pad, ys_lens, self.ctc_loss.blank)
+        return self.forward(hs_pad, hlens, ys_pad, ys_lens)[0]
+
     def log_softmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
         """ctc.py:106-114.  Inference on the GPU: the (B, T', V) logits -- the largest activation of the pass -- are
         normalised in place by one kernel that reads them once; with autograd (training) the framework op is used."""

@@ -134,8 +134,15 @@ def test_dir_dropout_eval_variants_on_the_fused_executor(hip, monkeypatch, kind,
             m.fused_inference = True
         assert torch.equal(masks, masks2)
         valid = masks.squeeze(1)
-        _assert_close(got[valid], ref[valid], True, f"fused dir-drop {kind} {env} {'bf16' if whole_bf16 else 'bf16slot'}",
-                      whole_model_bf16=whole_bf16)
+        if whole_bf16:
+            # two schedules of a whole-bf16 model differ by bf16 rounding at every op (ulp 0.03 at |x| = 4), single elements by
+            # more where a LayerNorm row has little variance: the bounds of test_full_size_encoder_properties (a wrong direction or
+            # a wrong block would move the MEAN to O(0.5))
+            d = (got[valid].float() - ref[valid].float()).abs()
+            parity_log.record(f"fused dir-drop {kind} {env} bf16", max_abs_err=float(d.max()), mean_abs_err=float(d.mean()))
+            assert float(d.mean()) < 2e-2 and float(d.max()) < 0.6, (float(d.mean()), float(d.max()))
+        else:
+            _assert_close(got[valid], ref[valid], True, f"fused dir-drop {kind} {env} bf16slot")
 
 
 @pytest.mark.parametrize("variant", ["bf16slot", "f32", "uni_bf16slot", "uni_bf16model"])

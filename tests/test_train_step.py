@@ -640,3 +640,58 @@ def test_c4_full_size_training_step(hip):
     assert moved >= 0.7 * len(params)      # (bf16 slot parameters of magnitude ~1 do not see an Adam step of 1e-4: < 1 ulp)
     assert abs(runs[1][0] - loss) <= 1e-3 * abs(loss)
     assert abs(runs[1][1] - gn) <= 2e-2 * gn
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,C", [(5000, 512), (40, 128)])
+def test_ctc_head_loss_kernels_equal_torch_ctc_loss(hip, V, C):
+    """hip_ops.ctc_head_loss (csrc/ctc_loss.hip: head GEMM + loss from the logits + gradient through the log-softmax, no (B, T, V)
+    log-probabilities, no host round trip) against the reference's own sequence -- Linear, log_softmax, torch.nn.CTCLoss(sum,
+    zero_infinity) / B, ctc.py:53-82 -- in fp32 on the same bf16-valued operands: ragged input lengths, targets with repeated
+    labels (which need a blank between them), an empty target, a target that exactly fills its frames, and an utterance with NO
+    alignment (more labels than frames: loss 0 and zero gradient under zero_infinity).  Loss to 1e-3 relative, gradients wrt the
+    encoder output, the weight and the bias to bf16 round-off of the dense gradient."""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    torch.manual_seed(5)
+    B, T = 6, 57
+    x = (torch.randn(B, T, C, device="cuda") * 0.7).bfloat16().float().requires_grad_()
+    lin = torch.nn.Linear(C, V).cuda()
+    with torch.no_grad():
+        lin.weight.copy_(lin.weight.bfloat16().float() * 3)
+        lin.bias.copy_(lin.bias.bfloat16().float())
+    hlens = torch.tensor([57, 40, 33, 12, 5, 9], device="cuda")
+    ylens = torch.tensor([20, 13, 0, 12, 7, 4], device="cuda")            # #3 fills its frames exactly, #4 has no alignment
+    ys = torch.full((B, 20), -1, dtype=torch.long, device="cuda")
+    g = torch.Generator().manual_seed(3)
+    for b, n in enumerate(ylens.tolist()):
+        if n:
+            ys[b, :n] = torch.randint(1, V, (n,), generator=g)
+    ys[0, 3] = ys[0, 2]                                                    # repeated labels
+    ys[1, 1] = ys[1, 0]
+    ys[3, :12] = torch.arange(1, 13)                                       # 12 distinct labels in 12 frames: one alignment
+    # reference: the module's own steps in fp32
+    logits = torch.nn.functional.linear(x, lin.weight, lin.bias)
+    lp = logits.transpose(0, 1).log_softmax(2)
+    want = torch.nn.functional.ctc_loss(lp, ys.clamp_min(0), hlens, ylens, blank=0, reduction="sum", zero_infinity=True) / B
+    want.backward()
+    gx, gw, gb = x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()
+    x.grad = None
+    lin.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert hip_ops.ctc_head_loss_eligible(x, lin.weight, ys)
+        got = hip_ops.ctc_head_loss(x, lin.weight, lin.bias, hlens, ys, ylens, 0)
+    (got * 1.0).backward()
+    assert torch.isfinite(got) and abs(float(got) - float(want)) <= 2e-3 * abs(float(want)) + 1e-3, (float(got), float(want))
+    for a, b_, name in ((x.grad, gx, "dx"), (lin.weight.grad, gw, "dW"), (lin.bias.grad, gb, "db")):
+        scale = float(b_.abs().max())
+        assert float((a - b_).abs().max()) <= 2 ** -6 * scale + 1e-6, (name, float((a - b_).abs().max()), scale)
+    assert float(x.grad[4].abs().max()) == 0.0 and float(gx[4].abs().max()) == 0.0      # no alignment: zero gradient
+    assert float(x.grad[1, 40:].abs().max()) == 0.0                                       # frames beyond the utterance
+    # the module entry point takes this path in the training step and the framework's otherwise
+    from paper_accurate_fast_cheap_amd.transformer.ctc import CTC
+    head = CTC(V, C).cuda()
+    head.ctc_lo.load_state_dict(lin.state_dict())
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        l1 = head.loss(x, hlens, ys, ylens)
+    l2 = head(x, hlens, ys.clamp_min(0), ylens)[0]
+    assert abs(float(l1) - float(got)) <= 1e-6 and abs(float(l2) - float(want)) <= 1e-5 * abs(float(want))
