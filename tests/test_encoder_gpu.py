@@ -142,7 +142,12 @@ def test_dir_dropout_eval_variants_on_the_fused_executor(hip, monkeypatch, kind,
             parity_log.record(f"fused dir-drop {kind} {env} bf16", max_abs_err=float(d.max()), mean_abs_err=float(d.mean()))
             assert float(d.mean()) < 2e-2 and float(d.max()) < 0.6, (float(d.mean()), float(d.max()))
         else:
-            _assert_close(got[valid], ref[valid], True, f"fused dir-drop {kind} {env} bf16slot")
+            # both sides round to bf16 inside the slot, at different points (the executor keeps fp32 accumulators across fused
+            # steps): recorded max 0.075-0.19, mean 0.005-0.007 on this 4-layer model with LoRA weights of 0.05 -- a wrong direction
+            # or block moves the mean to O(0.3)
+            d = (got[valid].float() - ref[valid].float()).abs()
+            parity_log.record(f"fused dir-drop {kind} {env} bf16slot", max_abs_err=float(d.max()), mean_abs_err=float(d.mean()))
+            assert float(d.mean()) <= 1.2e-2 and float(d.max()) <= 0.3, (float(d.mean()), float(d.max()))
 
 
 @pytest.mark.parametrize("variant", ["bf16slot", "f32", "uni_bf16slot", "uni_bf16model"])
@@ -1321,11 +1326,60 @@ def test_graph_cache_follows_parameter_updates(hip):
     model.encoder._graphs.clear()
 
 
+_REFUSED_CAPTURE_CHILD = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["PAFC_ROOT"])
+from tests import synth
+from tests.conftest import load_golden
+from paper_accurate_fast_cheap_amd.transformer import fused
+from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+g = load_golden("encoder_reduced_f32")
+sd = {k: v for k, v in synth.synth_state_dict(g["spec"], g["seed"]).items() if not k.startswith("global_cmvn")}
+enc = ConformerEncoder(80, **g["conf"])
+enc.load_state_dict(sd)
+enc = enc.cuda().eval()
+x = synth.randn((2, 95, 80), 31, 2.0).cuda()
+lens = torch.tensor([95, 60], device="cuda")
+real = fused.encoder_layers_forward
+def refused(*a, **kw):
+    if torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize()              # not permitted under capture: the runtime refuses (hipErrorStreamCapture*)
+    return real(*a, **kw)
+with torch.no_grad():
+    want = enc(x, lens)[0].cpu()
+    enc.graph_cache_size = 2
+    enc(x, lens)                              # first sighting: eager
+    fused.encoder_layers_forward = refused
+    try:
+        got = enc(x, lens)[0]                 # second sighting: the capture is refused -> this shape stays eager
+        states = [v for v in enc._graphs.values()]
+        ok = states == ["eager"] and torch.allclose(got.cpu(), want, rtol=1e-4, atol=2e-5)
+        print("FALLBACK", "OK" if ok else f"WRONG {states}", flush=True)
+    except BaseException as e:                # (a runtime that cannot recover inside this process says so here)
+        print("FALLBACK RAISED", type(e).__name__, str(e)[:200], flush=True)
+os._exit(0)                                   # the refused capture may have left the process's HIP state unusable: no teardown
+"""
+
+
+def test_refused_capture_falls_back_to_eager_in_a_child_process(hip):
+    """BaseEncoder._forward_graphed keeps a shape eager when the RUNTIME refuses its capture (an operation the capture mode does not
+    permit), as opposed to an error of the captured work, which surfaces (next test).  Staging a refused capture leaves
+    hipErrorStreamCaptureInvalidated behind for the next unrelated call of the process on this runtime (round 5 found that the
+    hard way), so the fallback is exercised in a child process that exits without teardown: the capture is refused, the call
+    returns the eager result, the shape is marked "eager"."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    env = dict(os.environ, PAFC_ROOT=ROOT, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", _REFUSED_CAPTURE_CHILD], env=env, capture_output=True, text=True, timeout=300)
+    assert "FALLBACK OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_graph_capture_errors_surface(hip, monkeypatch):
     """An error of the captured work itself (a failing launch, a PafcError from the C ABI) is raised to the caller, not turned
-    into "eager from now on"; only a capture the runtime REFUSES (hipErrorStreamCapture*) falls back.  (That fallback is not
-    provoked here: on this runtime an operation that invalidates a global-mode capture -- a synchronize, say -- also fails the next
-    unrelated call of the process, so it cannot be staged inside a test session.)"""
+    into "eager from now on"; only a capture the runtime REFUSES (hipErrorStreamCapture*) falls back (previous test, in a child
+    process: on this runtime an operation that invalidates a global-mode capture also fails the next unrelated call)."""
     from paper_accurate_fast_cheap_amd import _lib
     from paper_accurate_fast_cheap_amd.transformer import fused
     from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
