@@ -21,6 +21,8 @@
 //     operand tile feed eight MFMAs (a dot product does not care in which order its terms are added).
 //   * accumulator layout of the 32 x 32 MFMA: lane l, register r holds row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32 -- a
 //     store instruction writes 128 contiguous bytes of two output rows.
+#include <cstdlib>
+
 #include "pafc_common.h"
 #include "../../include/pafc_encoder_ops.h"
 
@@ -167,6 +169,107 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
     }
 }
 
+// ---- few rows: no operand staging at all ------------------------------------------------------------------------------------
+// A decode batch of short windows is a few hundred rows: 128 x 128 or 64 x 64 tiles leave most CUs idle and every K-step of the
+// staged kernel exposes a barrier and a global-load round trip (16 of them at K = 512, 64 at K = 2048).  Here a block owns a
+// 32 x (32 TN) output tile and its four waves SPLIT K: wave w takes the 64-wide K-steps w, w + 4, ... -- two steps per wave at
+// K = 512 -- straight from global memory (L2: the operands of a few-rows product are small) into MFMA operand registers: lane
+// (m = lane % 32, h = lane / 32) reads the 32 contiguous k of its half of the step from row m (eight 16-byte quads per operand
+// tile), which is exactly the operand the 32 x 32 x 2 MFMA wants from it under the K permutation of the staged kernel (MFMA j of
+// the step multiplies the k pair {j, 32 + j}).  The next step's quads are requested before the current step's MFMAs.  The four
+// partial accumulators meet in LDS once, at the end; wave w then finishes rows 8 w + 4 h + (0 .. 3) of every 8-row group.
+template <int TN>
+__global__ __launch_bounds__(256) void gemm_f32_small_kernel(const GemmF32Params p) {
+    constexpr int KS2 = 64;
+    __shared__ float red[4][TN][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lrow = lane & 31, half = lane >> 5;
+    const int tn = blockIdx.x % p.tiles_n;
+    const long tm = blockIdx.x / p.tiles_n;
+    const int z = blockIdx.z;
+    const long m0 = tm * 32;
+    const int n0 = tn * 32 * TN;
+    const long ra = m0 + lrow;
+    const float *ga = p.A + z * p.sA + (ra < p.M ? ra : p.M - 1) * p.lda + 32 * half;
+    const float *gb[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int rb = n0 + j * 32 + lrow;
+        gb[j] = p.W + z * p.sW + (long)(rb < p.N ? rb : p.N - 1) * p.ldw + 32 * half;
+    }
+    const int ksteps = (p.K + KS2 - 1) / KS2;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a[2][8], b[2][TN][8];
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#define PAFC_F32_SMALL_FETCH(buf_, ks_)                                                                               \
+    {                                                                                                                 \
+        const int k0_ = (ks_) * KS2 + 32 * half;                                                                      \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                               \
+            const bool in_ = k0_ + 4 * e < p.K;                                                                       \
+            a[buf_][e] = in_ ? *reinterpret_cast<const f32x4 *>(ga + (long)(ks_) * KS2 + 4 * e) : zero4;               \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                            \
+                b[buf_][j][e] = in_ ? *reinterpret_cast<const f32x4 *>(gb[j] + (long)(ks_) * KS2 + 4 * e) : zero4;     \
+        }                                                                                                             \
+    }
+#define PAFC_F32_SMALL_MMA(buf_)                                                                                      \
+    {                                                                                                                 \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                                 \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                             \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                        \
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf_][e][c], b[buf_][j][e][c], acc[j], 0, 0, 0);  \
+    }
+    int ks = wv;
+    if (ks < ksteps) PAFC_F32_SMALL_FETCH(0, ks)
+    for (; ks < ksteps; ks += 8) {                  // two of this wave's steps per trip: register sets 0 and 1 by name
+        if (ks + 4 < ksteps) PAFC_F32_SMALL_FETCH(1, ks + 4)
+        PAFC_F32_SMALL_MMA(0)
+        if (ks + 4 < ksteps) {
+            if (ks + 8 < ksteps) PAFC_F32_SMALL_FETCH(0, ks + 8)
+            PAFC_F32_SMALL_MMA(1)
+        }
+    }
+#undef PAFC_F32_SMALL_FETCH
+#undef PAFC_F32_SMALL_MMA
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wv][j][r][lane] = acc[j][r];
+    __syncthreads();
+    const float *bias = p.bias ? p.bias + z * p.sB : nullptr;
+    const float *res = p.res ? p.res + z * p.sR : nullptr;
+    float *out = p.out + z * p.sO;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + j * 32 + lrow;
+        if (col >= p.N) continue;
+        const float bj = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {               // register r = 4 g + wv of every wave's partial: row 8 g + 4 half + wv
+            const int r = 4 * g + wv;
+            const long row = m0 + 8 * g + 4 * half + wv;
+            if (row >= p.M) continue;
+            const float sum = (red[0][j][r][lane] + red[1][j][r][lane]) + (red[2][j][r][lane] + red[3][j][r][lane]);
+            float v = p.alpha * sum + bj;
+            if (res) v += res[row * p.ldr + col];
+            out[row * p.ldo + col] = act_apply(v, p.act);
+        }
+    }
+}
+
+template <int TN>
+int launch_small(const GemmF32Params &p, int batch, hipStream_t s) {
+    GemmF32Params q = p;
+    q.tiles_n = (p.N + 32 * TN - 1) / (32 * TN);
+    const long blocks = ((p.M + 31) / 32) * q.tiles_n;
+    if (blocks > 0x7fffffffL || batch > 65535) return PAFC_ERR_BAD_DIMS;
+    hipLaunchKernelGGL(gemm_f32_small_kernel<TN>, dim3((unsigned)blocks, 1, (unsigned)batch), dim3(256), 0, s, q);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
 #undef PAFC_F32_FETCH
 #undef PAFC_F32_STASH
 
@@ -208,6 +311,15 @@ extern "C" int pafc_gemm_f32(long M, int N, int K, int batch, const float *A, lo
     // 128 x 128 tiles once they give every CU a block or more (two fit a CU); smaller problems take 64 x 64 tiles, four times the
     // blocks (a decode batch of a few hundred rows x N = 512 is 16 big tiles on 256 CUs)
     const long big = ((M + 127) / 128) * ((N + 127) / 128) * batch;
-    if (big >= pafc::device_cus()) return pafc::launch<2, 2>(p, batch, s);
+    const int cus = pafc::device_cus();
+    static const int force = getenv("PAFC_GEMM_F32_KERNEL") ? atoi(getenv("PAFC_GEMM_F32_KERNEL")) : 0;   // A/B: 1 big, 2 mid, 3 / 4 small
+    if (force == 1 || (!force && big >= cus)) return pafc::launch<2, 2>(p, batch, s);
+    // few rows (a decode batch of short windows, a streaming chunk): split-K over the waves of a block, operands straight to registers
+    const long mid = ((M + 63) / 64) * ((N + 63) / 64) * batch;
+    if (force == 3 || force == 4 || (!force && mid < 2L * cus)) {
+        const long small1 = ((M + 31) / 32) * ((N + 31) / 32) * batch;
+        if (force == 4 || (force != 3 && small1 >= 4L * cus && N % 64 == 0)) return pafc::launch_small<2>(p, batch, s);
+        return pafc::launch_small<1>(p, batch, s);
+    }
     return pafc::launch<1, 1>(p, batch, s);
 }

@@ -896,16 +896,37 @@ def test_merged_window_launches_decode_the_same_token_lists(hip):
         lit = decode_windows(model, feats, chunk, batch, streams=1, graph_cache=False)
         mer = decode_windows(model, feats, chunk, batch, streams=1, graph_cache=False, merge_frames=chunk * nwin)
         two = decode_windows(model, feats, chunk, batch, streams=2, merge_frames=2 * chunk * batch)     # 8 windows per launch, 2 in flight
-    assert len(lit["windows"]) == nwin == len(mer["windows"]) == len(two["windows"])
+        # frame by frame: the argmax of the literal schedule's log-probabilities against the one-launch schedule's
+        lp_lit = torch.cat([model.ctc_logprobs(model._forward_encoder(fb, lens)[0]) for fb, lens in feats_batcher(feats, chunk, batch, feats.device)])
+        fb_all, lens_all = next(iter(feats_batcher(feats, chunk, nwin, feats.device)))
+        lp_mer = model.ctc_logprobs(model._forward_encoder(fb_all, lens_all)[0])
+    assert len(lit["windows"]) == nwin == len(mer["windows"]) == len(two["windows"]) and lp_lit.shape == lp_mer.shape
+    flipped = int((lp_lit.argmax(-1) != lp_mer.argmax(-1)).sum())
+    frames = lp_lit.shape[0] * lp_lit.shape[1]
+
+    def edits(x, y):                                               # Levenshtein distance of two token lists
+        prev = list(range(len(y) + 1))
+        for i, xi in enumerate(x, 1):
+            cur = [i]
+            for j, yj in enumerate(y, 1):
+                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (xi != yj)))
+            prev = cur
+        return prev[-1]
     same = sum(1 for x, y in zip(lit["windows"], mer["windows"]) if x == y)
     same2 = sum(1 for x, y in zip(lit["windows"], two["windows"]) if x == y)
+    ed = sum(edits(x, y) for x, y in zip(lit["windows"], mer["windows"]))
+    ed2 = sum(edits(x, y) for x, y in zip(lit["windows"], two["windows"]))
     ntok = sum(len(w) for w in lit["windows"])
-    parity_log.record("merged window launches, decisive head", windows=nwin, tokens_literal_schedule=ntok,
-                      windows_equal_one_launch=same, windows_equal_8_per_launch=same2,
-                      tokens_one_launch=sum(len(w) for w in mer["windows"]))
-    print(f"[merged windows] {same} / {same2} of {nwin} windows decode to the literal schedule's list ({ntok} tokens)")
+    parity_log.record("merged window launches, decisive head", windows=nwin, tokens_literal_schedule=ntok, frames=frames,
+                      frames_flipped_one_launch=flipped, windows_equal_one_launch=same, windows_equal_8_per_launch=same2,
+                      token_edits_one_launch=ed, token_edits_8_per_launch=ed2)
+    print(f"[merged windows] {flipped} of {frames} frames flipped; {same} / {same2} of {nwin} windows equal; {ed} / {ed2} token edits of {ntok} tokens")
+    # the literal schedule runs 996 rows per launch (exact fp32 products below split_gemm_min_rows), the merged one 5 976 (split
+    # operands, other scan chunking): bf16-slot noise on the frames where the component grazes zero.  The bars of the other
+    # decisive-head tests: <= 0.5 % of the frames; a flipped frame that the collapse does not absorb costs two token edits
     assert ntok > 10 * nwin                                       # a real token sequence per window
-    assert same >= 0.9 * nwin and same2 >= 0.9 * nwin, (same, same2, nwin)
+    assert flipped <= 0.005 * frames, (flipped, frames)
+    assert ed <= 0.02 * ntok and ed2 <= 0.02 * ntok, (ed, ed2, ntok)
 
 
 @pytest.mark.parametrize("variant", ["bf16slot", "f32", "uni_bf16slot"])
