@@ -10,15 +10,15 @@
 // inference path: those kernels stall when two HIP streams issue them concurrently ("the c2 stall":
 // tools/repro_plan_churn.py, tools/micro/two_stream_linear.py), and decode batches run two or three streams deep.
 //
-// Block = 256 threads = 2 x 2 waves, block tile (64 TM) x (64 TN), wave tile (32 TM) x (32 TN), K-step 32, two LDS stages:
+// Block = 256 threads = 2 x 2 waves, block tile (64 TM) x (64 TN), wave tile (32 TM) x (32 TN), K-step 32 / 64, two LDS stages:
 //   * global -> registers -> LDS: a thread fetches one 16-byte quad of TM + TN ... rows per K-step (8 consecutive lanes cover
 //     128 contiguous bytes of a row), the NEXT step's quads are requested before the current step's MFMAs and stored behind
 //     them; rows beyond M / N are clamped (their results are never stored), quads beyond K are zero.
 //   * LDS rows are 36 dwords apart: ds_write_b128 of 8 lanes = one row's 128 bytes; ds_read_b128 of a 16-lane group hits 16
 //     distinct 4-bank runs of the 64 banks (36 m mod 64, m in the group's rows).
 //   * K order inside a step is permuted identically for both operands so that a lane reads CONTIGUOUS k: lane half h of a wave
-//     owns k = 16 h .. 16 h + 15 of the step, and MFMA j of the step multiplies k pair {j, 16 + j} -- two ds_read_b128 per
-//     operand tile feed eight MFMAs (a dot product does not care in which order its terms are added).
+//     owns k = (KS / 2) h .. (KS / 2) (h + 1) - 1 of the step, and MFMA j of the step multiplies k pair {j, KS / 2 + j} -- two
+//     ds_read_b128 per operand tile feed eight MFMAs (a dot product does not care in which order its terms are added).
 //   * accumulator layout of the 32 x 32 MFMA: lane l, register r holds row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32 -- a
 //     store instruction writes 128 contiguous bytes of two output rows.
 #include <cstdlib>
@@ -32,8 +32,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // (HIP's float4 is a struct: selects and array elements of it go through memory)
 
-constexpr int KS = 32;          // K-step
-constexpr int LDT = KS + 4;     // LDS row stride in dwords
+// K-step KS (32 for the 128 x 128 tiles, 64 for the 64 x 64 ones: a block of few-rows problems has the CU to itself, and every
+// K-step exposes a global-load round trip of ~1 us behind only 16 MFMAs per wave -- half as many, twice as long steps);
+// LDS row stride KS + 4 dwords: 36 m or 68 m mod 64 hits 16 distinct 4-bank runs over the 16 rows of a ds_read_b128 group
 
 struct GemmF32Params {
     const float *A, *W, *bias, *res;
@@ -53,10 +54,13 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int KS>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int RA = BM / 32, RB = BN / 32;                      // quads per thread and K-step (rows 32 apart)
+    constexpr int LDT = KS + 4;                                    // LDS row stride in dwords
+    constexpr int QR = KS / 4;                                     // quads per row and K-step: 8 or 16 consecutive lanes cover a row's KS floats
+    constexpr int RS = 256 / QR;                                   // rows one pass of the block's 256 threads covers
+    constexpr int RA = BM / RS, RB = BN / RS;                      // quads per thread and K-step (rows RS apart)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *As = lds;                                               // [2][BM][LDT]
     float *Bs = lds + 2 * BM * LDT;                                // [2][BN][LDT]
@@ -68,16 +72,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
     const float *A = p.A + z * p.sA, *W = p.W + z * p.sW;
     const long m0 = tm * BM;
     const int n0 = tn * BN;
-    const int q = tid & 7, r0 = tid >> 3;                          // this thread's quad of the K-step and first row
+    const int q = tid % QR, r0 = tid / QR;                         // this thread's quad of the K-step and first row
     const float *ga[RA], *gb[RB];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        long r = m0 + r0 + 32 * i;
+        long r = m0 + r0 + RS * i;
         ga[i] = A + (r < p.M ? r : p.M - 1) * p.lda + 4 * q;
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        int r = n0 + r0 + 32 * i;
+        int r = n0 + r0 + RS * i;
         gb[i] = W + (long)(r < p.N ? r : p.N - 1) * p.ldw + 4 * q;
     }
     const int ksteps = (p.K + KS - 1) / KS;
@@ -95,9 +99,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
 #define PAFC_F32_STASH(buf_)                                                                                          \
     {                                                                                                                 \
         _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                                \
-            *reinterpret_cast<f32x4 *>(As + ((buf_) * BM + r0 + 32 * i) * LDT + 4 * q) = pa[i];                      \
+            *reinterpret_cast<f32x4 *>(As + ((buf_) * BM + r0 + RS * i) * LDT + 4 * q) = pa[i];                      \
         _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                                \
-            *reinterpret_cast<f32x4 *>(Bs + ((buf_) * BN + r0 + 32 * i) * LDT + 4 * q) = pb[i];                      \
+            *reinterpret_cast<f32x4 *>(Bs + ((buf_) * BN + r0 + RS * i) * LDT + 4 * q) = pb[i];                      \
     }
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -113,10 +117,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
     for (int ks = 0; ks < ksteps; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < ksteps) PAFC_F32_FETCH(ks + 1)                // in flight under this step's MFMAs
-        const float *ab = As + (buf * BM + wm * 32 * TM + lrow) * LDT + 16 * half;
-        const float *bb = Bs + (buf * BN + wn * 32 * TN + lrow) * LDT + 16 * half;
+        const float *ab = As + (buf * BM + wm * 32 * TM + lrow) * LDT + (KS / 2) * half;
+        const float *bb = Bs + (buf * BN + wn * 32 * TN + lrow) * LDT + (KS / 2) * half;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < KS / 16; ++hh) {
             f32x4 a[TM][2], b[TN][2];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -273,16 +277,16 @@ int launch_small(const GemmF32Params &p, int batch, hipStream_t s) {
 #undef PAFC_F32_FETCH
 #undef PAFC_F32_STASH
 
-template <int TM, int TN>
+template <int TM, int TN, int KS>
 int launch(const GemmF32Params &p, int batch, hipStream_t s) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int BM = 64 * TM, BN = 64 * TN, LDT = KS + 4;
     GemmF32Params q = p;
     q.tiles_n = (p.N + BN - 1) / BN;
     const long tiles_m = (p.M + BM - 1) / BM;
     const long blocks = tiles_m * q.tiles_n;
     if (blocks > 0x7fffffffL || batch > 65535) return PAFC_ERR_BAD_DIMS;
     const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
-    auto kern = gemm_f32_kernel<TM, TN>;
+    auto kern = gemm_f32_kernel<TM, TN, KS>;
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PAFC_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1, (unsigned)batch), dim3(256), lds, s, q);
@@ -313,13 +317,13 @@ extern "C" int pafc_gemm_f32(long M, int N, int K, int batch, const float *A, lo
     const long big = ((M + 127) / 128) * ((N + 127) / 128) * batch;
     const int cus = pafc::device_cus();
     static const int force = getenv("PAFC_GEMM_F32_KERNEL") ? atoi(getenv("PAFC_GEMM_F32_KERNEL")) : 0;   // A/B: 1 big, 2 mid, 3 / 4 small
-    if (force == 1 || (!force && big >= cus)) return pafc::launch<2, 2>(p, batch, s);
-    // few rows (a decode batch of short windows, a streaming chunk): split-K over the waves of a block, operands straight to registers
+    if (force == 1 || (!force && big >= cus)) return pafc::launch<2, 2, 32>(p, batch, s);
+    // so few 64 x 64 tiles that three quarters of the CUs would idle (a single short window: 499 rows x N = 512 is 64 tiles): the
+    // few-rows kernel -- 32 x 32 tiles, K split over the four waves of a block, operands straight from L2 to registers.  Its
+    // operand traffic grows with the tile count (each tile re-reads its 64 rows of K floats), so wider / taller problems keep the
+    // staged tiles (tools/bench_gemm_f32.py, profiles/r06h_gemm_f32_variants.txt)
     const long mid = ((M + 63) / 64) * ((N + 63) / 64) * batch;
-    if (force == 3 || force == 4 || (!force && mid < 2L * cus)) {
-        const long small1 = ((M + 31) / 32) * ((N + 31) / 32) * batch;
-        if (force == 4 || (force != 3 && small1 >= 4L * cus && N % 64 == 0)) return pafc::launch_small<2>(p, batch, s);
-        return pafc::launch_small<1>(p, batch, s);
-    }
-    return pafc::launch<1, 1>(p, batch, s);
+    if (force == 3 || (!force && 4 * mid <= cus)) return pafc::launch_small<1>(p, batch, s);
+    if (force == 4) return pafc::launch_small<2>(p, batch, s);
+    return pafc::launch<1, 1, 64>(p, batch, s);
 }

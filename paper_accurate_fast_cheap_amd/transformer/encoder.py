@@ -178,7 +178,16 @@ class BaseEncoder(torch.nn.Module):
             except RuntimeError as e:              # a REFUSED capture (an operation the capture mode does not permit): this shape
                 if not _capture_refused(e):        # stays eager; anything else -- a failing launch, a PafcError -- surfaces
                     raise
-                torch.cuda.synchronize(xs.device)
+                # On this runtime an invalidated capture reports itself ONCE MORE, through the next synchronising call of the
+                # process (hipErrorStreamCaptureInvalidated): that report is taken here, where it is expected, and not by the
+                # caller's next unrelated operation
+                for _ in range(2):
+                    try:
+                        torch.cuda.synchronize(xs.device)
+                        break
+                    except RuntimeError as again:
+                        if not _capture_refused(again):
+                            raise
                 self._graphs[key] = "eager"
                 return None
         if ent == "eager":
