@@ -30,6 +30,41 @@ def _post_load_bump(module, incompatible_keys):
     _bump_epoch()
 
 
+_CAPTURE_STREAMS = {}
+
+
+def _capture_stream(device) -> torch.cuda.Stream:
+    """The side stream this module's graph captures run on (one per device, as torch.cuda.graph keeps one of its own)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _CAPTURE_STREAMS:
+        _CAPTURE_STREAMS[idx] = torch.cuda.Stream(device=device)
+    return _CAPTURE_STREAMS[idx]
+
+
+def _abandon_capture(stream: torch.cuda.Stream, device) -> None:
+    """After a capture the runtime refused: leave the process usable.  On ROCm 7 an invalidated capture stays attached to its
+    stream when torch's capture_end fails, and every later call of the process reports hipErrorStreamCaptureInvalidated: end the
+    capture on the stream by hand (the call reports the same error once more and detaches it), drop the half-built graph, read the
+    last error away, and let the device drain.  Best effort: anything this cannot clear surfaces at the caller's next call."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        g = ctypes.c_void_p()
+        hip.hipStreamEndCapture(ctypes.c_void_p(stream.cuda_stream), ctypes.byref(g))
+        if g.value:
+            hip.hipGraphDestroy(g)
+        hip.hipGetLastError()
+    except OSError:
+        pass
+    for _ in range(2):
+        try:
+            torch.cuda.synchronize(device)
+            break
+        except RuntimeError as again:
+            if not _capture_refused(again):
+                raise
+
+
 def _capture_refused(e: BaseException) -> bool:
     """Is this the runtime refusing an operation under stream capture (hipErrorStreamCapture* -- a synchronising call, an
     allocation the graph pool cannot serve, a capture-unsafe library call), as opposed to an error of the work itself?"""
@@ -170,7 +205,8 @@ class BaseEncoder(torch.nn.Module):
             try:
                 sx, sl = xs.clone(), xs_lens.clone()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                cap_stream = _capture_stream(xs.device)        # ours, so that a refused capture can be ended by hand (below)
+                with torch.cuda.graph(graph, stream=cap_stream):
                     oy, om, _ = self.forward_return_layers(sx, sl, all_full=full)
                 ent = self._graphs[key] = (graph, sx, sl, oy, om)
                 self._graphs[key] = self._graphs.pop(key)     # newest last, then drop the oldest graphs beyond the bound
@@ -178,16 +214,7 @@ class BaseEncoder(torch.nn.Module):
             except RuntimeError as e:              # a REFUSED capture (an operation the capture mode does not permit): this shape
                 if not _capture_refused(e):        # stays eager; anything else -- a failing launch, a PafcError -- surfaces
                     raise
-                # On this runtime an invalidated capture reports itself ONCE MORE, through the next synchronising call of the
-                # process (hipErrorStreamCaptureInvalidated): that report is taken here, where it is expected, and not by the
-                # caller's next unrelated operation
-                for _ in range(2):
-                    try:
-                        torch.cuda.synchronize(xs.device)
-                        break
-                    except RuntimeError as again:
-                        if not _capture_refused(again):
-                            raise
+                _abandon_capture(cap_stream, xs.device)
                 self._graphs[key] = "eager"
                 return None
         if ent == "eager":
