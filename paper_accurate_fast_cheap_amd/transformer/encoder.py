@@ -42,10 +42,11 @@ def _capture_stream(device) -> torch.cuda.Stream:
 
 
 def _abandon_capture(stream: torch.cuda.Stream, device) -> None:
-    """After a capture the runtime refused: leave the process usable.  On ROCm 7 an invalidated capture stays attached to its
-    stream when torch's capture_end fails, and every later call of the process reports hipErrorStreamCaptureInvalidated: end the
-    capture on the stream by hand (the call reports the same error once more and detaches it), drop the half-built graph, read the
-    last error away, and let the device drain.  Best effort: anything this cannot clear surfaces at the caller's next call."""
+    """After a capture the runtime refused: try to leave the process usable -- end the capture on its stream by hand, drop the
+    half-built graph, read the last error away, let the device drain.  Best effort: on ROCm 7.0's HIP inside torch 2.10 an
+    invalidated capture keeps failing every later call of the process with hipErrorStreamCaptureInvalidated whatever is done here
+    (tests/test_encoder_gpu.py::test_refused_capture_is_never_silent_in_a_child_process records which way a runtime behaves);
+    what cannot be cleared surfaces at the caller's next call, naming the capture."""
     import ctypes
     try:
         hip = ctypes.CDLL("libamdhip64.so")
