@@ -135,6 +135,26 @@ class BaseEncoder(torch.nn.Module):
     def output_size(self) -> int:
         return self._output_size
 
+    def multi_stream_safe(self) -> bool:
+        """May several forward passes of this encoder be in flight on different HIP streams?  Only when every GEMM of the pass is
+        one of this package's kernels: the framework's library GEMM (F.linear, torch.bmm: what the op-by-op module path calls)
+        stalls for good when two streams issue it concurrently (DESIGN.md section 4 "the c2 stall").  True for the fused
+        executor over eligible layers (RWKV slots, or the Mamba-2 block on its fused kernels); the schedulers of utils.longform
+        keep everything on ONE stream otherwise."""
+        if not (self.fused_inference and self.normalize_before and not self.training):
+            return False
+        from . import fused
+        from .mamba2 import MambaAttWrapper
+        for layer in self.encoders:
+            if not fused.eligible(layer):
+                return False
+            slot = layer.self_attn
+            if isinstance(slot, MambaAttWrapper):
+                blocks = [slot.mamba] if not hasattr(slot.mamba, "mamba_forward") else [slot.mamba.mamba_forward, slot.mamba.mamba_backward]
+                if not all(b.fused_inference and b.d_state == 128 and b.d_inner <= 1024 for b in blocks):
+                    return False
+        return True
+
     def _apply(self, fn, *args, **kwargs):
         """model.to() / .cuda() / .half(): the parameters move to new storage -- every derived copy and captured graph is stale."""
         _bump_epoch()

@@ -95,7 +95,9 @@ class Mamba2(nn.Module):
         y1 = wkv6_forward(r1, k1, v, w, u0, reverse=reverse)
         y = hip_ops.mamba2_finish(y0, y1, xbc, dt_raw, z, self.dt_bias.float(), self.D.float(), self.norm.weight,
                                   self.norm.eps, di)
-        return self.out_proj(y)
+        # (the module call `self.out_proj(y)` = the framework's F.linear stood here until round 6: with two or three window batches
+        #  in flight on side streams its fp32 GEMM never finishes -- DESIGN section 4 "the c2 stall"; found by the Mamba-2 sweep)
+        return lin(y, self.out_proj)
 
     def fused_eligible(self, u: torch.Tensor) -> bool:
         return (self.fused_inference and u.is_cuda and not torch.is_grad_enabled() and self.d_state == 128

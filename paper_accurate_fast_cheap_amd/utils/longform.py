@@ -50,6 +50,15 @@ def merged_batch_size(chunk_size: int, batch_size: int, merge_frames: int) -> in
 _SIDE = {}
 
 
+def _multi_stream_safe(model) -> bool:
+    """Several batches in flight on side streams only for models whose whole pass runs on this package's kernels
+    (BaseEncoder.multi_stream_safe): the framework's fp32 library GEMM deadlocks under concurrent streams."""
+    enc = getattr(model, "encoder", None)
+    fn = getattr(enc, "multi_stream_safe", None)
+    return bool(fn()) if callable(fn) else False
+
+
+
 def _side_streams(device: torch.device, n: int):
     """The same n side streams for every call on a device: the encoder's graph cache is keyed by (shape, stream), so fresh
     streams per file would mean fresh captures per file."""
@@ -73,6 +82,8 @@ def greedy_decode_batches(model, batches, streams: int = 2, blank_id: int = 0, w
         return ([] if want_tokens else None), None
     device = batches[0][0].device
     n_side = max(1, min(int(streams), len(batches)))
+    if n_side > 1 and not _multi_stream_safe(model):
+        n_side = 1                   # a pass that calls the framework's library GEMMs must not overlap another one (see there)
     main = torch.cuda.current_stream(device)
     side = _side_streams(device, n_side) if n_side > 1 else []
     for s_ in side:
@@ -111,6 +122,8 @@ def decode_windows(model, feats: torch.Tensor, chunk_size: int, batch_size: int,
         batch_size = merged_batch_size(chunk_size, batch_size, merge_frames)
         batches = list(feats_batcher(feats, chunk_size, batch_size, feats.device))
         n_side = max(1, min(int(streams), len(batches)))
+        if n_side > 1 and not _multi_stream_safe(model):
+            n_side = 1               # a pass that calls the framework's library GEMMs must not overlap another one
         main = torch.cuda.current_stream(feats.device)
         side = _side_streams(feats.device, n_side) if n_side > 1 else []
         for s_ in side:

@@ -319,3 +319,25 @@ def test_subsampled_length_is_the_mask_slicing():
         m = ~make_pad_mask(torch.tensor([n]), 70).unsqueeze(1)
         assert int(m[:, :, 2::2][:, :, 2::2].sum()) == sub.subsampled_length(n), n
     assert sub.subsampled_length(179998) == 44998 and sub.subsampled_length(179995) == 44998 and sub.subsampled_length(179994) == 44997
+
+
+def test_multi_stream_safe_only_for_all_own_kernel_passes():
+    """BaseEncoder.multi_stream_safe: batches may be in flight on several HIP streams only when every GEMM of the pass is one of the
+    package's kernels (the framework's library GEMM never finishes when two streams issue it: DESIGN.md "the c2 stall").  True for
+    the fused executor over eligible layers -- RWKV slots, the Mamba-2 block --, False for the module path (switched off, a
+    batch-norm conv module, training mode); utils.longform then keeps one stream."""
+    import bench
+    from paper_accurate_fast_cheap_amd.transformer.encoder import ConformerEncoder
+    from paper_accurate_fast_cheap_amd.utils import longform
+    conf = dict(bench.encoder_conf(), num_blocks=2, output_size=128, attention_heads=2, linear_units=256)
+    enc = ConformerEncoder(80, **conf).eval()
+    assert enc.multi_stream_safe()
+    enc.fused_inference = False
+    assert not enc.multi_stream_safe()
+    assert ConformerEncoder(80, **dict(conf, selfattention_layer_type="mamba_att", rnn_att_version="mamba2")).eval().multi_stream_safe()
+    assert not ConformerEncoder(80, **dict(conf, cnn_module_norm="batch_norm")).eval().multi_stream_safe()
+    assert not ConformerEncoder(80, **conf).train().multi_stream_safe()
+
+    class M:
+        encoder = enc
+    assert not longform._multi_stream_safe(M()) and not longform._multi_stream_safe(object())

@@ -160,3 +160,38 @@ def test_mamba_scan_bf16_output_carries_the_skip_term(hip, reverse):
     g = (y16 * torch.nn.functional.silu(z)).float()
     ref = (g * torch.rsqrt(g.pow(2).mean(-1, keepdim=True) + 1e-5) * w.float()).to(torch.bfloat16)
     torch.testing.assert_close(got.float(), ref.float(), rtol=2 ** -6, atol=2e-2)
+
+
+def test_mamba_fp32_batches_in_flight_call_no_library_gemm(hip, monkeypatch):
+    """The Mamba-2 models of the paper's sweep ship fp32 parameters (conf/mamba/*.yaml): utils.longform runs their decode batches
+    two or three streams deep, so the pass must not contain a single call of the framework's library GEMM -- its fp32 kernel never
+    finishes when two streams issue it (DESIGN.md "the c2 stall"; the block's `self.out_proj(y)` did exactly that until round 6
+    and stalled the sweep at 100 000-frame windows).  F.linear / torch.bmm / torch.matmul are made to raise for the duration of
+    the pass; two batches in flight give the one-stream results bit for bit."""
+    import torch.nn.functional as F
+    import bench
+    from paper_accurate_fast_cheap_amd.utils.init_model import init_model
+    from paper_accurate_fast_cheap_amd.utils.longform import greedy_decode_batches
+    conf = dict(bench.encoder_conf(), num_blocks=2, selfattention_layer_type="mamba_att", rnn_att_version="mamba2", rnn_att_direction="bi")
+    configs = dict(encoder="conformer", encoder_conf=conf, input_dim=80, output_dim=64, ctc="ctc", ctc_conf={"ctc_blank_id": 0},
+                   model_conf={}, dataset_conf={})
+
+    class A:
+        checkpoint = None
+
+    torch.manual_seed(4)
+    model, _ = init_model(A(), configs)
+    model = model.eval().cuda()
+    assert model.encoder.multi_stream_safe()
+    batches = [(synth.randn((3, 400 + 64 * i, 80), 70 + i, 2.0).cuda(), torch.tensor([400 + 64 * i, 333, 250], dtype=torch.int32, device="cuda"))
+               for i in range(6)]
+    want, _ = greedy_decode_batches(model, batches, streams=1)
+
+    def refuse(*a, **k):
+        raise AssertionError("a library GEMM was called on an inference path")
+    for name in ("linear",):
+        monkeypatch.setattr(F, name, refuse)
+    monkeypatch.setattr(torch, "bmm", refuse)
+    monkeypatch.setattr(torch, "matmul", refuse)
+    got, _ = greedy_decode_batches(model, batches, streams=2)
+    assert [[list(r.tokens) for r in b] for b in got] == [[list(r.tokens) for r in b] for b in want]
