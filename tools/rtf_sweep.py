@@ -115,6 +115,9 @@ def main():
         feats = feats.to(torch.bfloat16)
     frames = feats.shape[1]
     lens = torch.tensor([frames], dtype=torch.int32, device=device)
+    precision = bench.PRECISION[args.dtype]
+    if args.slot == "mamba_att" and args.dtype == "bf16slot":
+        precision = "fp32 model, fp32 Mamba-2 slot (conf/mamba/*.yaml as shipped: fp32 parameters; exact fp32 products, no bf16 slot)"
     enc = model.encoder
 
     def one_sequence():
@@ -125,7 +128,7 @@ def main():
     records = []
     with open(args.out + ".jsonl", "w") as fj:
         head = {"one_sequence_ms": round(one_ms, 3), "one_sequence_audio_sec_per_sec": round(one_rate, 1), "dtype": args.dtype,
-                "precision": bench.PRECISION[args.dtype], "frames": frames, "streams": args.streams, "merge_frames": args.merge_frames,
+                "precision": precision, "frames": frames, "streams": args.streams, "merge_frames": args.merge_frames,
                 "model": MODEL_NAME,
                 "device": torch.cuda.get_device_name(0)}
         fj.write(json.dumps(head) + "\n")
@@ -175,7 +178,7 @@ def main():
     enc.graph_cache_size = 0
     enc._graphs.clear()
     with open(args.out + ".md", "w") as fm:
-        fm.write(f"# Encoder RTF sweep, {MODEL_NAME}, one MI355X, {bench.PRECISION[args.dtype]}\n\n"
+        fm.write(f"# Encoder RTF sweep, {MODEL_NAME}, one MI355X, {precision}\n\n"
                  f"One synthetic 30-minute file ({frames} frames), `utils.longform.decode_windows` (encoder + CTC log-softmax + greedy "
                  f"tokens + stitching inside the timing), {args.streams} window batches in flight, "
                  + (f"consecutive batches merged into launches of up to {args.merge_frames} frames, " if args.merge_frames else
