@@ -316,7 +316,7 @@ extern "C" int pafc_gemm_f32(long M, int N, int K, int batch, const float *A, lo
     // blocks (a decode batch of a few hundred rows x N = 512 is 16 big tiles on 256 CUs)
     const long big = ((M + 127) / 128) * ((N + 127) / 128) * batch;
     const int cus = pafc::device_cus();
-    static const int force = getenv("PAFC_GEMM_F32_KERNEL") ? atoi(getenv("PAFC_GEMM_F32_KERNEL")) : 0;   // A/B: 1 big, 2 mid, 3 / 4 small
+    static const int force = getenv("PAFC_GEMM_F32_KERNEL") ? atoi(getenv("PAFC_GEMM_F32_KERNEL")) : 0;   // A/B: 1 big, 2 mid, 3 few-rows
     if (force == 1 || (!force && big >= cus)) return pafc::launch<2, 2, 32>(p, batch, s);
     // so few 64 x 64 tiles that three quarters of the CUs would idle (a single short window: 499 rows x N = 512 is 64 tiles): the
     // few-rows kernel -- 32 x 32 tiles, K split over the four waves of a block, operands straight from L2 to registers.  Its
@@ -324,6 +324,5 @@ extern "C" int pafc_gemm_f32(long M, int N, int K, int batch, const float *A, lo
     // staged tiles (tools/bench_gemm_f32.py, profiles/r06h_gemm_f32_variants.txt)
     const long mid = ((M + 63) / 64) * ((N + 63) / 64) * batch;
     if (force == 3 || (!force && 4 * mid <= cus)) return pafc::launch_small<1>(p, batch, s);
-    if (force == 4) return pafc::launch_small<2>(p, batch, s);
     return pafc::launch<1, 1, 64>(p, batch, s);
 }

@@ -3,7 +3,7 @@
 single 2 000-frame window (499 rows) to a c2 batch (16 000 rows), against the framework's F.linear on ONE stream.
 
   python tools/bench_gemm_f32.py            runs itself once per variant (PAFC_GEMM_F32_KERNEL = 0 auto, 1 = 128 x 128 staged tiles,
-                                            2 = 64 x 64 staged tiles, 3 / 4 = few-rows split-K kernel with 32 x 32 / 32 x 64 tiles)
+                                            2 = 64 x 64 staged tiles, 3 = few-rows split-K kernel with 32 x 32 tiles)
                                             and prints one table; a correctness check of every variant against float64 rides along."""
 import json
 import os
@@ -64,7 +64,7 @@ def main():
     if os.environ.get("PAFC_GEMM_F32_CHILD") == "1":
         return child()
     res = {}
-    for v in ("0", "1", "2", "3", "4"):
+    for v in ("0", "1", "2", "3"):
         env = dict(os.environ, PAFC_GEMM_F32_CHILD="1", PAFC_GEMM_F32_KERNEL=v, PYTHONPATH=ROOT)
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=280)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
@@ -72,11 +72,11 @@ def main():
             print(f"variant {v} failed:\n{r.stdout[-500:]}\n{r.stderr[-1500:]}")
             continue
         res[v] = json.loads(line[0][7:])
-    print("us per launch, fp32; columns: auto | 128x128 staged | 64x64 staged | few-rows 32x32 | few-rows 32x64 | torch F.linear (+ separate epilogue ops), one stream")
+    print("us per launch, fp32; columns: auto | 128x128 staged | 64x64 staged | few-rows 32x32 | torch F.linear (+ separate epilogue ops), one stream")
     for name, K, N, act, resd in SHAPES:
         for M in ROWS:
             key = f"{name} {M}"
-            cells = [res.get(v, {}).get(key) for v in ("0", "1", "2", "3", "4")] + [res.get("0", {}).get("torch " + key)]
+            cells = [res.get(v, {}).get(key) for v in ("0", "1", "2", "3")] + [res.get("0", {}).get("torch " + key)]
             print(f"{name:5s} {K:4d}->{N:4d} rows {M:6d}: " + " | ".join(f"{c:8.1f}" if c is not None else "       -" for c in cells))
 
 
