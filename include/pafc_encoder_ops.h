@@ -265,6 +265,18 @@ size_t pafc_gemm_tn_workspace_bytes(long R, int M, int N);
 int pafc_gemm_tn_bf16(long R, int M, int N, const void *dy, long lda, const void *x, long ldb, void *dw, void *dbias,
                       int dw_dtype, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
 
+/* fp32 results from bf16 operands on the small tiles of csrc/gemm_bf16.hip (128 x 128 / 128 x 64 / 64 x 64, picked by row count): the
+ * operand forms of pafc_gemm_ph_ex for problems too small for its 256-wide tiles -- a_split != 0: A = planes [hi K | lo K] of an
+ * fp32 activation, W = [hi | hi | lo] (N x 3 K), three bf16 products per fp32 product (~2^-16); a_split == 0: plain bf16 A (M, K),
+ * W (N, K).  out_kind 1: fp32 out (+ fp32 residual, which may alias out); 2: the fp32 result as bf16 planes hi | lo (lo at column
+ * offset lo_off, ldo in bf16 elements; no residual).  bias fp32 (added as given), act 0 none / 1 SiLU / 2 tanh / 3 ReLU applied to
+ * alpha * product + bias (before the residual add, as pafc_gemm_ph_ex has it).  N % 8 == 0, K % 64 == 0, 16-byte aligned rows.
+ * The same call sites as pafc_gemm_ph_ex (positionwise_feed_forward.py:47-55, convolution.py:118-141, encoder_layer.py:201-259,
+ * rwkv_wrapper_bidirectional.py:55-56) for decode batches of a few hundred to a few thousand rows. */
+int pafc_gemm_bf16_f32out(long M, int N, int K, const void *A, long lda, int a_split, const void *W, long ldw, const float *bias,
+                          const float *residual, long ldr, void *out, int out_kind, long ldo, long lo_off, float alpha, int act,
+                          pafc_stream_t stream);
+
 /* ---- CTC loss of the training step, from the logits (csrc/ctc_loss.hip) -------------------------------------------------------
  * `ys_hat.log_softmax(2)` + `torch.nn.CTCLoss(reduction="sum", zero_infinity=True)` of CTC.forward (wenet/transformer/ctc.py:
  * 53-82) and their autograd, without the (B, T, V) log-probability tensor and without a host round trip.

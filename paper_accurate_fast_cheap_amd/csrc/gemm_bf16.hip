@@ -40,6 +40,11 @@ struct GemmParams {
     float alpha;
     int act;                          // 0 none, 1 SiLU, 2 tanh, 3 ReLU
     int mtiles, ntiles;
+    // fp32-output forms (EPI 3 / 4, pafc_gemm_bf16_f32out): bias / residual are fp32 (the bf16_t pointers above are reinterpreted),
+    // out fp32 or bf16 planes hi | lo (lo at column offset lo_off); split-operand A (SPL): A = planes [hi K1 | lo K1] of an fp32
+    // activation, W = [hi | hi | lo] (N x 3 K1), K = 3 K1 columns walked as hi, lo, hi of A -- nk1 = K1 / 64 K-steps per segment
+    int nk1, K1;
+    long lo_off;
 };
 
 __device__ __forceinline__ void gdma16(const bf16_t *src, bf16_t *lds_base) {
@@ -63,7 +68,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // 64 x 64: same loop, the wave's share of the tile shrinks (MI x NI MFMA tiles of 16 x 16), more tiles fill the chip.
 // NST = LDS stages: 2 for 128 x 128 (two blocks of 64 KiB per CU), 3 for the smaller tiles -- a few-thousand-row problem
 // with a long K (w_2: 32 K-steps) is bound by the latency of each K-step's operands, one more step in flight hides it.
-template <int EPI, int BM = GBM, int BN = GBN, int NST = 2>
+// EPI 3 / 4 (round 6): fp32 results -- 3 = fp32 out (+ fp32 bias, + fp32 residual), 4 = the fp32 result as bf16 planes hi | lo --
+// and SPL = a split-operand A: the fp32 projections of a model with the bf16 slot at a FEW HUNDRED to a few thousand rows (a
+// single 2 000-frame window is 499), where the 256-wide phase-pipelined tiles cannot fill the chip and exact fp32 products on the
+// fp32 matrix cores cost four times the matrix time of three bf16 products.
+template <int EPI, int BM = GBM, int BN = GBN, int NST = 2, bool SPL = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     constexpr bool HAS_RES = EPI == 1;
     constexpr int MI = BM / 32, NI = BN / 32;      // 16 x 16 MFMA tiles per wave along m / n (2 x 2 waves)
@@ -107,8 +116,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         bf16_t *A = lds + buf * STAGE;
         bf16_t *Wt = A + BM * GBK;
         const int koff = it * GBK;
+        int koffA = koff;
+        if constexpr (SPL) {                                 // A walks hi, lo, hi while W walks [hi | hi | lo] straight through
+            const int seg = (it >= p.nk1) + (it >= 2 * p.nk1);
+            koffA = (seg == 1 ? p.K1 : 0) + (it - seg * p.nk1) * GBK;
+        }
 #pragma unroll
-        for (int j = 0; j < MI; ++j) gdma16(a_src[j] + koff, A + (wave * (BM / 4) + j * 8) * GBK);
+        for (int j = 0; j < MI; ++j) gdma16(a_src[j] + koffA, A + (wave * (BM / 4) + j * 8) * GBK);
 #pragma unroll
         for (int j = 0; j < NI; ++j) gdma16(w_src[j] + koff, Wt + (wave * (BN / 4) + j * 8) * GBK);
     };
@@ -161,7 +175,63 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     // ---- epilogue: C/D layout col = lane & 15 (n), row = 4 (lane >> 4) + reg (m) --------------------------------
     const bf16_t *bz = p.bias ? p.bias + z * p.sB : nullptr;
     bf16_t *Oz = p.out + z * p.sO;
-    if constexpr (HAS_RES) {
+    if constexpr (EPI == 3 || EPI == 4) {
+        constexpr int LDF = BN + 4;   // fp32 staging [BM][BN + 4]
+        float *O = reinterpret_cast<float *>(lds);
+        const float *bf = p.bias ? reinterpret_cast<const float *>(p.bias) + z * p.sB : nullptr;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = wn * (BN / 2) + j * 16 + fr;
+            const float bv = bf ? bf[min(n0 + col, p.N - 1)] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    O[(wm * (BM / 2) + i * 16 + 4 * kq + g) * LDF + col] = apply_act(fmaf(acc[i][j][g], p.alpha, bv), p.act);
+        }
+        __syncthreads();
+        if constexpr (EPI == 3) {
+            const float *Rf = p.res ? reinterpret_cast<const float *>(p.res) + z * p.sR : nullptr;
+            float *Of = reinterpret_cast<float *>(p.out) + z * p.sO;
+            constexpr int CPR = BN / 4, RPP = 256 / CPR;   // 16-byte chunks (4 floats) per row, rows per pass
+#pragma unroll
+            for (int q = 0; q < BM / RPP; ++q) {
+                const int row = q * RPP + tid / CPR, c4 = (tid % CPR) * 4;
+                const long m = m0 + row;
+                if (m < p.M && n0 + c4 < p.N) {
+                    float4 o = *reinterpret_cast<const float4 *>(O + row * LDF + c4);
+                    if (Rf) {
+                        const float4 r = *reinterpret_cast<const float4 *>(Rf + m * p.ldr + n0 + c4);
+                        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                    }
+                    *reinterpret_cast<float4 *>(Of + m * p.ldo + n0 + c4) = o;
+                }
+            }
+        } else {
+            constexpr int CPR = BN / 8, RPP = 256 / CPR;
+#pragma unroll
+            for (int q = 0; q < BM / RPP; ++q) {
+                const int row = q * RPP + tid / CPR, c8 = (tid % CPR) * 8;
+                const long m = m0 + row;
+                if (m < p.M && n0 + c8 < p.N) {
+                    const float4 o0 = *reinterpret_cast<const float4 *>(O + row * LDF + c8);
+                    const float4 o1 = *reinterpret_cast<const float4 *>(O + row * LDF + c8 + 4);
+                    const float o[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+                    uint32_t h[8], l[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        h[e] = f32_to_bf16_bits(o[e]);
+                        l[e] = f32_to_bf16_bits(o[e] - bf16_bits_to_f32(h[e]));
+                    }
+                    uint4 wh, wl;
+                    wh.x = h[0] | (h[1] << 16); wh.y = h[2] | (h[3] << 16); wh.z = h[4] | (h[5] << 16); wh.w = h[6] | (h[7] << 16);
+                    wl.x = l[0] | (l[1] << 16); wl.y = l[2] | (l[3] << 16); wl.z = l[4] | (l[5] << 16); wl.w = l[6] | (l[7] << 16);
+                    *reinterpret_cast<uint4 *>(Oz + m * p.ldo + n0 + c8) = wh;
+                    *reinterpret_cast<uint4 *>(Oz + m * p.ldo + p.lo_off + n0 + c8) = wl;
+                }
+            }
+        }
+    } else if constexpr (HAS_RES) {
         constexpr int LDF = BN + 4;   // fp32 staging [BM][BN + 4] (66 KiB at 128 x 128)
         float *O = reinterpret_cast<float *>(lds);
 #pragma unroll
@@ -373,5 +443,56 @@ extern "C" int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, lo
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PAFC_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+
+// fp32 results from bf16 operands on the 128 x 128 / 128 x 64 / 64 x 64 tiles (include/pafc_encoder_ops.h): the split-operand
+// projections of an fp32 model with the bf16 slot at few rows, and the slot's bf16 output projection into the fp32 residual stream.
+extern "C" int pafc_gemm_bf16_f32out(long M, int N, int K, const void *A, long lda, int a_split, const void *W, long ldw,
+                                     const float *bias, const float *residual, long ldr, void *out, int out_kind, long ldo,
+                                     long lo_off, float alpha, int act, pafc_stream_t stream) {
+    if (!A || !W || !out) return PAFC_ERR_NULL_POINTER;
+    if (M <= 0 || N <= 0 || K <= 0) return PAFC_ERR_BAD_DIMS;
+    if (N % 8 || K % pafc::GBK) return PAFC_ERR_UNSUPPORTED;
+    if ((out_kind != 1 && out_kind != 2) || act < 0 || act > 3) return PAFC_ERR_UNSUPPORTED;
+    if (out_kind == 2 && residual) return PAFC_ERR_UNSUPPORTED;
+    const int Kw = a_split ? 3 * K : K;
+    if (lda < (a_split ? 2 * K : K) || ldw < Kw || (residual && ldr < N)) return PAFC_ERR_BAD_DIMS;
+    if (out_kind == 2 ? (lo_off < N || ldo < lo_off + N) : ldo < N) return PAFC_ERR_BAD_DIMS;
+    if ((lda | ldw) % 8 || (out_kind == 1 ? ldo % 4 : (ldo | lo_off) % 8) || (residual && ldr % 4)) return PAFC_ERR_ALIGNMENT;
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)residual) & 15) != 0) return PAFC_ERR_ALIGNMENT;
+    pafc::GemmParams p{};
+    p.A = (const pafc::bf16_t *)A; p.W = (const pafc::bf16_t *)W; p.bias = (const pafc::bf16_t *)bias;
+    p.res = (const pafc::bf16_t *)residual; p.out = (pafc::bf16_t *)out;
+    p.M = M; p.N = N; p.K = Kw; p.K1 = K; p.nk1 = K / pafc::GBK;
+    p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr; p.lo_off = lo_off;
+    p.alpha = alpha; p.act = act;
+    const long cus = pafc::device_cus();
+    auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    int bm = 128, bn = 128;
+    if (tiles(128, 128) < 2 * cus) {
+        if (tiles(128, 64) >= 2 * cus) bn = 64;
+        else { bm = 64; bn = 64; }
+    }
+    p.mtiles = (int)((M + bm - 1) / bm);
+    p.ntiles = (N + bn - 1) / bn;
+    const long nblk = (long)p.mtiles * p.ntiles;
+    if (nblk > 0x7fffffffL) return PAFC_ERR_BAD_DIMS;
+    const int nst = (bm == 128 && bn == 128) ? 2 : 3;
+    const size_t stage_bytes = (size_t)nst * (bm + bn) * pafc::GBK * sizeof(pafc::bf16_t);
+    const size_t out_bytes = (size_t)bm * (bn + 4) * sizeof(float);
+    const size_t lds = out_bytes > stage_bytes ? out_bytes : stage_bytes;
+    typedef void (*kern_t)(const pafc::GemmParams);
+    kern_t kern;
+#define PAFC_PICK(E, S)                                                                                                   \
+    (bm == 64 ? (kern_t)pafc::gemm_bf16_kernel<E, 64, 64, 3, S> : bn == 64 ? (kern_t)pafc::gemm_bf16_kernel<E, 128, 64, 3, S> \
+                                                                          : (kern_t)pafc::gemm_bf16_kernel<E, 128, 128, 2, S>)
+    if (out_kind == 1) kern = a_split ? PAFC_PICK(3, true) : PAFC_PICK(3, false);
+    else kern = a_split ? PAFC_PICK(4, true) : PAFC_PICK(4, false);
+#undef PAFC_PICK
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PAFC_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, 1), dim3(256), lds, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }

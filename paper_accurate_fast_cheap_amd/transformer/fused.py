@@ -184,6 +184,7 @@ class LayerPlan:
             ff_w1=sp(L.feed_forward.w_1.weight.contiguous(), True), ff_w2=sp(L.feed_forward.w_2.weight.contiguous(), True),
             pw1=sp(hip_ops.glu_interleave(pw1.weight.squeeze(-1), 32).contiguous(), True),
             pw1_b=hip_ops.glu_interleave(pw1.bias, 32).contiguous() if pw1.bias is not None else None,
+            pw1_plain=sp(pw1.weight.squeeze(-1).contiguous(), True),          # rows as they lie: the few-rows form (GLU in the dwconv)
             pw2=sp(cm.pointwise_conv2.weight.squeeze(-1).contiguous(), True))
 
     def _refresh_rwkv(self, bl):
@@ -491,8 +492,9 @@ def layer_forward_lnfold(plan: LayerPlan, x: torch.Tensor, st: torch.Tensor, nex
 _FFN_ROW_BLOCK = int(os.environ.get("PAFC_FFN_ROW_BLOCK", "0"))
 
 
-# fp32 streams shorter than this take exact fp32 products (csrc/gemm_f32.hip; small problems do not fill 256-wide tiles)
-_SPLIT_GEMM_MIN_ROWS = hip_ops.DISPATCH["split_gemm_min_rows"]
+# fp32 streams of a model with the bf16 slot shorter than this take exact fp32 products (csrc/gemm_f32.hip); from here on the
+# split-operand schedule (small tiles up to hip_ops.DISPATCH["split_small_max_rows"] rows, the 256-wide kernel beyond)
+_SPLIT_GEMM_MIN_ROWS = hip_ops.DISPATCH["split_layers_min_rows"]
 
 
 def split_eligible(plan: LayerPlan, x: torch.Tensor) -> bool:
@@ -528,8 +530,13 @@ def layer_forward_split(plan: LayerPlan, x: torch.Tensor, hp: torch.Tensor, lens
     if cm.lorder > 0:    # causal module: lorder zero frames in front of pointwise_conv1 (convolution.py:112-118)
         hc = torch.cat([hc.new_zeros(B, cm.lorder, 2 * C), hc], dim=1)
         left_pad, Tc = 0, T + cm.lorder
-    p = G(hc.view(B * Tc, 2 * C), S["pw1"], S["pw1_b"], "glu", a_split=True, out_kind="f32").view(B, Tc, C)
-    dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, left_pad, T)
+    if B * Tc <= hip_ops._SPLIT_SMALL_MAX_ROWS:
+        # few rows (the small-tile kernel has no GLU epilogue): the plain projection, F.glu inside the depthwise convolution
+        p = G(hc.view(B * Tc, 2 * C), S["pw1_plain"], cm.pointwise_conv1.bias, a_split=True, out_kind="f32").view(B, Tc, 2 * C)
+        dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, left_pad, T, glu=True)
+    else:
+        p = G(hc.view(B * Tc, 2 * C), S["pw1"], S["pw1_b"], "glu", a_split=True, out_kind="f32").view(B, Tc, C)
+        dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, left_pad, T)
     _, g, _ = hip_ops.add_layernorm(dw, None, 1.0, cm.norm.weight, cm.norm.bias, silu=True, eps=cm.norm.eps, split1=True)
     if not masked:
         x2 = x.view(M, C)

@@ -104,6 +104,19 @@ def test_argument_validation_returns_error_codes_without_a_gpu(so_path):
     assert L.pafc_gemm_f32(8, 8, 6, 1, one, 8, 0, one, 8, 0, NULL, 0, NULL, 0, 0, one, 8, 0, 1.0, 0, NULL) == -7    # K % 4
     assert L.pafc_gemm_f32(8, 8, 8, 1, P(8), 8, 0, one, 8, 0, NULL, 0, NULL, 0, 0, one, 8, 0, 1.0, 0, NULL) == -8   # alignment
     assert L.pafc_gemm_f32(8, 8, 8, 1, one, 8, 0, one, 8, 0, NULL, 0, NULL, 0, 0, one, 8, 0, 1.0, 4, NULL) == -7    # no GLU here
+    # the CTC loss kernels: workspace query and argument checks
+    Z = ctypes.c_size_t
+    L.pafc_ctc_loss_workspace_bytes.restype = Z
+    L.pafc_ctc_loss_workspace_bytes.argtypes = [I, I, I]
+    assert L.pafc_ctc_loss_workspace_bytes(32, 499, 160) == (32 * 499 * (1 + 2 * 321) + 32) * 4
+    assert L.pafc_ctc_loss_workspace_bytes(0, 499, 160) == 0
+    L.pafc_ctc_loss_forward.argtypes = [I, I, I, I, P, G, P, P, I, P, I, I, P, P, Z, P]
+    assert L.pafc_ctc_loss_forward(1, 2, 8, 16, NULL, 16, one, one, 4, one, 4, 0, one, one, 1 << 20, NULL) == ERR_NULL
+    assert L.pafc_ctc_loss_forward(1, 2, 8, 16, one, 8, one, one, 4, one, 4, 0, one, one, 1 << 20, NULL) == ERR_DIMS     # ldl < V
+    assert L.pafc_ctc_loss_forward(1, 2, 8, 16, one, 16, one, one, 4, one, 4, 0, one, one, 16, NULL) == -4             # workspace
+    L.pafc_ctc_loss_backward.argtypes = [I, I, I, I, P, G, P, P, I, P, I, I, P, P, F, P, G, P, Z, P]
+    assert L.pafc_ctc_loss_backward(1, 2, 8, 16, one, 16, one, one, 4, one, 4, 0, one, NULL, 1.0, one, 64, one, 1 << 20, NULL) == ERR_NULL
+    assert L.pafc_ctc_loss_backward(1, 2, 8, 16, one, 16, one, one, 4, one, 4, 0, one, one, 1.0, one, 8, one, 1 << 20, NULL) == ERR_DIMS   # ldg < V
     L.pafc_wkv6_forward_bf16.argtypes = [I, I, I, I, P, P, P, P, P, P, I, P, ctypes.c_size_t, P]
     assert L.pafc_wkv6_forward_bf16(1, 8, 128, 2, one, one, one, one, one, NULL, 0, NULL, 0, NULL) == ERR_NULL
     assert L.pafc_wkv6_forward_bf16(1, 8, 100, 2, one, one, one, one, one, one, 0, NULL, 0, NULL) == -3    # head size
