@@ -50,10 +50,13 @@ from ._lib import c_int, c_void_p
 #                                   the 30-minute sequence measured the same or 0.2 ms slower with it (the convolution kernel is
 #                                   latency-bound at two waves per SIMD and the epilogue's two block reductions add to that), so
 #                                   long inputs keep the two kernels
-#   split_small_max_rows      1536  split-operand (and bf16 -> fp32) products of at most this many rows run on the small tiles of
-#                                   csrc/gemm_bf16.hip (pafc_gemm_bf16_f32out: 64 x 64 / 128 x 64 tiles, three-stage ring) instead of
-#                                   the 256-wide phase-pipelined kernel, whose tiles cost ~25 us each however few there are:
-#                                   profiles/r06n_split_small_rows.txt
+#   split_small_max_rows      4096  split-operand (and bf16 -> fp32) products of at most this many rows AND at most 2^22 outputs
+#                                   (w_1, N = 2048: 2 048 rows) run on the small tiles of csrc/gemm_bf16.hip
+#                                   (pafc_gemm_bf16_f32out: 64 x 64 / 128 x 64 tiles, three-stage ring) instead of the 256-wide
+#                                   phase-pipelined kernel, whose tiles cost ~25 us (K = 512) / ~72 us (K = 2048) each however few
+#                                   there are: at 3 992 rows 17 / 21 / 53 us against 27 / 28 / 72 for pointwise_conv2 / pointwise_conv1
+#                                   / w_2, w_1 22.7 against 30.5 at 1 996 rows and 37.5 against 30.4 at 2 500
+#                                   (profiles/r06n_split_small_rows.txt)
 #   split_layers_min_rows      256  the LAYERS of a model with the bf16 slot take the split-operand schedule
 #                                   (fused.layer_forward_split) from this many rows on -- since round 6 also below
 #                                   split_gemm_min_rows, where their projections run on the small tiles (a single 2 000-frame
@@ -63,7 +66,7 @@ from ._lib import c_int, c_void_p
 # PAFC_PH_MIN_FILL=<percent> (round 3's rule: 256-wide tiles must cover that share of the CUs) and PAFC_GEMM_TILE (force a tile
 # of the small kernel) are A/B switches of the kernels themselves.
 DISPATCH = dict(skinny_max_rows=640, own_gemm_min_rows=1, lds_resident_min_rows=8192, split_gemm_min_rows=1024,
-                ln_fold_min_rows=24576, dwconv_ln_silu_max_rows=24575, split_small_max_rows=1536, split_layers_min_rows=256)
+                ln_fold_min_rows=24576, dwconv_ln_silu_max_rows=24575, split_small_max_rows=4096, split_layers_min_rows=256)
 
 
 def _load_dispatch():
@@ -989,8 +992,8 @@ def gemm_ph_ex(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         _lib._sig(L.pafc_gemm_bf16_f32out, I, G, I, I, P, G, I, P, G, P, P, G, P, I, G, G, c_float, I, P)
         L._pafc_gemmex_bound = True
     from .profiling import op_timer
-    if (M <= _SPLIT_SMALL_MAX_ROWS and ok != 0 and act in ("none", "silu", "tanh", "relu") and not a_plane_block and not tile_m
-            and K % 64 == 0):
+    if (M <= _SPLIT_SMALL_MAX_ROWS and M * N <= (1 << 22) and ok != 0 and act in ("none", "silu", "tanh", "relu")
+            and not a_plane_block and not tile_m and K % 64 == 0):
         # few rows: the small tiles of csrc/gemm_bf16.hip (same operand forms, same epilogue order)
         with op_timer("gemm%ss_%dx%d" % ("3" if a_split else "", K, N), sample=12, flops=2.0 * M * N * K * (3 if a_split else 1)):
             rc = L.pafc_gemm_bf16_f32out(M, N, K, _lib.ptr(a), a.stride(0), int(a_split), _lib.ptr(w), w.stride(0), _lib.ptr(bias),

@@ -530,7 +530,7 @@ def layer_forward_split(plan: LayerPlan, x: torch.Tensor, hp: torch.Tensor, lens
     if cm.lorder > 0:    # causal module: lorder zero frames in front of pointwise_conv1 (convolution.py:112-118)
         hc = torch.cat([hc.new_zeros(B, cm.lorder, 2 * C), hc], dim=1)
         left_pad, Tc = 0, T + cm.lorder
-    if B * Tc <= hip_ops._SPLIT_SMALL_MAX_ROWS:
+    if B * Tc <= hip_ops._SPLIT_SMALL_MAX_ROWS and B * Tc * 2 * C <= (1 << 22):
         # few rows (the small-tile kernel has no GLU epilogue): the plain projection, F.glu inside the depthwise convolution
         p = G(hc.view(B * Tc, 2 * C), S["pw1_plain"], cm.pointwise_conv1.bias, a_split=True, out_kind="f32").view(B, Tc, 2 * C)
         dw = hip_ops.depthwise_conv1d_cl(p, cm.depthwise_conv.weight, cm.depthwise_conv.bias, left_pad, T, glu=True)
