@@ -135,20 +135,33 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 
     const int fr = lane & 15, kq = lane >> 4;
     issue(0, 0);
-    if constexpr (NST == 3) { if (iters > 1) issue(1, 1); }
+    if constexpr (NST >= 3) {
+#pragma unroll
+        for (int s_ = 1; s_ < NST - 1; ++s_)
+            if (iters > s_) issue(s_, s_);
+    }
     for (int it = 0; it < iters; ++it) {
-        if constexpr (NST == 3) {
-            // stage `it` has landed when at most the next stage's loads are outstanding (loads complete in order)
-            if (it + 1 < iters) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI + NI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                   // everyone is done reading stage it - 1 = the buffer of it + 2
-            if (it + 2 < iters) issue(it + 2, (it + 2) % 3);
+        if constexpr (NST >= 3) {
+            // a ring of NST stages with NST - 1 in flight: stage `it` has landed when at most the NST - 2 stages issued after it
+            // are outstanding (loads complete in order; fewer near the end of K).  NST = 3 for the few-thousand-row problems;
+            // NST = 6 (round 6) for the few-HUNDRED-row ones, whose single block per CU walks up to 96 K-steps of a split-operand
+            // K = 2048 with nothing but its own ring to hide the ~1 us L2 -> LDS round trip of each
+            const int newer = min(NST - 2, iters - 1 - it);
+            switch (newer) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * (MI + NI)) : "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST >= 4 ? 2 : 1) * (MI + NI)) : "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST >= 5 ? 3 : 1) * (MI + NI)) : "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST >= 6 ? 4 : 1) * (MI + NI)) : "memory"); break;
+            }
+            __syncthreads();                                   // everyone is done reading stage it - 1 = the buffer of it + NST - 1
+            if (it + NST - 1 < iters) issue(it + NST - 1, (it + NST - 1) % NST);
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (it + 1 < iters) issue(it + 1, (it + 1) & 1);
         }
-        const bf16_t *A = lds + (NST == 3 ? it % 3 : (it & 1)) * STAGE;
+        const bf16_t *A = lds + (NST >= 3 ? it % NST : (it & 1)) * STAGE;
         const bf16_t *Wt = A + BM * GBK;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -479,15 +492,18 @@ extern "C" int pafc_gemm_bf16_f32out(long M, int N, int K, const void *A, long l
     p.ntiles = (N + bn - 1) / bn;
     const long nblk = (long)p.mtiles * p.ntiles;
     if (nblk > 0x7fffffffL) return PAFC_ERR_BAD_DIMS;
-    const int nst = (bm == 128 && bn == 128) ? 2 : 3;
+    // a deep ring when the grid is at most one 64 x 64 block per CU (few hundred rows): see the kernel's K loop
+    const bool deep = bm == 64 && nblk <= cus;
+    const int nst = (bm == 128 && bn == 128) ? 2 : deep ? 6 : 3;
     const size_t stage_bytes = (size_t)nst * (bm + bn) * pafc::GBK * sizeof(pafc::bf16_t);
     const size_t out_bytes = (size_t)bm * (bn + 4) * sizeof(float);
     const size_t lds = out_bytes > stage_bytes ? out_bytes : stage_bytes;
     typedef void (*kern_t)(const pafc::GemmParams);
     kern_t kern;
 #define PAFC_PICK(E, S)                                                                                                   \
-    (bm == 64 ? (kern_t)pafc::gemm_bf16_kernel<E, 64, 64, 3, S> : bn == 64 ? (kern_t)pafc::gemm_bf16_kernel<E, 128, 64, 3, S> \
-                                                                          : (kern_t)pafc::gemm_bf16_kernel<E, 128, 128, 2, S>)
+    (deep ? (kern_t)pafc::gemm_bf16_kernel<E, 64, 64, 6, S>                                                                   \
+          : bm == 64 ? (kern_t)pafc::gemm_bf16_kernel<E, 64, 64, 3, S> : bn == 64 ? (kern_t)pafc::gemm_bf16_kernel<E, 128, 64, 3, S> \
+                                                                                : (kern_t)pafc::gemm_bf16_kernel<E, 128, 128, 2, S>)
     if (out_kind == 1) kern = a_split ? PAFC_PICK(3, true) : PAFC_PICK(3, false);
     else kern = a_split ? PAFC_PICK(4, true) : PAFC_PICK(4, false);
 #undef PAFC_PICK
