@@ -154,7 +154,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
                 case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST >= 5 ? 3 : 1) * (MI + NI)) : "memory"); break;
                 default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST >= 6 ? 4 : 1) * (MI + NI)) : "memory"); break;
             }
-            __syncthreads();                                   // everyone is done reading stage it - 1 = the buffer of it + NST - 1
+            // a RAW barrier: __syncthreads() compiles to s_waitcnt vmcnt(0) + s_barrier, which drains every stage in flight and
+            // turns the ring into one exposed L2 -> LDS round trip per K-step (measured in round 6: 0.54 us per K-step whatever the
+            // ring's depth).  Each wave has waited for ITS OWN loads of stage `it` above; behind the barrier every wave's have landed.
+            // Everyone is also done reading stage it - 1 (its fragments are in registers: the MFMAs that consumed them were issued
+            // before this point in program order) = the buffer stage it + NST - 1 is written to.
+            asm volatile("s_barrier" ::: "memory");
             if (it + NST - 1 < iters) issue(it + NST - 1, (it + NST - 1) % NST);
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
