@@ -275,7 +275,10 @@ int pafc_gemm_tn_bf16(long R, int M, int N, const void *dy, long lda, const void
  * rwkv_wrapper_bidirectional.py:55-56) for decode batches of a few hundred to a few thousand rows. */
 int pafc_gemm_bf16_f32out(long M, int N, int K, const void *A, long lda, int a_split, const void *W, long ldw, const float *bias,
                           const float *residual, long ldr, void *out, int out_kind, long ldo, long lo_off, float alpha, int act,
-                          pafc_stream_t stream);
+                          void *workspace, size_t workspace_bytes, pafc_stream_t stream);
+/* Bytes of workspace with which pafc_gemm_bf16_f32out splits K over several blocks per tile (a few hundred rows against a long K:
+ * partials + a second, reducing launch, deterministic); 0: the problem runs as one launch, workspace may be null. */
+size_t pafc_gemm_bf16_f32out_workspace_bytes(long M, int N, int K, int a_split);
 
 /* ---- CTC loss of the training step, from the logits (csrc/ctc_loss.hip) -------------------------------------------------------
  * `ys_hat.log_softmax(2)` + `torch.nn.CTCLoss(reduction="sum", zero_infinity=True)` of CTC.forward (wenet/transformer/ctc.py:

@@ -45,6 +45,9 @@ struct GemmParams {
     // activation, W = [hi | hi | lo] (N x 3 K1), K = 3 K1 columns walked as hi, lo, hi of A -- nk1 = K1 / 64 K-steps per segment
     int nk1, K1;
     long lo_off;
+    // K split over blockIdx.y (ksplit > 1, pafc_gemm_bf16_f32out with a workspace): block z walks its share of the K-steps of the
+    // SAME operands and leaves a raw fp32 partial (EPI 3 with alpha 1, no bias, no residual) at out + z * sO
+    int ksplit;
 };
 
 __device__ __forceinline__ void gdma16(const bf16_t *src, bf16_t *lds_base) {
@@ -109,17 +112,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         const int n = min(n0 + row, p.N - 1);               // N tail: clamped rows feed columns that are never stored
         w_src[j] = Wz + (long)n * p.ldw + 8 * c;
     }
-    const int iters = p.K / GBK;
+    int iters = p.K / GBK, it0 = 0;
+    if (p.ksplit > 1) {                                     // this block's share of the K-steps
+        const int per = (iters + p.ksplit - 1) / p.ksplit;
+        it0 = z * per;
+        iters = max(0, min(iters, it0 + per) - it0);
+    }
     constexpr int STAGE = (BM + BN) * GBK;                  // elements per stage
 
     auto issue = [&](int it, int buf) {
         bf16_t *A = lds + buf * STAGE;
         bf16_t *Wt = A + BM * GBK;
-        const int koff = it * GBK;
+        const int git = it0 + it;                            // K-step of the whole product
+        const int koff = git * GBK;
         int koffA = koff;
         if constexpr (SPL) {                                 // A walks hi, lo, hi while W walks [hi | hi | lo] straight through
-            const int seg = (it >= p.nk1) + (it >= 2 * p.nk1);
-            koffA = (seg == 1 ? p.K1 : 0) + (it - seg * p.nk1) * GBK;
+            const int seg = (git >= p.nk1) + (git >= 2 * p.nk1);
+            koffA = (seg == 1 ? p.K1 : 0) + (git - seg * p.nk1) * GBK;
         }
 #pragma unroll
         for (int j = 0; j < MI; ++j) gdma16(a_src[j] + koffA, A + (wave * (BM / 4) + j * 8) * GBK);
@@ -465,11 +474,74 @@ extern "C" int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, lo
 }
 
 
+namespace pafc {
+namespace {
+
+// second pass of a K-split product: out = act(alpha * (sum of the S partials, in order) + bias) + residual, fp32 or planes
+__global__ __launch_bounds__(256) void gemm_ksplit_reduce_kernel(long M, int N, int S, const float *part, const float *bias, float alpha,
+                                                                 int act, const float *res, long ldr, void *out, int out_kind, long ldo,
+                                                                 long lo_off) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;           // one float4 of the (M, N) result
+    const int n4 = N / 4;
+    if (q >= M * n4) return;
+    const long m = q / n4;
+    const int c = (int)(q % n4) * 4;
+    const long MN = M * (long)N;
+    float4 a = *reinterpret_cast<const float4 *>(part + m * N + c);
+    for (int z = 1; z < S; ++z) {
+        const float4 b = *reinterpret_cast<const float4 *>(part + z * MN + m * N + c);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float o[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = apply_act(fmaf(o[e], alpha, bias ? bias[c + e] : 0.f), act);
+    if (res) {
+        const float4 r = *reinterpret_cast<const float4 *>(res + m * ldr + c);
+        o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+    }
+    if (out_kind == 1) {
+        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(out) + m * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = f32_to_bf16_bits(o[e]);
+            l[e] = f32_to_bf16_bits(o[e] - bf16_bits_to_f32(h[e]));
+        }
+        bf16_t *ob = reinterpret_cast<bf16_t *>(out) + m * ldo + c;
+        *reinterpret_cast<uint2 *>(ob) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        *reinterpret_cast<uint2 *>(ob + lo_off) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    }
+}
+
+// K-split factor of a few-rows product: the 64 x 64 tiles cover less than half of the CUs AND K is long (a split-operand w_2: 96
+// K-steps, 42 us as one chain at 499 rows) -> S blocks per tile walk K / S each, a second launch adds the partials (deterministic)
+int ksplit_factor(long M, int N, int Kw) {
+    const long cus = device_cus();
+    const long nblk = ((M + 63) / 64) * ((N + 63) / 64);
+    const int iters = Kw / GBK;
+    if (iters < 48 || nblk * 2 > cus) return 1;
+    long s = cus / nblk;
+    if (s > 4) s = 4;
+    if (s > iters / 12) s = iters / 12;
+    return s < 2 ? 1 : (int)s;
+}
+
+}  // namespace
+}  // namespace pafc
+
+extern "C" size_t pafc_gemm_bf16_f32out_workspace_bytes(long M, int N, int K, int a_split) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % 8 || K % pafc::GBK) return 0;
+    const int S = pafc::ksplit_factor(M, N, a_split ? 3 * K : K);
+    return S > 1 ? (size_t)S * M * N * sizeof(float) : 0;
+}
+
 // fp32 results from bf16 operands on the 128 x 128 / 128 x 64 / 64 x 64 tiles (include/pafc_encoder_ops.h): the split-operand
 // projections of an fp32 model with the bf16 slot at few rows, and the slot's bf16 output projection into the fp32 residual stream.
 extern "C" int pafc_gemm_bf16_f32out(long M, int N, int K, const void *A, long lda, int a_split, const void *W, long ldw,
                                      const float *bias, const float *residual, long ldr, void *out, int out_kind, long ldo,
-                                     long lo_off, float alpha, int act, pafc_stream_t stream) {
+                                     long lo_off, float alpha, int act, void *workspace, size_t workspace_bytes,
+                                     pafc_stream_t stream) {
     if (!A || !W || !out) return PAFC_ERR_NULL_POINTER;
     if (M <= 0 || N <= 0 || K <= 0) return PAFC_ERR_BAD_DIMS;
     if (N % 8 || K % pafc::GBK) return PAFC_ERR_UNSUPPORTED;
@@ -485,7 +557,7 @@ extern "C" int pafc_gemm_bf16_f32out(long M, int N, int K, const void *A, long l
     p.res = (const pafc::bf16_t *)residual; p.out = (pafc::bf16_t *)out;
     p.M = M; p.N = N; p.K = Kw; p.K1 = K; p.nk1 = K / pafc::GBK;
     p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr; p.lo_off = lo_off;
-    p.alpha = alpha; p.act = act;
+    p.alpha = alpha; p.act = act; p.ksplit = 1;
     const long cus = pafc::device_cus();
     auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     int bm = 128, bn = 128;
@@ -497,8 +569,18 @@ extern "C" int pafc_gemm_bf16_f32out(long M, int N, int K, const void *A, long l
     p.ntiles = (N + bn - 1) / bn;
     const long nblk = (long)p.mtiles * p.ntiles;
     if (nblk > 0x7fffffffL) return PAFC_ERR_BAD_DIMS;
+    // K split over blocks when the caller brought the workspace for it (pafc_gemm_bf16_f32out_workspace_bytes > 0)
+    const int S = pafc::ksplit_factor(M, N, Kw);
+    const bool split_k = S > 1 && bm == 64 && workspace && workspace_bytes >= (size_t)S * M * N * sizeof(float) && N % 4 == 0;
+    const int out_kind_final = out_kind;
+    if (split_k) {          // pass 1: raw partials (alpha 1, no bias / activation / residual) into the workspace
+        p.ksplit = S;
+        p.out = (pafc::bf16_t *)workspace; p.ldo = N; p.sO = (long)M * N;
+        p.bias = nullptr; p.res = nullptr; p.alpha = 1.f; p.act = 0;
+        out_kind = 1;
+    }
     // a deep ring when the grid is at most one 64 x 64 block per CU (few hundred rows): see the kernel's K loop
-    const bool deep = bm == 64 && nblk <= cus;
+    const bool deep = bm == 64 && nblk * p.ksplit <= cus;
     const int nst = (bm == 128 && bn == 128) ? 2 : deep ? 6 : 3;
     const size_t stage_bytes = (size_t)nst * (bm + bn) * pafc::GBK * sizeof(pafc::bf16_t);
     const size_t out_bytes = (size_t)bm * (bn + 4) * sizeof(float);
@@ -514,6 +596,11 @@ extern "C" int pafc_gemm_bf16_f32out(long M, int N, int K, const void *A, long l
 #undef PAFC_PICK
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PAFC_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, 1), dim3(256), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)p.ksplit), dim3(256), lds, (hipStream_t)stream, p);
+    if (split_k) {
+        const long q = M * (long)(N / 4);
+        hipLaunchKernelGGL(pafc::gemm_ksplit_reduce_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, N, S,
+                           (const float *)workspace, bias, alpha, act, residual, ldr, out, out_kind_final, ldo, lo_off);
+    }
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
