@@ -692,7 +692,11 @@ def test_conv_sub_f32split_matches_fp32_convolutions(hip, B, T, Fd, C):
 
 
 @pytest.mark.parametrize("R,M,N", [(64, 128, 128), (1, 8, 8), (63, 136, 72), (1000, 512, 512), (4097, 2048, 512),
-                                   (16000, 512, 2048), (300, 5000, 512)])
+                                   (16000, 512, 2048), (300, 5000, 512),
+                                   # round 6 (ring of four stages, two K groups): every ring fill 1 .. 5 K-steps with a ragged
+                                   # last one, and the LoRA shapes of the training step
+                                   (129, 2048, 2048), (200, 2048, 2048), (257, 2048, 2048), (15392, 512, 128),
+                                   (15392, 64, 512), (15392, 512, 512)])
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
 def test_gemm_tn_weight_gradient(hip, R, M, N, out_dtype):
     """dw = dy^T x (nn.Linear's weight gradient): every tile / split / ragged-R / ragged-column path against a float64

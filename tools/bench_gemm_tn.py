@@ -22,7 +22,7 @@ def timed(fn, reps=20):
     return a.elapsed_time(b) / reps * 1e3
 
 
-for M, N in ((2048, 512), (512, 2048), (512, 512), (1024, 512), (5000, 512)):
+for M, N in ((2048, 512), (512, 2048), (512, 512), (1024, 512), (512, 1024), (5000, 512), (512, 128), (128, 512), (512, 64), (64, 512)):
     dy = torch.randn(R, M, device=dev).to(torch.bfloat16)
     x = torch.randn(R, N, device=dev).to(torch.bfloat16)
     t_own = timed(lambda: gemm_tn(dy, x))
