@@ -213,6 +213,11 @@ int pafc_tmix_shift_mix_bwd(int dtype, int B, int T, int C, int reverse, const v
 int pafc_tmix_mix4_bwd(int dtype, int B, int T, int C, int reverse, const void *x, const void *m, const void *maa,
                        const void *dz_r, const void *dz_k, const void *dz_v, const void *dz_w, void *dx, void *dm,
                        float *dmaa, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
+/* ... with dm laid out (B*T, 4, C) instead of (4, B*T, C) (round 6: the gradients of the LoRA-up matrices src/model.py:277-278 read it
+ * as one (B*T, 4 C) operand of pafc_gemm_tn_bf16 and as four column blocks of pafc_gemm_bf16). */
+int pafc_tmix_mix4_bwd_rows(int dtype, int B, int T, int C, int reverse, const void *x, const void *m, const void *maa,
+                       const void *dz_r, const void *dz_k, const void *dz_v, const void *dz_w, void *dx, void *dm,
+                       float *dmaa, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
 
 /* 3x3 stride-2 convolution + bias (+ ReLU), NHWC, bf16, as an implicit GEMM on the matrix cores:
  *   out[b][t2][f2][co] = act(bias[co] + sum_{kh,kw,ci} w[co][ci][kh][kw] in[b][2 t2 + kh][2 f2 + kw][ci]),

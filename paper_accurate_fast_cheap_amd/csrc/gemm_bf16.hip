@@ -441,9 +441,12 @@ extern "C" int pafc_gemm_bf16(long M, int N, int K, int batch, const void *A, lo
     const long cus = pafc::device_cus();
     auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)batch; };
     // the largest tile that still gives two tiles per CU (two blocks are co-resident and cover each other's barriers); measured
-    // at 1 024 - 8 192 rows on every layer shape: profiles/r04d_gemm_mid_rows_own_tiles_vs_library.txt
+    // at 1 024 - 8 192 rows on every layer shape: profiles/r04d_gemm_mid_rows_own_tiles_vs_library.txt.  128 x 128 from 1.4 tiles
+    // per CU on (round 6: the training step's 15 392 rows x 512 columns = 484 tiles went to 128 x 64, which moves 1.5 x the bytes
+    // through L2 -> LDS per flop -- 47.1 vs 43.7 us at K = 2048, 28.1 vs 24.2 at K = 1024; at 10 000 rows = 316 tiles the small
+    // tiles still tie: profiles/r06x_gemm_train_tiles_by_rows.txt)
     int bm = 128, bn = 128;
-    if (!glu && tiles(128, 128) < 2 * cus) {
+    if (!glu && tiles(128, 128) * 5 < 7 * cus) {
         if (tiles(128, 64) >= 2 * cus) bn = 64;
         else { bm = 64; bn = 64; }
     }

@@ -50,7 +50,8 @@ template <> __device__ __forceinline__ void ts8<float>(float *p, const float *f)
 struct MixBwdArgs {
     const void *x, *m, *maa;          // x (rows, C); m (NQ, rows, C) or null; maa (NQ, C)
     const void *dz[4];                // NQ incoming gradients (rows, C)
-    void *dx, *dm;                    // dx (rows, C); dm (NQ, rows, C) or null
+    void *dx, *dm;                    // dx (rows, C); dm (NQ, rows, C) -- or (rows, NQ, C): dm_qs / dm_rs -- or null
+    long dm_qs, dm_rs;                // element strides of dm between q and between rows
     float *part;                      // [nblk][NQ][C]
     long rows;
     int T, C, reverse;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void tmix_mix_bwd_kernel(const MixBwdArgs a) {
                         dxx[e] = fmaf(g[e], w, dxx[e]);
                         dxx_n[e] = fmaf(has_next ? gn[e] : 0.f, wn, dxx_n[e]);
                     }
-                    if (NQ > 1) ts8<ET>((ET *)a.dm + ((size_t)q * a.rows + row) * C + c, dmq);
+                    if (NQ > 1) ts8<ET>((ET *)a.dm + (size_t)q * a.dm_qs + (size_t)row * a.dm_rs + c, dmq);
                 }
                 float o[TV];
 #pragma unroll
@@ -192,15 +193,32 @@ extern "C" int pafc_tmix_shift_mix_bwd(int dtype, int B, int T, int C, int rever
     return pafc::launch_mix_bwd<1>(dtype, a, dmaa_x, (hipStream_t)stream);
 }
 
-extern "C" int pafc_tmix_mix4_bwd(int dtype, int B, int T, int C, int reverse, const void *x, const void *m, const void *maa,
-                                  const void *dz_r, const void *dz_k, const void *dz_v, const void *dz_w, void *dx, void *dm,
-                                  float *dmaa, void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
+static int mix4_bwd_launch(int dtype, int B, int T, int C, int reverse, const void *x, const void *m, const void *maa,
+                           const void *dz_r, const void *dz_k, const void *dz_v, const void *dz_w, void *dx, void *dm, bool dm_by_rows,
+                           float *dmaa, void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
     if (!x || !m || !maa || !dz_r || !dz_k || !dz_v || !dz_w || !dx || !dm || !dmaa || !workspace) return PAFC_ERR_NULL_POINTER;
     if (!pafc::mix_dims_ok(B, T, C)) return PAFC_ERR_BAD_DIMS;
     const long rows = (long)B * T;
     if (workspace_bytes < pafc_tmix_bwd_workspace_bytes(rows, C)) return PAFC_ERR_WORKSPACE;
     pafc::MixBwdArgs a{};
     a.x = x; a.m = m; a.maa = maa; a.dz[0] = dz_r; a.dz[1] = dz_k; a.dz[2] = dz_v; a.dz[3] = dz_w; a.dx = dx; a.dm = dm;
+    a.dm_qs = dm_by_rows ? C : rows * C;
+    a.dm_rs = dm_by_rows ? 4L * C : C;
     a.part = (float *)workspace; a.rows = rows; a.T = T; a.C = C; a.reverse = reverse ? 1 : 0;
     return pafc::launch_mix_bwd<4>(dtype, a, dmaa, (hipStream_t)stream);
+}
+
+extern "C" int pafc_tmix_mix4_bwd(int dtype, int B, int T, int C, int reverse, const void *x, const void *m, const void *maa,
+                                  const void *dz_r, const void *dz_k, const void *dz_v, const void *dz_w, void *dx, void *dm,
+                                  float *dmaa, void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
+    return mix4_bwd_launch(dtype, B, T, C, reverse, x, m, maa, dz_r, dz_k, dz_v, dz_w, dx, dm, false, dmaa, workspace, workspace_bytes,
+                           stream);
+}
+
+// the same with dm laid out (B*T, 4, C): the LoRA-up matrices' gradients then read it as ONE (B*T, 4 C) operand
+extern "C" int pafc_tmix_mix4_bwd_rows(int dtype, int B, int T, int C, int reverse, const void *x, const void *m, const void *maa,
+                                       const void *dz_r, const void *dz_k, const void *dz_v, const void *dz_w, void *dx, void *dm,
+                                       float *dmaa, void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
+    return mix4_bwd_launch(dtype, B, T, C, reverse, x, m, maa, dz_r, dz_k, dz_v, dz_w, dx, dm, true, dmaa, workspace, workspace_bytes,
+                           stream);
 }

@@ -689,7 +689,7 @@ def linear_train_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
         return False
     if weight.shape[0] % 8 or weight.shape[1] % 8 or x.numel() // max(1, x.shape[-1]) < 256:
         return False
-    if weight.numel() > 2048 * 1024:      # many output tiles already fill the chip: the library's kernel is as good
+    if weight.numel() > int(os.environ.get("PAFC_TRAIN_LINEAR_MAX_NUMEL", 2048 * 1024)):      # many output tiles already fill the chip: the library's kernel is as good
         return False
     if x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16:
         return True
@@ -1068,6 +1068,7 @@ def _bind_tmix_bwd():
         L.pafc_tmix_bwd_workspace_bytes.argtypes = [c_long, c_int]
         _lib._sig(L.pafc_tmix_shift_mix_bwd, I, I, I, I, I, I, P, P, P, P, P, P, c_size_t, P)
         _lib._sig(L.pafc_tmix_mix4_bwd, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P)
+        _lib._sig(L.pafc_tmix_mix4_bwd_rows, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P)
         L._pafc_tmixbwd_bound = True
     return L
 
@@ -1130,6 +1131,89 @@ class _Mix4Train(torch.autograd.Function):
                                   P(dz[2]), P(dz[3]), P(dx), P(dm), P(dmaa), P(ws), nbytes, _lib.stream_of(x))
         _lib.check(rc, "pafc_tmix_mix4_bwd")
         return dx, dm.view(ctx.m_shape).to(ctx.m_dtype), dmaa.to(ctx.maa_dtype).view(ctx.maa_shape), None
+
+
+_eye4 = {}      # device -> (4, 1, 4, 1) bf16 identity: the block-diagonal placement of the four LoRA-up matrices
+
+
+class _LoraMix4Train(torch.autograd.Function):
+    """m_q = t_q W2_q (the LoRA-up products, src/model.py:277-278: `torch.bmm` over four (B*T, 32) x (32, C) pairs) followed by the
+    four lerps z_q = x + (shift(x) - x) (maa_q + m_q) (280-284), for one direction, every product on the hand-written kernels:
+      forward   m = t (B*T, 128) against the four matrices laid out block-diagonally along K ((4, C, 128): block q of the K axis
+                holds W2_q^T, zeros elsewhere -- 4 x the flops of a product that is 2 GFLOP) as ONE batched pafc_gemm_bf16, then
+                pafc_tmix_mix4;
+      backward  pafc_tmix_mix4_bwd_rows leaves dm as (B*T, 4, C); dt = ONE batched pafc_gemm_bf16 (dm's four column blocks against
+                W2_q as they lie, into the four column blocks of dt); dW2 = the diagonal blocks of ONE pafc_gemm_tn_bf16
+                t^T (128, B*T) x dm (B*T, 4 C).
+    Round 5 ran the three products through the library (Cijk MT256x256x32 32 us, MT32x128x32 19 us, MT16x16x128 74 us per direction
+    and layer) with a transposed copy of t in front of the last one."""
+
+    @staticmethod
+    def forward(ctx, x, t, w2, maa4, reverse):
+        B, T, C = x.shape
+        M, R = B * T, w2.shape[1]
+        tb = t.reshape(M, 4 * R)
+        if tb.dtype != torch.bfloat16 or not tb.is_contiguous():
+            tb = tb.to(torch.bfloat16).contiguous()
+        w2b = _param_as(w2, torch.bfloat16).contiguous()                          # (4, R, C)
+        eye = _eye4.get(x.device)
+        if eye is None:
+            eye = _eye4[x.device] = torch.eye(4, dtype=torch.bfloat16, device=x.device).view(4, 1, 4, 1)
+        w2p = torch.empty((4, C, 4, R), dtype=torch.bfloat16, device=x.device)
+        torch.mul(w2b.transpose(1, 2).unsqueeze(2), eye, out=w2p)                  # one launch
+        w2p = w2p.view(4, C, 4 * R)
+        m = gemm_bf16(tb.unsqueeze(0).expand(4, M, 4 * R), w2p)                    # (4, M, C)
+        mm = m.view(1, 4, M, C) if x.dtype == torch.bfloat16 else m.view(1, 4, M, C).to(x.dtype)
+        a4 = maa4.reshape(1, 4, C).to(x.dtype).contiguous()
+        z = tmix_mix4(x, mm, a4, reverse)                                          # (4, 1, M, C)
+        ctx.save_for_backward(x, tb, w2b, mm, a4)
+        ctx.reverse, ctx.maa_shape, ctx.maa_dtype, ctx.t_shape, ctx.t_dtype, ctx.w2_dtype = (reverse, maa4.shape, maa4.dtype, t.shape,
+                                                                                             t.dtype, w2.dtype)
+        return tuple(z[q, 0].view(B, T, C) for q in range(4))
+
+    @staticmethod
+    def backward(ctx, *dz):
+        x, tb, w2b, mm, a4 = ctx.saved_tensors
+        B, T, C = x.shape
+        M, R = B * T, w2b.shape[1]
+        dz = [(torch.zeros_like(x) if g is None else g.contiguous()) for g in dz]
+        L = _bind_tmix_bwd()
+        nbytes = L.pafc_tmix_bwd_workspace_bytes(M, C)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        dx = torch.empty_like(x)
+        dm = torch.empty((M, 4, C), dtype=x.dtype, device=x.device)
+        dmaa = torch.empty(4, C, dtype=torch.float32, device=x.device)
+        P = _lib.ptr
+        rc = L.pafc_tmix_mix4_bwd_rows(_lib.dtype_code(x.dtype), B, T, C, int(ctx.reverse), P(x), P(mm), P(a4), P(dz[0]), P(dz[1]),
+                                       P(dz[2]), P(dz[3]), P(dx), P(dm), P(dmaa), P(ws), nbytes, _lib.stream_of(x))
+        _lib.check(rc, "pafc_tmix_mix4_bwd_rows")
+        if dm.dtype != torch.bfloat16:
+            dm = dm.to(torch.bfloat16)
+        dt = dw2 = None
+        if ctx.needs_input_grad[1]:
+            dt = torch.empty((M, 4 * R), dtype=torch.bfloat16, device=x.device)
+            gemm_bf16(dm.transpose(0, 1), w2b, out=dt.view(M, 4, R).transpose(0, 1))    # (4, M, C) x (4, R, C)^T -> (4, M, R)
+            dt = dt.view(ctx.t_shape).to(ctx.t_dtype)
+        if ctx.needs_input_grad[2]:
+            od = ctx.w2_dtype if ctx.w2_dtype in (torch.float32, torch.bfloat16) else torch.float32
+            full = gemm_tn(tb, dm.view(M, 4 * C), od)                                  # (4 R, 4 C): its diagonal blocks
+            dw2 = torch.stack([full[q * R:(q + 1) * R, q * C:(q + 1) * C] for q in range(4)]).to(ctx.w2_dtype)
+        return dx, dt, dw2, dmaa.to(ctx.maa_dtype).view(ctx.maa_shape), None
+
+
+def lora_mix4_train_eligible(x: torch.Tensor, t: torch.Tensor, w2: torch.Tensor) -> bool:
+    """The LoRA-up + lerp group on own kernels: the element-wise group's conditions, bf16 LoRA activations, four (R, C) matrices with
+    4 R a multiple of 64 (the K axis of the block-diagonal product) and C of 64 (that of the input-gradient product)."""
+    if os.environ.get("PAFC_TRAIN_LORA_UP", "1") == "0":          # A/B runs: torch.bmm + mix4_train, as in round 5
+        return False
+    return (tmix_train_eligible(x) and train_gemms_own() and t.dtype == torch.bfloat16 and w2.dim() == 3 and w2.shape[0] == 4
+            and (4 * w2.shape[1]) % 64 == 0 and w2.shape[2] == x.shape[-1] and x.shape[-1] % 64 == 0
+            and w2.dtype in (torch.float32, torch.bfloat16) and t.numel() == x.shape[0] * x.shape[1] * 4 * w2.shape[1])
+
+
+def lora_mix4_train(x: torch.Tensor, t: torch.Tensor, w2: torch.Tensor, maa4: torch.Tensor, reverse: bool):
+    """t: (B, T, 4 R) = tanh(xxx W1); w2: (4, R, C); maa4: (4, C).  -> z_r, z_k, z_v, z_w (B, T, C)."""
+    return _LoraMix4Train.apply(x.contiguous(), t, w2, maa4, reverse)
 
 
 def tmix_train_eligible(x: torch.Tensor) -> bool:

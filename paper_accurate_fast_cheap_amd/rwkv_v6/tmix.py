@@ -75,11 +75,14 @@ class RWKV_Tmix_x060c(nn.Module):
             if hip_ops.tmix_train_eligible(x) and self.time_maa_x.dtype == x.dtype:
                 # GPU training step: the two element-wise groups as one kernel each, forward and backward
                 xxx = hip_ops.shift_mix_train(x, self.time_maa_x, reverse)
-                xxx = torch.tanh(mm(xxx, self.time_maa_rkvw_w1)).view(B * T, 4, -1).transpose(0, 1)
-                m = torch.bmm(xxx, self.time_maa_rkvw_w2).view(4, B, T, C)
+                t = torch.tanh(mm(xxx, self.time_maa_rkvw_w1))
                 maa4 = torch.stack([self.time_maa_r.reshape(C), self.time_maa_k.reshape(C), self.time_maa_v.reshape(C),
                                     self.time_maa_w.reshape(C)])
-                zr, zk, zv, zw = hip_ops.mix4_train(x, m, maa4, reverse)
+                if hip_ops.lora_mix4_train_eligible(x, t, self.time_maa_rkvw_w2):
+                    zr, zk, zv, zw = hip_ops.lora_mix4_train(x, t, self.time_maa_rkvw_w2, maa4, reverse)   # own GEMMs each way
+                else:
+                    m = torch.bmm(t.view(B * T, 4, -1).transpose(0, 1), self.time_maa_rkvw_w2).view(4, B, T, C)
+                    zr, zk, zv, zw = hip_ops.mix4_train(x, m, maa4, reverse)
                 r = lin(zr, self.receptance.weight, None)
                 k = lin(zk, self.key.weight, None)
                 v = lin(zv, self.value.weight, None)

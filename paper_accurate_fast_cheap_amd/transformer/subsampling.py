@@ -3,6 +3,8 @@ Conv2d(C->C,3,s2)+ReLU, flatten (C x F') per frame, Linear -> C, then the positi
 Parameter names match the reference (embed.conv.{0,2}.*, embed.out.0.*)."""
 from typing import Tuple, Union
 
+import os
+
 import torch
 
 
@@ -126,7 +128,10 @@ class Conv2dSubsampling4(BaseSubsampling):
             y = hip_ops.conv_sub_train(x, c1.weight, c1.bias, c2.weight, c2.bias)
             b, t, f, c = y.shape
             w_lin = lin.weight.view(-1, c, f).permute(0, 2, 1).reshape(-1, f * c)
-            x = torch.nn.functional.linear(y.view(b, t, f * c), w_lin, lin.bias)
+            if os.environ.get("PAFC_TRAIN_SUB_LINEAR", "1") != "0" and hip_ops.train_gemms_own() and y.dtype == torch.bfloat16:
+                x = hip_ops.linear_train(y.view(b, t, f * c), w_lin, lin.bias)       # round 6: the last library GEMMs of the step
+            else:
+                x = torch.nn.functional.linear(y.view(b, t, f * c), w_lin, lin.bias)
             x, pos_emb = self.pos_enc(x, offset)
             return x, pos_emb, x_mask[:, :, 2::2][:, :, 2::2]
         x = x.unsqueeze(1)  # (B, 1, T, F)

@@ -862,6 +862,48 @@ def test_tmix_elementwise_backward_kernels(hip, dtype, reverse, B, T, C):
     assert float((a4g.grad.cpu().double() - a4r.grad).abs().max()) <= (2 ** -6 if lo else 1e-4) * max(1.0, float(a4r.grad.abs().max()))
 
 
+@pytest.mark.parametrize("xdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("B,T,C", [(2, 150, 128), (3, 333, 512)])
+def test_lora_up_and_lerps_on_own_kernels_each_way(hip, xdtype, reverse, B, T, C):
+    """lora_mix4_train (round 6: the LoRA-up products of src/model.py:277-278 as one block-diagonal batched GEMM, their input
+    gradient as one batched GEMM over dm's column blocks, their weight gradient as the diagonal blocks of one dy^T x product)
+    against float64 autograd through torch.bmm + the four lerps on the same bf16-rounded operands; x fp32 (autocast over an fp32
+    residual stream) and bf16 (the slot)."""
+    import torch.nn.functional as F
+    from paper_accurate_fast_cheap_amd.hip_ops import lora_mix4_train, lora_mix4_train_eligible
+    R = 32
+    x = synth.randn((B, T, C), 71, 1.0).to(xdtype)
+    t = torch.tanh(synth.randn((B, T, 4 * R), 72, 1.0)).to(torch.bfloat16)
+    w2 = (0.05 * synth.randn((4, R, C), 73, 1.0)).to(torch.bfloat16)
+    maa4 = torch.rand(4, C).to(xdtype)
+    g4 = [synth.randn((B, T, C), 74 + q, 1.0).to(xdtype) for q in range(4)]
+
+    def shift(v):
+        return F.pad(v, (0, 0, -1, 1)) if reverse else F.pad(v, (0, 0, 1, -1))
+    xr, tr, wr, ar = (v.double().requires_grad_() for v in (x, t, w2, maa4))
+    m_ref = torch.bmm(tr.view(B * T, 4, R).transpose(0, 1), wr).view(4, B, T, C)
+    xx = shift(xr) - xr
+    z_ref = [xr + xx * (ar[q].view(1, 1, C) + m_ref[q]) for q in range(4)]
+    sum((z_ref[q] * g4[q].double()).sum() for q in range(4)).backward()
+
+    xg, tg, wg, ag = (v.cuda().requires_grad_() for v in (x, t, w2, maa4))
+    assert lora_mix4_train_eligible(xg, tg, wg)
+    z = lora_mix4_train(xg, tg, wg, ag, reverse)
+    lo = xdtype == torch.bfloat16
+    # m is rounded to bf16 between the product and the lerp (as torch.bmm's bf16 output is); |xx| reaches ~8
+    tol = dict(rtol=2 ** -6, atol=8e-2) if lo else dict(rtol=2 ** -7, atol=4e-2)
+    for q in range(4):
+        torch.testing.assert_close(z[q].detach().cpu().double(), z_ref[q].detach(), **tol)
+    sum((z[q] * g4[q].cuda()).sum() for q in range(4)).backward()
+    torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, **(dict(rtol=2 ** -5, atol=1e-1) if lo else dict(rtol=2 ** -7, atol=4e-2)))
+    # dt = dm W2^T: sums of C products of bf16-rounded dm; dW2 = t^T dm: sums of B T products, fp32 accumulation
+    for got, ref in ((tg.grad, tr.grad), (wg.grad, wr.grad)):
+        assert got.dtype == torch.bfloat16 and got.shape == ref.shape
+        assert float((got.cpu().double() - ref).abs().max()) <= 2 ** -6 * float(ref.abs().max()) + 1e-3
+    assert float((ag.grad.cpu().double() - ar.grad).abs().max()) <= (2 ** -6 if lo else 1e-4) * max(1.0, float(ar.grad.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("reverse", [False, True])
 def test_tmix_block_training_path_equals_framework_autograd(hip, dtype, reverse, monkeypatch):
