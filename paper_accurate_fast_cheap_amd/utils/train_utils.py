@@ -65,28 +65,42 @@ def wrap_model_ddp(model: torch.nn.Module, device: Optional[torch.device] = None
     return ddp
 
 
-def clip_grad_norm_(params, max_norm: float) -> torch.Tensor:
-    """torch.nn.utils.clip_grad_norm_(params, max_norm) (L2; the reference's call, wenet/utils/train_utils.py:700) with the
-    same arithmetic in far fewer launches when gradient dtypes are mixed: torch multiplies every (device, dtype) group by the
-    fp32 clip-coefficient TENSOR, and `_foreach_mul_` then falls to one kernel per tensor for each group that is not fp32 (the
-    bf16 time-mix slot: ~400 launches per step).  Here every group is multiplied by the coefficient in the group's own dtype,
-    which takes the multi-tensor kernel and is the same product (bit for bit: tests/test_train_step.py).  The coefficient is
-    read back once (the caller tests the norm for inf / nan on the host right afterwards anyway): a coefficient of 1 (no
-    clipping) multiplies nothing.  Returns the total norm (fp32 tensor), like torch."""
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
-        return torch.zeros(())
+def _total_grad_norm(grads):
+    """(L2 norm of all gradients as torch.nn.utils.clip_grad_norm_ forms it -- per-tensor norms by torch's own (device, dtype)
+    grouping, stacked and summed in that order --, the groups)."""
     from torch.utils._foreach_utils import _group_tensors_by_device_and_dtype
-    # torch's own grouping, so that the norms are stacked -- and summed -- in the same order
     groups = {key: gs[0] for key, (gs, _) in _group_tensors_by_device_and_dtype([grads]).items()}
     first = grads[0].device
     norms = []
     for gs in groups.values():
         norms.extend(torch._foreach_norm(gs, 2.0))
-    total = torch.linalg.vector_norm(torch.stack([n.to(first) for n in norms]), 2.0)
+    return torch.linalg.vector_norm(torch.stack([n.to(first) for n in norms]), 2.0), groups
+
+
+def total_grad_norm(params) -> torch.Tensor:
+    """The norm clip_grad_norm_ would return, gradients untouched (train_step hands the clip coefficient to a fused optimizer
+    as its `grad_scale` instead of rescaling every gradient first)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    return _total_grad_norm(grads)[0] if grads else torch.zeros(())
+
+
+def clip_grad_norm_(params, max_norm: float) -> torch.Tensor:
+    """torch.nn.utils.clip_grad_norm_(params, max_norm) (L2; the reference's call, wenet/utils/train_utils.py:700) with the
+    same arithmetic in far fewer launches when gradient dtypes are mixed: torch multiplies every (device, dtype) group by the
+    fp32 clip-coefficient TENSOR, and `_foreach_mul_` then falls to one kernel per tensor for each group that is not fp32 (the
+    bf16 time-mix slot: ~400 launches per step).  Here every group is multiplied by the coefficient in the group's own dtype,
+    which takes the multi-tensor kernel and is the same product (bit for bit: tests/test_train_step.py).  On the GPU the
+    coefficient is never read back (round 6: rounds 3-5 did `float(coef)` to skip the multiplication when nothing is clipped --
+    one host synchronisation per step, right between backward and the update: the host, 5 ms ahead of the GPU by then, waited,
+    and the GPU then idled while the host queued the optimizer and the next forward); a coefficient of 1 multiplies by 1.
+    Returns the total norm (fp32 tensor), like torch."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return torch.zeros(())
+    total, groups = _total_grad_norm(grads)
     coef_t = torch.clamp(max_norm / (total + 1e-6), max=1.0)
-    coef = float(coef_t)
-    if coef < 1.0:        # nan compares false: nothing is scaled, the caller drops the update
+    on_gpu = grads[0].device.type == "cuda"
+    if on_gpu or float(coef_t) < 1.0:        # nan compares false: nothing is scaled, the caller drops the update
         for (dev, dt), gs in groups.items():
             if dt == torch.float32:
                 torch._foreach_mul_(gs, coef_t.to(dev))
@@ -136,21 +150,26 @@ def train_step(model: torch.nn.Module, batch: dict, optimizer: torch.optim.Optim
             scaler.update()
             info["updated"] = bool(torch.isfinite(grad_norm)) and scaler.get_scale() >= scale_before
         else:
-            grad_norm = clip_grad_norm_(params, grad_clip)
             hard = not (clip_hard_maxvalue == float("inf") or step_index < clip_hard_warmup)
-            if (not hard and grad_norm.is_cuda and getattr(optimizer, "_step_supports_amp_scaling", False)
-                    and getattr(optimizer, "found_inf", None) is None):
+            on_device = (not hard and device.type == "cuda" and getattr(optimizer, "_step_supports_amp_scaling", False)
+                         and getattr(optimizer, "found_inf", None) is None and getattr(optimizer, "grad_scale", None) is None)
+            # a fused optimizer un-scales by `grad_scale` inside its own launches (the GradScaler protocol: g / grad_scale): the clip
+            # g * min(1, max_norm / (norm + 1e-6)) rides there as grad_scale = max(1, (norm + 1e-6) / max_norm) -- no pass over the
+            # gradients, no launch (clip_grad_norm_ itself costs ~40 multi-tensor launches per step on two dtype groups)
+            grad_norm = total_grad_norm(params) if on_device else clip_grad_norm_(params, grad_clip)
+            if on_device and grad_norm.is_cuda:
                 # the skip-on-inf / nan decision (train_utils.py:702-711) taken ON THE DEVICE: a fused optimizer reads a
                 # `found_inf` flag (the GradScaler protocol) and leaves parameters, moments and step counts alone when it is
                 # set -- no host synchronisation between backward and the update, the host keeps queueing the next step.
                 # info["updated"] is then a 0-dim bool tensor (bool() of it synchronises, like any tensor).
                 finite = torch.isfinite(grad_norm)
                 optimizer.found_inf = (~finite).to(torch.float32).reshape(())
-                optimizer.grad_scale = None
+                optimizer.grad_scale = torch.clamp((grad_norm + 1e-6) / grad_clip, min=1.0).to(torch.float32).reshape(())
                 try:
                     optimizer.step()
                 finally:
                     optimizer.found_inf = None
+                    optimizer.grad_scale = None
                 info["updated"] = finite
             elif torch.isfinite(grad_norm):     # train_utils.py:702-711: skip the update on inf / nan
                 if not hard or float(grad_norm) <= clip_hard_maxvalue:

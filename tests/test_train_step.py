@@ -109,6 +109,43 @@ def test_train_step_updates_and_skips_nonfinite(hip):
 
 
 @pytest.mark.gpu
+def test_train_step_with_a_fused_optimizer_never_synchronises_the_host(hip):
+    """Round 6: rounds 3-5 read the clip coefficient back (`float(coef)`) between backward and the update -- one host synchronisation
+    per step, found with torch.cuda.set_sync_debug_mode.  Now the clip rides in the fused optimizer's `grad_scale`; a step under
+    sync-debug "error" must not raise (bf16 autocast: the CTC objective on the hand-written kernels -- torch's ctc_loss copies the
+    lengths to the host)."""
+    from paper_accurate_fast_cheap_amd.utils.init_model import init_model
+    from paper_accurate_fast_cheap_amd.utils.train_utils import train_step
+    g = load_golden("encoder_reduced_f32")
+    cfg = dict(encoder="conformer", encoder_conf=dict(g["conf"], dropout_rate=0.0, positional_dropout_rate=0.0), input_dim=80,
+               output_dim=56, ctc="ctc", ctc_conf={"ctc_blank_id": 0}, model_conf={}, dataset_conf={})
+
+    class A:
+        checkpoint = None
+    dev = torch.device("cuda")
+    batch = {"feats": synth.randn((4, 120, 80), 1, 2.0).cuda(), "feats_lengths": torch.tensor([120, 100, 90, 64]).cuda(),
+             "target": torch.randint(1, 50, (4, 6), generator=torch.Generator().manual_seed(2)).cuda(),
+             "target_lengths": torch.tensor([6, 5, 4, 3]).cuda()}
+    torch.manual_seed(3)
+    model, _ = init_model(A(), cfg)
+    model = model.cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+    from paper_accurate_fast_cheap_amd.hip_ops import ctc_head_loss_eligible
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert ctc_head_loss_eligible(torch.zeros(4, 29, model.ctc.ctc_lo.in_features, device="cuda"), model.ctc.ctc_lo.weight, batch["target"])
+    for i in range(2):
+        train_step(model, batch, opt, dev, grad_clip=0.1, step_index=i, amp_dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        info = train_step(model, batch, opt, dev, grad_clip=0.1, step_index=2, amp_dtype=torch.bfloat16)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert isinstance(info["updated"], torch.Tensor) and bool(info["updated"]) and float(info["grad_norm"]) > 0.1     # clipping was active
+    assert getattr(opt, "grad_scale", None) is None and getattr(opt, "found_inf", None) is None
+
+
+@pytest.mark.gpu
 def test_train_step_fused_optimizer_skips_nonfinite_on_the_device(hip):
     """With a fused optimizer the skip-on-inf / nan decision (train_utils.py:702-711) is taken on the device (the optimizer's
     `found_inf` flag): no host synchronisation in the step, info["updated"] is a 0-dim bool tensor; a NaN batch leaves the

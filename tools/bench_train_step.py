@@ -88,6 +88,7 @@ def main():
         info = train_step(model, batch, opt, device, step_index=i, amp_dtype=amp)
         if os.environ.get("PAFC_BENCH_TRACE_LOSS") == "1" and rank == 0:
             print(f"step {i}: loss {float(info['loss']):.3f} grad_norm {float(info['grad_norm']):.2f}", file=sys.stderr)
+    t_issued = time.perf_counter() - t0          # the host has queued every step; what is left is the GPU draining its queue
     sync(); dt = time.perf_counter() - t0
     dt_nosync = None
     if use_ddp:        # the same steps without the gradient exchange: the difference is the all-reduce time not hidden by backward
@@ -106,6 +107,7 @@ def main():
         print(json.dumps({"metric": "training audio-sec/sec (c4: fwd + bwd + all-reduce + clip + Adam, CTC objective)",
                           "value": round(frames / 100.0 / dt, 1), "unit": "audio-sec/sec", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+                          "host_issue_ms_per_step": round(t_issued / args.steps * 1e3, 2),
                           "utts_per_gpu": args.batch, "frames_per_gpu_step": int(lens.sum()),
                           "loss": float(info["loss"]), "grad_norm": float(info["grad_norm"]), "dtype": "fp32 + bf16 slot" + (", bf16 autocast" if amp else ""),
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),

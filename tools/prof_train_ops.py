@@ -27,7 +27,8 @@ for i in range(3):
     train_step(model, batch, opt, device, amp_dtype=torch.bfloat16, step_index=i)
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
+STACKS = "--stacks" in sys.argv        # attribute the small ops (casts, copies, adds) to the package line that calls them
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=STACKS) as prof:
     train_step(model, batch, opt, device, amp_dtype=torch.bfloat16, step_index=3)
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60))
@@ -35,3 +36,23 @@ rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("at
 rows.sort(key=lambda e: -e.count)
 for e in rows[:60]:
     print(f"{e.key:16s} {e.count:5d}  cpu {e.cpu_time_total / 1e3:7.2f} ms  {str(e.input_shapes)[:150]}")
+
+if STACKS:
+    import collections
+    small = ("aten::copy_", "aten::_to_copy", "aten::clone", "aten::contiguous", "aten::add", "aten::add_", "aten::mul", "aten::sum",
+             "aten::cat", "aten::stack", "aten::empty", "aten::zeros_like", "aten::fill_", "aten::zero_", "aten::to")
+    by = collections.Counter()
+    for e in prof.events():
+        if e.name not in small:
+            continue
+        where = "(no python frame: autograd engine / C++)"
+        for fr in (e.stack or []):
+            if "paper_accurate_fast_cheap_amd/" in fr:
+                where = fr.split("paper_accurate_fast_cheap_amd/")[-1]
+                break
+        shape = str(e.input_shapes)[:60] if e.input_shapes else ""
+        by[(e.name, where, shape)] += 1
+    print("\nsmall ops by calling line (count >= 12):")
+    for (name, where, shape), n in sorted(by.items(), key=lambda kv: -kv[1]):
+        if n >= 12:
+            print(f"{n:5d}  {name:18s} {where[:90]:90s} {shape}")
