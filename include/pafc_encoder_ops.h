@@ -281,6 +281,11 @@ int pafc_gemm_tn_bf16(long R, int M, int N, const void *dy, long lda, const void
 int pafc_gemm_bf16_f32out(long M, int N, int K, const void *A, long lda, int a_split, const void *W, long ldw, const float *bias,
                           const float *residual, long ldr, void *out, int out_kind, long ldo, long lo_off, float alpha, int act,
                           void *workspace, size_t workspace_bytes, pafc_stream_t stream);
+/* ... with the split A's planes alternating in blocks of a_plane_block columns ([hi PB | lo PB] ..., PB a power of two >= 64 that
+ * divides K; 0 = [hi K | lo K]), as pafc_gemm_ph_ex2 takes it: Conv2dSubsampling4's plane output into Linear(F' C, odim) at few rows. */
+int pafc_gemm_bf16_f32out_pb(long M, int N, int K, const void *A, long lda, int a_split, int a_plane_block, const void *W, long ldw,
+                             const float *bias, const float *residual, long ldr, void *out, int out_kind, long ldo, long lo_off,
+                             float alpha, int act, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
 /* Bytes of workspace with which pafc_gemm_bf16_f32out splits K over several blocks per tile (a few hundred rows against a long K:
  * partials + a second, reducing launch, deterministic); 0: the problem runs as one launch, workspace may be null. */
 size_t pafc_gemm_bf16_f32out_workspace_bytes(long M, int N, int K, int a_split);

@@ -44,6 +44,7 @@ struct GemmParams {
     // out fp32 or bf16 planes hi | lo (lo at column offset lo_off); split-operand A (SPL): A = planes [hi K1 | lo K1] of an fp32
     // activation, W = [hi | hi | lo] (N x 3 K1), K = 3 K1 columns walked as hi, lo, hi of A -- nk1 = K1 / 64 K-steps per segment
     int nk1, K1;
+    int pb_sh;                        // > 0: A's planes alternate in blocks of 1 << pb_sh columns ([hi PB | lo PB] ...), else [hi K1 | lo K1]
     long lo_off;
     // K split over blockIdx.y (ksplit > 1, pafc_gemm_bf16_f32out with a workspace): block z walks its share of the K-steps of the
     // SAME operands and leaves a raw fp32 partial (EPI 3 with alpha 1, no bias, no residual) at out + z * sO
@@ -128,7 +129,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         int koffA = koff;
         if constexpr (SPL) {                                 // A walks hi, lo, hi while W walks [hi | hi | lo] straight through
             const int seg = (git >= p.nk1) + (git >= 2 * p.nk1);
-            koffA = (seg == 1 ? p.K1 : 0) + (git - seg * p.nk1) * GBK;
+            const int k0 = (git - seg * p.nk1) * GBK;
+            if (p.pb_sh > 0)     // (the subsampling convolution's plane output: [hi C | lo C] per frequency bin)
+                koffA = ((k0 >> p.pb_sh) << (p.pb_sh + 1)) + (k0 & ((1 << p.pb_sh) - 1)) + (seg == 1 ? (1 << p.pb_sh) : 0);
+            else
+                koffA = (seg == 1 ? p.K1 : 0) + k0;
         }
 #pragma unroll
         for (int j = 0; j < MI; ++j) gdma16(a_src[j] + koffA, A + (wave * (BM / 4) + j * 8) * GBK);
@@ -545,7 +550,25 @@ extern "C" int pafc_gemm_bf16_f32out(long M, int N, int K, const void *A, long l
                                      const float *bias, const float *residual, long ldr, void *out, int out_kind, long ldo,
                                      long lo_off, float alpha, int act, void *workspace, size_t workspace_bytes,
                                      pafc_stream_t stream) {
+    return pafc_gemm_bf16_f32out_pb(M, N, K, A, lda, a_split, 0, W, ldw, bias, residual, ldr, out, out_kind, ldo, lo_off, alpha, act,
+                                    workspace, workspace_bytes, stream);
+}
+
+// ... with a_plane_block as pafc_gemm_ph_ex2 takes it (a split A whose planes alternate in blocks of that many columns: the
+// subsampling convolution's output feeding Linear(F' C, odim) -- at a few hundred to a few thousand rows that product is 2-8 tiles
+// of the 256-wide kernel against K = 9 728 x 3: 400 us at 3 992 rows, 205 us at 499)
+extern "C" int pafc_gemm_bf16_f32out_pb(long M, int N, int K, const void *A, long lda, int a_split, int a_plane_block, const void *W,
+                                        long ldw, const float *bias, const float *residual, long ldr, void *out, int out_kind,
+                                        long ldo, long lo_off, float alpha, int act, void *workspace, size_t workspace_bytes,
+                                        pafc_stream_t stream) {
     if (!A || !W || !out) return PAFC_ERR_NULL_POINTER;
+    int pb_sh = 0;
+    if (a_plane_block) {
+        if (!a_split) return PAFC_ERR_UNSUPPORTED;
+        pb_sh = 6;
+        while ((1 << pb_sh) < a_plane_block) ++pb_sh;
+        if ((1 << pb_sh) != a_plane_block || K % a_plane_block) return PAFC_ERR_UNSUPPORTED;
+    }
     if (M <= 0 || N <= 0 || K <= 0) return PAFC_ERR_BAD_DIMS;
     if (N % 8 || K % pafc::GBK) return PAFC_ERR_UNSUPPORTED;
     if ((out_kind != 1 && out_kind != 2) || act < 0 || act > 3) return PAFC_ERR_UNSUPPORTED;
@@ -558,7 +581,7 @@ extern "C" int pafc_gemm_bf16_f32out(long M, int N, int K, const void *A, long l
     pafc::GemmParams p{};
     p.A = (const pafc::bf16_t *)A; p.W = (const pafc::bf16_t *)W; p.bias = (const pafc::bf16_t *)bias;
     p.res = (const pafc::bf16_t *)residual; p.out = (pafc::bf16_t *)out;
-    p.M = M; p.N = N; p.K = Kw; p.K1 = K; p.nk1 = K / pafc::GBK;
+    p.M = M; p.N = N; p.K = Kw; p.K1 = K; p.nk1 = K / pafc::GBK; p.pb_sh = pb_sh;
     p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr; p.lo_off = lo_off;
     p.alpha = alpha; p.act = act; p.ksplit = 1;
     const long cus = pafc::device_cus();

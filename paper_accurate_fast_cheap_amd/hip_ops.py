@@ -990,20 +990,21 @@ def gemm_ph_ex(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         P, I, G = c_void_p, c_int, c_long
         _lib._sig(L.pafc_gemm_ph_ex2, I, G, I, I, I, P, G, G, I, I, P, G, G, P, G, P, I, G, G, P, I, G, G, G, c_float, I, I, P)
         from ctypes import c_size_t
-        _lib._sig(L.pafc_gemm_bf16_f32out, I, G, I, I, P, G, I, P, G, P, P, G, P, I, G, G, c_float, I, P, c_size_t, P)
+        _lib._sig(L.pafc_gemm_bf16_f32out_pb, I, G, I, I, P, G, I, I, P, G, P, P, G, P, I, G, G, c_float, I, P, c_size_t, P)
         _lib._sig(L.pafc_gemm_bf16_f32out_workspace_bytes, c_size_t, G, I, I, I)
         L._pafc_gemmex_bound = True
     from .profiling import op_timer
+    pb_ok = not a_plane_block or (a_split and a_plane_block >= 64 and a_plane_block & (a_plane_block - 1) == 0 and K % a_plane_block == 0)
     if (M <= _SPLIT_SMALL_MAX_ROWS and M * N <= (1 << 22) and ok != 0 and act in ("none", "silu", "tanh", "relu")
-            and not a_plane_block and not tile_m and K % 64 == 0):
+            and pb_ok and not tile_m and K % 64 == 0):
         # few rows: the small tiles of csrc/gemm_bf16.hip (same operand forms, same epilogue order)
         nws = L.pafc_gemm_bf16_f32out_workspace_bytes(M, N, K, int(a_split))     # > 0: few rows x long K, K split over blocks
         ws = torch.empty(nws, dtype=torch.uint8, device=a.device) if nws else None
         with op_timer("gemm%ss_%dx%d" % ("3" if a_split else "", K, N), sample=12, flops=2.0 * M * N * K * (3 if a_split else 1)):
-            rc = L.pafc_gemm_bf16_f32out(M, N, K, _lib.ptr(a), a.stride(0), int(a_split), _lib.ptr(w), w.stride(0), _lib.ptr(bias),
-                                         _lib.ptr(residual), residual.stride(0) if residual is not None else 0, _lib.ptr(out), ok,
-                                         out.stride(0), No if ok == 2 else 0, float(alpha), _ACTS[act], _lib.ptr(ws), nws,
-                                         _lib.stream_of(a))
+            rc = L.pafc_gemm_bf16_f32out_pb(M, N, K, _lib.ptr(a), a.stride(0), int(a_split), int(a_plane_block), _lib.ptr(w), w.stride(0),
+                                            _lib.ptr(bias), _lib.ptr(residual), residual.stride(0) if residual is not None else 0,
+                                            _lib.ptr(out), ok, out.stride(0), No if ok == 2 else 0, float(alpha), _ACTS[act], _lib.ptr(ws),
+                                            nws, _lib.stream_of(a))
         _lib.check(rc, "pafc_gemm_bf16_f32out")
         return out
     with op_timer("gemm%s_%dx%d" % ("3" if a_split else "", K, N), sample=12, flops=2.0 * M * N * K * (3 if a_split else 1)):

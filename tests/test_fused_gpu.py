@@ -1099,6 +1099,22 @@ def test_gemm_split_operand_forms(hip, M, N, K):
     torch.testing.assert_close(got.double(), ab.double() @ wb.double().t() + r.double(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("M", [61, 499, 3992, 4500])
+def test_gemm_split_plane_blocks_at_few_rows(hip, M):
+    """Linear(F' C, odim) behind the subsampling convolutions at window row counts: A = conv2's plane output, [hi C | lo C] per
+    frequency bin (a_plane_block = C), K = 19 x 512 = 9 728.  Round 6: up to 4 096 rows this runs on the small tiles
+    (pafc_gemm_bf16_f32out_pb; with the K split over blocks at 61 and 499 rows) instead of 1-16 tiles of the 256-wide kernel;
+    4 500 rows still take that one.  Against a float64 product of the same fp32 operands."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_ph_ex, split_planes
+    Fp, C = 19, 512
+    a = (synth.randn((M, Fp * C), 41) * 0.5).cuda()
+    w = (synth.randn((512, Fp * C), 42) / (Fp * C) ** 0.5).cuda()
+    b = (synth.randn((512,), 43) * 0.3).cuda()
+    ap = split_planes(a.view(M * Fp, C)).view(M, Fp * 2 * C)
+    got = gemm_ph_ex(ap, split_planes(w, triple=True), b, a_split=True, out_kind="f32", a_plane_block=C)
+    torch.testing.assert_close(got.double(), a.double() @ w.double().t() + b.double(), rtol=2e-4, atol=2e-4)
+
+
 @pytest.mark.parametrize("form", ["w_1 planes+SiLU", "w_2 residual", "w_2 residual in place", "pointwise_conv1 GLU",
                                   "pointwise_conv2 residual in place", "slot output bf16 operands", "CTC head",
                                   "Linear(9728,512) plane blocks"])
