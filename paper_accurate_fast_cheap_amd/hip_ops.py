@@ -262,6 +262,9 @@ class _LayerNormTrain(torch.autograd.Function):
     def backward(ctx, dy):
         x, g = ctx.saved_tensors
         dx, dg, db = layernorm_bwd(x, dy.contiguous(), g, ctx.eps)
+        if ctx.w_dtype == ctx.b_dtype and ctx.w_dtype != torch.float32:
+            dgb = dg._base.to(ctx.w_dtype)          # (2, C): one cast for both (the bf16 ln_x of the slot)
+            return dx, dgb[0], dgb[1], None, None
         return dx, dg.to(ctx.w_dtype), db.to(ctx.b_dtype), None, None
 
 

@@ -121,7 +121,9 @@ def wkv6_backward(r, k, v, w, u, gy, *, reverse: bool = False, chunk_len: int = 
     rc = L.pafc_wkv6_backward_state(code, B, T, C, H, P(r), P(k), P(v), P(w), P(u), P(s_in), P(gy), P(gr), P(gk), P(gv),
                                     P(gw), P(gu), P(gs), int(reverse), chunk_len, P(ws), nbytes, _lib.stream_of(r))
     _lib.check(rc, "pafc_wkv6_backward_state")
-    out = (gr, gk, gv, gw, torch.sum(gu.float(), 0).to(r.dtype).view(H, C // H))
+    # (model.py:151: torch.sum(gu, 0) on the bf16 per-batch sums -- ONE reduction kernel, fp32 accumulation, one rounding;
+    # `gu.float()` in front and `.to()` behind it were two more launches per direction and layer for the same value)
+    out = (gr, gk, gv, gw, torch.sum(gu, 0).view(H, C // H))
     return out + (gs,) if want_gs else out
 
 

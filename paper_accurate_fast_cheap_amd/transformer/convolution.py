@@ -45,7 +45,9 @@ class ConvolutionModule(nn.Module):
         from ..hip_ops import depthwise_conv1d_cl, depthwise_conv1d_cl_autograd, linear
         keep = mask_pad.transpose(1, 2) if mask_pad.size(2) > 0 else None  # (B, T, 1)
         if keep is not None:
-            x = x.masked_fill(~keep, 0.0)
+            # masked_fill(~keep, 0) as ONE kernel each way: masked_fill = clone + fill, its mask a bitwise_not, and its autograd the
+            # same again (10 launches per layer and training step for the two fills of this module; where: 4)
+            x = torch.where(keep, x, 0.0)
         if self.lorder > 0:
             if cache.size(2) == 0:
                 x = F.pad(x, (0, 0, self.lorder, 0), "constant", 0.0)
@@ -79,5 +81,5 @@ class ConvolutionModule(nn.Module):
             x = self.activation(self.norm(x.transpose(1, 2)).transpose(1, 2))
         x = linear(x, self.pointwise_conv2.weight.squeeze(-1), self.pointwise_conv2.bias)
         if keep is not None:
-            x = x.masked_fill(~keep, 0.0)
+            x = torch.where(keep, x, 0.0)
         return x, new_cache

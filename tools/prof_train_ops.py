@@ -38,21 +38,33 @@ for e in rows[:60]:
     print(f"{e.key:16s} {e.count:5d}  cpu {e.cpu_time_total / 1e3:7.2f} ms  {str(e.input_shapes)[:150]}")
 
 if STACKS:
+    # (Python frames are not recorded by this build's profiler; the op tree is: attribute every small op to the nearest enclosing
+    # event that is not an aten:: op -- a custom Function's forward / backward, an autograd node, an optimizer section)
     import collections
     small = ("aten::copy_", "aten::_to_copy", "aten::clone", "aten::contiguous", "aten::add", "aten::add_", "aten::mul", "aten::sum",
-             "aten::cat", "aten::stack", "aten::empty", "aten::zeros_like", "aten::fill_", "aten::zero_", "aten::to")
+             "aten::cat", "aten::stack", "aten::div", "aten::fill_", "aten::zero_", "aten::zeros_like", "aten::sub", "aten::neg",
+             "aten::mul_", "aten::masked_fill", "aten::masked_fill_", "aten::where", "aten::bitwise_not", "aten::flip", "aten::glu",
+             "aten::silu", "aten::tanh", "aten::sigmoid", "aten::eq", "aten::lt", "aten::ge", "aten::arange")
+    launches = {}
+    for e in prof.events():
+        if e.device_type.name != "CPU":
+            continue
     by = collections.Counter()
     for e in prof.events():
-        if e.name not in small:
+        if e.name not in small or e.device_type.name != "CPU":
             continue
-        where = "(no python frame: autograd engine / C++)"
-        for fr in (e.stack or []):
-            if "paper_accurate_fast_cheap_amd/" in fr:
-                where = fr.split("paper_accurate_fast_cheap_amd/")[-1]
+        par = e.cpu_parent
+        if par is not None and par.name in small:
+            continue                      # the outer aten op is counted (contiguous -> clone -> copy_)
+        where = "(top level)"
+        while par is not None:
+            if not par.name.startswith("aten::"):
+                where = par.name
                 break
-        shape = str(e.input_shapes)[:60] if e.input_shapes else ""
-        by[(e.name, where, shape)] += 1
-    print("\nsmall ops by calling line (count >= 12):")
+            par = par.cpu_parent
+        shape = str(e.input_shapes)[:70] if e.input_shapes else ""
+        by[(e.name, where[:70], shape)] += 1
+    print("\nsmall ops by enclosing event (count >= 12):")
     for (name, where, shape), n in sorted(by.items(), key=lambda kv: -kv[1]):
         if n >= 12:
-            print(f"{n:5d}  {name:18s} {where[:90]:90s} {shape}")
+            print(f"{n:5d}  {name:18s} {where:70s} {shape}")
