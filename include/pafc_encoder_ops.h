@@ -269,6 +269,13 @@ int pafc_conv3x3s2_nhwc_f32split(int B, int T1, int F1, int Ci, int Co, const vo
 size_t pafc_gemm_tn_workspace_bytes(long R, int M, int N);
 int pafc_gemm_tn_bf16(long R, int M, int N, const void *dy, long lda, const void *x, long ldb, void *dw, void *dbias,
                       int dw_dtype, void *workspace, size_t workspace_bytes, pafc_stream_t stream);
+/* `batch` products of one shape in one launch pair (the r / k / v weight gradients of a time-mix block): entry z reads
+ * dy + z * stride_dy and x + z * stride_x (elements, multiples of 8) and writes dw + z * M * N (dbias + z * M).
+ * workspace: pafc_gemm_tn_batched_workspace_bytes(R, M, N, batch). */
+size_t pafc_gemm_tn_batched_workspace_bytes(long R, int M, int N, int batch);
+int pafc_gemm_tn_bf16_batched(long R, int M, int N, int batch, const void *dy, long lda, long stride_dy, const void *x, long ldb,
+                              long stride_x, void *dw, void *dbias, int dw_dtype, void *workspace, size_t workspace_bytes,
+                              pafc_stream_t stream);
 
 /* fp32 results from bf16 operands on the small tiles of csrc/gemm_bf16.hip (128 x 128 / 128 x 64 / 64 x 64, picked by row count): the
  * operand forms of pafc_gemm_ph_ex for problems too small for its 256-wide tiles -- a_split != 0: A = planes [hi K | lo K] of an

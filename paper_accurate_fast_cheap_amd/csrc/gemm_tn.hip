@@ -46,7 +46,8 @@ struct TnParams {
     float *part;             // (S, M, N) fp32
     float *bias_part;        // (S, M) fp32 column sums of dY (the bias gradient), or null
     long R, lda, ldb, rows_per_split;
-    int M, N, mtiles, ntiles, S;
+    long sA, sB;             // batch strides of dY and X (elements); the partials of entry z start at part + z * S * M * N
+    int M, N, mtiles, ntiles, S, batch;
 };
 
 __device__ __forceinline__ void tdma16(const bf16_t *src, bf16_t *lds_base) {
@@ -78,7 +79,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_kernel(const TnParams p) {
     const long per = (long)gridDim.x / 8;
     if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
     const int tiles = p.mtiles * p.ntiles;
-    const int split = (int)(bid / tiles), tile = (int)(bid % tiles);
+    const int zs = (int)(bid / tiles), tile = (int)(bid % tiles);      // zs = batch entry * S + split
+    const int z = zs / p.S, split = zs % p.S;
+    const bf16_t *const Ab = p.A + (long)z * p.sA, *const Bb = p.B + (long)z * p.sB;
     const int mt = tile / p.ntiles, nt = tile % p.ntiles;
     const int m0 = mt * TBM, n0 = nt * TBN;
     const long k_begin = (long)split * p.rows_per_split;
@@ -103,8 +106,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_kernel(const TnParams p) {
         for (int j = 0; j < 2; ++j) {
             const long r = min(kb + d_row[j], k_end - 1);
             const int base = (j * 8 + wave) * 4 * TBM;
-            tdma16(p.A + r * p.lda + a_col[j], At + base);
-            tdma16(p.B + r * p.ldb + b_col[j], Bt + base);
+            tdma16(Ab + r * p.lda + a_col[j], At + base);
+            tdma16(Bb + r * p.ldb + b_col[j], Bt + base);
         }
     };
 
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_kernel(const TnParams p) {
         }
     __syncthreads();
     const float *O0 = reinterpret_cast<const float *>(lds), *O1 = O0 + TN_EPI_FLOATS;
-    float *out = p.part + (size_t)split * p.M * p.N;
+    float *out = p.part + (size_t)zs * p.M * p.N;
 #pragma unroll
     for (int qq = 0; qq < TBM * TBN / 4 / 512; ++qq) {
         const int idx = qq * 512 + tid;
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_kernel(const TnParams p) {
         }
     }
     if (p.bias_part != nullptr && nt == 0 && tid < TBM && m0 + tid < p.M)
-        p.bias_part[(size_t)split * p.M + m0 + tid] = O0[TBM * LDF + tid] + O1[TBM * LDF + tid];
+        p.bias_part[(size_t)zs * p.M + m0 + tid] = O0[TBM * LDF + tid] + O1[TBM * LDF + tid];
 }
 
 // dW = sum of the S partials in a FIXED order (four quarter sums of consecutive partials, then (q0 + q1) + (q2 + q3));
@@ -262,6 +265,17 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(long n4, int S, lon
     const int col = threadIdx.x & 63, sg = threadIdx.x >> 6;
     long i = (long)blockIdx.x * 64 + col;
     const bool live = i < n4 + nb4;
+    {   // batch entry blockIdx.y: its S partials and its outputs
+        const long z = blockIdx.y;
+        part += z * S * n4;
+        if (out_f32) out_f32 += z * n4;
+        if (out_bf16) out_bf16 += z * n4;
+        if (nb4) {
+            bias_part += z * S * nb4;
+            if (bias_f32) bias_f32 += z * nb4;
+            if (bias_bf16) bias_bf16 += z * nb4;
+        }
+    }
     if (i >= n4) {                                   // (block-uniform except in one block)
         i -= n4; part = bias_part; stride4 = nb4; out_f32 = bias_f32; out_bf16 = bias_bf16;
     }
@@ -298,8 +312,8 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(long n4, int S, lon
 // Splits of R per output tile.  Cost of a choice in ROWS of the K loop (one 64-row K-step of a block ~ 0.37 us): rounds of
 // one-block-per-CU work x (rows per block + ~448 rows for prologue and the 64 KiB partial-tile store) + the reduce pass over
 // S x M x N x 4 bytes at ~3 TB/s (~58 rows per MiB).  Measured at 15 392 rows (profiles/r06x_gemm_tn_by_shape.txt).
-void plan(long R, int M, int N, int *S, long *rows_per_split) {
-    const long tiles = (long)((M + TBM - 1) / TBM) * ((N + TBN - 1) / TBN);
+void plan(long R, int M, int N, int batch, int *S, long *rows_per_split) {
+    const long tiles = (long)((M + TBM - 1) / TBM) * ((N + TBN - 1) / TBN) * batch;
     const long cus = device_cus();
     long max_s = (R + 2 * TBK - 1) / (2 * TBK);         // at least two K steps per block
     if (max_s > 256) max_s = 256;
@@ -310,7 +324,7 @@ void plan(long R, int M, int N, int *S, long *rows_per_split) {
         const long rps = ((R + s - 1) / s + TBK - 1) / TBK * TBK;
         const long sr = (R + rps - 1) / rps;              // the split count this row share really gives
         const long rounds = (tiles * sr + cus - 1) / cus;
-        const double cost = (double)rounds * (double)(rps + 448) + 58.0 * (double)sr * M * N * 4.0 / 1048576.0;
+        const double cost = (double)rounds * (double)(rps + 448) + 58.0 * (double)sr * batch * M * N * 4.0 / 1048576.0;
         if (best < 0 || cost < best) { best = cost; best_s = s; }
     }
     long rps = ((R + best_s - 1) / best_s + TBK - 1) / TBK * TBK;
@@ -321,41 +335,53 @@ void plan(long R, int M, int N, int *S, long *rows_per_split) {
 }  // namespace
 }  // namespace pafc
 
-extern "C" size_t pafc_gemm_tn_workspace_bytes(long R, int M, int N) {
-    if (R <= 0 || M <= 0 || N <= 0) return 0;
+extern "C" size_t pafc_gemm_tn_batched_workspace_bytes(long R, int M, int N, int batch) {
+    if (R <= 0 || M <= 0 || N <= 0 || batch <= 0) return 0;
     int S; long rps;
-    pafc::plan(R, M, N, &S, &rps);
-    return (size_t)S * M * (N + 1) * sizeof(float);      // partial tiles + partial column sums
+    pafc::plan(R, M, N, batch, &S, &rps);
+    return (size_t)batch * S * M * (N + 1) * sizeof(float);      // partial tiles + partial column sums
 }
 
-extern "C" int pafc_gemm_tn_bf16(long R, int M, int N, const void *dy, long lda, const void *x, long ldb, void *dw,
-                                 void *dbias, int dw_dtype, void *workspace, size_t workspace_bytes,
-                                 pafc_stream_t stream) {
+extern "C" size_t pafc_gemm_tn_workspace_bytes(long R, int M, int N) { return pafc_gemm_tn_batched_workspace_bytes(R, M, N, 1); }
+
+// `batch` products of the same shape in one launch pair (the r / k / v weight gradients of a time-mix block: three 512 x 512
+// products of 15 392 rows are 48 tiles -- S = 5 instead of 16 each, a third of the launches): entry z reads dy + z * stride_dy,
+// x + z * stride_x and writes dw + z * M * N (dbias + z * M).
+extern "C" int pafc_gemm_tn_bf16_batched(long R, int M, int N, int batch, const void *dy, long lda, long stride_dy, const void *x,
+                                         long ldb, long stride_x, void *dw, void *dbias, int dw_dtype, void *workspace,
+                                         size_t workspace_bytes, pafc_stream_t stream) {
     if (!dy || !x || !dw || !workspace) return PAFC_ERR_NULL_POINTER;
-    if (R <= 0 || M < 8 || N < 8 || (M % 8) || (N % 8) || lda < M || ldb < N || (lda % 8) || (ldb % 8))
+    if (R <= 0 || M < 8 || N < 8 || (M % 8) || (N % 8) || lda < M || ldb < N || (lda % 8) || (ldb % 8) || batch < 1 || batch > 65535 ||
+        (batch > 1 && ((stride_dy % 8) || (stride_x % 8))))
         return PAFC_ERR_BAD_DIMS;
     if (dw_dtype != PAFC_F32 && dw_dtype != PAFC_BF16) return PAFC_ERR_DTYPE;
     if ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dw | (uintptr_t)dbias | (uintptr_t)workspace) & 15) != 0)
         return PAFC_ERR_ALIGNMENT;
     pafc::TnParams p{};
-    pafc::plan(R, M, N, &p.S, &p.rows_per_split);
-    if (workspace_bytes < (size_t)p.S * M * (N + 1) * sizeof(float)) return PAFC_ERR_WORKSPACE;
+    pafc::plan(R, M, N, batch, &p.S, &p.rows_per_split);
+    if (workspace_bytes < (size_t)batch * p.S * M * (N + 1) * sizeof(float)) return PAFC_ERR_WORKSPACE;
     p.A = (const pafc::bf16_t *)dy; p.B = (const pafc::bf16_t *)x; p.part = (float *)workspace;
-    p.bias_part = dbias ? p.part + (size_t)p.S * M * N : nullptr;
-    p.R = R; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N;
+    p.bias_part = dbias ? p.part + (size_t)batch * p.S * M * N : nullptr;
+    p.R = R; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.batch = batch; p.sA = stride_dy; p.sB = stride_x;
     p.mtiles = (M + pafc::TBM - 1) / pafc::TBM; p.ntiles = (N + pafc::TBN - 1) / pafc::TBN;
-    if ((long)p.mtiles * p.ntiles * p.S > 2147483647L) return PAFC_ERR_BAD_DIMS;
+    if ((long)p.mtiles * p.ntiles * p.S * batch > 2147483647L) return PAFC_ERR_BAD_DIMS;
     hipStream_t s = (hipStream_t)stream;
     size_t lds = (size_t)pafc::TN_NST * pafc::TN_STAGE * sizeof(pafc::bf16_t);                   // the ring: 128 KiB
     if (lds < 2 * pafc::TN_EPI_FLOATS * sizeof(float)) lds = 2 * pafc::TN_EPI_FLOATS * sizeof(float);   // the epilogue: 133 KiB
     if (hipFuncSetAttribute((const void *)pafc::gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
         return PAFC_ERR_LAUNCH;
-    hipLaunchKernelGGL(pafc::gemm_tn_kernel, dim3((unsigned)(p.mtiles * p.ntiles * p.S)), dim3(512), lds, s, p);
+    hipLaunchKernelGGL(pafc::gemm_tn_kernel, dim3((unsigned)(p.mtiles * p.ntiles * p.S * batch)), dim3(512), lds, s, p);
     const long n4 = (long)M * N / 4, nb4 = dbias ? M / 4 : 0;
-    hipLaunchKernelGGL(pafc::gemm_tn_reduce_kernel, dim3((unsigned)((n4 + nb4 + 63) / 64)), dim3(256), 0, s, n4, p.S, n4,
+    hipLaunchKernelGGL(pafc::gemm_tn_reduce_kernel, dim3((unsigned)((n4 + nb4 + 63) / 64), (unsigned)batch), dim3(256), 0, s, n4, p.S, n4,
                        (const float4 *)workspace, dw_dtype == PAFC_F32 ? (float4 *)dw : nullptr,
                        dw_dtype == PAFC_BF16 ? (uint2 *)dw : nullptr, nb4, (const float4 *)p.bias_part,
                        dw_dtype == PAFC_F32 ? (float4 *)dbias : nullptr, dw_dtype == PAFC_BF16 ? (uint2 *)dbias : nullptr);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+extern "C" int pafc_gemm_tn_bf16(long R, int M, int N, const void *dy, long lda, const void *x, long ldb, void *dw,
+                                 void *dbias, int dw_dtype, void *workspace, size_t workspace_bytes,
+                                 pafc_stream_t stream) {
+    return pafc_gemm_tn_bf16_batched(R, M, N, 1, dy, lda, 0, x, ldb, 0, dw, dbias, dw_dtype, workspace, workspace_bytes, stream);
 }

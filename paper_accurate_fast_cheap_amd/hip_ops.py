@@ -289,28 +289,32 @@ def layer_norm(x: torch.Tensor, weight, bias, eps: float, bf16_out: bool = False
 
 def gemm_tn(dy: torch.Tensor, x: torch.Tensor, out_dtype: torch.dtype = torch.float32, want_bias: bool = False):
     """dw (M, N) = dy^T @ x for dy (R, M), x (R, N) bf16 with unit column stride: nn.Linear's weight gradient;
-    with want_bias also db (M) = dy.sum(0) from the same pass -> (dw, db)."""
+    with want_bias also db (M) = dy.sum(0) from the same pass -> (dw, db).  dy (Z, R, M), x (Z, R, N): Z products in one launch
+    pair -> dw (Z, M, N) (db (Z, M))."""
     if not (dy.is_cuda and x.is_cuda):
         raise _lib.PafcError("gemm_tn runs on the MI355X only; there is no CPU fallback")
-    R, M = dy.shape
-    N = x.shape[1]
-    if (dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or x.shape[0] != R or dy.stride(1) != 1
-            or x.stride(1) != 1 or out_dtype not in (torch.float32, torch.bfloat16)):
-        raise _lib.PafcError("gemm_tn: dy (R, M) and x (R, N) bf16 with unit column stride; fp32 or bf16 output")
+    batched = dy.dim() == 3
+    Z = dy.shape[0] if batched else 1
+    R, M = dy.shape[-2], dy.shape[-1]
+    N = x.shape[-1]
+    if (dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or x.dim() != dy.dim() or x.shape[-2] != R or dy.stride(-1) != 1
+            or x.stride(-1) != 1 or out_dtype not in (torch.float32, torch.bfloat16) or (batched and x.shape[0] != Z)):
+        raise _lib.PafcError("gemm_tn: dy (R, M) and x (R, N) bf16 with unit column stride (or both with a leading batch); fp32 or bf16 output")
     L = _lib.lib()
     if not getattr(L, "_pafc_tn_bound", False):
         from ctypes import c_long, c_size_t
-        L.pafc_gemm_tn_workspace_bytes.restype = c_size_t
-        L.pafc_gemm_tn_workspace_bytes.argtypes = [c_long, c_int, c_int]
-        _lib._sig(L.pafc_gemm_tn_bf16, c_int, c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
-                  c_int, c_void_p, c_size_t, c_void_p)
+        L.pafc_gemm_tn_batched_workspace_bytes.restype = c_size_t
+        L.pafc_gemm_tn_batched_workspace_bytes.argtypes = [c_long, c_int, c_int, c_int]
+        _lib._sig(L.pafc_gemm_tn_bf16_batched, c_int, c_long, c_int, c_int, c_int, c_void_p, c_long, c_long, c_void_p, c_long, c_long,
+                  c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p)
         L._pafc_tn_bound = True
-    nbytes = L.pafc_gemm_tn_workspace_bytes(R, M, N)
+    nbytes = L.pafc_gemm_tn_batched_workspace_bytes(R, M, N, Z)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
-    dw = torch.empty(M, N, dtype=out_dtype, device=dy.device)
-    db = torch.empty(M, dtype=out_dtype, device=dy.device) if want_bias else None
-    rc = L.pafc_gemm_tn_bf16(R, M, N, _lib.ptr(dy), dy.stride(0), _lib.ptr(x), x.stride(0), _lib.ptr(dw), _lib.ptr(db),
-                             _lib.dtype_code(out_dtype), _lib.ptr(ws), nbytes, _lib.stream_of(dy))
+    dw = torch.empty((Z, M, N) if batched else (M, N), dtype=out_dtype, device=dy.device)
+    db = (torch.empty((Z, M) if batched else (M,), dtype=out_dtype, device=dy.device)) if want_bias else None
+    rc = L.pafc_gemm_tn_bf16_batched(R, M, N, Z, _lib.ptr(dy), dy.stride(-2), dy.stride(0) if batched else 0, _lib.ptr(x), x.stride(-2),
+                                     x.stride(0) if batched else 0, _lib.ptr(dw), _lib.ptr(db), _lib.dtype_code(out_dtype), _lib.ptr(ws),
+                                     nbytes, _lib.stream_of(dy))
     _lib.check(rc, "pafc_gemm_tn_bf16")
     return (dw, db) if want_bias else dw
 
@@ -445,6 +449,7 @@ def silu_dropout(h: torch.Tensor, p: float, training: bool) -> torch.Tensor:
 _shadows = {}      # id(parameter) -> [weak reference to the parameter, bf16 copy]  (tensors compare element-wise: they cannot
                    # be keys of a WeakKeyDictionary)
 _shadows_on = False
+_wgroups = {}     # (id(p0), id(p1), ...) -> [weak references, (Z, N, K) bf16 copy]: equally shaped weights as ONE batched operand
 
 
 def _param_of(p: torch.Tensor) -> torch.Tensor:
@@ -561,6 +566,13 @@ def refresh_train_shadows() -> None:
             live.append((p, ent[1]))
     for key in dead:
         del _shadows[key]
+    for key in list(_wgroups):                      # grouped bf16 copies (r / k / v of a time-mix block as one (3, N, K) operand)
+        refs, g = _wgroups[key]
+        ps = [r() for r in refs]
+        if any(p is None or p.device != g.device or tuple(p.shape) != tuple(g.shape[1:]) for p in ps):
+            del _wgroups[key]
+        else:
+            live.extend((p, g[i]) for i, p in enumerate(ps))
     if live:
         with torch.no_grad():
             torch._foreach_copy_([sh for _, sh in live], [p.detach() for p, _ in live])
@@ -713,6 +725,139 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) 
     if linear_train_eligible(x, weight):
         return linear_train(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+def _weight_group(ws) -> Optional[torch.Tensor]:
+    """Z equally shaped weights as ONE (Z, N, K) bf16 operand, inside train_shadows() only (None elsewhere).
+    bf16 parameters (the time-mix slot): the parameters THEMSELVES are moved into one buffer the first time they are asked for
+    together (`p.data = group[i]`: the Parameter objects, their optimizer state and their names stay; load_state_dict copies in
+    place; a later `.to()` that breaks the layout is noticed here and mended) -- no copy to keep fresh, no launch per step.
+    fp32 parameters: a grouped bf16 copy beside them, refreshed with the other copies when train_shadows() is entered."""
+    if not _shadows_on or any(not isinstance(w, torch.nn.Parameter) or w.dim() != 2 or w.shape != ws[0].shape
+                              or w.device != ws[0].device or w.dtype != ws[0].dtype for w in ws):
+        return None
+    if ws[0].dtype == torch.bfloat16:
+        g = _as_batch([w.detach() for w in ws])
+        if g is None or not g.is_contiguous():
+            with torch.no_grad():
+                g = torch.stack([w.detach() for w in ws]).contiguous()
+                for i, w in enumerate(ws):
+                    w.data = g[i]
+        return g
+    if ws[0].dtype != torch.float32:
+        return None
+    key = tuple(id(w) for w in ws)
+    ent = _wgroups.get(key)
+    if ent is not None and all(r() is w for r, w in zip(ent[0], ws)) and ent[1].device == ws[0].device:
+        return ent[1]
+    g = torch.stack([w.detach().to(torch.bfloat16) for w in ws]).contiguous()
+    _wgroups[key] = [[weakref.ref(w) for w in ws], g]
+    return g
+
+
+def _weight_t_group(ws) -> Optional[torch.Tensor]:
+    """(Z, K, N) bf16: the transposed copies of _bf16_shadow_t for Z equally shaped weights, as views of ONE tensor (the
+    multi-tensor transpose that refreshes the copies writes into the views)."""
+    global _tr_table
+    if not _shadows_on or any(not isinstance(w, torch.nn.Parameter) or w.dim() != 2 or w.shape != ws[0].shape for w in ws):
+        return None
+    N, K = ws[0].shape
+    ents = [_shadows_t.get(id(w)) for w in ws]
+    if all(e is not None and e[0]() is w for e, w in zip(ents, ws)):
+        b = ents[0][1]._base
+        if (b is not None and tuple(b.shape) == (len(ws), K, N) and b.is_contiguous()
+                and all(e[1]._base is b and e[1].data_ptr() == b[i].data_ptr() for i, e in enumerate(ents))):
+            for e, w in zip(ents, ws):                       # a copy whose stamp is not the present one is re-made on the spot
+                stamp = (_param_epoch, w._version)
+                if e[2] != stamp:
+                    with torch.no_grad():
+                        e[1].copy_(w.detach().t())
+                    e[2] = stamp
+            return b
+    g = torch.empty((len(ws), K, N), dtype=torch.bfloat16, device=ws[0].device)
+    with torch.no_grad():
+        for i, w in enumerate(ws):
+            g[i].copy_(w.detach().t())
+            _shadows_t[id(w)] = [weakref.ref(w), g[i], (_param_epoch, w._version)]
+    _tr_table = None
+    return g
+
+
+def _as_batch(ts) -> Optional[torch.Tensor]:
+    """Z equally shaped 2-d row-major views of ONE storage at equal distances -> the (Z, M, K) strided view over them (no copy),
+    else None.  (The lerp kernel leaves z_r, z_k, z_v as slices of one tensor; the WKV backward leaves g_r, g_k, g_v so.)"""
+    a = ts[0]
+    if a.dim() != 2 or a.stride(1) != 1 or any(t.shape != a.shape or t.stride() != a.stride() or t.dtype != a.dtype
+                                                or t.untyped_storage().data_ptr() != a.untyped_storage().data_ptr() for t in ts):
+        return None
+    d = ts[1].storage_offset() - a.storage_offset()
+    if d <= 0 or d % 8 or any(ts[i + 1].storage_offset() - ts[i].storage_offset() != d for i in range(len(ts) - 1)):
+        return None
+    return torch.as_strided(a, (len(ts),) + tuple(a.shape), (d,) + tuple(a.stride()), a.storage_offset())
+
+
+class _LinearGroupTrainBf16(torch.autograd.Function):
+    """Z bias-free nn.Linear of one shape on Z inputs -- the r / k / v projections of a time-mix block (src/model.py:286-288) -- as
+    ONE batched launch each way: forward against the grouped bf16 weight copy, input gradients against the grouped transposed
+    copies, the Z weight gradients from one batched gemm_tn pair.  (Three _LinearTrainBf16 nodes: 3 + 3 + 6 launches and three
+    Python backward calls per direction and layer.)"""
+
+    @staticmethod
+    def forward(ctx, *args):
+        Z = len(args) // 2
+        xs, ws = args[:Z], args[Z:]
+        N, K = ws[0].shape
+        x2 = [x.reshape(-1, K) for x in xs]
+        xb = _as_batch(x2)
+        if xb is None:
+            xb = torch.stack(x2)
+        y = gemm_bf16(xb, _weight_group(ws))                           # (Z, M, N)
+        ctx.save_for_backward(xb)
+        ctx.ws, ctx.x_shape = ws, xs[0].shape
+        return tuple(y[i].view(xs[0].shape[:-1] + (N,)) for i in range(Z))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        (xb,) = ctx.saved_tensors
+        ws = ctx.ws
+        Z = len(ws)
+        N, K = ws[0].shape
+        d2 = [(torch.zeros(xb.shape[1], N, dtype=xb.dtype, device=xb.device) if g is None else g.reshape(-1, N)) for g in dys]
+        db = _as_batch(d2)
+        if db is None:
+            db = torch.stack(d2)
+        dxs = [None] * Z
+        if any(ctx.needs_input_grad[:Z]):
+            wt = _weight_t_group(ws)
+            if wt is None:                                               # (a backward pass outside train_shadows())
+                wt = torch.stack([w.detach().t().to(torch.bfloat16) for w in ws]).contiguous()
+            dx = gemm_bf16(db, wt)                                       # (Z, M, N) x (Z, K, N)^T -> (Z, M, K)
+            dxs = [dx[i].view(ctx.x_shape) for i in range(Z)]
+        dws = [None] * Z
+        if any(ctx.needs_input_grad[Z:]):
+            od = ws[0].dtype if ws[0].dtype in (torch.float32, torch.bfloat16) else torch.float32
+            dw = gemm_tn(db, xb, od)                                     # (Z, N, K)
+            dws = [dw[i] for i in range(Z)]
+        return (*dxs, *dws)
+
+
+def linear_group_train_eligible(xs, ws) -> bool:
+    """Inside train_shadows(), own training GEMMs, bf16 inputs of one shape, equally shaped bias-free weights the tiles take."""
+    if not (_shadows_on and train_gemms_own() and os.environ.get("PAFC_TRAIN_LINEAR_GROUP", "1") != "0"):
+        return False
+    w0, x0 = ws[0], xs[0]
+    if not all(isinstance(w, torch.nn.Parameter) and w.requires_grad and w.dim() == 2 and w.shape == w0.shape and w.dtype == w0.dtype
+               and w.is_contiguous() for w in ws):
+        return False
+    N, K = w0.shape
+    return (K % 64 == 0 and N % 64 == 0 and w0.dtype in (torch.float32, torch.bfloat16)
+            and all(x.is_cuda and x.dtype == torch.bfloat16 and x.shape == x0.shape and x.shape[-1] == K and x.is_contiguous() for x in xs)
+            and x0.numel() // K >= 256 and torch.is_grad_enabled())
+
+
+def linear_group_train(xs, ws):
+    """[F.linear(x_i, w_i)] for equally shaped (x_i, w_i): see _LinearGroupTrainBf16."""
+    return _LinearGroupTrainBf16.apply(*xs, *ws)
 
 
 class _CtcHeadLoss(torch.autograd.Function):

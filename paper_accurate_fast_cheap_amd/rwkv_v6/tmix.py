@@ -83,9 +83,11 @@ class RWKV_Tmix_x060c(nn.Module):
                 else:
                     m = torch.bmm(t.view(B * T, 4, -1).transpose(0, 1), self.time_maa_rkvw_w2).view(4, B, T, C)
                     zr, zk, zv, zw = hip_ops.mix4_train(x, m, maa4, reverse)
-                r = lin(zr, self.receptance.weight, None)
-                k = lin(zk, self.key.weight, None)
-                v = lin(zv, self.value.weight, None)
+                ws = (self.receptance.weight, self.key.weight, self.value.weight)
+                if hip_ops.linear_group_train_eligible((zr, zk, zv), ws):
+                    r, k, v = hip_ops.linear_group_train((zr, zk, zv), ws)       # one batched launch each way
+                else:
+                    r, k, v = (lin(z_, w_, None) for z_, w_ in zip((zr, zk, zv), ws))
                 w = self.time_decay + mm(torch.tanh(mm(zw, self.time_decay_w1)), self.time_decay_w2)
                 return r.contiguous(), k.contiguous(), v.contiguous(), w.contiguous()
         # model.py:262,274: ZeroPad2d((0,0,1,-1)) = x_{t-1}, zero at t=0; reversed time: x_{t+1}, zero at T-1

@@ -111,7 +111,8 @@ def wkv6_backward(r, k, v, w, u, gy, *, reverse: bool = False, chunk_len: int = 
     code = _same(r, k, v, w, u, gy)
     if s_in is not None and (s_in.dtype != torch.float32 or s_in.shape != (B, H, HEAD_SIZE, HEAD_SIZE)):
         raise _lib.PafcError("s_in must be float32 (B, H, 64, 64)")
-    gr, gk, gv, gw = (torch.empty_like(r) for _ in range(4))
+    g4 = torch.empty((4,) + tuple(r.shape), dtype=r.dtype, device=r.device)     # one buffer: the r / k / v projections' backward reads
+    gr, gk, gv, gw = g4[0], g4[1], g4[2], g4[3]                                 # g_r, g_k, g_v as one batched operand (no stacking copy)
     gu = torch.empty(B, C, dtype=r.dtype, device=r.device)
     gs = torch.empty(B, H, HEAD_SIZE, HEAD_SIZE, dtype=torch.float32, device=r.device) if want_gs else None
     L = _lib.lib()

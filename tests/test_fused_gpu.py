@@ -862,6 +862,57 @@ def test_tmix_elementwise_backward_kernels(hip, dtype, reverse, B, T, C):
     assert float((a4g.grad.cpu().double() - a4r.grad).abs().max()) <= (2 ** -6 if lo else 1e-4) * max(1.0, float(a4r.grad.abs().max()))
 
 
+@pytest.mark.parametrize("wdtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,T,C", [(2, 150, 128), (4, 481, 512)])
+def test_grouped_linear_training_function(hip, wdtype, B, T, C):
+    """linear_group_train (round 6: the r / k / v projections of a time-mix block as ONE batched launch each way -- forward
+    against a grouped bf16 copy of the three weights, input gradients against grouped transposed copies, the three weight
+    gradients from one batched gemm_tn pair) against float64 autograd through three F.linear on the same bf16-rounded operands;
+    the inputs are slices of one tensor as the lerp kernel leaves them, the incoming gradients slices of one tensor as the WKV
+    backward leaves them (no stacking copy), and once more as separate tensors (stacked).  Stale copies: a second step after an
+    in-place weight update must see the new weights."""
+    import torch.nn.functional as F
+    from paper_accurate_fast_cheap_amd import hip_ops
+    z = synth.randn((4, B, T, C), 81, 1.0).to(torch.bfloat16).cuda()
+    ws = [torch.nn.Parameter((synth.randn((C, C), 82 + i, 1.0) / C ** 0.5).to(wdtype).cuda()) for i in range(3)]
+    g4 = synth.randn((4, B, T, C), 86, 1.0).to(torch.bfloat16).cuda()
+
+    def reference(ws_now):
+        zr = z[:3].double().detach().requires_grad_()
+        wr = [w.detach().to(torch.bfloat16).double().requires_grad_() for w in ws_now]
+        ys = [F.linear(zr[i], wr[i]) for i in range(3)]
+        sum((ys[i] * g4[i].double()).sum() for i in range(3)).backward()
+        return ys, zr.grad, [w.grad for w in wr]
+
+    def check(sep_grads):
+        for w in ws:
+            w.grad = None
+        zz = z.clone().requires_grad_()
+        xs = tuple(zz[i] for i in range(3))
+        with hip_ops.train_shadows():
+            assert hip_ops.linear_group_train_eligible(xs, ws)
+            ys = hip_ops.linear_group_train(xs, ws)
+        gs = [g4[i].clone() for i in range(3)] if sep_grads else [g4[i] for i in range(3)]
+        torch.autograd.backward(ys, gs)
+        ry, rdz, rdw = reference(ws)
+        for i in range(3):
+            assert ys[i].shape == (B, T, C) and ys[i].dtype == torch.bfloat16
+            torch.testing.assert_close(ys[i].detach().double(), ry[i].detach(), rtol=2 ** -7, atol=2e-2)
+            torch.testing.assert_close(zz.grad[i].double(), rdz[i], rtol=2 ** -7, atol=2e-2)
+            assert ws[i].grad.dtype == wdtype and ws[i].grad.shape == (C, C)
+            tol = 2 ** -7 if wdtype == torch.bfloat16 else 2e-5 * max(1.0, (B * T / 1000) ** 0.5)
+            assert float((ws[i].grad.double() - rdw[i]).abs().max()) <= tol * float(rdw[i].abs().max())
+        assert float(zz.grad[3].abs().max()) == 0.0
+
+    check(False)
+    check(True)
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(-0.5)                  # an optimizer step: the kept copies are stale until train_shadows() is entered again
+    hip_ops.bump_param_epoch()
+    check(False)
+
+
 @pytest.mark.parametrize("xdtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("reverse", [False, True])
 @pytest.mark.parametrize("B,T,C", [(2, 150, 128), (3, 333, 512)])
