@@ -522,17 +522,45 @@ __global__ __launch_bounds__(256) void gemm_ksplit_reduce_kernel(long M, int N, 
     }
 }
 
-// K-split factor of a few-rows product: the 64 x 64 tiles cover less than half of the CUs AND K is long (a split-operand w_2: 96
-// K-steps, 42 us as one chain at 499 rows) -> S blocks per tile walk K / S each, a second launch adds the partials (deterministic)
-int ksplit_factor(long M, int N, int Kw) {
+// Tile and K split of a product on the small tiles (pafc_gemm_bf16_f32out).  Tile: the largest that still gives two per CU.  K
+// split (S blocks per tile walk K / S each, a second launch adds the partials in order: deterministic) where K is long (>= 48
+// K-steps: a split-operand w_2 has 96, the subsampling Linear 456):
+//   * a few hundred rows -- the 64 x 64 tiles cover less than half of the CUs: S = CUs / tiles (<= 4), 64 x 64 tiles, deep ring
+//     (w_2 at 499 rows: 42 us as one chain -> 18 us);
+//   * ~1 000 - 4 000 rows -- every CU has its 64 x 64 tiles, and the loop runs at the L2 -> LDS ceiling on them (774 MB per
+//     launch at 3 992 rows x 512 columns): 128 x 128 tiles move half the bytes per flop, four K shares per tile keep the chip
+//     full (w_2: 43.7 -> 30.6 us at 1 996 rows, 47.1 -> 41.0 at 3 992; products of 8 K-steps lose with any split:
+//     profiles/r06z_split_small_tile_variants.txt).
+struct F32outPlan { int bm, bn, S; };
+F32outPlan f32out_plan(long M, int N, int Kw, bool may_split = true) {
     const long cus = device_cus();
-    const long nblk = ((M + 63) / 64) * ((N + 63) / 64);
+    auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    F32outPlan pl{128, 128, 1};
+    if (tiles(128, 128) < 2 * cus) {
+        if (tiles(128, 64) >= 2 * cus) pl.bn = 64;
+        else { pl.bm = 64; pl.bn = 64; }
+    }
     const int iters = Kw / GBK;
-    if (iters < 48 || nblk * 2 > cus) return 1;
-    long s = cus / nblk;
-    if (s > 4) s = 4;
-    if (s > iters / 12) s = iters / 12;
-    return s < 2 ? 1 : (int)s;
+    if (iters >= 48 && may_split) {
+        const long nblk = tiles(64, 64);
+        if (nblk * 2 <= cus) {
+            long s = cus / nblk;
+            if (s > 4) s = 4;
+            if (s > iters / 12) s = iters / 12;
+            if (s >= 2) { pl.bm = 64; pl.bn = 64; pl.S = (int)s; }
+        } else if (tiles(128, 128) * 4 <= 2 * cus) {
+            pl.bm = 128; pl.bn = 128; pl.S = 4;
+        }
+    }
+    if (const char *e = getenv("PAFC_F32OUT_TILE")) {        // A/B runs: "128x128", "128x64", "64x64"
+        int fm = 0, fn = 0;
+        if (sscanf(e, "%dx%d", &fm, &fn) == 2 && ((fm == 128 && (fn == 128 || fn == 64)) || (fm == 64 && fn == 64))) { pl.bm = fm; pl.bn = fn; }
+    }
+    if (const char *e = getenv("PAFC_F32OUT_KSPLIT")) {      // A/B runs: force the factor (1-8)
+        const int v = atoi(e);
+        if (v >= 1 && v <= 8 && iters >= v && may_split) pl.S = v;
+    }
+    return pl;
 }
 
 }  // namespace
@@ -540,7 +568,7 @@ int ksplit_factor(long M, int N, int Kw) {
 
 extern "C" size_t pafc_gemm_bf16_f32out_workspace_bytes(long M, int N, int K, int a_split) {
     if (M <= 0 || N <= 0 || K <= 0 || N % 8 || K % pafc::GBK) return 0;
-    const int S = pafc::ksplit_factor(M, N, a_split ? 3 * K : K);
+    const int S = pafc::f32out_plan(M, N, a_split ? 3 * K : K).S;
     return S > 1 ? (size_t)S * M * N * sizeof(float) : 0;
 }
 
@@ -585,19 +613,16 @@ extern "C" int pafc_gemm_bf16_f32out_pb(long M, int N, int K, const void *A, lon
     p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = ldr; p.lo_off = lo_off;
     p.alpha = alpha; p.act = act; p.ksplit = 1;
     const long cus = pafc::device_cus();
-    auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-    int bm = 128, bn = 128;
-    if (tiles(128, 128) < 2 * cus) {
-        if (tiles(128, 64) >= 2 * cus) bn = 64;
-        else { bm = 64; bn = 64; }
-    }
+    pafc::F32outPlan pl = pafc::f32out_plan(M, N, Kw);
+    if (pl.S > 1 && !(workspace && workspace_bytes >= (size_t)pl.S * M * N * sizeof(float) && N % 4 == 0))
+        pl = pafc::f32out_plan(M, N, Kw, false);         // no workspace from the caller: the tile of the unsplit product
+    const int bm = pl.bm, bn = pl.bn, S = pl.S;
     p.mtiles = (int)((M + bm - 1) / bm);
     p.ntiles = (N + bn - 1) / bn;
     const long nblk = (long)p.mtiles * p.ntiles;
     if (nblk > 0x7fffffffL) return PAFC_ERR_BAD_DIMS;
     // K split over blocks when the caller brought the workspace for it (pafc_gemm_bf16_f32out_workspace_bytes > 0)
-    const int S = pafc::ksplit_factor(M, N, Kw);
-    const bool split_k = S > 1 && bm == 64 && workspace && workspace_bytes >= (size_t)S * M * N * sizeof(float) && N % 4 == 0;
+    const bool split_k = S > 1;
     const int out_kind_final = out_kind;
     if (split_k) {          // pass 1: raw partials (alpha 1, no bias / activation / residual) into the workspace
         p.ksplit = S;
