@@ -717,6 +717,28 @@ def test_gemm_tn_weight_gradient(hip, R, M, N, out_dtype):
     assert float((db.cpu().double() - rb).abs().max()) <= btol
 
 
+@pytest.mark.parametrize("R,M,N,Z", [(300, 128, 128, 3), (1924, 512, 512, 3), (777, 136, 72, 2), (15392, 512, 512, 3)])
+def test_gemm_tn_batched(hip, R, M, N, Z):
+    """pafc_gemm_tn_bf16_batched (round 6): Z products of one shape in one launch pair -- strided batch entries (slices of wider
+    buffers), the bias gradients of every entry from the same pass, bit-identical to Z single calls (same splits per entry only when
+    the plan agrees, so: against float64, and repeatable)."""
+    from paper_accurate_fast_cheap_amd.hip_ops import gemm_tn
+    dyw = synth.randn((Z + 1, R, M + 8), 21, 1.0).to(torch.bfloat16).cuda()
+    xw = synth.randn((Z, R, N), 22, 1.0).to(torch.bfloat16).cuda()
+    dy, x = dyw[:Z, :, :M], xw
+    dw, db = gemm_tn(dy, x, torch.float32, want_bias=True)
+    assert dw.shape == (Z, M, N) and db.shape == (Z, M)
+    for z in range(Z):
+        ref = dy[z].double().t() @ x[z].double()
+        assert float((dw[z].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) * max(1.0, (R / 1000) ** 0.5)
+        rb = dy[z].double().sum(0)
+        assert float((db[z].double() - rb).abs().max()) <= 2e-5 * max(1.0, float(rb.abs().max()))
+    again = gemm_tn(dy, x, torch.float32)
+    assert torch.equal(again, dw)
+    lo = gemm_tn(dy, x, torch.bfloat16)
+    assert lo.dtype == torch.bfloat16 and float((lo.double() - dw.double()).abs().max()) <= 2 ** -7 * float(dw.abs().max())
+
+
 def test_gemm_tn_strided_operands_and_determinism(hip):
     """Column slices of wider activations (row stride > width) and bit-identical repeats (fixed summation order)."""
     from paper_accurate_fast_cheap_amd.hip_ops import gemm_tn

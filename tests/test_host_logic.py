@@ -341,3 +341,54 @@ def test_multi_stream_safe_only_for_all_own_kernel_passes():
     class M:
         encoder = enc
     assert not longform._multi_stream_safe(M()) and not longform._multi_stream_safe(object())
+
+
+def test_grouped_weights_keep_names_values_checkpoints_and_optimizer_state(tmp_path):
+    """hip_ops._weight_group (round 6: the r / k / v weights of a time-mix block as ONE batched operand): bf16 parameters are moved
+    into one buffer (`p.data = group[i]`) the first time they are asked for together inside train_shadows().  The Parameter
+    objects, their values and their state_dict keys stay; an in-place update (an optimizer step, load_state_dict) is seen through
+    the group; a checkpoint round trip and a `.to()` that breaks the layout are mended on the next call; outside train_shadows()
+    there is no group.  fp32 parameters get a grouped bf16 COPY that is refreshed when the context is entered."""
+    from paper_accurate_fast_cheap_amd import hip_ops
+    torch.manual_seed(0)
+    m = torch.nn.ModuleDict({n: torch.nn.Linear(64, 64, bias=False) for n in ("receptance", "key", "value")}).to(torch.bfloat16)
+    ws = [m[n].weight for n in ("receptance", "key", "value")]
+    before = [w.detach().clone() for w in ws]
+    ids = [id(w) for w in ws]
+    assert hip_ops._weight_group(ws) is None                                  # no context: nothing vouches for a grouped view
+    with hip_ops.train_shadows():
+        g = hip_ops._weight_group(ws)
+        assert g.shape == (3, 64, 64) and g.is_contiguous()
+        assert [id(w) for w in ws] == ids and all(isinstance(w, torch.nn.Parameter) for w in ws)
+        assert all(w.data_ptr() == g[i].data_ptr() and torch.equal(w.detach(), before[i]) for i, w in enumerate(ws))
+        assert hip_ops._weight_group(ws).data_ptr() == g.data_ptr()           # found again, nothing re-made
+        opt = torch.optim.SGD(m.parameters(), lr=0.5)
+        for w in ws:
+            w.grad = torch.ones_like(w)
+        opt.step()                                                            # in place: the group sees it
+        assert all(torch.equal(hip_ops._weight_group(ws)[i], w.detach()) and not torch.equal(w.detach(), before[i]) for i, w in enumerate(ws))
+    assert sorted(m.state_dict()) == ["key.weight", "receptance.weight", "value.weight"]
+    torch.save(m.state_dict(), tmp_path / "sd.pt")
+    sd = torch.load(tmp_path / "sd.pt")
+    m2 = torch.nn.ModuleDict({n: torch.nn.Linear(64, 64, bias=False) for n in ("receptance", "key", "value")}).to(torch.bfloat16)
+    m2.load_state_dict(sd)
+    assert all(torch.equal(m2[n].weight, m[n].weight) for n in ("receptance", "key", "value"))
+    m.load_state_dict({k: torch.zeros_like(v) for k, v in sd.items()})        # copies in place: still one buffer
+    with hip_ops.train_shadows():
+        g = hip_ops._weight_group(ws)
+        assert float(g.abs().max()) == 0.0 and all(w.data_ptr() == g[i].data_ptr() for i, w in enumerate(ws))
+    m.to(torch.float32).to(torch.bfloat16)                                    # new storage per parameter: the layout is gone ...
+    ws = [m[n].weight for n in ("receptance", "key", "value")]
+    with hip_ops.train_shadows():
+        g = hip_ops._weight_group(ws)                                         # ... and mended here
+        assert all(w.data_ptr() == g[i].data_ptr() for i, w in enumerate(ws))
+    # fp32 parameters: a grouped bf16 copy, refreshed on entry
+    f = [torch.nn.Parameter(torch.randn(64, 64)) for _ in range(3)]
+    with hip_ops.train_shadows():
+        g = hip_ops._weight_group(f)
+        assert g.dtype == torch.bfloat16 and all(torch.equal(g[i], w.detach().to(torch.bfloat16)) and w.data_ptr() != g[i].data_ptr() for i, w in enumerate(f))
+    with torch.no_grad():
+        f[1].mul_(2.0)
+    with hip_ops.train_shadows():
+        g2 = hip_ops._weight_group(f)
+        assert g2.data_ptr() == g.data_ptr() and torch.equal(g2[1], f[1].detach().to(torch.bfloat16))
