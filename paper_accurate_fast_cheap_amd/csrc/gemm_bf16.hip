@@ -529,8 +529,9 @@ __global__ __launch_bounds__(256) void gemm_ksplit_reduce_kernel(long M, int N, 
 //     (w_2 at 499 rows: 42 us as one chain -> 18 us);
 //   * ~1 000 - 4 000 rows -- every CU has its 64 x 64 tiles, and the loop runs at the L2 -> LDS ceiling on them (774 MB per
 //     launch at 3 992 rows x 512 columns): 128 x 128 tiles move half the bytes per flop, four K shares per tile keep the chip
-//     full (w_2: 43.7 -> 30.6 us at 1 996 rows, 47.1 -> 41.0 at 3 992; products of 8 K-steps lose with any split:
-//     profiles/r06z_split_small_tile_variants.txt).
+//     full -- min(4, two blocks per CU) of them (w_2: 43.7 -> 30.6 us at 1 996 rows, 47.1 -> 41.0 at 3 992, and against the
+//     256-wide kernel 76.9 -> 49.3 at 5 000 rows (3 shares), 82.5 -> 66.0 at 7 984 (2); products of 8 K-steps lose with any
+//     split: profiles/r06z_split_small_tile_variants.txt).
 struct F32outPlan { int bm, bn, S; };
 F32outPlan f32out_plan(long M, int N, int Kw, bool may_split = true) {
     const long cus = device_cus();
@@ -548,8 +549,10 @@ F32outPlan f32out_plan(long M, int N, int Kw, bool may_split = true) {
             if (s > 4) s = 4;
             if (s > iters / 12) s = iters / 12;
             if (s >= 2) { pl.bm = 64; pl.bn = 64; pl.S = (int)s; }
-        } else if (tiles(128, 128) * 4 <= 2 * cus) {
-            pl.bm = 128; pl.bn = 128; pl.S = 4;
+        } else {
+            long s = 2 * cus / tiles(128, 128);          // K shares that keep <= two 128 x 128 blocks per CU
+            if (s > 4) s = 4;
+            if (s >= 2) { pl.bm = 128; pl.bn = 128; pl.S = (int)s; }
         }
     }
     if (const char *e = getenv("PAFC_F32OUT_TILE")) {        // A/B runs: "128x128", "128x64", "64x64"

@@ -50,7 +50,7 @@ from ._lib import c_int, c_void_p
 #                                   the 30-minute sequence measured the same or 0.2 ms slower with it (the convolution kernel is
 #                                   latency-bound at two waves per SIMD and the epilogue's two block reductions add to that), so
 #                                   long inputs keep the two kernels
-#   split_small_max_rows      4096  split-operand (and bf16 -> fp32) products of at most this many rows AND at most 2^22 outputs
+#   split_small_max_rows      8192  split-operand (and bf16 -> fp32) products of at most this many rows AND at most 2^22 outputs
 #                                   (w_1, N = 2048: 2 048 rows) run on the small tiles of csrc/gemm_bf16.hip
 #                                   (pafc_gemm_bf16_f32out: 64 x 64 / 128 x 64 tiles, three-stage ring) instead of the 256-wide
 #                                   phase-pipelined kernel, whose tiles cost ~25 us (K = 512) / ~72 us (K = 2048) each however few
@@ -66,7 +66,7 @@ from ._lib import c_int, c_void_p
 # PAFC_PH_MIN_FILL=<percent> (round 3's rule: 256-wide tiles must cover that share of the CUs) and PAFC_GEMM_TILE (force a tile
 # of the small kernel) are A/B switches of the kernels themselves.
 DISPATCH = dict(skinny_max_rows=640, own_gemm_min_rows=1, lds_resident_min_rows=8192, split_gemm_min_rows=1024,
-                ln_fold_min_rows=24576, dwconv_ln_silu_max_rows=24575, split_small_max_rows=4096, split_layers_min_rows=256)
+                ln_fold_min_rows=24576, dwconv_ln_silu_max_rows=24575, split_small_max_rows=8192, split_layers_min_rows=256)
 
 
 def _load_dispatch():
@@ -1143,7 +1143,7 @@ def gemm_ph_ex(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         L._pafc_gemmex_bound = True
     from .profiling import op_timer
     pb_ok = not a_plane_block or (a_split and a_plane_block >= 64 and a_plane_block & (a_plane_block - 1) == 0 and K % a_plane_block == 0)
-    if (M <= _SPLIT_SMALL_MAX_ROWS and M * N <= (1 << 22) and ok != 0 and act in ("none", "silu", "tanh", "relu")
+    if (M <= _SPLIT_SMALL_MAX_ROWS and M * N <= _SPLIT_SMALL_MAX_OUT and ok != 0 and act in ("none", "silu", "tanh", "relu")
             and pb_ok and not tile_m and K % 64 == 0):
         # few rows: the small tiles of csrc/gemm_bf16.hip (same operand forms, same epilogue order)
         nws = L.pafc_gemm_bf16_f32out_workspace_bytes(M, N, K, int(a_split))     # > 0: few rows x long K, K split over blocks
@@ -1166,6 +1166,7 @@ def gemm_ph_ex(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
 
 
 _SPLIT_SMALL_MAX_ROWS = DISPATCH["split_small_max_rows"]
+_SPLIT_SMALL_MAX_OUT = 1 << 22          # ... and at most this many outputs (rows x columns)
 
 
 def wkv6_single_chunk(B: int, T: int, C: int, H: int) -> bool:

@@ -28,6 +28,7 @@ def timed(f, n=40):
 
 rows = [int(v) for v in sys.argv[1:]] or [1996, 3992]
 hip_ops._SPLIT_SMALL_MAX_ROWS = 1 << 30
+hip_ops._SPLIT_SMALL_MAX_OUT = 1 << 40
 for name, K, N, act, kind, res in FORMS:
     w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
     b = torch.randn(N, device=dev, generator=g) * 0.1
@@ -44,19 +45,17 @@ for name, K, N, act, kind, res in FORMS:
                     os.environ.pop(k_, None)
                 else:
                     os.environ[k_] = v_
-            if M * N > (1 << 22) and label == "auto":
-                out.append("auto (256-wide) %.1f" % timed(lambda: hip_ops.gemm_ph_ex(ap, w3, b, act, alpha=0.5 if res else 1.0, residual=r, a_split=True, out_kind=kind)))
+            if label == "auto":          # what the package does today (the 256-wide kernel beyond DISPATCH's small-tile bounds)
+                hip_ops._SPLIT_SMALL_MAX_ROWS, hip_ops._SPLIT_SMALL_MAX_OUT = hip_ops.DISPATCH["split_small_max_rows"], 1 << 22
+                out.append("auto %.1f" % timed(lambda: hip_ops.gemm_ph_ex(ap, w3, b, act, alpha=0.5 if res else 1.0, residual=r, a_split=True, out_kind=kind)))
+                hip_ops._SPLIT_SMALL_MAX_ROWS, hip_ops._SPLIT_SMALL_MAX_OUT = 1 << 30, 1 << 40
                 continue
-            old = hip_ops.gemm_ph_ex.__globals__
-            call = lambda: hip_ops.gemm_ph_ex(ap, w3, b, act, alpha=1.0, residual=None, a_split=True, out_kind=kind)
-            if M * N > (1 << 22):      # force the small-tile path for the forms auto sends to the 256-wide kernel
-                import paper_accurate_fast_cheap_amd.hip_ops as H
-                lim = 1 << 40
-                call = lambda: H.gemm_ph_ex(ap, w3, b, act, a_split=True, out_kind=kind)
+            call = lambda: hip_ops.gemm_ph_ex(ap, w3, b, act, alpha=0.5 if res else 1.0, residual=r, a_split=True, out_kind=kind)
             t = timed(call)
             got = call()
             if kind == "f32" and act == "none":
-                err = float((got.double() - ref).abs().max())
+                want = (0.5 * (a.double() @ w.double().t()) + b.double() + r.double()) if res else ref
+                err = float((got.double() - want).abs().max())
                 assert err < 1e-3, (label, err)
             out.append("%s %.1f" % (label, t))
         for k_ in ("PAFC_F32OUT_TILE", "PAFC_F32OUT_KSPLIT"):
