@@ -55,7 +55,9 @@ from ._lib import c_int, c_void_p
 #                                   (pafc_gemm_bf16_f32out: 64 x 64 / 128 x 64 tiles, three-stage ring) instead of the 256-wide
 #                                   phase-pipelined kernel, whose tiles cost ~25 us (K = 512) / ~72 us (K = 2048) each however few
 #                                   there are: at 3 992 rows 17 / 21 / 53 us against 27 / 28 / 72 for pointwise_conv2 / pointwise_conv1
-#                                   / w_2, w_1 22.7 against 30.5 at 1 996 rows and 37.5 against 30.4 at 2 500
+#                                   / w_2, w_1 22.7 against 30.5 at 1 996 rows and 37.5 against 30.4 at 2 500.  Round 6, late: 8 192
+#                                   (N = 512 products; long-K ones on 128 x 128 tiles with 2-4 K shares per tile: w_2 76.9 -> 49.3 us at
+#                                   5 000 rows, 82.5 -> 66.0 at 7 984: profiles/r06z_split_small_tile_variants.txt)
 #                                   (profiles/r06n_split_small_rows.txt)
 #   split_layers_min_rows      256  the LAYERS of a model with the bf16 slot take the split-operand schedule
 #                                   (fused.layer_forward_split) from this many rows on -- since round 6 also below
