@@ -1,5 +1,7 @@
+"""Where a whole-file window of decode_windows (chunk >= the file: the batcher pads it to the chunk size) spends its time against the
+one-sequence pass: batcher, encoder on the padded window, CTC greedy kernel, token fetch.  python tools/micro/decode_tail_cost.py"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from paper_accurate_fast_cheap_amd import _lib

@@ -1,5 +1,7 @@
+"""Host synchronisations inside one training step (torch.cuda.set_sync_debug_mode("warn") with the package frames of each warning):
+round 6 found `float(coef)` of clip_grad_norm_ this way.  python tools/micro/train_sync_debug.py"""
 import os, sys, warnings, traceback
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench as B
 from paper_accurate_fast_cheap_amd import _lib
@@ -23,7 +25,7 @@ def showwarning(message, category, filename, lineno, file=None, line=None):
     print("SYNC WARNING:", message)
     for fr in traceback.extract_stack()[:-1]:
         if "paper_accurate_fast_cheap_amd" in fr.filename or "torch/optim" in fr.filename or "torch/nn/utils" in fr.filename:
-            print("   ", fr.filename.split("/root/repo/")[-1], fr.lineno, fr.name)
+            print("   ", os.path.relpath(fr.filename), fr.lineno, fr.name)
 warnings.showwarning = showwarning
 warnings.simplefilter("always")
 train_step(model, batch, opt, device, amp_dtype=torch.bfloat16, step_index=3)
