@@ -652,27 +652,40 @@ class _LinearTrainBf16(torch.autograd.Function):
 
 
 class _MatmulTrainBf16(torch.autograd.Function):
-    """y = x @ W for a parameter stored (K, N) -- the LoRA matrices of the time-mix (src/model.py:277,289) -- on the hand-written
-    kernels: forward against the bf16 copy of W^T (N, K) that train_shadows() keeps, input gradient dx = dy W^T against W as
-    it lies, weight gradient x^T dy through gemm_tn."""
+    """y = act(x @ W + bias) for a parameter stored (K, N) -- the LoRA matrices of the time-mix (src/model.py:277,289) -- on the
+    hand-written kernels: forward against the bf16 copy of W^T (N, K) that train_shadows() keeps, input gradient dx = dy W^T against
+    W as it lies, weight gradient x^T dy through gemm_tn.  act "tanh" and a bias (the decay's `time_decay + ...`, model.py:289) ride in
+    the forward GEMM's epilogue (round 6: one launch instead of three); backward: tanh' from the saved output, the bias gradient a
+    column sum."""
 
     @staticmethod
-    def forward(ctx, x, weight):
-        ctx.save_for_backward(x, weight)
+    def forward(ctx, x, weight, act="none", bias=None):
         K, N = weight.shape
         x2 = x.reshape(-1, K)
+        ctx.act, ctx.has_bias = act, bias is not None
         if train_gemms_own() and K % 64 == 0 and N % 8 == 0 and _own_gemm_rows(x2):
             if _shadows_on and isinstance(_param_of(weight), torch.nn.Parameter):
                 wt = _bf16_shadow_t(weight)                 # kept beside the parameter, refreshed when train_shadows() was entered
             else:
                 wt = weight.detach().t().contiguous()       # outside the step's context nothing vouches for a kept copy
-            return gemm_bf16(x2, wt).view(x.shape[:-1] + (N,))                           # (M, K) x (W^T)(N, K)^T
-        return x @ weight
+            bb = None if bias is None else bias.detach().reshape(-1).to(torch.bfloat16)
+            y = gemm_bf16(x2, wt, bb, act).view(x.shape[:-1] + (N,))                     # (M, K) x (W^T)(N, K)^T
+        else:
+            y = x @ weight
+            if bias is not None:
+                y = y + bias.reshape(-1).to(y.dtype)
+            if act == "tanh":
+                y = torch.tanh(y)
+        ctx.save_for_backward(x, weight, y if act == "tanh" else None)
+        ctx.bias_shape, ctx.bias_dtype = (None, None) if bias is None else (bias.shape, bias.dtype)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, y = ctx.saved_tensors
         K, N = weight.shape
+        if ctx.act == "tanh":
+            dy = torch.ops.aten.tanh_backward(dy.contiguous(), y)
         dy2 = dy.reshape(-1, N)
         if dy2.stride(1) != 1 or dy2.stride(0) % 8 or dy2.data_ptr() % 16:
             dy2 = dy2.contiguous()
@@ -686,16 +699,24 @@ class _MatmulTrainBf16(torch.autograd.Function):
             else:
                 dx = (dy2 @ weight.t()).view(x.shape)
         dw = gemm_tn(x2, dy2, torch.bfloat16) if ctx.needs_input_grad[1] else None
-        return dx, dw
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = dy2.sum(0, dtype=torch.float32).to(ctx.bias_dtype).view(ctx.bias_shape)
+        return dx, dw, None, db
 
 
-def matmul_param(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
-    """x @ weight for a 2-D bf16 parameter; in the GPU training step the weight gradient takes the hand-written kernel."""
+def matmul_param(x: torch.Tensor, weight: torch.Tensor, act: str = "none", bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x @ weight + bias) for a 2-D bf16 parameter (act "none" | "tanh"); in the GPU training step on the hand-written kernels
+    with the activation and the bias in the GEMM's epilogue."""
     if (x.is_cuda and torch.is_grad_enabled() and weight.requires_grad and weight.dim() == 2 and train_kernels_enabled()
             and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.shape[0] % 8 == 0
-            and weight.shape[1] % 8 == 0 and x.numel() // x.shape[-1] >= 256):
-        return _MatmulTrainBf16.apply(x, weight)
-    return x @ weight
+            and weight.shape[1] % 8 == 0 and x.numel() // x.shape[-1] >= 256
+            and (bias is None or (bias.dtype == torch.bfloat16 and bias.numel() == weight.shape[1]))):
+        return _MatmulTrainBf16.apply(x, weight, act, bias)
+    y = x @ weight
+    if bias is not None:
+        y = bias + y
+    return torch.tanh(y) if act == "tanh" else y
 
 
 def linear_train_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:

@@ -75,7 +75,8 @@ class RWKV_Tmix_x060c(nn.Module):
             if hip_ops.tmix_train_eligible(x) and self.time_maa_x.dtype == x.dtype:
                 # GPU training step: the two element-wise groups as one kernel each, forward and backward
                 xxx = hip_ops.shift_mix_train(x, self.time_maa_x, reverse)
-                t = torch.tanh(mm(xxx, self.time_maa_rkvw_w1))
+                fold = mm is hip_ops.matmul_param       # tanh (and the decay's bias) in the GEMM epilogue: one launch instead of two (three)
+                t = mm(xxx, self.time_maa_rkvw_w1, "tanh") if fold else torch.tanh(mm(xxx, self.time_maa_rkvw_w1))
                 maa4 = torch.stack([self.time_maa_r.reshape(C), self.time_maa_k.reshape(C), self.time_maa_v.reshape(C),
                                     self.time_maa_w.reshape(C)])
                 if hip_ops.lora_mix4_train_eligible(x, t, self.time_maa_rkvw_w2):
@@ -88,7 +89,10 @@ class RWKV_Tmix_x060c(nn.Module):
                     r, k, v = hip_ops.linear_group_train((zr, zk, zv), ws)       # one batched launch each way
                 else:
                     r, k, v = (lin(z_, w_, None) for z_, w_ in zip((zr, zk, zv), ws))
-                w = self.time_decay + mm(torch.tanh(mm(zw, self.time_decay_w1)), self.time_decay_w2)
+                if fold:
+                    w = mm(mm(zw, self.time_decay_w1, "tanh"), self.time_decay_w2, "none", self.time_decay)
+                else:
+                    w = self.time_decay + mm(torch.tanh(mm(zw, self.time_decay_w1)), self.time_decay_w2)
                 return r.contiguous(), k.contiguous(), v.contiguous(), w.contiguous()
         # model.py:262,274: ZeroPad2d((0,0,1,-1)) = x_{t-1}, zero at t=0; reversed time: x_{t+1}, zero at T-1
         prev = F.pad(x, (0, 0, -1, 1)) if reverse else F.pad(x, (0, 0, 1, -1))
