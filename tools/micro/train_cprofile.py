@@ -21,10 +21,12 @@ for i in range(3):
     train_step(model, batch, opt, device, amp_dtype=torch.bfloat16, step_index=i)
 torch.cuda.synchronize()
 pr = cProfile.Profile()
-pr.enable()
-for i in range(5):
-    train_step(model, batch, opt, device, amp_dtype=torch.bfloat16, step_index=3 + i)
-pr.disable()
+# (backward on the calling thread, so that the profile sees the Python side of the custom Functions' backward too)
+with torch.autograd.set_multithreading_enabled(False):
+    pr.enable()
+    for i in range(5):
+        train_step(model, batch, opt, device, amp_dtype=torch.bfloat16, step_index=3 + i)
+    pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(int(sys.argv[1]) if len(sys.argv) > 1 else 45)
