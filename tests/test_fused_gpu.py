@@ -1141,12 +1141,15 @@ def test_layernorm_and_split_plane_outputs(hip):
     torch.testing.assert_close(_planes_value(sg), og, rtol=2 ** -15, atol=1e-7)
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 512, 256), (2500, 2048, 512), (301, 1024, 128), (499, 512, 2048), (999, 512, 2048)])
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 256), (2500, 2048, 512), (301, 1024, 128), (499, 512, 2048), (999, 512, 2048),
+                                   # round 6, late: long-K products on 128 x 128 tiles with 4 / 4 / 3 / 2 K shares per tile
+                                   (1996, 512, 2048), (3992, 512, 2048), (5000, 512, 2048), (7984, 512, 2048)])
 def test_gemm_split_operand_forms(hip, M, N, K):
     """pafc_gemm_ph_ex: fp32 activations and weights as bf16 planes (three bf16 products per fp32 product), fp32 / plane
     outputs, fp32 bias and residual, GLU -- against fp32 torch: the error is that of 16-bit significands, not of bf16.  Up to
-    4 096 rows the non-GLU forms run on the small tiles of csrc/gemm_bf16.hip (pafc_gemm_bf16_f32out); the last two shapes (a
-    single window's w_2: few rows against K = 2048) also take its K split over blocks with the reducing second launch."""
+    8 192 rows (and 2^22 outputs) the non-GLU forms run on the small tiles of csrc/gemm_bf16.hip (pafc_gemm_bf16_f32out); the
+    K = 2048 shapes also take its K split over blocks with the reducing second launch (64 x 64 tiles at few rows, 128 x 128 tiles
+    with 2-4 K shares from ~1 000 rows on)."""
     from paper_accurate_fast_cheap_amd.hip_ops import gemm_ph_ex, glu_interleave, split_planes
     a = synth.randn((M, K), 31).cuda()
     w = (synth.randn((N, K), 32) / K ** 0.5).cuda()
