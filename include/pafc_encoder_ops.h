@@ -114,6 +114,16 @@ int pafc_layernorm_bwd(int dtype_x, int dtype_dy, long rows, int C, const void *
                        float eps, void *dx, float *dgamma_dbeta, void *workspace, size_t workspace_bytes,
                        pafc_stream_t stream);
 
+/* LayerNorm + SiLU of the conv module in the training step (convolution.py:136-138, `activation(norm(x))` between the depthwise
+ * convolution and pointwise_conv2), one kernel each way: y = silu(LayerNorm(x)), arithmetic in fp32 against the norm's own
+ * parameters (dtype_g: fp32 under autocast, or bf16), x / y / dy / dx in dtype_x (bf16: the convolution's output; fp32 with fp32
+ * parameters).  Backward recomputes mean / rstd / z from x: dx, dgamma_dbeta float32 (2, C) as pafc_layernorm_bwd (same workspace). */
+int pafc_layernorm_silu_fwd(int dtype_x, int dtype_g, long rows, int C, const void *x, const void *gamma, const void *beta, float eps,
+                            void *y, pafc_stream_t stream);
+int pafc_layernorm_silu_bwd(int dtype_x, int dtype_g, long rows, int C, const void *x, const void *dy, const void *gamma,
+                            const void *beta, float eps, void *dx, float *dgamma_dbeta, void *workspace, size_t workspace_bytes,
+                            pafc_stream_t stream);
+
 /* Skinny bf16 GEMM for the streaming chunk step (csrc/gemm_skinny.hip): out = act(alpha * A W^T + bias [+ residual]) for FEW
  * rows -- the projections of a layer while it serves 64-frame chunks with state carry (the same nn.Linear / 1x1 Conv1d call
  * sites as pafc_gemm_bf16: positionwise_feed_forward.py:47-55, convolution.py:118-141, src/model.py:286-324,

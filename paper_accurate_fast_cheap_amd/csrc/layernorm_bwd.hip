@@ -149,6 +149,154 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_reduce_kernel(int n, int n
     }
 }
 
+// ---- LayerNorm + SiLU of the conv module in the training step (convolution.py:136-138: `activation(norm(x))` between the
+// depthwise convolution and pointwise_conv2).  Under bf16 autocast the framework runs this as cast (bf16 -> fp32), LayerNorm,
+// SiLU, cast (fp32 -> bf16 at the projection) forward and the same four again backward, all over (B, T, C); here one kernel each
+// way: x and y / dy and dx in the convolution's dtype (bf16), the arithmetic in fp32 against the norm's own (fp32 or bf16)
+// parameters EG, the SAME values as the chain (one rounding, at the end).
+//   z = xhat gamma + beta,  y = z sigmoid(z);   dz = dy sigmoid(z) (1 + z (1 - sigmoid(z))),  then LayerNorm's backward on dz.
+template <typename EX, typename EG>
+__global__ __launch_bounds__(256) void ln_silu_fwd_kernel(long rows, int C, const EX *__restrict__ x, const EG *__restrict__ gamma,
+                                                          const EG *__restrict__ beta, float eps, EX *__restrict__ y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_c = 1.f / (float)C;
+    float gm[LMAXIT][LVEC], bt[LMAXIT][LVEC];
+#pragma unroll
+    for (int it = 0; it < LMAXIT; ++it) {
+        const int c = (it * 64 + lane) * LVEC;
+#pragma unroll
+        for (int e = 0; e < LVEC; ++e) { gm[it][e] = 0.f; bt[it][e] = 0.f; }
+        if (c < C) { ld8<EG>(gamma + c, gm[it]); ld8<EG>(beta + c, bt[it]); }
+    }
+    const long r_end = min(rows, ((long)blockIdx.x + 1) * ROWS_PER_BLOCK);
+    for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < r_end; row += 4) {
+        float xv[LMAXIT][LVEC];
+        float sum = 0.f;
+#pragma unroll
+        for (int it = 0; it < LMAXIT; ++it) {
+            const int c = (it * 64 + lane) * LVEC;
+            if (c < C) {
+                ld8<EX>(x + (size_t)row * C + c, xv[it]);
+#pragma unroll
+                for (int e = 0; e < LVEC; ++e) sum += xv[it][e];
+            }
+        }
+        const float mean = wave_sum(sum) * inv_c;
+        float sq = 0.f;
+#pragma unroll
+        for (int it = 0; it < LMAXIT; ++it) {
+            const int c = (it * 64 + lane) * LVEC;
+            if (c < C) {
+#pragma unroll
+                for (int e = 0; e < LVEC; ++e) { const float d = xv[it][e] - mean; sq = fmaf(d, d, sq); }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) * inv_c + eps);
+#pragma unroll
+        for (int it = 0; it < LMAXIT; ++it) {
+            const int c = (it * 64 + lane) * LVEC;
+            if (c < C) {
+                float o[LVEC];
+#pragma unroll
+                for (int e = 0; e < LVEC; ++e) {
+                    const float z = fmaf((xv[it][e] - mean) * rstd, gm[it][e], bt[it][e]);
+                    o[e] = z / (1.f + __expf(-z));
+                }
+                st8<EX>(y + (size_t)row * C + c, o);
+            }
+        }
+    }
+}
+
+template <typename EX, typename EG>
+__global__ __launch_bounds__(256) void ln_silu_bwd_kernel(long rows, int C, const EX *__restrict__ x, const EX *__restrict__ dy,
+                                                          const EG *__restrict__ gamma, const EG *__restrict__ beta, float eps,
+                                                          EX *__restrict__ dx, float *__restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_c = 1.f / (float)C;
+    float gm[LMAXIT][LVEC], bt[LMAXIT][LVEC], ag[LMAXIT][LVEC], ab[LMAXIT][LVEC];
+#pragma unroll
+    for (int it = 0; it < LMAXIT; ++it) {
+        const int c = (it * 64 + lane) * LVEC;
+#pragma unroll
+        for (int e = 0; e < LVEC; ++e) { gm[it][e] = 0.f; bt[it][e] = 0.f; ag[it][e] = 0.f; ab[it][e] = 0.f; }
+        if (c < C) { ld8<EG>(gamma + c, gm[it]); ld8<EG>(beta + c, bt[it]); }
+    }
+    const long r_end = min(rows, ((long)blockIdx.x + 1) * ROWS_PER_BLOCK);
+    for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < r_end; row += 4) {
+        float xv[LMAXIT][LVEC], gv[LMAXIT][LVEC];
+        float sum = 0.f;
+#pragma unroll
+        for (int it = 0; it < LMAXIT; ++it) {
+            const int c = (it * 64 + lane) * LVEC;
+            if (c < C) {
+                ld8<EX>(x + (size_t)row * C + c, xv[it]);
+                ld8<EX>(dy + (size_t)row * C + c, gv[it]);
+#pragma unroll
+                for (int e = 0; e < LVEC; ++e) sum += xv[it][e];
+            }
+        }
+        const float mean = wave_sum(sum) * inv_c;
+        float sq = 0.f;
+#pragma unroll
+        for (int it = 0; it < LMAXIT; ++it) {
+            const int c = (it * 64 + lane) * LVEC;
+            if (c < C) {
+#pragma unroll
+                for (int e = 0; e < LVEC; ++e) { const float d = xv[it][e] - mean; sq = fmaf(d, d, sq); }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) * inv_c + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < LMAXIT; ++it) {
+            const int c = (it * 64 + lane) * LVEC;
+            if (c < C) {
+#pragma unroll
+                for (int e = 0; e < LVEC; ++e) {
+                    const float xh = (xv[it][e] - mean) * rstd;
+                    const float z = fmaf(xh, gm[it][e], bt[it][e]);
+                    const float sg = 1.f / (1.f + __expf(-z));
+                    const float d = gv[it][e] * (sg * fmaf(z, 1.f - sg, 1.f));     // dL/dz
+                    ag[it][e] = fmaf(d, xh, ag[it][e]);
+                    ab[it][e] += d;
+                    const float g = d * gm[it][e];
+                    s1 += g;
+                    s2 = fmaf(g, xh, s2);
+                    xv[it][e] = xh;
+                    gv[it][e] = g;
+                }
+            }
+        }
+        s1 = wave_sum(s1) * inv_c;
+        s2 = wave_sum(s2) * inv_c;
+#pragma unroll
+        for (int it = 0; it < LMAXIT; ++it) {
+            const int c = (it * 64 + lane) * LVEC;
+            if (c < C) {
+                float o[LVEC];
+#pragma unroll
+                for (int e = 0; e < LVEC; ++e) o[e] = rstd * (gv[it][e] - s1 - xv[it][e] * s2);
+                st8<EX>(dx + (size_t)row * C + c, o);
+            }
+        }
+    }
+    __shared__ float s_red[2][4][64 * LVEC * LMAXIT];
+#pragma unroll
+    for (int it = 0; it < LMAXIT; ++it)
+#pragma unroll
+        for (int e = 0; e < LVEC; ++e) {
+            s_red[0][wave][(it * 64 + lane) * LVEC + e] = ag[it][e];
+            s_red[1][wave][(it * 64 + lane) * LVEC + e] = ab[it][e];
+        }
+    __syncthreads();
+    float *po = part + (size_t)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int k = i / C, c = i - k * C;
+        po[i] = s_red[k][0][c] + s_red[k][1][c] + s_red[k][2][c] + s_red[k][3][c];
+    }
+}
+
 template <typename EX, typename ED>
 int launch_ln_bwd(long rows, int C, const void *x, const void *dy, const void *gamma, float eps, void *dx, float *dgb,
                   float *part, hipStream_t s) {
@@ -186,4 +334,47 @@ extern "C" int pafc_layernorm_bwd(int dtype_x, int dtype_dy, long rows, int C, c
     if (dtype_x == PAFC_BF16 && dtype_dy == PAFC_F32)
         return pafc::launch_ln_bwd<bf16_t, float>(rows, C, x, dy, gamma, eps, dx, dgamma_dbeta, part, s);
     return PAFC_ERR_DTYPE;
+}
+
+/* LayerNorm + SiLU of the conv module, training step: see the kernels.  dtype_x: x, y, dy, dx; dtype_g: gamma, beta. */
+extern "C" int pafc_layernorm_silu_fwd(int dtype_x, int dtype_g, long rows, int C, const void *x, const void *gamma, const void *beta,
+                                       float eps, void *y, pafc_stream_t stream) {
+    if (!x || !gamma || !beta || !y) return PAFC_ERR_NULL_POINTER;
+    if (rows <= 0 || C <= 0 || C % pafc::LVEC || C > 64 * pafc::LVEC * pafc::LMAXIT || rows > 0x7fffffffL * pafc::ROWS_PER_BLOCK)
+        return PAFC_ERR_BAD_DIMS;
+    const int nblk = (int)((rows + pafc::ROWS_PER_BLOCK - 1) / pafc::ROWS_PER_BLOCK);
+    hipStream_t s = (hipStream_t)stream;
+    using pafc::bf16_t;
+#define PAFC_LNS_F(EX, EG)                                                                                                 \
+    hipLaunchKernelGGL((pafc::ln_silu_fwd_kernel<EX, EG>), dim3(nblk), dim3(256), 0, s, rows, C, (const EX *)x, (const EG *)gamma, \
+                       (const EG *)beta, eps, (EX *)y)
+    if (dtype_x == PAFC_BF16 && dtype_g == PAFC_F32) PAFC_LNS_F(bf16_t, float);
+    else if (dtype_x == PAFC_BF16 && dtype_g == PAFC_BF16) PAFC_LNS_F(bf16_t, bf16_t);
+    else if (dtype_x == PAFC_F32 && dtype_g == PAFC_F32) PAFC_LNS_F(float, float);
+    else return PAFC_ERR_DTYPE;
+#undef PAFC_LNS_F
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
+extern "C" int pafc_layernorm_silu_bwd(int dtype_x, int dtype_g, long rows, int C, const void *x, const void *dy, const void *gamma,
+                                       const void *beta, float eps, void *dx, float *dgamma_dbeta, void *workspace,
+                                       size_t workspace_bytes, pafc_stream_t stream) {
+    if (!x || !dy || !gamma || !beta || !dx || !dgamma_dbeta || !workspace) return PAFC_ERR_NULL_POINTER;
+    if (rows <= 0 || C <= 0 || C % pafc::LVEC || C > 64 * pafc::LVEC * pafc::LMAXIT || rows > 0x7fffffffL * pafc::ROWS_PER_BLOCK)
+        return PAFC_ERR_BAD_DIMS;
+    if (workspace_bytes < pafc_layernorm_bwd_workspace_bytes(rows, C)) return PAFC_ERR_WORKSPACE;
+    const int nblk = (int)((rows + pafc::ROWS_PER_BLOCK - 1) / pafc::ROWS_PER_BLOCK);
+    hipStream_t s = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    using pafc::bf16_t;
+#define PAFC_LNS_B(EX, EG)                                                                                                 \
+    hipLaunchKernelGGL((pafc::ln_silu_bwd_kernel<EX, EG>), dim3(nblk), dim3(256), 0, s, rows, C, (const EX *)x, (const EX *)dy,    \
+                       (const EG *)gamma, (const EG *)beta, eps, (EX *)dx, part)
+    if (dtype_x == PAFC_BF16 && dtype_g == PAFC_F32) PAFC_LNS_B(bf16_t, float);
+    else if (dtype_x == PAFC_BF16 && dtype_g == PAFC_BF16) PAFC_LNS_B(bf16_t, bf16_t);
+    else if (dtype_x == PAFC_F32 && dtype_g == PAFC_F32) PAFC_LNS_B(float, float);
+    else return PAFC_ERR_DTYPE;
+#undef PAFC_LNS_B
+    hipLaunchKernelGGL(pafc::layernorm_bwd_reduce_kernel, dim3((2 * C + 15) / 16), dim3(1024), 0, s, 2 * C, nblk, part, dgamma_dbeta);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }

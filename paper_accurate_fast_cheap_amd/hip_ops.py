@@ -270,6 +270,70 @@ class _LayerNormTrain(torch.autograd.Function):
         return dx, dg.to(ctx.w_dtype), db.to(ctx.b_dtype), None, None
 
 
+class _LnSiluTrain(torch.autograd.Function):
+    """silu(LayerNorm(x)) of the conv module (convolution.py:136-138) for the GPU training step as one kernel each way
+    (pafc_layernorm_silu_fwd / _bwd): x -- the depthwise convolution's bf16 output -- in, bf16 out, fp32 arithmetic against the
+    norm's own parameters.  Under bf16 autocast the framework chain is cast, LayerNorm (fp32), SiLU, cast -- four passes over
+    (B, T, C) forward and four more backward for the same values."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        L = _lib.lib()
+        if not getattr(L, "_pafc_lns_bound", False):
+            from ctypes import c_float, c_long, c_size_t
+            _lib._sig(L.pafc_layernorm_silu_fwd, c_int, c_int, c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p)
+            _lib._sig(L.pafc_layernorm_silu_bwd, c_int, c_int, c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                      c_void_p, c_void_p, c_size_t, c_void_p)
+            L.pafc_layernorm_bwd_workspace_bytes.restype = c_size_t
+            L.pafc_layernorm_bwd_workspace_bytes.argtypes = [c_long, c_int]
+            L._pafc_lns_bound = True
+        C = x.shape[-1]
+        rows = x.numel() // C
+        g, b = weight.detach().contiguous(), bias.detach().contiguous()
+        y = torch.empty_like(x)
+        _lib.check(L.pafc_layernorm_silu_fwd(_lib.dtype_code(x.dtype), _lib.dtype_code(g.dtype), rows, C, _lib.ptr(x), _lib.ptr(g), _lib.ptr(b),
+                                             float(eps), _lib.ptr(y), _lib.stream_of(x)), "pafc_layernorm_silu_fwd")
+        ctx.save_for_backward(x, g, b)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, b = ctx.saved_tensors
+        L = _lib.lib()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        nbytes = L.pafc_layernorm_bwd_workspace_bytes(rows, C)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        dx = torch.empty_like(x)
+        dgb = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        _lib.check(L.pafc_layernorm_silu_bwd(_lib.dtype_code(x.dtype), _lib.dtype_code(g.dtype), rows, C, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(g),
+                                             _lib.ptr(b), float(ctx.eps), _lib.ptr(dx), _lib.ptr(dgb), _lib.ptr(ws), nbytes, _lib.stream_of(x)),
+                   "pafc_layernorm_silu_bwd")
+        if g.dtype != torch.float32:
+            dgb = dgb.to(g.dtype)
+        return dx, dgb[0], dgb[1], None
+
+
+def ln_silu_train_eligible(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor]) -> bool:
+    """The conv module's LayerNorm + SiLU as one kernel each way: GPU training step, x contiguous bf16 (fp32 or bf16 parameters) or
+    fp32 (fp32 parameters), C % 8 == 0, C <= 1024.  PAFC_TRAIN_LN_SILU=0: the separate LayerNorm and SiLU (A/B runs)."""
+    if not (x.is_cuda and torch.is_grad_enabled() and weight is not None and bias is not None and train_kernels_enabled()
+            and os.environ.get("PAFC_TRAIN_LN_SILU", "1") != "0"):
+        return False
+    if weight.dtype != bias.dtype or x.shape[-1] % 8 or x.shape[-1] > 1024 or not (x.requires_grad or weight.requires_grad):
+        return False
+    return ((x.dtype == torch.bfloat16 and weight.dtype in (torch.float32, torch.bfloat16))
+            or (x.dtype == torch.float32 and weight.dtype == torch.float32))
+
+
+def ln_silu_train(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:
+    return _LnSiluTrain.apply(x.contiguous(), weight, bias, eps)
+
+
 def layer_norm_train_eligible(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor]) -> bool:
     return (x.is_cuda and torch.is_grad_enabled() and weight is not None and bias is not None and train_kernels_enabled()
             and x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] % 8 == 0 and x.shape[-1] <= 1024

@@ -76,7 +76,12 @@ class ConvolutionModule(nn.Module):
         else:
             x = depthwise_conv1d_cl(x, self.depthwise_conv.weight, self.depthwise_conv.bias, left_pad=lp, out_len=out_len)
         if self.use_layer_norm:
-            x = self.activation(self.norm(x))
+            from ..hip_ops import ln_silu_train, ln_silu_train_eligible
+            if isinstance(self.activation, torch.nn.SiLU) and isinstance(self.norm, torch.nn.LayerNorm) and self.norm.elementwise_affine \
+                    and ln_silu_train_eligible(x, self.norm.weight, self.norm.bias):
+                x = ln_silu_train(x, self.norm.weight, self.norm.bias, self.norm.eps)       # GPU training step: one kernel each way
+            else:
+                x = self.activation(self.norm(x))
         else:
             x = self.activation(self.norm(x.transpose(1, 2)).transpose(1, 2))
         x = linear(x, self.pointwise_conv2.weight.squeeze(-1), self.pointwise_conv2.bias)

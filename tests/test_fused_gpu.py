@@ -884,6 +884,35 @@ def test_tmix_elementwise_backward_kernels(hip, dtype, reverse, B, T, C):
     assert float((a4g.grad.cpu().double() - a4r.grad).abs().max()) <= (2 ** -6 if lo else 1e-4) * max(1.0, float(a4r.grad.abs().max()))
 
 
+@pytest.mark.parametrize("xdtype,gdtype", [(torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)])
+@pytest.mark.parametrize("B,T,C", [(1, 1, 64), (3, 50, 512), (2, 481, 512), (1, 37, 1024)])
+def test_layernorm_silu_training_kernels(hip, xdtype, gdtype, B, T, C):
+    """ln_silu_train (round 6: the conv module's `activation(norm(x))`, convolution.py:136-138, as one kernel each way) against
+    float64 autograd through F.layer_norm + F.silu on the same (rounded) operands: bf16 x with the norm's fp32 parameters (bf16
+    autocast over an fp32 model: the chain it replaces is cast, LayerNorm, SiLU, cast), bf16 with bf16 parameters, fp32."""
+    import torch.nn.functional as F
+    from paper_accurate_fast_cheap_amd.hip_ops import ln_silu_train, ln_silu_train_eligible
+    x = synth.randn((B, T, C), 91, 1.5).to(xdtype)
+    g = (1.0 + 0.3 * synth.randn((C,), 92, 1.0)).to(gdtype)
+    b = (0.2 * synth.randn((C,), 93, 1.0)).to(gdtype)
+    dy = synth.randn((B, T, C), 94, 1.0).to(xdtype)
+    xr, gr, br = (t.double().requires_grad_() for t in (x, g, b))
+    ref = F.silu(F.layer_norm(xr, (C,), gr, br, 1e-5))
+    ref.backward(dy.double())
+    xg, gg, bg = (t.cuda().requires_grad_() for t in (x, g, b))
+    assert ln_silu_train_eligible(xg, gg, bg)
+    y = ln_silu_train(xg, gg, bg, 1e-5)
+    assert y.dtype == xdtype and y.shape == x.shape
+    lo = xdtype == torch.bfloat16
+    torch.testing.assert_close(y.detach().cpu().double(), ref.detach(), **(dict(rtol=2 ** -7, atol=2e-2) if lo else dict(rtol=1e-5, atol=1e-5)))
+    y.backward(dy.cuda())
+    torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, **(dict(rtol=2 ** -6, atol=3e-2) if lo else dict(rtol=1e-4, atol=1e-5)))
+    for got, want in ((gg.grad, gr.grad), (bg.grad, br.grad)):
+        assert got.dtype == gdtype and got.shape == (C,)
+        tol = 2 ** -7 if gdtype == torch.bfloat16 else 1e-4
+        assert float((got.cpu().double() - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+
+
 @pytest.mark.parametrize("wdtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("B,T,C", [(2, 150, 128), (4, 481, 512)])
 def test_grouped_linear_training_function(hip, wdtype, B, T, C):
