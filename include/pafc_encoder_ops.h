@@ -113,6 +113,11 @@ size_t pafc_layernorm_bwd_workspace_bytes(long rows, int C);
 int pafc_layernorm_bwd(int dtype_x, int dtype_dy, long rows, int C, const void *x, const void *dy, const void *gamma,
                        float eps, void *dx, float *dgamma_dbeta, void *workspace, size_t workspace_bytes,
                        pafc_stream_t stream);
+/* ... + dx_add (dtype_x, may be null): dx = the norm's input gradient + dx_add, the gradient that reaches x past the norm (the
+ * residual path of a pre-norm branch, encoder_layer.py:201-256) -- autograd's accumulation pass folded into this one. */
+int pafc_layernorm_bwd_add(int dtype_x, int dtype_dy, long rows, int C, const void *x, const void *dy, const void *gamma, float eps,
+                           const void *dx_add, void *dx, float *dgamma_dbeta, void *workspace, size_t workspace_bytes,
+                           pafc_stream_t stream);
 
 /* LayerNorm + SiLU of the conv module in the training step (convolution.py:136-138, `activation(norm(x))` between the depthwise
  * convolution and pointwise_conv2), one kernel each way: y = silu(LayerNorm(x)), arithmetic in fp32 against the norm's own

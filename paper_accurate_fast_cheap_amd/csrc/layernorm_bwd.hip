@@ -44,7 +44,8 @@ template <> __device__ __forceinline__ void st8<float>(float *p, const float *f)
 template <typename EX, typename ED>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(long rows, int C, const EX *__restrict__ x,
                                                             const ED *__restrict__ dy, const EX *__restrict__ gamma,
-                                                            float eps, EX *__restrict__ dx, float *__restrict__ part) {
+                                                            float eps, EX *__restrict__ dx, float *__restrict__ part,
+                                                            const EX *__restrict__ dx_add) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_c = 1.f / (float)C;
     float gm[LMAXIT][LVEC], ag[LMAXIT][LVEC], ab[LMAXIT][LVEC];
@@ -108,6 +109,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(long rows, int C, co
                 float o[LVEC];
 #pragma unroll
                 for (int e = 0; e < LVEC; ++e) o[e] = rstd * (gv[it][e] - s1 - xv[it][e] * s2);
+                if (dx_add != nullptr) {     // the gradient that reaches x past the norm (the residual path of a pre-norm branch)
+                    float av[LVEC];
+                    ld8<EX>(dx_add + (size_t)row * C + c, av);
+#pragma unroll
+                    for (int e = 0; e < LVEC; ++e) o[e] += av[e];
+                }
                 st8<EX>(dx + (size_t)row * C + c, o);
             }
         }
@@ -299,10 +306,10 @@ __global__ __launch_bounds__(256) void ln_silu_bwd_kernel(long rows, int C, cons
 
 template <typename EX, typename ED>
 int launch_ln_bwd(long rows, int C, const void *x, const void *dy, const void *gamma, float eps, void *dx, float *dgb,
-                  float *part, hipStream_t s) {
+                  float *part, const void *dx_add, hipStream_t s) {
     const int nblk = (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     hipLaunchKernelGGL((layernorm_bwd_kernel<EX, ED>), dim3(nblk), dim3(256), 0, s, rows, C, (const EX *)x, (const ED *)dy,
-                       (const EX *)gamma, eps, (EX *)dx, part);
+                       (const EX *)gamma, eps, (EX *)dx, part, (const EX *)dx_add);
     hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * C + 15) / 16), dim3(1024), 0, s, 2 * C, nblk, part, dgb);
     return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
 }
@@ -315,9 +322,11 @@ extern "C" size_t pafc_layernorm_bwd_workspace_bytes(long rows, int C) {
     return (size_t)((rows + pafc::ROWS_PER_BLOCK - 1) / pafc::ROWS_PER_BLOCK) * 2 * C * sizeof(float);
 }
 
-extern "C" int pafc_layernorm_bwd(int dtype_x, int dtype_dy, long rows, int C, const void *x, const void *dy,
-                                  const void *gamma, float eps, void *dx, float *dgamma_dbeta, void *workspace,
-                                  size_t workspace_bytes, pafc_stream_t stream) {
+// ... + dx_add (dtype_x, or null): dx = LayerNorm's input gradient + dx_add -- the gradient that reaches x past the norm (the residual
+// path of a pre-norm branch, encoder_layer.py:201-256), which autograd would add in a pass of its own
+extern "C" int pafc_layernorm_bwd_add(int dtype_x, int dtype_dy, long rows, int C, const void *x, const void *dy,
+                                      const void *gamma, float eps, const void *dx_add, void *dx, float *dgamma_dbeta,
+                                      void *workspace, size_t workspace_bytes, pafc_stream_t stream) {
     if (!x || !dy || !gamma || !dx || !dgamma_dbeta || !workspace) return PAFC_ERR_NULL_POINTER;
     if (rows <= 0 || C <= 0 || C % pafc::LVEC || C > 64 * pafc::LVEC * pafc::LMAXIT || rows > 0x7fffffffL * pafc::ROWS_PER_BLOCK)
         return PAFC_ERR_BAD_DIMS;
@@ -326,14 +335,21 @@ extern "C" int pafc_layernorm_bwd(int dtype_x, int dtype_dy, long rows, int C, c
     float *part = (float *)workspace;
     using pafc::bf16_t;
     if (dtype_x == PAFC_F32 && dtype_dy == PAFC_F32)
-        return pafc::launch_ln_bwd<float, float>(rows, C, x, dy, gamma, eps, dx, dgamma_dbeta, part, s);
+        return pafc::launch_ln_bwd<float, float>(rows, C, x, dy, gamma, eps, dx, dgamma_dbeta, part, dx_add, s);
     if (dtype_x == PAFC_F32 && dtype_dy == PAFC_BF16)
-        return pafc::launch_ln_bwd<float, bf16_t>(rows, C, x, dy, gamma, eps, dx, dgamma_dbeta, part, s);
+        return pafc::launch_ln_bwd<float, bf16_t>(rows, C, x, dy, gamma, eps, dx, dgamma_dbeta, part, dx_add, s);
     if (dtype_x == PAFC_BF16 && dtype_dy == PAFC_BF16)
-        return pafc::launch_ln_bwd<bf16_t, bf16_t>(rows, C, x, dy, gamma, eps, dx, dgamma_dbeta, part, s);
+        return pafc::launch_ln_bwd<bf16_t, bf16_t>(rows, C, x, dy, gamma, eps, dx, dgamma_dbeta, part, dx_add, s);
     if (dtype_x == PAFC_BF16 && dtype_dy == PAFC_F32)
-        return pafc::launch_ln_bwd<bf16_t, float>(rows, C, x, dy, gamma, eps, dx, dgamma_dbeta, part, s);
+        return pafc::launch_ln_bwd<bf16_t, float>(rows, C, x, dy, gamma, eps, dx, dgamma_dbeta, part, dx_add, s);
     return PAFC_ERR_DTYPE;
+}
+
+extern "C" int pafc_layernorm_bwd(int dtype_x, int dtype_dy, long rows, int C, const void *x, const void *dy,
+                                  const void *gamma, float eps, void *dx, float *dgamma_dbeta, void *workspace,
+                                  size_t workspace_bytes, pafc_stream_t stream) {
+    return pafc_layernorm_bwd_add(dtype_x, dtype_dy, rows, C, x, dy, gamma, eps, nullptr, dx, dgamma_dbeta, workspace, workspace_bytes,
+                                  stream);
 }
 
 /* LayerNorm + SiLU of the conv module, training step: see the kernels.  dtype_x: x, y, dy, dx; dtype_g: gamma, beta. */

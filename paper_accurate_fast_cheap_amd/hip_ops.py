@@ -221,9 +221,12 @@ def depthwise_conv1d_cl_autograd(x: torch.Tensor, weight: torch.Tensor, bias: Op
     return _DepthwiseConvCL.apply(x.contiguous(), weight, bias, left_pad, out_len)
 
 
-def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float):
-    """(dx in x's dtype, dgamma, dbeta in float32) of y = LayerNorm(x) over the last axis."""
-    _lib.require_gpu(x, dy, gamma)
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float, dx_add: Optional[torch.Tensor] = None):
+    """(dx in x's dtype, dgamma, dbeta in float32) of y = LayerNorm(x) over the last axis; dx_add (like x): added to dx in the same
+    pass (the gradient that reaches x past the norm)."""
+    _lib.require_gpu(x, dy, gamma, dx_add)
+    if dx_add is not None and (dx_add.dtype != x.dtype or dx_add.shape != x.shape or not dx_add.is_contiguous()):
+        raise _lib.PafcError("layernorm_bwd: dx_add contiguous, shaped and typed like x")
     C = x.shape[-1]
     rows = x.numel() // C
     if dy.shape != x.shape or gamma.dtype != x.dtype or gamma.shape != (C,):
@@ -233,16 +236,16 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: f
         from ctypes import c_float, c_long, c_size_t
         L.pafc_layernorm_bwd_workspace_bytes.restype = c_size_t
         L.pafc_layernorm_bwd_workspace_bytes.argtypes = [c_long, c_int]
-        _lib._sig(L.pafc_layernorm_bwd, c_int, c_int, c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+        _lib._sig(L.pafc_layernorm_bwd_add, c_int, c_int, c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                   c_void_p, c_void_p, c_size_t, c_void_p)
         L._pafc_lnb_bound = True
     nbytes = L.pafc_layernorm_bwd_workspace_bytes(rows, C)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     dx = torch.empty_like(x)
     dgb = torch.empty(2, C, dtype=torch.float32, device=x.device)
-    rc = L.pafc_layernorm_bwd(_lib.dtype_code(x.dtype), _lib.dtype_code(dy.dtype), rows, C, _lib.ptr(x), _lib.ptr(dy),
-                              _lib.ptr(gamma), float(eps), _lib.ptr(dx), _lib.ptr(dgb), _lib.ptr(ws), nbytes,
-                              _lib.stream_of(x))
+    rc = L.pafc_layernorm_bwd_add(_lib.dtype_code(x.dtype), _lib.dtype_code(dy.dtype), rows, C, _lib.ptr(x), _lib.ptr(dy),
+                                  _lib.ptr(gamma), float(eps), _lib.ptr(dx_add), _lib.ptr(dx), _lib.ptr(dgb), _lib.ptr(ws), nbytes,
+                                  _lib.stream_of(x))
     _lib.check(rc, "pafc_layernorm_bwd")
     return dx, dgb[0], dgb[1]
 
@@ -250,24 +253,30 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: f
 class _LayerNormTrain(torch.autograd.Function):
     """nn.LayerNorm for the GPU training step: forward = the inference kernel (one pass, optionally straight to bf16 for
     a consumer that would cast anyway), backward = one pass over (x, dy) + a small reduction, instead of the framework's
-    fp32 forward, cast and three backward kernels."""
+    fp32 forward, cast and three backward kernels.  with_skip (round 6): x is handed on as a second output -- the residual
+    path of a pre-norm branch, x + f(norm(x)) -- so that its gradient comes back HERE and is added inside the backward
+    kernel (pafc_layernorm_bwd_add) instead of by autograd's accumulation pass (one (B, T, C) fp32 add per branch)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, out_dtype):
+    def forward(ctx, x, weight, bias, eps, out_dtype, with_skip=False):
         g, b = _param_as(weight, x.dtype), _param_as(bias, x.dtype)
         _, y, _ = add_layernorm(x, None, 1.0, g, b, out_dtype=out_dtype, want_x=False, eps=eps)
         ctx.save_for_backward(x, g)
         ctx.eps, ctx.w_dtype, ctx.b_dtype = eps, weight.dtype, bias.dtype
-        return y
+        return (y, x.view_as(x)) if with_skip else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, g = ctx.saved_tensors
-        dx, dg, db = layernorm_bwd(x, dy.contiguous(), g, ctx.eps)
+        if dy is None:
+            dy = torch.zeros_like(x)
+        if dskip is not None and (dskip.dtype != x.dtype or not dskip.is_contiguous()):
+            dskip = dskip.to(x.dtype).contiguous()
+        dx, dg, db = layernorm_bwd(x, dy.contiguous(), g, ctx.eps, dx_add=dskip)
         if ctx.w_dtype == ctx.b_dtype and ctx.w_dtype != torch.float32:
             dgb = dg._base.to(ctx.w_dtype)          # (2, C): one cast for both (the bf16 ln_x of the slot)
-            return dx, dgb[0], dgb[1], None, None
-        return dx, dg.to(ctx.w_dtype), db.to(ctx.b_dtype), None, None
+            return dx, dgb[0], dgb[1], None, None, None
+        return dx, dg.to(ctx.w_dtype), db.to(ctx.b_dtype), None, None, None
 
 
 class _LnSiluTrain(torch.autograd.Function):
@@ -340,6 +349,19 @@ def layer_norm_train_eligible(x: torch.Tensor, weight: Optional[torch.Tensor], b
             and (x.requires_grad or weight.requires_grad))
 
 
+def layer_norm_with_skip(x: torch.Tensor, weight, bias, eps: float, bf16_out: bool = False):
+    """(LayerNorm(x), x) for a pre-norm residual branch x + f(norm(x)) in the GPU training step: use the SECOND value as the
+    branch's residual input and its gradient is added inside the norm's backward kernel (see _LayerNormTrain).  None when the
+    kernels do not take the call (the caller then norms and adds as usual)."""
+    if not (layer_norm_train_eligible(x, weight, bias) and x.requires_grad and os.environ.get("PAFC_TRAIN_LN_SKIP", "1") != "0"):
+        return None
+    amp = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+    if amp and x.dtype == torch.bfloat16 and weight.dtype == torch.float32:
+        return None                       # (autocast would run this norm in fp32 on a cast copy: not the residual stream itself)
+    out_dtype = torch.bfloat16 if (bf16_out and amp) else x.dtype
+    return _LayerNormTrain.apply(x.contiguous(), weight, bias, eps, out_dtype, True)
+
+
 def layer_norm(x: torch.Tensor, weight, bias, eps: float, bf16_out: bool = False) -> torch.Tensor:
     """F.layer_norm over the last axis as the modules call it; in the GPU training step the kernels above.  bf16_out:
     the consumer is a projection that autocast would feed bf16 anyway -- under bf16 autocast the fp32 norm then writes
@@ -349,7 +371,7 @@ def layer_norm(x: torch.Tensor, weight, bias, eps: float, bf16_out: bool = False
         if amp and x.dtype == torch.bfloat16 and weight.dtype == torch.float32:
             x = x.float()                 # autocast runs layer_norm in fp32
         out_dtype = torch.bfloat16 if (bf16_out and amp) else x.dtype
-        return _LayerNormTrain.apply(x.contiguous(), weight, bias, eps, out_dtype)
+        return _LayerNormTrain.apply(x.contiguous(), weight, bias, eps, out_dtype, False)
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), weight, bias, eps)
 
 

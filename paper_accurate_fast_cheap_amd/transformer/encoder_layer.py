@@ -58,7 +58,11 @@ class ConformerEncoderLayer(nn.Module):
 
         def branch(x, norm, fn, scale=1.0):
             # pre-norm: x + scale * fn(norm(x));  post-norm: norm(x + scale * fn(x))   (encoder_layer.py:201-256)
-            y = fn(norm(x) if pre else x)
+            if pre and hasattr(norm, "forward_skip"):
+                h, x = norm.forward_skip(x)     # (GPU training step: the residual path's gradient is added inside the norm's backward)
+                y = fn(h)
+            else:
+                y = fn(norm(x) if pre else x)
             if isinstance(y, tuple):
                 y, side["cache"] = y
             if x.is_cuda and torch.is_grad_enabled():

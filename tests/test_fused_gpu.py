@@ -884,6 +884,37 @@ def test_tmix_elementwise_backward_kernels(hip, dtype, reverse, B, T, C):
     assert float((a4g.grad.cpu().double() - a4r.grad).abs().max()) <= (2 ** -6 if lo else 1e-4) * max(1.0, float(a4r.grad.abs().max()))
 
 
+@pytest.mark.parametrize("bf16_out", [False, True])
+def test_layernorm_with_skip_adds_the_residual_gradient_in_its_backward(hip, bf16_out):
+    """layer_norm_with_skip (round 6): a pre-norm residual branch x + f(norm(x)) takes its residual input from the norm's second
+    output, and the gradient of that path is added inside the norm's backward kernel (pafc_layernorm_bwd_add) -- the same
+    gradients as norm + autograd's accumulation, fp32 stream, fp32 or bf16 norm output."""
+    import torch.nn.functional as F
+    from paper_accurate_fast_cheap_amd.hip_ops import layer_norm_with_skip
+    C = 512
+    x = synth.randn((3, 77, C), 95, 1.0)
+    g = 1.0 + 0.2 * synth.randn((C,), 96, 1.0)
+    b = 0.1 * synth.randn((C,), 97, 1.0)
+    w = synth.randn((C, C), 98, 1.0) / C ** 0.5
+    dy = synth.randn((3, 77, C), 99, 1.0)
+    xr, gr, br = (t.double().requires_grad_() for t in (x, g, b))
+    out_ref = xr + 0.5 * torch.tanh(F.layer_norm(xr, (C,), gr, br, 1e-5) @ w.double())
+    out_ref.backward(dy.double())
+    xg, gg, bg = (t.cuda().requires_grad_() for t in (x, g, b))
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16_out):
+        got = layer_norm_with_skip(xg, gg, bg, 1e-5, bf16_out=bf16_out)
+        assert got is not None
+        h, xs = got
+        assert h.dtype == (torch.bfloat16 if bf16_out else torch.float32) and xs.dtype == torch.float32 and xs.data_ptr() == xg.data_ptr()
+    out = xs + 0.5 * torch.tanh(h.float() @ w.cuda())
+    out.backward(dy.cuda())
+    tol = dict(rtol=2e-2, atol=3e-2) if bf16_out else dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out.detach().cpu().double(), out_ref.detach(), **tol)
+    torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, **tol)
+    for got_g, want in ((gg.grad, gr.grad), (bg.grad, br.grad)):
+        assert float((got_g.cpu().double() - want).abs().max()) <= (3e-2 if bf16_out else 1e-4) * max(1.0, float(want.abs().max()))
+
+
 @pytest.mark.parametrize("xdtype,gdtype", [(torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)])
 @pytest.mark.parametrize("B,T,C", [(1, 1, 64), (3, 50, 512), (2, 481, 512), (1, 37, 1024)])
 def test_layernorm_silu_training_kernels(hip, xdtype, gdtype, B, T, C):
