@@ -25,6 +25,8 @@
 //   * all tiles of one split sit on one XCD (they share that split's rows of dY and X in its L2);
 //   * rows past the end of a block's R range are fetched from the last valid row (in bounds) and the dY tile's rows
 //     are zeroed in LDS, so ragged R costs one extra pass over <= 63 LDS rows in one block per tile.
+#include <cstdlib>
+
 #include "pafc_common.h"
 #include "../../include/pafc_encoder_ops.h"
 
@@ -326,6 +328,10 @@ void plan(long R, int M, int N, int batch, int *S, long *rows_per_split) {
         const long rounds = (tiles * sr + cus - 1) / cus;
         const double cost = (double)rounds * (double)(rps + 448) + 58.0 * (double)sr * batch * M * N * 4.0 / 1048576.0;
         if (best < 0 || cost < best) { best = cost; best_s = s; }
+    }
+    if (const char *e = getenv("PAFC_GEMM_TN_S")) {     // A/B runs: force the split count
+        const long v = atol(e);
+        if (v >= 1 && v <= max_s) best_s = v;
     }
     long rps = ((R + best_s - 1) / best_s + TBK - 1) / TBK * TBK;
     *rows_per_split = rps;
