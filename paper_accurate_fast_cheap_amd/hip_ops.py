@@ -864,6 +864,24 @@ def _weight_group(ws) -> Optional[torch.Tensor]:
     return g
 
 
+def _params_as_one(ps) -> Optional[torch.Tensor]:
+    """Z equally shaped parameters of one dtype as ONE contiguous (Z, numel) tensor WITHOUT a copy per use: they are moved into one
+    buffer the first time they are asked for together (`p.data = buffer[i].view(shape)`, as _weight_group does for the bf16
+    projection weights) -- the four lerp coefficients time_maa_r / k / v / w of a time-mix block (src/model.py:236-240), which the
+    training step otherwise stacks on every call (four device-to-device copies).  None when they are not such parameters."""
+    p0 = ps[0]
+    if any(not isinstance(p, torch.nn.Parameter) or p.shape != p0.shape or p.dtype != p0.dtype or p.device != p0.device
+           or not p.is_contiguous() for p in ps) or p0.numel() % 8:
+        return None
+    g = _as_batch([p.detach().view(1, -1) for p in ps])
+    if g is None or not g.is_contiguous():
+        with torch.no_grad():
+            g = torch.stack([p.detach().reshape(1, -1) for p in ps]).contiguous()
+            for i, p in enumerate(ps):
+                p.data = g[i].view(p.shape)
+    return g.view(len(ps), -1)
+
+
 def _weight_t_group(ws) -> Optional[torch.Tensor]:
     """(Z, K, N) bf16: the transposed copies of _bf16_shadow_t for Z equally shaped weights, as views of ONE tensor (the
     multi-tensor transpose that refreshes the copies writes into the views)."""
@@ -1408,9 +1426,13 @@ class _LoraMix4Train(torch.autograd.Function):
     and layer) with a transposed copy of t in front of the last one."""
 
     @staticmethod
-    def forward(ctx, x, t, w2, maa4, reverse):
+    def forward(ctx, x, t, w2, maa_r, maa_k, maa_v, maa_w, reverse):
         B, T, C = x.shape
         M, R = B * T, w2.shape[1]
+        maas = (maa_r, maa_k, maa_v, maa_w)
+        maa4 = _params_as_one(maas)                                               # (4, C): no launch once the four live in one buffer
+        if maa4 is None:
+            maa4 = torch.stack([m_.detach().reshape(C) for m_ in maas])
         tb = t.reshape(M, 4 * R)
         if tb.dtype != torch.bfloat16 or not tb.is_contiguous():
             tb = tb.to(torch.bfloat16).contiguous()
@@ -1426,7 +1448,7 @@ class _LoraMix4Train(torch.autograd.Function):
         a4 = maa4.reshape(1, 4, C).to(x.dtype).contiguous()
         z = tmix_mix4(x, mm, a4, reverse)                                          # (4, 1, M, C)
         ctx.save_for_backward(x, tb, w2b, mm, a4)
-        ctx.reverse, ctx.maa_shape, ctx.maa_dtype, ctx.t_shape, ctx.t_dtype, ctx.w2_dtype = (reverse, maa4.shape, maa4.dtype, t.shape,
+        ctx.reverse, ctx.maa_shape, ctx.maa_dtype, ctx.t_shape, ctx.t_dtype, ctx.w2_dtype = (reverse, maa_r.shape, maa_r.dtype, t.shape,
                                                                                              t.dtype, w2.dtype)
         return tuple(z[q, 0].view(B, T, C) for q in range(4))
 
@@ -1457,7 +1479,9 @@ class _LoraMix4Train(torch.autograd.Function):
             od = ctx.w2_dtype if ctx.w2_dtype in (torch.float32, torch.bfloat16) else torch.float32
             full = gemm_tn(tb, dm.view(M, 4 * C), od)                                  # (4 R, 4 C): its diagonal blocks
             dw2 = torch.stack([full[q * R:(q + 1) * R, q * C:(q + 1) * C] for q in range(4)]).to(ctx.w2_dtype)
-        return dx, dt, dw2, dmaa.to(ctx.maa_dtype).view(ctx.maa_shape), None
+        dm4 = dmaa.to(ctx.maa_dtype)
+        return (dx, dt, dw2, dm4[0].view(ctx.maa_shape), dm4[1].view(ctx.maa_shape), dm4[2].view(ctx.maa_shape),
+                dm4[3].view(ctx.maa_shape), None)
 
 
 def lora_mix4_train_eligible(x: torch.Tensor, t: torch.Tensor, w2: torch.Tensor) -> bool:
@@ -1470,9 +1494,10 @@ def lora_mix4_train_eligible(x: torch.Tensor, t: torch.Tensor, w2: torch.Tensor)
             and w2.dtype in (torch.float32, torch.bfloat16) and t.numel() == x.shape[0] * x.shape[1] * 4 * w2.shape[1])
 
 
-def lora_mix4_train(x: torch.Tensor, t: torch.Tensor, w2: torch.Tensor, maa4: torch.Tensor, reverse: bool):
-    """t: (B, T, 4 R) = tanh(xxx W1); w2: (4, R, C); maa4: (4, C).  -> z_r, z_k, z_v, z_w (B, T, C)."""
-    return _LoraMix4Train.apply(x.contiguous(), t, w2, maa4, reverse)
+def lora_mix4_train(x: torch.Tensor, t: torch.Tensor, w2: torch.Tensor, maas, reverse: bool):
+    """t: (B, T, 4 R) = tanh(xxx W1); w2: (4, R, C); maas: the four lerp coefficients (time_maa_r, _k, _v, _w), C elements each.
+    -> z_r, z_k, z_v, z_w (B, T, C)."""
+    return _LoraMix4Train.apply(x.contiguous(), t, w2, *maas, reverse)
 
 
 def tmix_train_eligible(x: torch.Tensor) -> bool:
@@ -2144,7 +2169,9 @@ class _Conv2Train(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         a, y, wb = ctx.saved_tensors
-        g = (dy * (y > 0)).permute(0, 3, 1, 2)                       # NCHW view of NHWC memory (channels_last)
+        # relu's backward as the framework's own one-pass kernel (`dy * (y > 0)` was a compare, a 150 MB bool tensor and a
+        # mixed-dtype multiply: 0.4 ms); NCHW view of NHWC memory (channels_last)
+        g = torch.ops.aten.threshold_backward(dy.contiguous(), y, 0.0).permute(0, 3, 1, 2)
         gi, gw, gb = torch.ops.aten.convolution_backward(g, a.permute(0, 3, 1, 2), wb, [wb.shape[0]], [2, 2], [0, 0], [1, 1],
                                                          False, [0, 0], 1, [ctx.needs_input_grad[0], True,
                                                                             ctx.b_dtype is not None])

@@ -77,11 +77,11 @@ class RWKV_Tmix_x060c(nn.Module):
                 xxx = hip_ops.shift_mix_train(x, self.time_maa_x, reverse)
                 fold = mm is hip_ops.matmul_param       # tanh (and the decay's bias) in the GEMM epilogue: one launch instead of two (three)
                 t = mm(xxx, self.time_maa_rkvw_w1, "tanh") if fold else torch.tanh(mm(xxx, self.time_maa_rkvw_w1))
-                maa4 = torch.stack([self.time_maa_r.reshape(C), self.time_maa_k.reshape(C), self.time_maa_v.reshape(C),
-                                    self.time_maa_w.reshape(C)])
+                maas = (self.time_maa_r, self.time_maa_k, self.time_maa_v, self.time_maa_w)
                 if hip_ops.lora_mix4_train_eligible(x, t, self.time_maa_rkvw_w2):
-                    zr, zk, zv, zw = hip_ops.lora_mix4_train(x, t, self.time_maa_rkvw_w2, maa4, reverse)   # own GEMMs each way
+                    zr, zk, zv, zw = hip_ops.lora_mix4_train(x, t, self.time_maa_rkvw_w2, maas, reverse)   # own GEMMs each way
                 else:
+                    maa4 = torch.stack([m_.reshape(C) for m_ in maas])
                     m = torch.bmm(t.view(B * T, 4, -1).transpose(0, 1), self.time_maa_rkvw_w2).view(4, B, T, C)
                     zr, zk, zv, zw = hip_ops.mix4_train(x, m, maa4, reverse)
                 ws = (self.receptance.weight, self.key.weight, self.value.weight)

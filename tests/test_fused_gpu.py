@@ -1020,9 +1020,11 @@ def test_lora_up_and_lerps_on_own_kernels_each_way(hip, xdtype, reverse, B, T, C
     z_ref = [xr + xx * (ar[q].view(1, 1, C) + m_ref[q]) for q in range(4)]
     sum((z_ref[q] * g4[q].double()).sum() for q in range(4)).backward()
 
-    xg, tg, wg, ag = (v.cuda().requires_grad_() for v in (x, t, w2, maa4))
+    xg, tg, wg = (v.cuda().requires_grad_() for v in (x, t, w2))
+    # the four lerp coefficients as the module holds them: separate (1, 1, C) parameters (moved into one buffer on first use)
+    maas = [torch.nn.Parameter(maa4[q].view(1, 1, C).clone().cuda()) for q in range(4)]
     assert lora_mix4_train_eligible(xg, tg, wg)
-    z = lora_mix4_train(xg, tg, wg, ag, reverse)
+    z = lora_mix4_train(xg, tg, wg, maas, reverse)
     lo = xdtype == torch.bfloat16
     # m is rounded to bf16 between the product and the lerp (as torch.bmm's bf16 output is); |xx| reaches ~8
     tol = dict(rtol=2 ** -6, atol=8e-2) if lo else dict(rtol=2 ** -7, atol=4e-2)
@@ -1034,7 +1036,12 @@ def test_lora_up_and_lerps_on_own_kernels_each_way(hip, xdtype, reverse, B, T, C
     for got, ref in ((tg.grad, tr.grad), (wg.grad, wr.grad)):
         assert got.dtype == torch.bfloat16 and got.shape == ref.shape
         assert float((got.cpu().double() - ref).abs().max()) <= 2 ** -6 * float(ref.abs().max()) + 1e-3
-    assert float((ag.grad.cpu().double() - ar.grad).abs().max()) <= (2 ** -6 if lo else 1e-4) * max(1.0, float(ar.grad.abs().max()))
+    ag = torch.stack([m_.grad.reshape(C) for m_ in maas])
+    assert all(m_.grad.shape == (1, 1, C) and m_.grad.dtype == xdtype for m_ in maas)
+    assert float((ag.cpu().double() - ar.grad).abs().max()) <= (2 ** -6 if lo else 1e-4) * max(1.0, float(ar.grad.abs().max()))
+    assert maas[1].data_ptr() - maas[0].data_ptr() == C * maas[0].element_size()          # one buffer now
+    z2 = lora_mix4_train(xg, tg, wg, maas, reverse)                                        # ... found again without a copy
+    torch.testing.assert_close(z2[0].detach(), z[0].detach(), rtol=0, atol=0)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

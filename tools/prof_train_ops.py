@@ -68,3 +68,41 @@ if STACKS:
     for (name, where, shape), n in sorted(by.items(), key=lambda kv: -kv[1]):
         if n >= 12:
             print(f"{n:5d}  {name:18s} {where:70s} {shape}")
+
+    # every aten::copy_ (casts and device-to-device copies) by its chain of enclosing ops
+    byc = collections.Counter()
+    for e in prof.events():
+        if e.name != "aten::copy_" or e.device_type.name != "CPU":
+            continue
+        chain, par, where = [], e.cpu_parent, "(top level)"
+        while par is not None:
+            if par.name.startswith("aten::"):
+                chain.append(par.name[6:])
+            else:
+                where = par.name
+                break
+            par = par.cpu_parent
+        byc[("<-".join(chain) or "-", where[:60], str(e.input_shapes)[:48])] += 1
+    print("\naten::copy_ by enclosing chain (count >= 6):")
+    for (chain, where, shape), n in sorted(byc.items(), key=lambda kv: -kv[1]):
+        if n >= 6:
+            print(f"{n:5d}  {chain:34s} {where:60s} {shape}")
+    agg = collections.Counter()
+    for (chain, where, shape), n in byc.items():
+        agg[(chain, where)] += n
+    print("\naten::copy_ by (chain, enclosing event), all:")
+    for (chain, where), n in sorted(agg.items(), key=lambda kv: -kv[1])[:30]:
+        print(f"{n:5d}  {chain:34s} {where}")
+    # device-to-device copies issued below the op level (hipMemcpyAsync) by enclosing event
+    mc = collections.Counter()
+    for e in prof.events():
+        if e.name not in ("hipMemcpyAsync", "hipMemcpyWithStream") or e.device_type.name != "CPU":
+            continue
+        chain, par = [], e.cpu_parent
+        while par is not None and len(chain) < 4:
+            chain.append(par.name[:48])
+            par = par.cpu_parent
+        mc[" <- ".join(chain)] += 1
+    print("\nhipMemcpyAsync by enclosing events:")
+    for k, n in sorted(mc.items(), key=lambda kv: -kv[1])[:25]:
+        print(f"{n:5d}  {k}")
