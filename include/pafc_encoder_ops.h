@@ -467,6 +467,9 @@ int pafc_silu_dropout(int backward, int dtype, long n, const void *h, const void
  * ceil(rows / 64) * ceil(cols / 64) over the earlier descriptors; total_tiles = that sum over all n.  Sources and destinations
  * must not overlap; nothing is allocated, the launch is asynchronous on `stream`. */
 int pafc_multi_transpose_bf16(const void *table, int n, int total_tiles, pafc_stream_t stream);
+/* The same descriptor table without the transposition: dst (bf16) = src (fp32 | bf16) element for element, rows x cols elements per
+ * tensor, tile0 counting chunks of 4 096 elements: the bf16 copies of the fp32 master weights, refreshed once per training step. */
+int pafc_multi_cast_bf16(const void *table, int n, int total_chunks, pafc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -178,6 +178,30 @@ __global__ __launch_bounds__(256) void multi_transpose_kernel(const TrDesc *__re
     }
 }
 
+// The same table, no transposition: dst (bf16) = src (fp32 or bf16) element for element -- the bf16 copies of the fp32 master weights
+// that train_shadows() refreshes once per step.  (torch._foreach_copy_ from fp32 to bf16 lists is one launch per tensor on this
+// build: 108 of the step's launches.)  A block moves one chunk of 4 096 elements; tile0 counts chunks; rows x cols = the element count.
+constexpr int CAST_CHUNK = 4096;
+__global__ __launch_bounds__(256) void multi_cast_kernel(const TrDesc *__restrict__ tab, int n) {
+    int lo = 0, hi = n - 1;
+    const int t = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].tile0 <= t) lo = mid; else hi = mid - 1;
+    }
+    const TrDesc d = tab[lo];
+    const long numel = (long)d.rows * d.cols;
+    const long base = (long)(t - d.tile0) * CAST_CHUNK;
+#pragma unroll
+    for (int i = 0; i < CAST_CHUNK / 256; ++i) {
+        const long idx = base + i * 256 + threadIdx.x;
+        if (idx < numel)
+            reinterpret_cast<unsigned short *>(d.dst)[idx] =
+                d.src_f32 ? (unsigned short)f32_to_bf16_bits(reinterpret_cast<const float *>(d.src)[idx])
+                          : reinterpret_cast<const unsigned short *>(d.src)[idx];
+    }
+}
+
 }  // namespace pafc
 
 using pafc::bf16_t;
@@ -234,6 +258,14 @@ extern "C" int pafc_silu_dropout(int backward, int dtype, long n, const void *h,
 // bf16 transposed copies of many matrices in ONE launch (include/pafc_encoder_ops.h).  `table`: n descriptors of 32 bytes in
 // DEVICE memory -- { const void *src; void *dst; int rows, cols, src_f32, tile0; } with tile0 = the running sum of
 // ceil(rows / 64) * ceil(cols / 64) over the earlier tensors; total_tiles = that sum over all n.
+extern "C" int pafc_multi_cast_bf16(const void *table, int n, int total_chunks, pafc_stream_t stream) {
+    if (!table) return PAFC_ERR_NULL_POINTER;
+    if (n <= 0 || total_chunks <= 0) return PAFC_ERR_BAD_DIMS;
+    hipLaunchKernelGGL(pafc::multi_cast_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream,
+                       (const pafc::TrDesc *)table, n);
+    return hipGetLastError() == hipSuccess ? PAFC_OK : PAFC_ERR_LAUNCH;
+}
+
 extern "C" int pafc_multi_transpose_bf16(const void *table, int n, int total_tiles, pafc_stream_t stream) {
     if (!table) return PAFC_ERR_NULL_POINTER;
     if (n <= 0 || total_tiles <= 0) return PAFC_ERR_BAD_DIMS;

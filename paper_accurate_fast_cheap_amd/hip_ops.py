@@ -662,8 +662,45 @@ def refresh_train_shadows() -> None:
         else:
             live.extend((p, g[i]) for i, p in enumerate(ps))
     if live:
+        _multi_cast(live)
+
+
+_cast_table = {}   # device -> (signature, device table of pafc_multi_cast_bf16 descriptors, n, total chunks)
+
+
+def _multi_cast(pairs) -> None:
+    """[(parameter, bf16 copy), ...]: copy <- parameter.  GPU tensors: ONE pafc_multi_cast_bf16 launch per device over a descriptor
+    table that is rebuilt only when a pointer changes (torch._foreach_copy_ across dtypes is one launch per tensor on this build:
+    108 of the training step's launches); anything else through torch._foreach_copy_."""
+    by_dev, rest = {}, []
+    for p, sh in pairs:
+        if (p.is_cuda and sh.is_cuda and p.device == sh.device and sh.dtype == torch.bfloat16 and p.dtype in (torch.float32, torch.bfloat16)
+                and p.is_contiguous() and sh.is_contiguous() and p.numel() == sh.numel() and 0 < p.numel() < (1 << 31)):
+            by_dev.setdefault(p.device, []).append((p, sh))
+        else:
+            rest.append((p, sh))
+    if rest:
         with torch.no_grad():
-            torch._foreach_copy_([sh for _, sh in live], [p.detach() for p, _ in live])
+            torch._foreach_copy_([sh for _, sh in rest], [p.detach() for p, _ in rest])
+    if not by_dev:
+        return
+    L = _bind()
+    if not getattr(L, "_pafc_mcast_bound", False):
+        _lib._sig(L.pafc_multi_cast_bf16, c_int, c_void_p, c_int, c_int, c_void_p)
+        L._pafc_mcast_bound = True
+    for dev, live in by_dev.items():
+        sig = tuple((p.data_ptr(), sh.data_ptr(), p.dtype, p.numel()) for p, sh in live)
+        ent = _cast_table.get(dev)
+        if ent is None or ent[0] != sig:
+            rows, c0 = [], 0
+            for p, sh in live:
+                # { src, dst, rows | cols << 32, src_f32 | chunk0 << 32 }: the 32-byte descriptor of pafc_multi_transpose_bf16, rows x cols = numel
+                rows.append([p.data_ptr(), sh.data_ptr(), p.numel() | (1 << 32), int(p.dtype == torch.float32) | (c0 << 32)])
+                c0 += (p.numel() + 4095) // 4096
+            ent = _cast_table[dev] = (sig, torch.tensor(rows, dtype=torch.int64).to(dev), len(live), c0)
+        _, tab, n, chunks = ent
+        with torch.cuda.device(dev):
+            _lib.check(L.pafc_multi_cast_bf16(_lib.ptr(tab), n, chunks, _lib.stream_of(tab)), "pafc_multi_cast_bf16")
 
 
 @contextlib.contextmanager
