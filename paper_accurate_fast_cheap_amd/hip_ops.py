@@ -824,7 +824,8 @@ class _MatmulTrainBf16(torch.autograd.Function):
         dw = gemm_tn(x2, dy2, torch.bfloat16) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[3]:
-            db = dy2.sum(0, dtype=torch.float32).to(ctx.bias_dtype).view(ctx.bias_shape)
+            # (one reduction kernel: fp32 accumulation inside, one rounding to the bias's dtype -- the value of sum(float32).to())
+            db = dy2.sum(0, dtype=ctx.bias_dtype).view(ctx.bias_shape)
         return dx, dw, None, db
 
 
