@@ -890,6 +890,7 @@ def _weight_group(ws) -> Optional[torch.Tensor]:
                 g = torch.stack([w.detach() for w in ws]).contiguous()
                 for i, w in enumerate(ws):
                     w.data = g[i]
+            bump_param_epoch()        # the parameters moved: plans and captured graphs that hold their old addresses are stale
         return g
     if ws[0].dtype != torch.float32:
         return None
@@ -917,6 +918,7 @@ def _params_as_one(ps) -> Optional[torch.Tensor]:
             g = torch.stack([p.detach().reshape(1, -1) for p in ps]).contiguous()
             for i, p in enumerate(ps):
                 p.data = g[i].view(p.shape)
+        bump_param_epoch()            # the parameters moved: plans and captured graphs that hold their old addresses are stale
     return g.view(len(ps), -1)
 
 

@@ -146,6 +146,52 @@ def test_train_step_with_a_fused_optimizer_never_synchronises_the_host(hip):
 
 
 @pytest.mark.gpu
+def test_inference_after_a_training_step_that_moved_parameters(hip):
+    """Round 6: the first bf16-autocast training step moves the r / k / v weights and the lerp coefficients of every time-mix block
+    into shared buffers (`p.data = group[i]`).  Inference plans and captured graphs made BEFORE hold the old addresses: the move
+    bumps the parameter epoch, so the next inference pass -- eager and from the graph cache -- reads the moved, updated parameters
+    and equals a fresh model loaded from the trained state_dict."""
+    from paper_accurate_fast_cheap_amd.utils.init_model import init_model
+    from paper_accurate_fast_cheap_amd.utils.train_utils import train_step
+    g = load_golden("encoder_reduced_bf16slot")        # fp32 model around the bf16 time-mix slot (the YAML default)
+    cfg = dict(encoder="conformer", encoder_conf=dict(g["conf"], dropout_rate=0.0, positional_dropout_rate=0.0), input_dim=80,
+               output_dim=56, ctc="ctc", ctc_conf={"ctc_blank_id": 0}, model_conf={}, dataset_conf={})
+
+    class A:
+        checkpoint = None
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    model, _ = init_model(A(), cfg)
+    model = model.cuda()
+    feats = synth.randn((12, 120, 80), 1, 2.0).cuda()          # 12 x 29 = 348 rows: the grouped projections want >= 256
+    lens = torch.tensor([120] * 12).cuda()
+    batch = {"feats": feats, "feats_lengths": lens, "target": torch.randint(1, 50, (12, 6), generator=torch.Generator().manual_seed(2)).cuda(),
+             "target_lengths": torch.tensor([6, 5, 4, 3] * 3).cuda()}
+
+    def infer(m):
+        m.eval()
+        with torch.no_grad():
+            return m.ctc_logprobs(m._forward_encoder(feats, lens)[0]).float().clone()
+    enc = model.encoder
+    enc.graph_cache_size = 2
+    before = [infer(model) for _ in range(4)]                     # the shape is replayed from a captured graph by now
+    assert all(torch.equal(before[0], b) for b in before[1:])
+    tm = model.encoder.encoders[0].self_attn.rwkv_wrapper_forward.tmix_block
+    ptr0 = tm.receptance.weight.data_ptr()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)
+    train_step(model, batch, opt, dev, grad_clip=0.1, amp_dtype=torch.bfloat16)
+    assert tm.receptance.weight.data_ptr() != ptr0 and tm.key.weight.data_ptr() - tm.receptance.weight.data_ptr() == tm.key.weight.numel() * 2
+    after = [infer(model) for _ in range(4)]
+    assert all(torch.equal(after[0], a) for a in after[1:])
+    assert float((after[0] - before[0]).abs().max()) > 1e-3       # the step changed the model (lr 1e-2: above bf16 resolution)
+    torch.manual_seed(4)
+    fresh, _ = init_model(A(), cfg)
+    fresh = fresh.cuda()
+    fresh.load_state_dict(model.state_dict())
+    torch.testing.assert_close(infer(fresh), after[0], rtol=0, atol=0)
+
+
+@pytest.mark.gpu
 def test_train_step_fused_optimizer_skips_nonfinite_on_the_device(hip):
     """With a fused optimizer the skip-on-inf / nan decision (train_utils.py:702-711) is taken on the device (the optimizer's
     `found_inf` flag): no host synchronisation in the step, info["updated"] is a 0-dim bool tensor; a NaN batch leaves the
